@@ -1,0 +1,89 @@
+// Shared device/host helpers for the AMS student kernels (gfx950 / CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ams_hip.h"
+
+namespace ams {
+
+// ---- error plumbing ------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define AMS_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::ams::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return AMS_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define AMS_CHECK_LAUNCH()                                                                    \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) {                                                               \
+            ::ams::set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return AMS_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define AMS_REQUIRE(cond, ...)                                                                \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            ::ams::set_error(__VA_ARGS__);                                                    \
+            return AMS_E_INVALID;                                                             \
+        }                                                                                     \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// TF 'SAME' padding: out = ceil(in/stride), surplus pad goes after.
+static inline void same_pad(int in, int k, int stride, int rate, int* out, int* before) {
+    int o = (in + stride - 1) / stride;
+    int eff = (k - 1) * rate + 1;
+    int total = (o - 1) * stride + eff - in;
+    if (total < 0) total = 0;
+    *out = o;
+    *before = total / 2;
+}
+
+constexpr int kNumXcd = 8;   // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
+
+// ---- device helpers --------------------------------------------------------------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == AMS_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    if (act == AMS_ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+
+// XCD-aware block remap: consecutive *logical* ids land on the same XCD (same private L2), so blocks that
+// share halos / operand panels hit in L2 instead of each XCD re-fetching them (guide T1, bijective form).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    unsigned q = nblocks / kNumXcd, r = nblocks % kNumXcd;
+    unsigned xcd = bid % kNumXcd, slot = bid / kNumXcd;
+    unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+}  // namespace ams

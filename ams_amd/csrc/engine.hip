@@ -1,0 +1,769 @@
+// The student engine: owns the launch plan of the AMS hot path over a caller-provided device arena.
+//   frozen inference  : stem -> 17 inverted-residual blocks -> head -> fused upsample/argmax(/metrics)
+//   live forward      : same graph with training-mode BN (batch statistics), activations kept for backward
+//   train step        : live forward -> CE -> backward -> BN moving averages -> Adam (+ coordinate-descent mask)
+// Replaces tf.Session.run over the graph built by create_student_v3 (reference utils/graph_utils.py:338-533).
+#include <math.h>
+#include <stdarg.h>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace ams {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+struct LayerRt {
+    ams_layer_desc d;
+    int Hin = 0, Win = 0, Hout = 0, Wout = 0;
+    int64_t px_in = 0, px_out = 0;         // pixels per image
+    // frozen (folded) BN coefficients
+    float *fscale = nullptr, *fshift = nullptr;
+    // live BN: forward coefficients, saved statistics, backward coefficients
+    float *scale = nullptr, *shift = nullptr, *mean = nullptr, *rstd = nullptr, *cA = nullptr, *cB = nullptr, *cC = nullptr;
+    double *fsums = nullptr, *bsums = nullptr;      // [2][cout] each, inside the BN_SYNC region
+    // training activations (max_batch images each)
+    float *z = nullptr, *a = nullptr, *da = nullptr;
+};
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base((char*)b) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace ams
+
+using namespace ams;
+
+struct ams_student {
+    ams_student_config cfg;
+    std::vector<LayerRt> L;          // 1-based: L[0] unused
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    int h = 0, w = 0;                // low-res (output stride 16) size
+    int n_backbone = 0;              // index of the last backbone layer
+    int iPool = 0, iAspp = 0, iProj = 0, iLogits = 0;
+    // regions
+    float *params = nullptr, *stats = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    float *fparams = nullptr, *fstats = nullptr;      // frozen snapshot
+    double* bn_sync = nullptr; size_t bn_sync_doubles = 0;
+    float* logits = nullptr;         // [B,h,w,32]
+    float* dlogits = nullptr;
+    float* act[4] = {nullptr, nullptr, nullptr, nullptr};   // inference ping-pong pool
+    size_t act_elems = 0;
+    float *pooled = nullptr, *pool_a = nullptr, *img_bias = nullptr;          // [B,cin_head], [B,256], [B,256]
+    float *d_img_bias = nullptr, *d_pool_a = nullptr, *d_pool_z = nullptr, *d_pooled = nullptr;
+    float* im2col = nullptr;         // [B*px1, 32]
+    float* dz = nullptr;             // scratch: gradient wrt a raw conv output, max layer size
+    float* scratch = nullptr; size_t scratch_floats = 0;
+    float* tmp_c = nullptr;          // [1024] small per-channel temp
+    double* loss_buf = nullptr;      // [2] sum, count (inside BN_SYNC region so DP can all-reduce it)
+    int64_t* conf_buf = nullptr;
+    int64_t adam_t = 0;
+    bool frozen_ready = false;
+};
+
+namespace ams {
+
+static int layout(ams_student* s, void* arena, size_t* bytes_out) {
+    const ams_student_config& c = s->cfg;
+    Carver cv(arena);
+    const int64_t nT = c.n_trainable, nS = c.n_stats;
+    const int B = c.max_batch;
+    s->params = cv.take<float>(nT);
+    s->stats = cv.take<float>(nS);
+    s->fparams = cv.take<float>(nT);
+    s->fstats = cv.take<float>(nS);
+    if (c.trainable) {
+        s->grads = cv.take<float>(nT);
+        s->adam_m = cv.take<float>(nT);
+        s->adam_v = cv.take<float>(nT);
+    }
+    size_t sum_c = 0, max_elems = 0, max_c = 0;
+    for (int i = 1; i <= c.n_layers; ++i) {
+        LayerRt& l = s->L[i];
+        sum_c += l.d.cout;
+        const size_t e = (size_t)l.px_out * l.d.cout;
+        if (e > max_elems) max_elems = e;
+        if ((size_t)l.d.cout > max_c) max_c = l.d.cout;
+        if ((size_t)l.d.cin > max_c) max_c = l.d.cin;
+    }
+    for (int i = 1; i <= c.n_layers; ++i) {
+        LayerRt& l = s->L[i];
+        l.fscale = cv.take<float>(l.d.cout);
+        l.fshift = cv.take<float>(l.d.cout);
+        l.scale = cv.take<float>(l.d.cout);
+        l.shift = cv.take<float>(l.d.cout);
+        l.mean = cv.take<float>(l.d.cout);
+        l.rstd = cv.take<float>(l.d.cout);
+        l.cA = cv.take<float>(l.d.cout);
+        l.cB = cv.take<float>(l.d.cout);
+        l.cC = cv.take<float>(l.d.cout);
+    }
+    // BN sync region: loss (2 doubles) then per layer fwd sums [2][C], bwd sums [2][C]
+    s->bn_sync_doubles = 2 + 4 * sum_c;
+    s->bn_sync = cv.take<double>(s->bn_sync_doubles);
+    s->loss_buf = s->bn_sync;
+    {
+        double* p = s->bn_sync ? s->bn_sync + 2 : nullptr;
+        for (int i = 1; i <= c.n_layers; ++i) {
+            LayerRt& l = s->L[i];
+            l.fsums = p; if (p) p += 2 * l.d.cout;
+            l.bsums = p; if (p) p += 2 * l.d.cout;
+        }
+    }
+    s->conf_buf = cv.take<int64_t>(32 * 32);
+    s->logits = cv.take<float>((size_t)B * s->h * s->w * 32);
+    const int head_cin = s->L[s->iPool].d.cin, aspp_c = s->L[s->iPool].d.cout;
+    s->pooled = cv.take<float>((size_t)B * head_cin);
+    s->pool_a = cv.take<float>((size_t)B * aspp_c);
+    s->img_bias = cv.take<float>((size_t)B * aspp_c);
+    s->tmp_c = cv.take<float>(4096);
+    s->act_elems = (size_t)B * max_elems;
+    for (int k = 0; k < 4; ++k) s->act[k] = cv.take<float>(s->act_elems);
+    // scratch: column-reduction partials, wgrad splits, depthwise wgrad partials
+    size_t sc = colstats_scratch(0, (int)max_c) + 1024;
+    if (image_colsum_scratch(B, (int)max_c) > sc) sc = image_colsum_scratch(B, (int)max_c);
+    if (c.trainable) {
+        for (int i = 1; i <= c.n_layers; ++i) {
+            const LayerRt& l = s->L[i];
+            size_t need;
+            const int64_t M = (int64_t)B * l.px_out;
+            if (l.d.role == AMS_ROLE_DEPTHWISE) need = depthwise_wgrad_scratch(B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate);
+            else if (l.d.role == AMS_ROLE_STEM) need = pointwise_wgrad_scratch(M, 27, l.d.cout);
+            else need = pointwise_wgrad_scratch(M, l.d.cin, l.d.cout);
+            if (need > sc) sc = need;
+        }
+    }
+    s->scratch_floats = sc;
+    s->scratch = cv.take<float>(sc);
+    if (c.trainable) {
+        s->dlogits = cv.take<float>((size_t)B * s->h * s->w * 32);
+        s->d_img_bias = cv.take<float>((size_t)B * aspp_c);
+        s->d_pool_a = cv.take<float>((size_t)B * aspp_c);
+        s->d_pool_z = cv.take<float>((size_t)B * aspp_c);
+        s->d_pooled = cv.take<float>((size_t)B * head_cin);
+        s->im2col = cv.take<float>((size_t)B * s->L[1].px_out * 32);
+        s->dz = cv.take<float>((size_t)B * max_elems);
+        for (int i = 1; i <= c.n_layers; ++i) {
+            LayerRt& l = s->L[i];
+            if (l.d.role == AMS_ROLE_LOGITS) continue;     // logits live in s->logits / s->dlogits
+            const size_t e = (size_t)B * l.px_out * l.d.cout;
+            l.z = cv.take<float>(e);
+            l.a = cv.take<float>(e);
+            l.da = cv.take<float>(e);
+        }
+    }
+    *bytes_out = (cv.off + 255) & ~(size_t)255;
+    return AMS_OK;
+}
+
+static int build(ams_student* s, const ams_student_config* cfg, const ams_layer_desc* layers) {
+    AMS_REQUIRE(cfg && layers, "student: null config");
+    AMS_REQUIRE(cfg->abi_version == AMS_ABI_VERSION, "student: ABI version %d, library is %d", cfg->abi_version, AMS_ABI_VERSION);
+    AMS_REQUIRE(cfg->height > 0 && cfg->width > 0 && cfg->max_batch > 0, "student: bad frame size / batch");
+    AMS_REQUIRE(cfg->n_selected > 0 && cfg->n_selected <= 32 && cfg->num_classes <= 32, "student: class counts out of range");
+    AMS_REQUIRE(cfg->n_layers >= 8 && cfg->n_layers < 512, "student: bad layer count");
+    AMS_REQUIRE(cfg->act_dtype == AMS_DT_F32, "student: only f32 activation storage is implemented in this build");
+    s->cfg = *cfg;
+    s->L.assign(cfg->n_layers + 1, LayerRt());
+    int H = cfg->height + 1, W = cfg->width + 1;       // the graph pads one row / column of 127.5 first
+    for (int i = 1; i <= cfg->n_layers; ++i) {
+        LayerRt& l = s->L[i];
+        l.d = layers[i - 1];
+        const int role = l.d.role;
+        if (role == AMS_ROLE_STEM) {
+            AMS_REQUIRE(i == 1 && l.d.cin == 3 && l.d.stride == 2, "student: layer 1 must be the 3x3/2 stem");
+            l.Hin = H; l.Win = W;
+            int p;
+            same_pad(H, 3, 2, 1, &l.Hout, &p);
+            same_pad(W, 3, 2, 1, &l.Wout, &p);
+            H = l.Hout; W = l.Wout;
+        } else if (role == AMS_ROLE_DEPTHWISE) {
+            AMS_REQUIRE(l.d.cin == l.d.cout, "student: depthwise layer %d must keep the channel count", i);
+            l.Hin = H; l.Win = W;
+            int p;
+            same_pad(H, 3, l.d.stride, l.d.rate, &l.Hout, &p);
+            same_pad(W, 3, l.d.stride, l.d.rate, &l.Wout, &p);
+            H = l.Hout; W = l.Wout;
+        } else if (role == AMS_ROLE_POOL_CONV) {
+            l.Hin = l.Win = l.Hout = l.Wout = 1;
+            s->iPool = i;
+        } else {
+            AMS_REQUIRE(l.d.stride == 1, "student: 1x1 layer %d must have stride 1", i);
+            l.Hin = l.Hout = H; l.Win = l.Wout = W;
+            if (role == AMS_ROLE_ASPP) s->iAspp = i;
+            if (role == AMS_ROLE_CONCAT_PROJ) s->iProj = i;
+            if (role == AMS_ROLE_LOGITS) s->iLogits = i;
+        }
+        l.px_in = (int64_t)l.Hin * l.Win;
+        l.px_out = (int64_t)l.Hout * l.Wout;
+        if (role <= AMS_ROLE_PROJECT) s->n_backbone = i;
+        if (l.d.residual_from) AMS_REQUIRE(l.d.residual_from < i && role == AMS_ROLE_PROJECT, "student: bad residual on layer %d", i);
+        AMS_REQUIRE(l.d.cout % 4 == 0 || role == AMS_ROLE_LOGITS, "student: layer %d cout=%d not a multiple of 4", i, l.d.cout);
+    }
+    AMS_REQUIRE(s->iPool && s->iAspp && s->iProj && s->iLogits == cfg->n_layers, "student: head layers missing");
+    AMS_REQUIRE(s->iPool == s->n_backbone + 1 && s->iAspp == s->iPool + 1 && s->iProj == s->iAspp + 1,
+                "student: head must be image_pooling, aspp0, concat_projection, logits");
+    AMS_REQUIRE(s->L[s->iProj].d.cin == s->L[s->iPool].d.cout + s->L[s->iAspp].d.cout, "student: concat width mismatch");
+    AMS_REQUIRE(s->L[s->iLogits].d.cout == cfg->num_classes, "student: logits width != num_classes");
+    s->h = H; s->w = W;
+    return AMS_OK;
+}
+
+// ---- helpers ------------------------------------------------------------------------------------------
+static PwArgs pw_args(const float* x, int64_t M, int K, int ldx, const float* w, int N, float* y, int ldy) {
+    PwArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.M = M; a.K = K; a.Kw = K; a.ldx = ldx; a.w = w; a.w_sk = N; a.w_sn = 1; a.N = N;
+    a.rows_per_img = 1; a.act = AMS_ACT_NONE; a.y = y; a.ldy = ldy;
+    return a;
+}
+
+#define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+struct SyncCtx { ams_allreduce_cb cb; void* user; ams_student* s; };
+
+static int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream_t) {
+    if (!sc || !sc->cb) return AMS_OK;
+    const int rc = sc->cb(sc->user, (size_t)((char*)p - sc->s->arena), n, AMS_DT_F64);
+    if (rc) { set_error("all-reduce callback failed (%d)", rc); return AMS_E_STATE; }
+    return AMS_OK;
+}
+
+// =======================================================================================================
+// frozen inference (BN folded; what the edge device runs)
+// =======================================================================================================
+static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, hipStream_t st) {
+    const ams_student_config& c = s->cfg;
+    const float* P = s->fparams;
+    float* cur = s->act[0];
+    int cur_i = 0;
+    {
+        LayerRt& l = s->L[1];
+        RUN(launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, l.fscale, l.fshift, l.d.act, c.pixel_scale,
+                        cur, st));
+    }
+    auto other = [&](int avoid0, int avoid1) { for (int k = 0; k < 4; ++k) if (k != avoid0 && k != avoid1) return k; return -1; };
+    int i = 2;
+    while (i <= s->n_backbone) {
+        // one inverted-residual block: [expand] -> depthwise -> project (+ block input)
+        const float* block_in = cur;
+        const float* x = cur;
+        int x_i = cur_i;
+        if (s->L[i].d.role == AMS_ROLE_EXPAND) {
+            LayerRt& l = s->L[i];
+            const int o = other(cur_i, -1);
+            PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
+            a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
+            RUN(launch_pointwise(a, st));
+            x = s->act[o]; x_i = o; ++i;
+        }
+        {
+            LayerRt& l = s->L[i];
+            AMS_REQUIRE(l.d.role == AMS_ROLE_DEPTHWISE, "engine: expected depthwise at layer %d", i);
+            const int o = other(cur_i, x_i);
+            RUN(launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, l.fscale, l.fshift, l.d.act,
+                                 s->act[o], st));
+            x = s->act[o]; x_i = o; ++i;
+        }
+        {
+            LayerRt& l = s->L[i];
+            AMS_REQUIRE(l.d.role == AMS_ROLE_PROJECT, "engine: expected project at layer %d", i);
+            const int o = other(cur_i, x_i);
+            PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
+            a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
+            if (l.d.residual_from) { a.res = block_in; a.ldr = l.d.cout; }
+            RUN(launch_pointwise(a, st));
+            cur = s->act[o]; cur_i = o; ++i;
+        }
+    }
+    // ---- head -------------------------------------------------------------------------------------------
+    LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];
+    const int64_t HW = (int64_t)s->h * s->w, M = (int64_t)B * HW;
+    RUN(launch_global_mean(cur, B, HW, lp.d.cin, s->pooled, s->scratch, st));
+    {   // image_pooling conv + BN + ReLU on the pooled vector
+        PwArgs a = pw_args(s->pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, s->pool_a, lp.d.cout);
+        a.scale = lp.fscale; a.shift = lp.fshift; a.act = lp.d.act;
+        RUN(launch_pointwise(a, st));
+        // the broadcast pool branch enters concat_projection as a per-image bias: W_proj[0:256]^T . pool
+        PwArgs b = pw_args(s->pool_a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, s->img_bias, lc.d.cout);
+        RUN(launch_pointwise(b, st));
+    }
+    const int o1 = other(cur_i, -1), o2 = other(cur_i, o1);
+    {
+        PwArgs a = pw_args(cur, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, s->act[o1], la.d.cout);
+        a.scale = la.fscale; a.shift = la.fshift; a.act = la.d.act;
+        RUN(launch_pointwise(a, st));
+        PwArgs b = pw_args(s->act[o1], M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout,
+                           s->act[o2], lc.d.cout);
+        b.img_bias = s->img_bias; b.rows_per_img = HW; b.scale = lc.fscale; b.shift = lc.fshift; b.act = lc.d.act;
+        RUN(launch_pointwise(b, st));
+        PwArgs d = pw_args(s->act[o2], M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits, 32);
+        d.shift = P + ll.d.gamma_off;      // biases
+        RUN(launch_pointwise(d, st));
+    }
+    return AMS_OK;
+}
+
+// =======================================================================================================
+// live forward: training-mode BN.  z = raw conv output, batch statistics -> (scale, shift), a = act(z*scale+shift)(+res)
+// =======================================================================================================
+static int bn_train(ams_student* s, LayerRt& l, int64_t M_local, double n_global, bool update_ema, const SyncCtx* sc,
+                    const float* res, hipStream_t st) {
+    const ams_student_config& c = s->cfg;
+    const float* center = s->stats + l.d.mean_off;       // shifted sums: moving_mean is a good, rank-identical centre
+    RUN(launch_colstats(l.z, M_local, l.d.cout, center, l.fsums, s->scratch, st));
+    RUN(sync_doubles(sc, l.fsums, 2 * (size_t)l.d.cout, st));
+    const float omd = 1.0f - c.bn_decay;
+    RUN(launch_bn_finalize(l.fsums, n_global, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
+                           update_ema ? s->stats + l.d.mean_off : nullptr, update_ema ? s->stats + l.d.var_off : nullptr,
+                           l.scale, l.shift, l.mean, l.rstd, st));
+    RUN(launch_bn_act(l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, res, l.a, st));
+    return AMS_OK;
+}
+
+static int forward_live(ams_student* s, const void* frames, int dtype, int B, int global_B, bool update_ema, const SyncCtx* sc,
+                        hipStream_t st) {
+    const ams_student_config& c = s->cfg;
+    AMS_REQUIRE(c.trainable, "live forward needs a trainable student (activations are not allocated)");
+    const float* P = s->params;
+    {
+        LayerRt& l = s->L[1];
+        RUN(launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, nullptr, nullptr, AMS_ACT_NONE,
+                        c.pixel_scale, l.z, st));
+        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, nullptr, st));
+    }
+    for (int i = 2; i <= s->n_backbone; ++i) {
+        LayerRt& l = s->L[i];
+        const float* x = s->L[i - 1].a;
+        if (l.d.role == AMS_ROLE_DEPTHWISE) {
+            RUN(launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, nullptr, nullptr, AMS_ACT_NONE,
+                                 l.z, st));
+        } else {
+            PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, l.z, l.d.cout);
+            RUN(launch_pointwise(a, st));
+        }
+        const float* res = l.d.residual_from ? s->L[l.d.residual_from].a : nullptr;
+        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st));
+    }
+    LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];
+    const float* feat = s->L[s->n_backbone].a;
+    const int64_t HW = (int64_t)s->h * s->w, M = (int64_t)B * HW;
+    RUN(launch_global_mean(feat, B, HW, lp.d.cin, s->pooled, s->scratch, st));
+    {
+        PwArgs a = pw_args(s->pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, lp.z, lp.d.cout);
+        RUN(launch_pointwise(a, st));
+        RUN(bn_train(s, lp, B, (double)global_B, update_ema, sc, nullptr, st));     // statistics over the batch only
+        PwArgs b = pw_args(lp.a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, s->img_bias, lc.d.cout);
+        RUN(launch_pointwise(b, st));
+    }
+    {
+        PwArgs a = pw_args(feat, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, la.z, la.d.cout);
+        RUN(launch_pointwise(a, st));
+        RUN(bn_train(s, la, M, (double)global_B * HW, update_ema, sc, nullptr, st));
+        PwArgs b = pw_args(la.a, M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout, lc.z, lc.d.cout);
+        b.img_bias = s->img_bias; b.rows_per_img = HW;
+        RUN(launch_pointwise(b, st));
+        RUN(bn_train(s, lc, M, (double)global_B * HW, update_ema, sc, nullptr, st));
+        PwArgs d = pw_args(lc.a, M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits, 32);
+        d.shift = P + ll.d.gamma_off;
+        RUN(launch_pointwise(d, st));
+    }
+    return AMS_OK;
+}
+
+// =======================================================================================================
+// backward + update
+// =======================================================================================================
+// BN backward of layer l given da (gradient wrt the layer's activated output): writes dz into s->dz, dgamma/dbeta into grads
+static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_local, double n_global, const SyncCtx* sc,
+                       hipStream_t st) {
+    RUN(launch_bn_bwd_reduce(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch, st));
+    RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
+    RUN(launch_bn_bwd_coef(l.bsums, n_global, l.d.cout, s->params + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC,
+                           s->grads + l.d.gamma_off, s->grads + l.d.beta_off, st));
+    RUN(launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, s->dz, st));
+    return AMS_OK;
+}
+
+static int pw_wgrad(ams_student* s, const float* x, int ldx, int K, const float* dy, int ldy, int N, int64_t M, float* dw,
+                    hipStream_t st) {
+    WgArgs a;
+    a.x = x; a.ldx = ldx; a.K = K; a.dy = dy; a.ldy = ldy; a.N = N; a.M = M; a.dw = dw;
+    a.scratch = s->scratch; a.scratch_floats = s->scratch_floats;
+    return launch_pointwise_wgrad(a, st);
+}
+
+// dx[M,K] = dy[M,N] @ w[K,N]^T (+ extras through the epilogue)
+static PwArgs dgrad_args(const float* dy, int64_t M, int N, int ldy, const float* w, int K, float* dx) {
+    PwArgs a = pw_args(dy, M, N, ldy, w, K, dx, K);
+    a.w_sk = 1; a.w_sn = N;          // B operand (k' = n, n' = k) = w[k][n]
+    return a;
+}
+
+static int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teacher, int B, int global_B, const SyncCtx* sc,
+                    hipStream_t st) {
+    const ams_student_config& c = s->cfg;
+    const float* P = s->params;
+    float* G = s->grads;
+    LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];
+    const int64_t HW = (int64_t)s->h * s->w, M = (int64_t)B * HW;
+    const double nHW = (double)global_B * HW;
+    const int NC = c.num_classes;
+    // d loss / d logits (already divided by the global number of valid pixels)
+    RUN(launch_ce_grad(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher, NC, s->loss_buf,
+                       s->dlogits, 32, st));
+    // logits layer: bias, weights, input gradient
+    RUN(launch_colsum(s->dlogits, M, 32, 32, s->tmp_c, s->scratch, st));
+    RUN(launch_copy(G + ll.d.gamma_off, s->tmp_c, NC, st));
+    RUN(pw_wgrad(s, lc.a, lc.d.cout, lc.d.cout, s->dlogits, 32, NC, M, G + ll.d.w_off, st));
+    {
+        PwArgs a = dgrad_args(s->dlogits, M, 32, 32, P + ll.d.w_off, ll.d.cin, lc.da);
+        a.Kw = NC; a.w_sn = NC;        // w is [cin][NC]; dlogits columns >= NC are zero
+        RUN(launch_pointwise(a, st));
+    }
+    // concat_projection
+    RUN(bn_backward(s, lc, lc.da, M, nHW, sc, st));
+    const float* Wc_top = P + lc.d.w_off;
+    const float* Wc_bot = P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout;
+    RUN(pw_wgrad(s, la.a, la.d.cout, la.d.cout, s->dz, lc.d.cout, lc.d.cout, M, G + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, st));
+    {
+        PwArgs a = dgrad_args(s->dz, M, lc.d.cout, lc.d.cout, Wc_bot, la.d.cout, la.da);
+        RUN(launch_pointwise(a, st));
+    }
+    // pool branch: the per-image bias collects the column sums of dz_proj
+    RUN(launch_image_colsum(s->dz, B, HW, lc.d.cout, lc.d.cout, s->d_img_bias, s->scratch, st));
+    RUN(pw_wgrad(s, lp.a, lp.d.cout, lp.d.cout, s->d_img_bias, lc.d.cout, lc.d.cout, B, G + lc.d.w_off, st));
+    {
+        PwArgs a = dgrad_args(s->d_img_bias, B, lc.d.cout, lc.d.cout, Wc_top, lp.d.cout, s->d_pool_a);
+        RUN(launch_pointwise(a, st));
+    }
+    {   // BN (over the batch) + ReLU of the pool branch; its dz goes to d_pool_z instead of s->dz (still in use? no: consumed)
+        RUN(launch_bn_bwd_reduce(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.mean, lp.rstd, lp.bsums, s->scratch, st));
+        RUN(sync_doubles(sc, lp.bsums, 2 * (size_t)lp.d.cout, st));
+        RUN(launch_bn_bwd_coef(lp.bsums, (double)global_B, lp.d.cout, P + lp.d.gamma_off, lp.mean, lp.rstd, lp.cA, lp.cB, lp.cC,
+                               G + lp.d.gamma_off, G + lp.d.beta_off, st));
+        RUN(launch_bn_bwd_apply(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.cA, lp.cB, lp.cC, s->d_pool_z, st));
+        RUN(pw_wgrad(s, s->pooled, lp.d.cin, lp.d.cin, s->d_pool_z, lp.d.cout, lp.d.cout, B, G + lp.d.w_off, st));
+        PwArgs a = dgrad_args(s->d_pool_z, B, lp.d.cout, lp.d.cout, P + lp.d.w_off, lp.d.cin, s->d_pooled);
+        a.scale = s->tmp_c + 2048;      // d mean / d feat = 1/HW, applied as a uniform scale
+        RUN(launch_fill(s->tmp_c + 2048, lp.d.cin, (float)(1.0 / (double)HW), st));
+        a.shift = s->tmp_c + 3072;
+        RUN(launch_fill(s->tmp_c + 3072, lp.d.cin, 0.f, st));
+        RUN(launch_pointwise(a, st));
+    }
+    // aspp0: its input gradient also receives the pooled gradient, broadcast over the image
+    LayerRt& lf = s->L[s->n_backbone];
+    RUN(bn_backward(s, la, la.da, M, nHW, sc, st));
+    RUN(pw_wgrad(s, lf.a, la.d.cin, la.d.cin, s->dz, la.d.cout, la.d.cout, M, G + la.d.w_off, st));
+    {
+        PwArgs a = dgrad_args(s->dz, M, la.d.cout, la.d.cout, P + la.d.w_off, la.d.cin, lf.da);
+        a.img_bias = s->d_pooled; a.rows_per_img = HW;
+        RUN(launch_pointwise(a, st));
+    }
+    // backbone, last layer to first
+    for (int i = s->n_backbone; i >= 1; --i) {
+        LayerRt& l = s->L[i];
+        const int64_t Mo = (int64_t)B * l.px_out;
+        RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st));
+        if (l.d.role == AMS_ROLE_STEM) {
+            RUN(launch_stem_im2col(frames, dtype, B, c.height, c.width, c.pixel_scale, s->im2col, st));
+            RUN(pw_wgrad(s, s->im2col, 32, 27, s->dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, st));
+            break;
+        }
+        LayerRt& prev = s->L[i - 1];
+        if (l.d.role == AMS_ROLE_DEPTHWISE) {
+            RUN(launch_depthwise_wgrad(prev.a, s->dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off, s->scratch,
+                                       s->scratch_floats, st));
+            RUN(launch_depthwise_dgrad(s->dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
+        } else {
+            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, s->dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, st));
+            PwArgs a = dgrad_args(s->dz, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, prev.da);
+            // the block input also feeds the residual add at the end of this block: add that gradient here
+            if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) {
+                a.res = s->L[i + 2].da; a.ldr = l.d.cin;
+            }
+            RUN(launch_pointwise(a, st));
+        }
+    }
+    return AMS_OK;
+}
+
+static int loss_forward(ams_student* s, const uint8_t* teacher, int B, int32_t* labels, hipStream_t st) {
+    const ams_student_config& c = s->cfg;
+    return launch_upsample_argmax(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher,
+                                  c.num_classes, labels, s->conf_buf, s->loss_buf, st);
+}
+
+}  // namespace ams
+
+// =========================================================================================================
+// C ABI
+// =========================================================================================================
+extern "C" {
+
+const char* ams_last_error(void) { return ams::last_error(); }
+int ams_abi_version(void) { return AMS_ABI_VERSION; }
+
+int ams_device_info(char* name_out, size_t name_cap, int32_t* n_cu, int64_t* hbm_bytes) {
+    int dev = 0;
+    AMS_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    AMS_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    if (name_out && name_cap) { snprintf(name_out, name_cap, "%s (%s)", p.name, p.gcnArchName); }
+    if (n_cu) *n_cu = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return AMS_OK;
+}
+
+int ams_student_arena_bytes(const ams_student_config* cfg, const ams_layer_desc* layers, size_t* bytes_out) {
+    AMS_REQUIRE(bytes_out, "arena_bytes: null output");
+    ams_student tmp;
+    int rc = build(&tmp, cfg, layers);
+    if (rc) return rc;
+    return layout(&tmp, nullptr, bytes_out);
+}
+
+int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* layers, void* arena_dev, size_t arena_bytes,
+                       ams_student** out) {
+    AMS_REQUIRE(out && arena_dev, "create: null pointer");
+    AMS_REQUIRE(((uintptr_t)arena_dev & 255) == 0, "create: arena must be 256-byte aligned");
+    ams_student* s = new ams_student();
+    int rc = build(s, cfg, layers);
+    size_t need = 0;
+    if (!rc) rc = layout(s, arena_dev, &need);
+    if (!rc && need > arena_bytes) { set_error("create: arena too small (%zu < %zu)", arena_bytes, need); rc = AMS_E_NOMEM; }
+    if (rc) { delete s; return rc; }
+    s->arena = (char*)arena_dev;
+    s->arena_bytes = arena_bytes;
+    *out = s;
+    return AMS_OK;
+}
+
+void ams_student_destroy(ams_student* s) { delete s; }
+
+int ams_student_region(const ams_student* s, int32_t region, size_t* offset_bytes, size_t* n_elems) {
+    AMS_REQUIRE(s && offset_bytes && n_elems, "region: null pointer");
+    const void* p = nullptr;
+    size_t n = 0;
+    switch (region) {
+        case AMS_REGION_PARAMS: p = s->params; n = s->cfg.n_trainable; break;
+        case AMS_REGION_STATS: p = s->stats; n = s->cfg.n_stats; break;
+        case AMS_REGION_GRADS: p = s->grads; n = s->cfg.n_trainable; break;
+        case AMS_REGION_ADAM_M: p = s->adam_m; n = s->cfg.n_trainable; break;
+        case AMS_REGION_ADAM_V: p = s->adam_v; n = s->cfg.n_trainable; break;
+        case AMS_REGION_FROZEN: p = s->fparams; n = s->cfg.n_trainable; break;
+        case AMS_REGION_BN_SYNC: p = s->bn_sync; n = s->bn_sync_doubles; break;
+        case AMS_REGION_LOGITS: p = s->logits; n = (size_t)s->cfg.max_batch * s->h * s->w * 32; break;
+        default: set_error("region: unknown region %d", region); return AMS_E_INVALID;
+    }
+    if (!p) { set_error("region %d is not allocated for this student (trainable=%d)", region, s->cfg.trainable); return AMS_E_STATE; }
+    *offset_bytes = (size_t)((const char*)p - s->arena);
+    *n_elems = n;
+    return AMS_OK;
+}
+
+int ams_student_lowres_size(const ams_student* s, int32_t* h, int32_t* w) {
+    AMS_REQUIRE(s && h && w, "lowres_size: null pointer");
+    *h = s->h; *w = s->w;
+    return AMS_OK;
+}
+
+int ams_student_freeze(ams_student* s, void* stream) {
+    AMS_REQUIRE(s, "freeze: null student");
+    hipStream_t st = (hipStream_t)stream;
+    RUN(launch_copy(s->fparams, s->params, s->cfg.n_trainable, st));
+    RUN(launch_copy(s->fstats, s->stats, s->cfg.n_stats, st));
+    for (int i = 1; i <= s->cfg.n_layers; ++i) {
+        LayerRt& l = s->L[i];
+        if (l.d.bn_eps < 0) continue;
+        RUN(launch_bn_fold(s->fparams + l.d.gamma_off, s->fparams + l.d.beta_off, s->fstats + l.d.mean_off, s->fstats + l.d.var_off,
+                           s->cfg.bn_eps_frozen, l.d.cout, l.fscale, l.fshift, st));
+    }
+    s->frozen_ready = true;
+    return AMS_OK;
+}
+
+static int check_call(const ams_student* s, const void* frames, int dtype, int batch) {
+    AMS_REQUIRE(s && frames, "null student or frames");
+    AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "frames must be uint8 or float32");
+    AMS_REQUIRE(batch > 0 && batch <= s->cfg.max_batch, "batch %d outside 1..%d", batch, s->cfg.max_batch);
+    return AMS_OK;
+}
+
+static int run_forward(ams_student* s, const void* frames, int dtype, int batch, int mode, hipStream_t st) {
+    if (mode == AMS_MODE_FROZEN) {
+        if (!s->frozen_ready) { set_error("predict: ams_student_freeze has not been called"); return AMS_E_STATE; }
+        return forward_frozen(s, frames, dtype, batch, st);
+    }
+    if (mode == AMS_MODE_LIVE) return forward_live(s, frames, dtype, batch, batch, /*update_ema=*/false, nullptr, st);
+    set_error("predict: unknown mode %d", mode);
+    return AMS_E_INVALID;
+}
+
+int ams_student_predict(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch, int32_t mode,
+                        int32_t* labels_out_dev, void* stream) {
+    RUN(check_call(s, frames_dev, frames_dtype, batch));
+    AMS_REQUIRE(labels_out_dev, "predict: null output");
+    hipStream_t st = (hipStream_t)stream;
+    RUN(run_forward(s, frames_dev, frames_dtype, batch, mode, st));
+    const ams_student_config& c = s->cfg;
+    return launch_upsample_argmax(s->logits, 32, batch, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, nullptr,
+                                  c.num_classes, labels_out_dev, nullptr, nullptr, st);
+}
+
+int ams_student_predict_with_metric(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch, int32_t mode,
+                                    const uint8_t* teacher_dev, int32_t* labels_out_dev, int64_t* conf_mat_dev, double* loss_dev,
+                                    void* stream) {
+    RUN(check_call(s, frames_dev, frames_dtype, batch));
+    AMS_REQUIRE(teacher_dev && labels_out_dev && conf_mat_dev && loss_dev, "predict_with_metric: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    RUN(run_forward(s, frames_dev, frames_dtype, batch, mode, st));
+    const ams_student_config& c = s->cfg;
+    return launch_upsample_argmax(s->logits, 32, batch, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher_dev,
+                                  c.num_classes, labels_out_dev, conf_mat_dev, loss_dev, st);
+}
+
+int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t n_pixels, int64_t* conf_mat_dev, void* stream) {
+    AMS_REQUIRE(s && labels_dev && conf_mat_dev && n_pixels > 0, "cross_confusion: bad argument");
+    int32_t lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = -1;
+    for (int k = 0; k < s->cfg.n_selected; ++k) lut[s->cfg.class_indices[k]] = k;
+    return launch_cross_confusion(labels_dev, labels_dev + n_pixels, n_pixels, lut, s->cfg.n_selected, conf_mat_dev,
+                                  (hipStream_t)stream);
+}
+
+int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
+                              int32_t batch, int32_t global_batch, float lr, const uint8_t* mask_dev, double* loss_dev,
+                              ams_allreduce_cb cb, void* user, void* stream) {
+    RUN(check_call(s, frames_dev, frames_dtype, batch));
+    AMS_REQUIRE(teacher_dev, "train_step: null teacher labels");
+    if (!s->cfg.trainable) { set_error("train_step: this student was created frozen (trainable=0)"); return AMS_E_STATE; }
+    AMS_REQUIRE(global_batch >= batch, "train_step: global batch %d < local batch %d", global_batch, batch);
+    hipStream_t st = (hipStream_t)stream;
+    SyncCtx sc{cb, user, s};
+    const SyncCtx* psc = cb ? &sc : nullptr;
+    RUN(forward_live(s, frames_dev, frames_dtype, batch, global_batch, /*update_ema=*/true, psc, st));
+    RUN(loss_forward(s, teacher_dev, batch, nullptr, st));
+    RUN(sync_doubles(psc, s->loss_buf, 2, st));         // loss sum and valid-pixel count over all ranks
+    RUN(backward(s, frames_dev, frames_dtype, teacher_dev, batch, global_batch, psc, st));
+    if (cb) {
+        const int rc = cb(user, (size_t)((char*)s->grads - s->arena), (size_t)s->cfg.n_trainable, AMS_DT_F32);
+        if (rc) { set_error("gradient all-reduce callback failed (%d)", rc); return AMS_E_STATE; }
+    }
+    if (loss_dev) AMS_CHECK_HIP(hipMemcpyAsync(loss_dev, s->loss_buf, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    // Adam, TF1 form; the step counter is never reset (SemanticNetwork.py:25, :154-156)
+    s->adam_t += 1;
+    const double b1 = 0.9, b2 = 0.999;
+    const double lr_t = (double)lr * sqrt(1.0 - pow(b2, (double)s->adam_t)) / (1.0 - pow(b1, (double)s->adam_t));
+    return launch_adam(s->params, s->grads, s->adam_m, s->adam_v, mask_dev, s->cfg.n_trainable, (float)lr_t, 0.9f, 0.999f, 1e-8f, st);
+}
+
+int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev, int32_t batch,
+                           float lr, const uint8_t* mask_dev, double* loss_dev, void* stream) {
+    return ams_student_train_step_dp(s, frames_dev, frames_dtype, teacher_dev, batch, batch, lr, mask_dev, loss_dev, nullptr, nullptr,
+                                     stream);
+}
+
+int ams_student_get_adam_step(const ams_student* s, int64_t* t) {
+    AMS_REQUIRE(s && t, "get_adam_step: null pointer");
+    *t = s->adam_t;
+    return AMS_OK;
+}
+int ams_student_set_adam_step(ams_student* s, int64_t t) {
+    AMS_REQUIRE(s && t >= 0, "set_adam_step: bad argument");
+    s->adam_t = t;
+    return AMS_OK;
+}
+
+int ams_pack_masked_fp16(const float* params_dev, const uint8_t* mask_dev, int64_t n, uint16_t* out_half_dev, int64_t* n_out_dev,
+                         void* stream) {
+    AMS_REQUIRE(params_dev && out_half_dev && n_out_dev && n > 0, "pack_masked_fp16: bad argument");
+    return launch_pack_fp16(params_dev, mask_dev, n, out_half_dev, n_out_dev, (hipStream_t)stream);
+}
+
+// ---- kernel-level entry points -----------------------------------------------------------------------------
+int ams_k_stem_conv(const void* frames, int32_t frames_dtype, int32_t B, int32_t H, int32_t W, const float* w, int32_t cout,
+                    const float* scale, const float* shift, int32_t act, float pixel_scale, float* y, void* stream) {
+    return launch_stem(frames, frames_dtype, B, H, W, w, cout, scale, shift, act, pixel_scale, y, (hipStream_t)stream);
+}
+
+int ams_k_depthwise3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t stride, int32_t rate,
+                       const float* scale, const float* shift, int32_t act, float* y, void* stream) {
+    return launch_depthwise(x, B, H, W, C, w, stride, rate, scale, shift, act, y, (hipStream_t)stream);
+}
+
+int ams_k_pointwise(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w, const float* img_bias,
+                    int64_t rows_per_img, const float* scale, const float* shift, int32_t act, const float* res, float* y,
+                    void* stream) {
+    PwArgs a = pw_args(x, M, K, K, w, N, y, N);
+    if (trans_w) { a.w_sk = 1; a.w_sn = K; }
+    a.img_bias = img_bias; a.rows_per_img = rows_per_img > 0 ? rows_per_img : 1;
+    a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
+    if (scale && !shift) { set_error("pointwise: scale without shift"); return AMS_E_INVALID; }
+    return launch_pointwise(a, (hipStream_t)stream);
+}
+
+int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,
+                      void* stream) {
+    AMS_REQUIRE(scratch && scratch_floats >= image_colsum_scratch(B, C), "global_mean: scratch too small (need %zu floats)",
+                image_colsum_scratch(B, C));
+    return launch_global_mean(x, B, HW, C, y, scratch, (hipStream_t)stream);
+}
+size_t ams_k_global_mean_scratch(int32_t B, int32_t C) { return image_colsum_scratch(B, C); }
+
+int ams_k_upsample_argmax(const float* logits, int32_t B, int32_t h, int32_t w, int32_t NC, const int32_t* class_idx_host, int32_t K,
+                          int32_t H, int32_t W, const uint8_t* teacher, int32_t* labels_out, int64_t* conf_mat, double* loss,
+                          void* stream) {
+    return launch_upsample_argmax(logits, NC, B, h, w, class_idx_host, K, H, W, teacher, NC, labels_out, conf_mat, loss,
+                                  (hipStream_t)stream);
+}
+
+int ams_k_ce_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t NC, const int32_t* class_idx_host, int32_t K, int32_t H,
+                  int32_t W, const uint8_t* teacher, const double* loss_and_count_dev, float* dlogits, void* stream) {
+    return launch_ce_grad(logits, NC, B, h, w, class_idx_host, K, H, W, teacher, NC, loss_and_count_dev, dlogits, NC,
+                          (hipStream_t)stream);
+}
+
+size_t ams_k_pointwise_wgrad_scratch(int64_t M, int32_t K, int32_t N) { return pointwise_wgrad_scratch(M, K, N); }
+
+int ams_k_pointwise_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw, float* scratch,
+                          size_t scratch_floats, void* stream) {
+    WgArgs a;
+    a.x = x; a.ldx = K; a.K = K; a.dy = dy; a.ldy = N; a.N = N; a.M = M; a.dw = dw; a.scratch = scratch; a.scratch_floats = scratch_floats;
+    return launch_pointwise_wgrad(a, (hipStream_t)stream);
+}
+
+int ams_k_depthwise3x3_dgrad(const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t stride, int32_t rate,
+                             float* dx, void* stream) {
+    return launch_depthwise_dgrad(dy, B, H, W, C, w, stride, rate, dx, (hipStream_t)stream);
+}
+
+int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t rate,
+                             float* dw, float* scratch, size_t scratch_floats, void* stream) {
+    return launch_depthwise_wgrad(x, dy, B, H, W, C, stride, rate, dw, scratch, scratch_floats, (hipStream_t)stream);
+}
+
+int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t, float beta1,
+               float beta2, float eps, void* stream) {
+    return launch_adam(params, grads, m, v, mask, n, lr_t, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,381 @@
+// Stem (dense 3x3 stride 2 on the raw frame) and depthwise 3x3 kernels of the AMS student, NHWC, gfx950.
+//
+// These layers have 3.6-9 FLOP per activation element moved: pure HBM streaming.  Lanes run along the channel
+// axis first (float4 = 4 channels per lane), then along x, so a wave's 64 lanes read/write 1 KiB of contiguous
+// NHWC memory per instruction; the 3x3 halo re-reads are served by L1/L2, and xcd_remap() keeps spatially
+// adjacent blocks on one XCD so the halo lines are fetched from HBM once.
+#include "kernels.hpp"
+
+namespace ams {
+
+// ---------------------------------------------------------------------------------------------------------
+// K1+K2  frame -> pad one row/col of 127.5 (nodes concat, concat_1) -> x*(1/127.5) - 1 (mul_4, sub_2)
+//        -> Conv2D 3x3 stride 2 SAME (MobilenetV2/Conv) -> scale/shift (folded BN) -> act
+// thread = (output pixel, group of 8 output channels)
+// ---------------------------------------------------------------------------------------------------------
+template <typename TIn>
+__device__ __forceinline__ float load_px(const TIn* p) { return (float)(*p); }
+
+template <typename TIn>
+__device__ __forceinline__ float norm_frame_value(const TIn* img, int H, int W, int iy, int ix, int ch, float ps) {
+    // coordinates are in the 127.5-padded (H+1)x(W+1) image; outside of it: SAME zero padding
+    if (iy < 0 || ix < 0 || iy > H || ix > W) return 0.f;
+    float raw = (iy == H || ix == W) ? 127.5f : load_px(img + ((int64_t)iy * W + ix) * 3 + ch);
+    return __fsub_rn(__fmul_rn(raw, ps), 1.0f);      // two roundings like the graph's Mul then Sub (no FMA contraction)
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const TIn* __restrict__ frames, int B, int H, int W,
+                                                        const float* __restrict__ wgt, int cout,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        int act, float ps, float* __restrict__ y, int Ho, int Wo, int pt,
+                                                        int pl) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];   // [27][cout]
+    for (int e = threadIdx.x; e < 27 * cout; e += blockDim.x) sw[e] = wgt[e];
+    __syncthreads();
+    const int groups = cout >> 3;
+    const int64_t total = (int64_t)B * Ho * Wo * groups;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        int64_t p = t / groups;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const TIn* img = frames + (int64_t)b * H * W * 3;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = oy * 2 - pt + i;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ix = ox * 2 - pl + j;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float v = norm_frame_value(img, H, W, iy, ix, ch, ps);
+                    const float* wr = sw + ((i * 3 + j) * 3 + ch) * cout + g * 8;
+                    const float4 w0 = ld4(wr), w1 = ld4(wr + 4);
+                    acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]);
+                    acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+                    acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]);
+                    acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+                }
+            }
+        }
+        float* out = y + t * 8;
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = acc[c];
+            if (scale) v = v * scale[g * 8 + c] + shift[g * 8 + c];
+            o[c] = apply_act(v, act);
+        }
+        st4(out, make_float4(o[0], o[1], o[2], o[3]));
+        st4(out + 4, make_float4(o[4], o[5], o[6], o[7]));
+    }
+}
+
+int launch_stem(const void* frames, int dtype, int B, int H, int W, const float* w, int cout, const float* scale,
+                const float* shift, int act, float pixel_scale, float* y, hipStream_t st) {
+    AMS_REQUIRE(cout % 8 == 0 && cout <= 256, "stem: cout %d must be a multiple of 8", cout);
+    AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "stem: frames must be uint8 or float32");
+    AMS_REQUIRE((scale == nullptr) == (shift == nullptr), "stem: scale and shift come together");
+    int Ho, Wo, pt, pl;
+    same_pad(H + 1, 3, 2, 1, &Ho, &pt);
+    same_pad(W + 1, 3, 2, 1, &Wo, &pl);
+    const int64_t total = (int64_t)B * Ho * Wo * (cout / 8);
+    const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+    const size_t lds = 27 * cout * sizeof(float);
+    if (dtype == AMS_DT_U8)
+        hipLaunchKernelGGL(stem_conv_kernel<uint8_t>, dim3(grid), dim3(256), lds, st, (const uint8_t*)frames, B, H, W, w, cout,
+                           scale, shift, act, pixel_scale, y, Ho, Wo, pt, pl);
+    else
+        hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)frames, B, H, W, w, cout,
+                           scale, shift, act, pixel_scale, y, Ho, Wo, pt, pl);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// im2col of the stem's receptive fields, [B*Ho*Wo, 32] (27 taps in (i,j,ch) order + 5 zero columns): the stem's
+// weight gradient then is the generic x^T @ dy GEMM.  thread = (pixel, 4 columns)
+template <typename TIn>
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const TIn* __restrict__ frames, int B, int H, int W, float ps,
+                                                          float* __restrict__ out, int Ho, int Wo, int pt, int pl) {
+    const int64_t total = (int64_t)B * Ho * Wo * 8;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t & 7);
+        int64_t p = t >> 3;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const TIn* img = frames + (int64_t)b * H * W * 3;
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = g * 4 + c;
+            float v = 0.f;
+            if (col < 27) {
+                const int tap = col / 3, ch = col % 3;
+                v = norm_frame_value(img, H, W, oy * 2 - pt + tap / 3, ox * 2 - pl + tap % 3, ch, ps);
+            }
+            o[c] = v;
+        }
+        st4(out + t * 4, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+int launch_stem_im2col(const void* frames, int dtype, int B, int H, int W, float pixel_scale, float* out, hipStream_t st) {
+    AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "stem_im2col: frames must be uint8 or float32");
+    int Ho, Wo, pt, pl;
+    same_pad(H + 1, 3, 2, 1, &Ho, &pt);
+    same_pad(W + 1, 3, 2, 1, &Wo, &pl);
+    const int64_t total = (int64_t)B * Ho * Wo * 8;
+    const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+    if (dtype == AMS_DT_U8)
+        hipLaunchKernelGGL(stem_im2col_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, (const uint8_t*)frames, B, H, W,
+                           pixel_scale, out, Ho, Wo, pt, pl);
+    else
+        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)frames, B, H, W,
+                           pixel_scale, out, Ho, Wo, pt, pl);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3  depthwise 3x3, stride S in {1,2}, rate R in {1,2} (rate 2 == the graph's SpaceToBatchND / VALID /
+//     BatchToSpaceND sandwich), SAME padding, fused scale/shift + activation.
+// block = CG x SLOTS threads: CG = C/4 channel groups (lanes first), SLOTS adjacent output columns;
+// each thread produces TH consecutive output rows for its (column, channel group).
+// ---------------------------------------------------------------------------------------------------------
+struct DwGeom {
+    int B, H, W, C, Ho, Wo, pt, pl, CG, slots, TH, tiles_x, tiles_y;
+};
+
+static int dw_geom(int B, int H, int W, int C, int stride, int rate, bool over_input, DwGeom* g) {
+    AMS_REQUIRE(C % 4 == 0 && C / 4 <= 256, "depthwise: C=%d must be a multiple of 4 and <= 1024", C);
+    AMS_REQUIRE((stride == 1 || stride == 2) && (rate == 1 || rate == 2) && !(stride == 2 && rate == 2),
+                "depthwise: unsupported stride %d / rate %d", stride, rate);
+    g->B = B; g->H = H; g->W = W; g->C = C;
+    same_pad(H, 3, stride, rate, &g->Ho, &g->pt);
+    same_pad(W, 3, stride, rate, &g->Wo, &g->pl);
+    g->CG = C / 4;
+    g->slots = 256 / g->CG < 1 ? 1 : 256 / g->CG;
+    g->TH = 4;
+    const int rows = over_input ? H : g->Ho, cols = over_input ? W : g->Wo;
+    g->tiles_x = cdiv(cols, g->slots);
+    g->tiles_y = cdiv(rows, g->TH);
+    return AMS_OK;
+}
+
+template <int S, int R>
+__global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        int act, float* __restrict__ y, DwGeom g, unsigned nblocks) {
+    const unsigned lb = xcd_remap(blockIdx.x, nblocks);
+    const int tx = lb % g.tiles_x;
+    const int ty = (lb / g.tiles_x) % g.tiles_y;
+    const int b = lb / (g.tiles_x * g.tiles_y);
+    const int cg = threadIdx.x % g.CG, slot = threadIdx.x / g.CG;
+    const int ox = tx * g.slots + slot;
+    if (slot >= g.slots || ox >= g.Wo) return;
+    const int c0 = cg * 4;
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + k * g.C + c0);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) { sc = ld4(scale + c0); sh = ld4(shift + c0); }
+    const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
+    float* yb = y + (int64_t)b * g.Ho * g.Wo * g.C + c0;
+    const int oy0 = ty * g.TH;
+#pragma unroll 1
+    for (int r = 0; r < g.TH; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= g.Ho) break;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = oy * S - g.pt + i * R;
+            if (iy < 0 || iy >= g.H) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ix = ox * S - g.pl + j * R;
+                if (ix < 0 || ix >= g.W) continue;
+                const float4 v = ld4(xb + ((int64_t)iy * g.W + ix) * g.C);
+                const float4 w4 = wv[i * 3 + j];
+                acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
+                acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
+            }
+        }
+        float4 o;
+        o.x = apply_act(acc.x * sc.x + sh.x, act); o.y = apply_act(acc.y * sc.y + sh.y, act);
+        o.z = apply_act(acc.z * sc.z + sh.z, act); o.w = apply_act(acc.w * sc.w + sh.w, act);
+        st4(yb + ((int64_t)oy * g.Wo + ox) * g.C, o);
+    }
+}
+
+int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w, int stride, int rate,
+                     const float* scale, const float* shift, int act, float* y, hipStream_t st) {
+    DwGeom g;
+    int rc = dw_geom(B, H, W, C, stride, rate, false, &g);
+    if (rc) return rc;
+    AMS_REQUIRE((scale == nullptr) == (shift == nullptr), "depthwise: scale and shift come together");
+    const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
+    const int threads = g.CG * g.slots;
+    if (stride == 1 && rate == 1)
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 1>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
+    else if (stride == 2)
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<2, 1>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
+    else
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 2>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// input gradient: dx[iy,ix,c] = sum_{i,j} dy[oy,ox,c] * w[i,j,c]  with  oy*S - pt + i*R == iy  (same for x)
+template <int S, int R>
+__global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wgt,
+                                                          float* __restrict__ dx, DwGeom g, unsigned nblocks) {
+    const unsigned lb = xcd_remap(blockIdx.x, nblocks);
+    const int tx = lb % g.tiles_x;
+    const int ty = (lb / g.tiles_x) % g.tiles_y;
+    const int b = lb / (g.tiles_x * g.tiles_y);
+    const int cg = threadIdx.x % g.CG, slot = threadIdx.x / g.CG;
+    const int ix = tx * g.slots + slot;
+    if (slot >= g.slots || ix >= g.W) return;
+    const int c0 = cg * 4;
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + k * g.C + c0);
+    const float* dyb = dy + (int64_t)b * g.Ho * g.Wo * g.C + c0;
+    float* dxb = dx + (int64_t)b * g.H * g.W * g.C + c0;
+#pragma unroll 1
+    for (int r = 0; r < g.TH; ++r) {
+        const int iy = ty * g.TH + r;
+        if (iy >= g.H) break;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ny = iy + g.pt - i * R;
+            if (ny < 0 || (S == 2 && (ny & 1))) continue;
+            const int oy = ny / S;
+            if (oy >= g.Ho) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int nx = ix + g.pl - j * R;
+                if (nx < 0 || (S == 2 && (nx & 1))) continue;
+                const int ox = nx / S;
+                if (ox >= g.Wo) continue;
+                const float4 v = ld4(dyb + ((int64_t)oy * g.Wo + ox) * g.C);
+                const float4 w4 = wv[i * 3 + j];
+                acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
+                acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
+            }
+        }
+        st4(dxb + ((int64_t)iy * g.W + ix) * g.C, acc);
+    }
+}
+
+int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const float* w, int stride, int rate,
+                           float* dx, hipStream_t st) {
+    DwGeom g;
+    int rc = dw_geom(B, H, W, C, stride, rate, true, &g);
+    if (rc) return rc;
+    const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
+    const int threads = g.CG * g.slots;
+    if (stride == 1 && rate == 1)
+        hipLaunchKernelGGL((dw3x3_dgrad_kernel<1, 1>), dim3(nblocks), dim3(threads), 0, st, dy, w, dx, g, nblocks);
+    else if (stride == 2)
+        hipLaunchKernelGGL((dw3x3_dgrad_kernel<2, 1>), dim3(nblocks), dim3(threads), 0, st, dy, w, dx, g, nblocks);
+    else
+        hipLaunchKernelGGL((dw3x3_dgrad_kernel<1, 2>), dim3(nblocks), dim3(threads), 0, st, dy, w, dx, g, nblocks);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// weight gradient: dw[i,j,c] = sum_{b,oy,ox} x[b, oy*S-pt+i*R, ox*S-pl+j*R, c] * dy[b,oy,ox,c]
+// each block owns a contiguous chunk of output pixels; per-thread 9 x float4 accumulators; the block's column
+// slots are reduced through LDS in fixed order and the chunk partials by launch_reduce_splits (deterministic).
+template <int S, int R>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ part, DwGeom g, int64_t px_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];   // [slots][9][C]
+    const int cg = threadIdx.x % g.CG, slot = threadIdx.x / g.CG;
+    const int c0 = cg * 4;
+    float4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t total = (int64_t)g.B * g.Ho * g.Wo;
+    const int64_t p_begin = blockIdx.x * px_per_block;
+    int64_t p_end = p_begin + px_per_block;
+    if (p_end > total) p_end = total;
+    if (slot < g.slots) {
+        for (int64_t p = p_begin + slot; p < p_end; p += g.slots) {
+            const int ox = (int)(p % g.Wo);
+            const int oy = (int)((p / g.Wo) % g.Ho);
+            const int b = (int)(p / ((int64_t)g.Wo * g.Ho));
+            const float4 d = ld4(dy + p * g.C + c0);
+            const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int iy = oy * S - g.pt + i * R;
+                if (iy < 0 || iy >= g.H) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ix = ox * S - g.pl + j * R;
+                    if (ix < 0 || ix >= g.W) continue;
+                    const float4 v = ld4(xb + ((int64_t)iy * g.W + ix) * g.C);
+                    float4& a = acc[i * 3 + j];
+                    a.x = fmaf(v.x, d.x, a.x); a.y = fmaf(v.y, d.y, a.y);
+                    a.z = fmaf(v.z, d.z, a.z); a.w = fmaf(v.w, d.w, a.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) st4(sred + ((int64_t)slot * 9 + k) * g.C + c0, acc[k]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * g.C; e += blockDim.x) {
+        float s = 0.f;
+        for (int sl = 0; sl < g.slots; ++sl) s += sred[(int64_t)sl * 9 * g.C + e];
+        part[(int64_t)blockIdx.x * 9 * g.C + e] = s;
+    }
+}
+
+static int dw_wgrad_blocks(int64_t total_px) {
+    int64_t blocks = cdiv64(total_px, 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate) {
+    int Ho, Wo, p;
+    same_pad(H, 3, stride, rate, &Ho, &p);
+    same_pad(W, 3, stride, rate, &Wo, &p);
+    return (size_t)dw_wgrad_blocks((int64_t)B * Ho * Wo) * 9 * C;
+}
+
+int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
+                           float* dw, float* scratch, size_t scratch_floats, hipStream_t st) {
+    DwGeom g;
+    int rc = dw_geom(B, H, W, C, stride, rate, false, &g);
+    if (rc) return rc;
+    const int64_t total = (int64_t)B * g.Ho * g.Wo;
+    const int blocks = dw_wgrad_blocks(total);
+    AMS_REQUIRE(scratch_floats >= (size_t)blocks * 9 * C, "depthwise wgrad: scratch too small");
+    const int64_t ppb = cdiv64(total, blocks);
+    const int threads = g.CG * g.slots;
+    const size_t lds = (size_t)g.slots * 9 * C * sizeof(float);
+    AMS_REQUIRE(lds <= 64 * 1024, "depthwise wgrad: LDS %zu too large", lds);
+    if (stride == 1 && rate == 1)
+        hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, 1>), dim3(blocks), dim3(threads), lds, st, x, dy, scratch, g, ppb);
+    else if (stride == 2)
+        hipLaunchKernelGGL((dw3x3_wgrad_kernel<2, 1>), dim3(blocks), dim3(threads), lds, st, x, dy, scratch, g, ppb);
+    else
+        hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, 2>), dim3(blocks), dim3(threads), lds, st, x, dy, scratch, g, ppb);
+    AMS_CHECK_LAUNCH();
+    return launch_reduce_splits(scratch, blocks, (int64_t)9 * C, dw, st);
+}
+
+}  // namespace ams

@@ -1,0 +1,418 @@
+// BatchNorm pieces (training-mode statistics, coefficient folding, backward), pooling, column reductions and
+// the fused Adam update.  All HBM-bound streaming kernels: float4 per lane, lanes along channels first so a
+// wave touches 1 KiB of contiguous NHWC memory per instruction.  Every reduction is two-stage with a fixed
+// summation order (block partials -> f64 finalize), so results are run-to-run deterministic.
+#include <hip/hip_fp16.h>
+
+#include "kernels.hpp"
+
+namespace ams {
+
+// ---------------------------------------------------------------------------------------------------------
+// generic column reduction over rows of a [groups*rows, C] tensor: NQ quantities per element, float4 lanes.
+// grid = (chunks, groups); block = CG x slots threads.  part[(group*chunks + chunk)][NQ][C]
+// ---------------------------------------------------------------------------------------------------------
+struct ColGeom {
+    int C, CG, slots, chunks, groups;
+    int64_t rows_per_group, rows_per_chunk;
+    int ldx;
+};
+
+static ColGeom col_geom(int64_t rows_per_group, int groups, int C, int ldx, int max_chunks) {
+    ColGeom g;
+    g.C = C; g.CG = C / 4; g.ldx = ldx; g.groups = groups; g.rows_per_group = rows_per_group;
+    g.slots = 256 / g.CG < 1 ? 1 : 256 / g.CG;
+    int64_t chunks = cdiv64(rows_per_group, (int64_t)g.slots * 8);      // >= 8 rows per thread
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    g.chunks = (int)chunks;
+    g.rows_per_chunk = cdiv64(rows_per_group, chunks);
+    return g;
+}
+
+struct OpStats {          // q0 = z - center, q1 = (z - center)^2
+    const float* z; const float* center;
+    __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
+        const float4 v = ld4(z + row * ld + c0);
+        const float4 c = center ? ld4(center + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        q0 = make_float4(v.x - c.x, v.y - c.y, v.z - c.z, v.w - c.w);
+        q1 = make_float4(q0.x * q0.x, q0.y * q0.y, q0.z * q0.z, q0.w * q0.w);
+    }
+};
+
+__device__ __forceinline__ float act_grad_mask(float y, int act) {
+    if (act == AMS_ACT_RELU6) return (y > 0.f && y < 6.f) ? 1.f : 0.f;     // Relu6Grad: 0 < features < 6
+    if (act == AMS_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+struct OpBnBwd {          // q0 = dy, q1 = dy * xhat ; dy = da * act'(z*scale+shift), xhat = (z-mean)*rstd
+    const float* da; const float* z; const float* scale; const float* shift; const float* mean; const float* rstd; int act;
+    __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
+        const float4 g = ld4(da + row * ld + c0), v = ld4(z + row * ld + c0);
+        const float4 sc = ld4(scale + c0), sh = ld4(shift + c0), mu = ld4(mean + c0), rs = ld4(rstd + c0);
+        q0.x = g.x * act_grad_mask(v.x * sc.x + sh.x, act); q0.y = g.y * act_grad_mask(v.y * sc.y + sh.y, act);
+        q0.z = g.z * act_grad_mask(v.z * sc.z + sh.z, act); q0.w = g.w * act_grad_mask(v.w * sc.w + sh.w, act);
+        q1.x = q0.x * (v.x - mu.x) * rs.x; q1.y = q0.y * (v.y - mu.y) * rs.y;
+        q1.z = q0.z * (v.z - mu.z) * rs.z; q1.w = q0.w * (v.w - mu.w) * rs.w;
+    }
+};
+
+struct OpSum {            // q0 = x
+    const float* x;
+    __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
+        q0 = ld4(x + row * ld + c0);
+        q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+
+template <int NQ, class Op>
+__global__ __launch_bounds__(256) void col_reduce_kernel(Op op, ColGeom g, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sred[];       // [slots][NQ][C]
+    const int cg = threadIdx.x % g.CG, slot = threadIdx.x / g.CG;
+    const int c0 = cg * 4;
+    const int chunk = blockIdx.x, group = blockIdx.y;
+    const int64_t r_begin = (int64_t)chunk * g.rows_per_chunk;
+    int64_t r_end = r_begin + g.rows_per_chunk;
+    if (r_end > g.rows_per_group) r_end = g.rows_per_group;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (slot < g.slots) {
+        const int64_t base = (int64_t)group * g.rows_per_group;
+        for (int64_t r = r_begin + slot; r < r_end; r += g.slots) {
+            float4 q0, q1;
+            op(base + r, c0, g.ldx, q0, q1);
+            a0.x += q0.x; a0.y += q0.y; a0.z += q0.z; a0.w += q0.w;
+            if (NQ > 1) { a1.x += q1.x; a1.y += q1.y; a1.z += q1.z; a1.w += q1.w; }
+        }
+        st4(sred + ((int64_t)slot * NQ + 0) * g.C + c0, a0);
+        if (NQ > 1) st4(sred + ((int64_t)slot * NQ + 1) * g.C + c0, a1);
+    }
+    __syncthreads();
+    float* out = part + ((int64_t)group * g.chunks + chunk) * NQ * g.C;
+    for (int e = threadIdx.x; e < NQ * g.C; e += blockDim.x) {
+        float s = 0.f;
+        for (int sl = 0; sl < g.slots; ++sl) s += sred[(int64_t)sl * NQ * g.C + e];
+        out[e] = s;
+    }
+}
+
+// second stage: out[group][q][c] = alpha * sum_chunk part[group][chunk][q][c]   (f64 accumulation, ascending chunk order)
+template <typename TOut>
+__global__ void col_finalize_kernel(const float* __restrict__ part, int chunks, int per_group /* NQ*C */, int groups,
+                                    double alpha, TOut* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_group * groups) return;
+    const int group = i / per_group, e = i % per_group;
+    const float* p = part + (int64_t)group * chunks * per_group + e;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = 0;
+    for (; k + 3 < chunks; k += 4) {
+        s0 += p[(int64_t)k * per_group]; s1 += p[(int64_t)(k + 1) * per_group];
+        s2 += p[(int64_t)(k + 2) * per_group]; s3 += p[(int64_t)(k + 3) * per_group];
+    }
+    for (; k < chunks; ++k) s0 += p[(int64_t)k * per_group];
+    out[i] = (TOut)(((s0 + s1) + (s2 + s3)) * alpha);
+}
+
+constexpr int kMaxChunks = 256;
+
+template <int NQ, class Op, typename TOut>
+static int run_col_reduce(Op op, int64_t rows_per_group, int groups, int C, int ldx, double alpha, float* scratch, TOut* out,
+                          hipStream_t st) {
+    AMS_REQUIRE(C % 4 == 0 && C / 4 <= 256 && ldx % 4 == 0, "column reduce: C=%d ld=%d must be multiples of 4 (C <= 1024)", C, ldx);
+    const ColGeom g = col_geom(rows_per_group, groups, C, ldx, kMaxChunks);
+    const size_t lds = (size_t)g.slots * NQ * C * sizeof(float);
+    hipLaunchKernelGGL((col_reduce_kernel<NQ, Op>), dim3(g.chunks, groups), dim3(g.CG * g.slots), lds, st, op, g, scratch);
+    AMS_CHECK_LAUNCH();
+    const int n = NQ * C * groups;
+    hipLaunchKernelGGL((col_finalize_kernel<TOut>), dim3(cdiv(n, 128)), dim3(128), 0, st, scratch, g.chunks, NQ * C, groups, alpha, out);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+size_t colstats_scratch(int64_t M, int C) { (void)M; return (size_t)kMaxChunks * 2 * C; }
+
+int launch_colstats(const float* z, int64_t M, int C, const float* center, double* sums, float* scratch, hipStream_t st) {
+    OpStats op{z, center};
+    return run_col_reduce<2, OpStats, double>(op, M, 1, C, C, 1.0, scratch, sums, st);
+}
+
+int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift,
+                         int act, const float* mean, const float* rstd, double* sums, float* scratch, hipStream_t st) {
+    OpBnBwd op{da, z, scale, shift, mean, rstd, act};
+    return run_col_reduce<2, OpBnBwd, double>(op, M, 1, C, C, 1.0, scratch, sums, st);
+}
+
+int launch_colsum(const float* x, int64_t M, int C, int ldx, float* out, float* scratch, hipStream_t st) {
+    OpSum op{x};
+    return run_col_reduce<1, OpSum, float>(op, M, 1, C, ldx, 1.0, scratch, out, st);
+}
+
+// per-image column sums (scratch: B * kMaxChunks * C floats); used for the global mean (alpha = 1/HW) and its gradient
+static int image_colsum_impl(const float* x, int B, int64_t HW, int C, int ldx, double alpha, float* out, float* scratch,
+                             hipStream_t st) {
+    OpSum op{x};
+    return run_col_reduce<1, OpSum, float>(op, HW, B, C, ldx, alpha, scratch, out, st);
+}
+
+size_t image_colsum_scratch(int B, int C) { return (size_t)B * kMaxChunks * C; }
+
+int launch_global_mean(const float* x, int B, int64_t HW, int C, float* y, float* scratch, hipStream_t st) {
+    return image_colsum_impl(x, B, HW, C, C, 1.0 / (double)HW, y, scratch, st);
+}
+
+int launch_image_colsum(const float* x, int B, int64_t HW, int C, int ldx, float* out, float* scratch, hipStream_t st) {
+    return image_colsum_impl(x, B, HW, C, ldx, 1.0, out, scratch, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BN coefficient kernels (per channel, tiny)
+// ---------------------------------------------------------------------------------------------------------
+// FusedBatchNormV3(is_training=True): normalise with the biased variance, feed the
+// UNBIASED one (var*n/max(n-1,1)) to AssignMovingAvg: moving -= (moving - stat) * (1 - decay), f32 arithmetic.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double n, int C, const float* __restrict__ center,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float one_minus_decay, float* moving_mean, float* moving_var, float* scale, float* shift,
+                                   float* save_mean, float* save_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double ctr = center ? (double)center[c] : 0.0;
+    const double d1 = sums[c] / n, d2 = sums[C + c] / n;
+    double var = d2 - d1 * d1;
+    if (var < 0) var = 0;
+    const float mean = (float)(ctr + d1);
+    const float varf = (float)var;
+    const float rstd = 1.0f / sqrtf(varf + eps);
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
+    if (moving_mean) {
+        const float unbiased = (float)(var * (n / (n > 1.5 ? n - 1.0 : 1.0)));
+        moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * one_minus_decay;
+        moving_var[c] = moving_var[c] - (moving_var[c] - unbiased) * one_minus_decay;
+    }
+}
+
+int launch_bn_finalize(const double* sums, double n, int C, const float* center, const float* gamma, const float* beta,
+                       float eps, float one_minus_decay, float* moving_mean, float* moving_var, float* scale,
+                       float* shift, float* save_mean, float* save_rstd, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums, n, C, center, gamma, beta, eps,
+                       one_minus_decay, moving_mean, moving_var, scale, shift, save_mean, save_rstd);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
+                               float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * (1.0f / sqrtf(var[c] + eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - mean[c] * sc;
+}
+
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
+                   float* scale, float* shift, hipStream_t st) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, gamma, beta, mean, var, eps, C, scale, shift);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)) rewritten as dz = A*dy + B + C*z per channel
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, double n, int C, const float* gamma, const float* mean,
+                                   const float* rstd, float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double sdy = sums[c], sdyx = sums[C + c];
+    const double A = (double)gamma[c] * rstd[c];
+    const double k = A * (sdyx / n) * rstd[c];
+    coefA[c] = (float)A;
+    coefC[c] = (float)(-k);
+    coefB[c] = (float)(-A * (sdy / n) + k * mean[c]);
+    if (dgamma) { dgamma[c] = (float)sdyx; dbeta[c] = (float)sdy; }
+}
+
+int launch_bn_bwd_coef(const double* sums, double n, int C, const float* gamma, const float* mean, const float* rstd,
+                       float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta, hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums, n, C, gamma, mean, rstd, coefA, coefB,
+                       coefC, dgamma, dbeta);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise passes over [M, C]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z, int64_t n4, int C4,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     int act, const float* __restrict__ res, float* __restrict__ a) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % C4) * 4;
+        const float4 v = ld4(z + i * 4), sc = ld4(scale + c0), sh = ld4(shift + c0);
+        float4 o;
+        o.x = apply_act(v.x * sc.x + sh.x, act); o.y = apply_act(v.y * sc.y + sh.y, act);
+        o.z = apply_act(v.z * sc.z + sh.z, act); o.w = apply_act(v.w * sc.w + sh.w, act);
+        if (res) {
+            const float4 r = ld4(res + i * 4);
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        st4(a + i * 4, o);
+    }
+}
+
+static int stream_grid(int64_t n_items) {
+    int64_t g = cdiv64(n_items, 256);
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int launch_bn_act(const float* z, int64_t M, int C, const float* scale, const float* shift, int act, const float* res,
+                  float* a, hipStream_t st) {
+    AMS_REQUIRE(C % 4 == 0, "bn_act: C=%d must be a multiple of 4", C);
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_act_kernel, dim3(stream_grid(n4)), dim3(256), 0, st, z, n4, C / 4, scale, shift, act, res, a);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                           int64_t n4, int C4, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act,
+                                                           const float* __restrict__ cA, const float* __restrict__ cB,
+                                                           const float* __restrict__ cC, float* __restrict__ dz) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % C4) * 4;
+        const float4 g = ld4(da + i * 4), v = ld4(z + i * 4);
+        const float4 sc = ld4(scale + c0), sh = ld4(shift + c0), A = ld4(cA + c0), Bc = ld4(cB + c0), Cc = ld4(cC + c0);
+        float4 o;
+        o.x = A.x * (g.x * act_grad_mask(v.x * sc.x + sh.x, act)) + Bc.x + Cc.x * v.x;
+        o.y = A.y * (g.y * act_grad_mask(v.y * sc.y + sh.y, act)) + Bc.y + Cc.y * v.y;
+        o.z = A.z * (g.z * act_grad_mask(v.z * sc.z + sh.z, act)) + Bc.z + Cc.z * v.z;
+        o.w = A.w * (g.w * act_grad_mask(v.w * sc.w + sh.w, act)) + Bc.w + Cc.w * v.w;
+        st4(dz + i * 4, o);
+    }
+}
+
+int launch_bn_bwd_apply(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift, int act,
+                        const float* coefA, const float* coefB, const float* coefC, float* dz, hipStream_t st) {
+    AMS_REQUIRE(C % 4 == 0, "bn_bwd_apply: C=%d must be a multiple of 4", C);
+    const int64_t n4 = M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, st, da, z, n4, C / 4, scale, shift, act, coefA,
+                       coefB, coefC, dz);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K14-K16: Adam (TF1 form: w -= lr_t * m / (sqrt(v) + eps), lr_t carries the bias correction) + mask revert.
+// The moments advance for every entry; entries with mask == 0 keep their old value (tf.where(mask, new, backup)).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const uint8_t* __restrict__ mask, int64_t n,
+                                                   float lr_t, float b1, float b2, float eps) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        if (!mask || mask[i]) p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t, float b1,
+                float b2, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, mask, n, lr_t, b1, b2, eps);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+__global__ void reduce_splits_kernel(const float* __restrict__ part, int splits, int64_t n, float* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+        s0 += part[(int64_t)k * n + i]; s1 += part[(int64_t)(k + 1) * n + i];
+        s2 += part[(int64_t)(k + 2) * n + i]; s3 += part[(int64_t)(k + 3) * n + i];
+    }
+    for (; k < splits; ++k) s0 += part[(int64_t)k * n + i];
+    out[i] = (s0 + s1) + (s2 + s3);
+}
+
+int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, splits, n, out);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int launch_fill(float* p, int64_t n, float v, hipStream_t st) {
+    if (n <= 0) return AMS_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, n, v);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+int launch_copy(float* dst, const float* src, int64_t n, hipStream_t st) {
+    if (n <= 0) return AMS_OK;
+    AMS_CHECK_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return AMS_OK;
+}
+
+// masked parameters -> fp16, compacted in order (downlink payload of run.py:316-336).  Single block per 4096-entry
+// segment computes its count, an exclusive scan over segments gives the offsets (two tiny kernels).
+__global__ void pack_count_kernel(const uint8_t* mask, int64_t n, int64_t seg, int64_t* counts) {
+    const int64_t s = blockIdx.x;
+    const int64_t b = s * seg, e = b + seg < n ? b + seg : n;
+    int local = 0;
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) local += (!mask || mask[i]) ? 1 : 0;
+    __shared__ int sh[256];
+    sh[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[s] = sh[0];
+}
+__global__ void pack_scan_kernel(int64_t* counts, int nseg, int64_t* total) {
+    if (threadIdx.x || blockIdx.x) return;
+    int64_t run = 0;
+    for (int i = 0; i < nseg; ++i) { const int64_t c = counts[i]; counts[i] = run; run += c; }
+    *total = run;
+}
+__global__ void pack_write_kernel(const float* p, const uint8_t* mask, int64_t n, int64_t seg, const int64_t* offs, __half* out) {
+    // one thread per segment keeps the output order identical to a sequential host loop
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t b = s * seg;
+    if (b >= n) return;
+    const int64_t e = b + seg < n ? b + seg : n;
+    int64_t o = offs[s];
+    for (int64_t i = b; i < e; ++i)
+        if (!mask || mask[i]) out[o++] = __float2half_rn(p[i]);
+}
+
+int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* out, int64_t* n_out, hipStream_t st) {
+    const int64_t seg = 256;
+    const int nseg = (int)cdiv64(n, seg);
+    static int64_t* counts = nullptr;
+    static int cap = 0;
+    if (nseg > cap) {
+        if (counts) (void)hipFree(counts);
+        AMS_CHECK_HIP(hipMalloc(&counts, (size_t)nseg * sizeof(int64_t)));
+        cap = nseg;
+    }
+    hipLaunchKernelGGL(pack_count_kernel, dim3(nseg), dim3(256), 0, st, mask, n, seg, counts);
+    AMS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1), 0, st, counts, nseg, n_out);
+    AMS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pack_write_kernel, dim3(cdiv(nseg, 64)), dim3(64), 0, st, p, mask, n, seg, counts, (__half*)out);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+}  // namespace ams

@@ -1,0 +1,272 @@
+// Output head of the AMS student: the full-resolution logits (B x H x W x 19 f32 = 40 MB per 512x1024 frame)
+// are never materialised.  One kernel interpolates the output-stride-16 logits (ResizeBilinear, align_corners),
+// gathers the K selected classes, takes the argmax and, when teacher labels are given, accumulates the K x K
+// confusion matrix and the masked cross-entropy sums (reference utils/graph_utils.py:373-408,
+// SemanticNetwork.py:96-115).  The backward kernel is the exact transpose: every low-resolution logit gathers
+// (softmax - onehot)/N from the full-resolution pixels it was interpolated into, in a fixed order.
+#include "kernels.hpp"
+
+namespace ams {
+
+constexpr int kMaxK = 32;
+
+struct HeadGeom {
+    int B, h, w, ld, K, H, W, NC;
+    float sy, sx;          // (h-1)/(H-1), (w-1)/(W-1) as f32 (TF: CalculateResizeScale with align_corners)
+};
+
+__device__ __forceinline__ void src_tap(int dst, float scale, int n_in, int& lo, int& hi, float& t) {
+    const float src = __fmul_rn((float)dst, scale);
+    const float fl = floorf(src);
+    lo = (int)fl;
+    hi = lo + 1 < n_in ? lo + 1 : n_in - 1;
+    t = __fsub_rn(src, fl);
+}
+
+// v = top + (bot - top) * ty,  top = tl + (tr - tl) * tx   (unfused, like the TF CPU kernel / the oracle)
+__device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, float tx, float ty) {
+    const float top = __fadd_rn(tl, __fmul_rn(__fsub_rn(tr, tl), tx));
+    const float bot = __fadd_rn(bl, __fmul_rn(__fsub_rn(br, bl), tx));
+    return __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ty));
+}
+
+struct ClassTable {
+    int32_t idx[kMaxK];      // selected class ids
+    int32_t lut[256];        // teacher id -> subset index, -1 = ignored
+};
+
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ logits, HeadGeom g, ClassTable ct,
+                                                              const uint8_t* __restrict__ teacher,
+                                                              int32_t* __restrict__ labels,
+                                                              unsigned long long* __restrict__ conf, double* __restrict__ loss) {
+    __shared__ int s_conf[kMaxK * kMaxK];
+    __shared__ float s_loss[4];
+    __shared__ int s_cnt[4];
+    const bool metric = teacher != nullptr;
+    if (metric)
+        for (int e = threadIdx.x; e < g.K * g.K; e += blockDim.x) s_conf[e] = 0;
+    const int y = blockIdx.y, b = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y0, y1; float ty;
+    src_tap(y, g.sy, g.h, y0, y1, ty);
+    if (metric) __syncthreads();
+    float my_loss = 0.f;
+    int my_cnt = 0;
+    if (x < g.W) {
+        int x0, x1; float tx;
+        src_tap(x, g.sx, g.w, x0, x1, tx);
+        const float* base = logits + (int64_t)b * g.h * g.w * g.ld;
+        const float* ptl = base + ((int64_t)y0 * g.w + x0) * g.ld;
+        const float* ptr = base + ((int64_t)y0 * g.w + x1) * g.ld;
+        const float* pbl = base + ((int64_t)y1 * g.w + x0) * g.ld;
+        const float* pbr = base + ((int64_t)y1 * g.w + x1) * g.ld;
+        const int64_t pix = ((int64_t)b * g.H + y) * g.W + x;
+        int target = -1;
+        if (metric) target = ct.lut[teacher[pix]];
+        float best = 0.f, zt = 0.f, zmax = 0.f, ssum = 0.f;
+        int arg = 0;
+        for (int k = 0; k < g.K; ++k) {
+            const int c = ct.idx[k];
+            const float v = bilerp(ptl[c], ptr[c], pbl[c], pbr[c], tx, ty);
+            if (k == 0 || v > best) { best = v; arg = k; }        // first maximum wins (tf.argmax)
+            if (target >= 0) {
+                // streaming log-sum-exp: keep the running max, rescale the running sum
+                if (k == 0) { zmax = v; ssum = 1.f; }
+                else if (v > zmax) { ssum = ssum * __expf(zmax - v) + 1.f; zmax = v; }
+                else ssum += __expf(v - zmax);
+                if (k == target) zt = v;
+            }
+        }
+        if (labels) labels[pix] = arg;
+        if (target >= 0) {
+            my_loss = (zmax + __logf(ssum)) - zt;
+            my_cnt = 1;
+            atomicAdd(&s_conf[target * g.K + arg], 1);
+        }
+    }
+    if (!metric) return;
+    my_loss = wave_sum(my_loss);
+    my_cnt = (int)wave_sum((float)my_cnt);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_loss[wave] = my_loss; s_cnt[wave] = my_cnt; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < g.K * g.K; e += blockDim.x)
+        if (s_conf[e]) atomicAdd(&conf[e], (unsigned long long)s_conf[e]);
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        double ls = 0; int cn = 0;
+        for (int i = 0; i < nw; ++i) { ls += s_loss[i]; cn += s_cnt[i]; }
+        if (cn) { atomicAdd(&loss[0], ls); atomicAdd(&loss[1], (double)cn); }
+    }
+}
+
+static int fill_class_table(const int32_t* cls_host, int K, int NC, ClassTable* ct) {
+    AMS_REQUIRE(K > 0 && K <= kMaxK, "head: K=%d out of range (1..%d)", K, kMaxK);
+    for (int i = 0; i < 256; ++i) ct->lut[i] = -1;
+    for (int k = 0; k < kMaxK; ++k) ct->idx[k] = 0;
+    for (int k = 0; k < K; ++k) {
+        AMS_REQUIRE(cls_host[k] >= 0 && cls_host[k] < NC && cls_host[k] < 256, "head: class id %d out of range", cls_host[k]);
+        ct->idx[k] = cls_host[k];
+        ct->lut[cls_host[k]] = k;
+    }
+    return AMS_OK;
+}
+
+static HeadGeom head_geom(int ld, int B, int h, int w, int K, int H, int W, int NC) {
+    HeadGeom g;
+    g.B = B; g.h = h; g.w = w; g.ld = ld; g.K = K; g.H = H; g.W = W; g.NC = NC;
+    g.sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    g.sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    return g;
+}
+
+// cls: HOST pointer to the K selected class ids (they travel to the kernel by value)
+int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
+                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st) {
+    ClassTable ct;
+    int rc = fill_class_table(cls, K, NC, &ct);
+    if (rc) return rc;
+    AMS_REQUIRE(teacher == nullptr || (conf != nullptr && loss != nullptr), "head: metrics need conf and loss buffers");
+    if (teacher) {
+        AMS_CHECK_HIP(hipMemsetAsync(conf, 0, sizeof(int64_t) * K * K, st));
+        AMS_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double) * 2, st));
+    }
+    const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
+    hipLaunchKernelGGL(upsample_argmax_kernel, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, logits, g, ct, teacher, labels,
+                       (unsigned long long*)conf, loss);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// d loss / d low-res logits.  One block per low-resolution cell (b, i, j): its threads walk the full-resolution
+// pixels whose bilinear footprint contains the cell, recompute that pixel's K interpolated logits and softmax,
+// and accumulate weight * (softmax_k - onehot_k) / N.  Fixed traversal + tree reduction = deterministic.
+// ---------------------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ logits, HeadGeom g, ClassTable ct,
+                                                      const uint8_t* __restrict__ teacher,
+                                                      const double* __restrict__ loss_and_count, float* __restrict__ dlogits,
+                                                      int ldd) {
+    __shared__ float s_part[4][KMAX];
+    const int j = blockIdx.x, i = blockIdx.y, b = blockIdx.z;
+    const double nvalid = loss_and_count[1];
+    const float inv_n = nvalid > 0.5 ? (float)(1.0 / nvalid) : 0.f;
+    // candidate full-resolution rows / columns: everything whose source coordinate can fall in [i-1, i+1)
+    const float ry = g.sy > 0.f ? 1.f / g.sy : 0.f, rx = g.sx > 0.f ? 1.f / g.sx : 0.f;
+    int ya = g.sy > 0.f ? (int)floorf((i - 1) * ry) - 1 : 0, yb = g.sy > 0.f ? (int)ceilf((i + 1) * ry) + 1 : g.H - 1;
+    int xa = g.sx > 0.f ? (int)floorf((j - 1) * rx) - 1 : 0, xb = g.sx > 0.f ? (int)ceilf((j + 1) * rx) + 1 : g.W - 1;
+    ya = ya < 0 ? 0 : ya; xa = xa < 0 ? 0 : xa;
+    yb = yb > g.H - 1 ? g.H - 1 : yb; xb = xb > g.W - 1 ? g.W - 1 : xb;
+    const int ny = yb - ya + 1, nx = xb - xa + 1;
+    float acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+    const float* base = logits + (int64_t)b * g.h * g.w * g.ld;
+    for (int p = threadIdx.x; p < ny * nx; p += blockDim.x) {
+        const int y = ya + p / nx, x = xa + p % nx;
+        int y0, y1, x0, x1; float ty, tx;
+        src_tap(y, g.sy, g.h, y0, y1, ty);
+        src_tap(x, g.sx, g.w, x0, x1, tx);
+        float wy = 0.f, wx = 0.f;
+        if (y0 == i) wy += 1.f - ty;
+        if (y1 == i) wy += ty;
+        if (x0 == j) wx += 1.f - tx;
+        if (x1 == j) wx += tx;
+        const float wgt = wy * wx;
+        if (wgt == 0.f) continue;
+        const int target = ct.lut[teacher[((int64_t)b * g.H + y) * g.W + x]];
+        if (target < 0) continue;
+        const float* ptl = base + ((int64_t)y0 * g.w + x0) * g.ld;
+        const float* ptr = base + ((int64_t)y0 * g.w + x1) * g.ld;
+        const float* pbl = base + ((int64_t)y1 * g.w + x0) * g.ld;
+        const float* pbr = base + ((int64_t)y1 * g.w + x1) * g.ld;
+        float z[KMAX];
+        float zmax = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < g.K) {
+                const int c = ct.idx[k];
+                z[k] = bilerp(ptl[c], ptr[c], pbl[c], pbr[c], tx, ty);
+                zmax = fmaxf(zmax, z[k]);
+            } else z[k] = 0.f;
+        }
+        float ssum = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < g.K) { z[k] = __expf(z[k] - zmax); ssum += z[k]; }
+        const float f = wgt * inv_n, rs = 1.f / ssum;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < g.K) acc[k] += f * (z[k] * rs - (k == target ? 1.f : 0.f));
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) s_part[wave][k] = s;
+    }
+    __syncthreads();
+    float* out = dlogits + (((int64_t)b * g.h + i) * g.w + j) * ldd;
+    for (int c = threadIdx.x; c < ldd; c += blockDim.x) {
+        float v = 0.f;
+        if (c < 256) {
+            const int k = ct.lut[c];
+            if (k >= 0) v = (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k]);
+        }
+        out[c] = v;
+    }
+}
+
+int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
+                   const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st) {
+    ClassTable ct;
+    int rc = fill_class_table(cls, K, NC, &ct);
+    if (rc) return rc;
+    AMS_REQUIRE(teacher && loss_and_count && dlogits, "ce_grad: null pointer");
+    AMS_REQUIRE(ldd >= NC && ldd <= 256, "ce_grad: ldd=%d must hold %d classes", ldd, NC);
+    const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
+    const dim3 grid(w, h, B);
+    if (K <= 8)
+        hipLaunchKernelGGL(ce_grad_kernel<8>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd);
+    else if (K <= 20)
+        hipLaunchKernelGGL(ce_grad_kernel<20>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd);
+    else
+        hipLaunchKernelGGL(ce_grad_kernel<32>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// phi-score confusion matrix between two teacher label maps (SemanticNetwork.py:124-139): pixels whose label is in the
+// subset in BOTH maps count 1 at [before][after].
+__global__ __launch_bounds__(256) void cross_conf_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int64_t n,
+                                                         ClassTable ct, int K, unsigned long long* __restrict__ conf) {
+    __shared__ int s_conf[kMaxK * kMaxK];
+    for (int e = threadIdx.x; e < K * K; e += blockDim.x) s_conf[e] = 0;
+    __syncthreads();
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ka = ct.lut[a[i]], kb = ct.lut[b[i]];
+        if (ka >= 0 && kb >= 0) atomicAdd(&s_conf[ka * K + kb], 1);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * K; e += blockDim.x)
+        if (s_conf[e]) atomicAdd(&conf[e], (unsigned long long)s_conf[e]);
+}
+
+// lut: HOST pointer, 256 entries (teacher id -> subset index or -1)
+int launch_cross_confusion(const uint8_t* a, const uint8_t* b, int64_t n, const int32_t* lut, int K, int64_t* conf,
+                           hipStream_t st) {
+    AMS_REQUIRE(K > 0 && K <= kMaxK, "cross_confusion: K=%d out of range", K);
+    ClassTable ct;
+    for (int i = 0; i < 256; ++i) ct.lut[i] = lut[i];
+    for (int k = 0; k < kMaxK; ++k) ct.idx[k] = 0;
+    AMS_CHECK_HIP(hipMemsetAsync(conf, 0, sizeof(int64_t) * K * K, st));
+    int grid = (int)cdiv64(n, 256 * 16);
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(cross_conf_kernel, dim3(grid), dim3(256), 0, st, a, b, n, ct, K, (unsigned long long*)conf);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+}  // namespace ams

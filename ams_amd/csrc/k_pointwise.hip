@@ -1,0 +1,297 @@
+// 1x1 convolutions of the AMS student as exact-f32 MFMA GEMMs (v_mfma_f32_16x16x4_f32, gfx950).
+//
+//   forward : y[M,N]  = epilogue(x[M,K] @ w[K,N])            (expand / project / head 1x1 convs, K4/K8 of SURVEY §2.2)
+//   dgrad   : dx[M,K] = dy[M,N] @ w^T                         (same kernel, w addressed with swapped strides)
+//   wgrad   : dw[K,N] = x[M,K]^T @ dy[M,N]                    (split over M, deterministic two-stage reduce)
+//
+// M = B*H*W pixels is huge (up to 8 x 131 841), K and N are channel counts (16..960): every layer is a skinny
+// GEMM whose activations stream from HBM exactly once, so the design is bandwidth-first:
+//   * A (activations) never touches LDS: each lane loads float4 = 4 consecutive k of one row straight to VGPRs;
+//     16 lanes x 16 B = one 64-byte row segment, 4 such rows per MFMA.  The contraction index may be permuted
+//     freely as long as A and B agree, so MFMA step j consumes k = 4*(lane>>4) + j of a 16-wide chunk.
+//   * B (weights, <= 1.2 MB, L2 resident) is staged per 32-k chunk into LDS with row pitch 16*NT+4 floats
+//     (pitch % 8 == 4 makes the two 16-lane halves of a ds_read_b32 group hit disjoint banks).
+//   * one block = 4 waves x RM x 16 rows; all NT*16 columns of the n-tile accumulate in registers (<= 80 f32),
+//     so for N <= 320 the activations are read once; wider N (expand layers, small K) re-reads a small A tile
+//     from L2, with the n-tiles of one m-tile placed on the same XCD by xcd_remap().
+//   * epilogue fuses per-image bias (pool branch), BN scale/shift, ReLU/ReLU6 and the residual add.
+#include "kernels.hpp"
+
+namespace ams {
+
+template <int RM, int NT>
+__global__ __launch_bounds__(256) void pw_gemm_f32(PwArgs a, int n_tiles_n, unsigned nblocks) {
+    constexpr int BK = 32;
+    constexpr int PITCH = 16 * NT + 4;
+    __shared__ float sW[BK * PITCH];
+
+    const unsigned lb = xcd_remap(blockIdx.x, nblocks);
+    const int tile_n = lb % n_tiles_n;
+    const int64_t tile_m = lb / n_tiles_n;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int n0 = tile_n * 16 * NT;
+    const int64_t m_base = tile_m * (64 * RM) + wave * (16 * RM);
+
+    f32x4 acc[RM][NT];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* arow[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        int64_t m = m_base + r * 16 + l15;
+        if (m > a.M - 1) m = a.M - 1;                 // clamp: rows past M are computed but never stored
+        arow[r] = a.x + m * (int64_t)a.ldx + 4 * q;
+    }
+
+    const int K = a.K;
+    const int n_chunks = (K + 15) / 16;
+    float4 a_cur[RM], a_nxt[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) a_cur[r] = (4 * q < K) ? ld4(arow[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int c = 0; c < n_chunks; ++c) {
+        if ((c & 1) == 0) {
+            __syncthreads();
+            // stage w[k0 .. k0+32) x [n0 .. n0+16*NT) ; zero-fill outside K x N
+            const int k0 = c * 16;
+            for (int e = tid; e < BK * 16 * NT; e += 256) {
+                int kk, nn;
+                if (a.w_sn == 1) { kk = e / (16 * NT); nn = e % (16 * NT); }     // n contiguous in memory
+                else             { nn = e / BK;        kk = e % BK; }             // k contiguous (transposed use)
+                float v = 0.f;
+                if (k0 + kk < a.Kw && n0 + nn < a.N) v = a.w[(int64_t)(k0 + kk) * a.w_sk + (int64_t)(n0 + nn) * a.w_sn];
+                sW[kk * PITCH + nn] = v;
+            }
+            __syncthreads();
+        }
+        // prefetch the next 16-k chunk of A while this one feeds the matrix pipe
+        const int kn = (c + 1) * 16 + 4 * q;
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+            a_nxt[r] = (c + 1 < n_chunks && kn < K) ? ld4(arow[r] + (c + 1) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+        const float* sB = sW + ((c & 1) * 16 + 4 * q) * PITCH + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float av[RM];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) av[r] = j == 0 ? a_cur[r].x : j == 1 ? a_cur[r].y : j == 2 ? a_cur[r].z : a_cur[r].w;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = sB[j * PITCH + 16 * t];
+#pragma unroll
+                for (int r = 0; r < RM; ++r)
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b, acc[r][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RM; ++r) a_cur[r] = a_nxt[r];
+    }
+
+    // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg --------------------
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = n0 + 16 * t + l15;
+        if (n >= a.N) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        const float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = m_base + r * 16 + 4 * q + i;
+                if (m >= a.M) continue;
+                float v = acc[r][t][i];
+                if (a.img_bias) v += a.img_bias[(m / a.rows_per_img) * a.N + n];
+                v = v * sc + sh;
+                v = apply_act(v, a.act);
+                if (a.res) v += a.res[m * a.ldr + n];
+                a.y[m * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+template <int RM, int NT>
+static int launch_pw_t(const PwArgs& a, hipStream_t st) {
+    const int n_tiles_n = cdiv(a.N, 16 * NT);
+    const int64_t n_tiles_m = cdiv64(a.M, 64 * RM);
+    const int64_t nblocks = n_tiles_m * n_tiles_n;
+    if (nblocks <= 0 || nblocks > 0x7fffffffLL) { set_error("pointwise: bad grid %lld", (long long)nblocks); return AMS_E_INVALID; }
+    hipLaunchKernelGGL((pw_gemm_f32<RM, NT>), dim3((unsigned)nblocks), dim3(256), 0, st, a, n_tiles_n, (unsigned)nblocks);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+int launch_pointwise(const PwArgs& a, hipStream_t st) {
+    AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0, "pointwise: empty problem M=%lld K=%d N=%d", (long long)a.M, a.K, a.N);
+    AMS_REQUIRE(a.Kw > 0 && a.Kw <= a.K, "pointwise: Kw=%d must be in 1..K=%d", a.Kw, a.K);
+    AMS_REQUIRE(a.K % 4 == 0 && a.ldx % 4 == 0, "pointwise: K (%d) and ldx (%d) must be multiples of 4", a.K, a.ldx);
+    AMS_REQUIRE((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "pointwise: x must be 16-byte aligned");
+    // pick the n-tile width: the narrowest instantiation that covers N in one tile, else the widest useful one
+    const int n16 = cdiv(a.N, 16);
+    // small M (head at batch 1, pool branch): prefer more, narrower tiles so the chip is not left idle
+    const bool small_m = a.M < 64 * 256;
+    if (n16 <= 1) return launch_pw_t<2, 1>(a, st);
+    if (n16 <= 2) return launch_pw_t<2, 2>(a, st);
+    if (small_m) {
+        if (n16 <= 4) return launch_pw_t<1, 4>(a, st);
+        if (n16 % 5 == 0) return launch_pw_t<1, 5>(a, st);
+        if (n16 % 6 == 0) return launch_pw_t<1, 6>(a, st);
+        return launch_pw_t<1, 4>(a, st);
+    }
+    if (n16 <= 4) return launch_pw_t<2, 4>(a, st);
+    if (n16 <= 6) return launch_pw_t<2, 6>(a, st);
+    if (n16 <= 9) return launch_pw_t<2, 9>(a, st);
+    if (n16 <= 10) return launch_pw_t<2, 10>(a, st);
+    if (n16 <= 12) return launch_pw_t<1, 12>(a, st);
+    if (n16 <= 16) return launch_pw_t<1, 16>(a, st);
+    if (n16 <= 20) return launch_pw_t<1, 20>(a, st);
+    if (n16 % 20 == 0) return launch_pw_t<1, 20>(a, st);     // 960 = 3 x 320
+    return launch_pw_t<1, 12>(a, st);                          // 384 = 2 x 192, 576 = 3 x 192
+}
+
+// =========================================================================================================
+// wgrad: dw[K,N] = sum_m x[m,K]^T dy[m,N].  Contraction over M (pixels).  MFMA 16x16x4: lane (i = lane&15,
+// kk = lane>>4) supplies A[i][kk] and B[kk][j]; here kk indexes 4 consecutive pixels and i / j index channels.
+// A float4 load along channels gives lane i the channels {4i .. 4i+3} of pixel kk, so MFMA (s,u) accumulates the
+// output sub-matrix rows {k0 + 4i + s}, cols {n0 + 4j + u}: a VA*16 x VB*16 tile from one vector load per side.
+// Each wave walks its own pixels; the block's 4 waves and the grid's M-splits are reduced in a fixed order
+// (LDS, then a second kernel over the split partials) so the result is run-to-run deterministic.
+// =========================================================================================================
+template <int V>
+struct VecLd;
+template <>
+struct VecLd<4> {
+    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[4]) {
+        float4 v = ok ? ld4(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+};
+template <>
+struct VecLd<2> {
+    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[2]) {
+        float2 v = ok ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
+        o[0] = v.x; o[1] = v.y;
+    }
+};
+template <>
+struct VecLd<1> {
+    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[1]) { o[0] = ok ? *p : 0.f; }
+};
+
+template <int VA, int VB>
+__global__ __launch_bounds__(256) void pw_wgrad_f32(WgArgs a, int tiles_k, int tiles_n, int64_t rows_per_split) {
+    __shared__ float sRed[3 * 64 * VA * VB * 4];   // partial tiles of waves 1..3
+    const int tile = blockIdx.y;
+    const int tk = tile / tiles_n, tn = tile % tiles_n;
+    const int split = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int k0 = tk * 16 * VA, n0 = tn * 16 * VB;
+    const int64_t m_begin = split * rows_per_split;
+    int64_t m_end = m_begin + rows_per_split;
+    if (m_end > a.M) m_end = a.M;
+
+    f32x4 acc[VA][VB];
+#pragma unroll
+    for (int s = 0; s < VA; ++s)
+#pragma unroll
+        for (int u = 0; u < VB; ++u) acc[s][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ka = k0 + VA * l15, nb = n0 + VB * l15;
+    const bool ka_ok = ka < a.K, nb_ok = nb < a.N;        // K, N are multiples of VA / VB for the chosen instantiation
+    // each wave takes every 4th group of 4 pixels; 2 groups in flight for latency hiding
+    // (loop bounds are wave-uniform: an MFMA must be issued by the whole wave)
+    for (int64_t mg = m_begin + wave * 4; mg < m_end; mg += 32) {
+        float xa[2][VA], yb[2][VB];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t mm = mg + q + h * 16;
+            const bool ok = mm < m_end;
+            VecLd<VA>::ld(a.x + mm * (int64_t)a.ldx + ka, ok && ka_ok, xa[h]);
+            VecLd<VB>::ld(a.dy + mm * (int64_t)a.ldy + nb, ok && nb_ok, yb[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < VA; ++s)
+#pragma unroll
+                for (int u = 0; u < VB; ++u)
+                    acc[s][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[h][s], yb[h][u], acc[s][u], 0, 0, 0);
+    }
+    // reduce the 4 waves in fixed order through LDS
+    if (wave > 0) {
+        float* dst = sRed + (wave - 1) * 64 * VA * VB * 4;
+#pragma unroll
+        for (int s = 0; s < VA; ++s)
+#pragma unroll
+            for (int u = 0; u < VB; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[((s * VB + u) * 4 + i) * 64 + lane] = acc[s][u][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.scratch + ((int64_t)split * a.K) * a.N;
+#pragma unroll
+        for (int s = 0; s < VA; ++s)
+#pragma unroll
+            for (int u = 0; u < VB; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = acc[s][u][i];
+                    for (int w = 0; w < 3; ++w) v += sRed[w * 64 * VA * VB * 4 + ((s * VB + u) * 4 + i) * 64 + lane];
+                    // C/D layout: col j = lane&15, row i' = 4*(lane>>4) + i  ->  channel k = k0 + VA*i' + s, n = n0 + VB*j + u
+                    const int kk = k0 + VA * (4 * q + i) + s;
+                    const int nn = n0 + VB * l15 + u;
+                    if (kk < a.K && nn < a.N) out[(int64_t)kk * a.N + nn] = v;
+                }
+    }
+}
+
+static int wgrad_splits(int64_t M, int K, int N) {
+    // enough M-splits to fill the chip (~4 blocks per CU overall), at least 256 rows each
+    const int tiles = cdiv(K, 64) * cdiv(N, 64);
+    int64_t want = (1024 + tiles - 1) / tiles;
+    int64_t max_by_rows = (M + 255) / 256;
+    if (want > max_by_rows) want = max_by_rows;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+size_t pointwise_wgrad_scratch(int64_t M, int K, int N) { return (size_t)wgrad_splits(M, K, N) * K * N; }
+
+template <int VA, int VB>
+static int launch_wg_t(const WgArgs& a, int splits, hipStream_t st) {
+    const int tiles_k = cdiv(a.K, 16 * VA), tiles_n = cdiv(a.N, 16 * VB);
+    int64_t rows = cdiv64(a.M, splits);
+    rows = (rows + 3) / 4 * 4;
+    hipLaunchKernelGGL((pw_wgrad_f32<VA, VB>), dim3(splits, tiles_k * tiles_n), dim3(256), 0, st, a, tiles_k, tiles_n, rows);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st) {
+    AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0, "wgrad: empty problem");
+    const int splits = wgrad_splits(a.M, a.K, a.N);
+    AMS_REQUIRE(a.scratch_floats >= (size_t)splits * a.K * a.N, "wgrad: scratch too small (%zu < %zu)", a.scratch_floats,
+                (size_t)splits * a.K * a.N);
+    // vector width per side: widest of 4/2/1 that divides the channel count and keeps the row stride aligned
+    auto vec = [](int c, int ld) { return (c % 4 == 0 && ld % 4 == 0) ? 4 : (c % 2 == 0 && ld % 2 == 0) ? 2 : 1; };
+    int va = vec(a.K, a.ldx), vb = vec(a.N, a.ldy);
+    if (a.K <= 16) va = 1; else if (a.K <= 32 && va > 2) va = 2;      // do not waste MFMA rows on absent channels
+    if (a.N <= 16) vb = 1; else if (a.N <= 32 && vb > 2) vb = 2;
+    int rc;
+#define WG_CASE(A_, B_) if (va == A_ && vb == B_) { rc = launch_wg_t<A_, B_>(a, splits, st); if (rc) return rc; } else
+    WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1) WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
+    { set_error("wgrad: no instantiation"); return AMS_E_INVALID; }
+#undef WG_CASE
+    return launch_reduce_splits(a.scratch, splits, (int64_t)a.K * a.N, a.dw, st);
+}
+
+}  // namespace ams

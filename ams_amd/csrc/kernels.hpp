@@ -1,0 +1,101 @@
+// Launcher prototypes shared by the engine (engine.hip) and the kernel-level C ABI (api.hip).
+#pragma once
+#include "common.hpp"
+
+namespace ams {
+
+// ---- k_pointwise.hip : 1x1 convolutions as f32-MFMA GEMMs ---------------------------------------------
+struct PwArgs {
+    const float* x;        // [M, ldx]
+    int64_t M;
+    int K;                 // contraction length (multiple of 4)
+    int Kw;                // rows of w that exist (<= K); x columns in [Kw, K) must hold finite values (they meet zeros)
+    int ldx;               // row stride of x in floats (multiple of 4)
+    const float* w;        // element (k, n) at w[k*w_sk + n*w_sn]
+    int64_t w_sk, w_sn;
+    int N;
+    const float* img_bias; // [M/rows_per_img, N] added before scale/shift, or nullptr
+    int64_t rows_per_img;
+    const float* scale;    // [N] or nullptr
+    const float* shift;    // [N] or nullptr (bias when scale == nullptr)
+    int act;
+    const float* res;      // [M, ldr] added after the activation, or nullptr
+    int ldr;
+    float* y;              // [M, ldy]
+    int ldy;
+};
+int launch_pointwise(const PwArgs& a, hipStream_t st);
+
+// dw[K,N] = x[M,K]^T @ dy[M,N];  scratch holds the per-split partial products.
+struct WgArgs {
+    const float* x;  int ldx;  int K;
+    const float* dy; int ldy;  int N;
+    int64_t M;
+    float* dw;             // [K, N] dense
+    float* scratch; size_t scratch_floats;
+};
+size_t pointwise_wgrad_scratch(int64_t M, int K, int N);
+int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st);
+
+// ---- k_conv.hip : stem and depthwise ------------------------------------------------------------------
+int launch_stem(const void* frames, int dtype, int B, int H, int W, const float* w, int cout, const float* scale,
+                const float* shift, int act, float pixel_scale, float* y, hipStream_t st);
+// im2col of the normalised, padded frame for the stem's weight gradient: out [B*Ho*Wo, 32] (27 taps + 5 zeros)
+int launch_stem_im2col(const void* frames, int dtype, int B, int H, int W, float pixel_scale, float* out, hipStream_t st);
+int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w, int stride, int rate,
+                     const float* scale, const float* shift, int act, float* y, hipStream_t st);
+int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const float* w, int stride, int rate,
+                           float* dx, hipStream_t st);
+size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate);
+int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
+                           float* dw, float* scratch, size_t scratch_floats, hipStream_t st);
+
+// ---- k_elementwise.hip : BN pieces, pooling, reductions, Adam ------------------------------------------
+// per-image column reductions; scratch >= image_colsum_scratch(B, C) floats
+size_t image_colsum_scratch(int B, int C);
+int launch_global_mean(const float* x, int B, int64_t HW, int C, float* y, float* scratch, hipStream_t st);
+// column sums per image: out[b, c] = sum_hw x[b, hw, c]
+int launch_image_colsum(const float* x, int B, int64_t HW, int C, int ldx, float* out, float* scratch, hipStream_t st);
+
+// per-channel shifted sums over rows: sums[0][c] = sum(z - center[c]), sums[1][c] = sum((z-center[c])^2)  (f64)
+size_t colstats_scratch(int64_t M, int C);
+int launch_colstats(const float* z, int64_t M, int C, const float* center, double* sums /*[2][C]*/, float* scratch,
+                    hipStream_t st);
+// BN forward coefficients from the sums; updates the moving statistics when moving_mean != nullptr.
+//   scale = gamma*rstd, shift = beta - mean*scale; save_mean, save_rstd for the backward pass.
+int launch_bn_finalize(const double* sums, double n, int C, const float* center, const float* gamma, const float* beta,
+                       float eps, float one_minus_decay, float* moving_mean, float* moving_var, float* scale,
+                       float* shift, float* save_mean, float* save_rstd, hipStream_t st);
+// frozen coefficients: scale = gamma*rsqrt(var+eps), shift = beta - mean*scale
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
+                   float* scale, float* shift, hipStream_t st);
+// a = act(z*scale + shift) (+ res)
+int launch_bn_act(const float* z, int64_t M, int C, const float* scale, const float* shift, int act, const float* res,
+                  float* a, hipStream_t st);
+// backward reductions: sums[0][c] = sum(dy), sums[1][c] = sum(dy * xhat), dy = da * act'(z*scale+shift)
+int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift,
+                         int act, const float* mean, const float* rstd, double* sums, float* scratch, hipStream_t st);
+// per-channel (A,B,C) with dz = A*dy + B + C*z; also writes dgamma, dbeta
+int launch_bn_bwd_coef(const double* sums, double n, int C, const float* gamma, const float* mean, const float* rstd,
+                       float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta, hipStream_t st);
+int launch_bn_bwd_apply(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift, int act,
+                        const float* coefA, const float* coefB, const float* coefC, float* dz, hipStream_t st);
+// plain column sums over rows (bias gradient): out[c] = sum_m x[m, c]
+int launch_colsum(const float* x, int64_t M, int C, int ldx, float* out, float* scratch, hipStream_t st);
+int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t, float b1,
+                float b2, float eps, hipStream_t st);
+// out[i] = sum_k part[k*n + i], k ascending (deterministic second stage of split reductions)
+int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st);
+int launch_fill(float* p, int64_t n, float v, hipStream_t st);
+int launch_copy(float* dst, const float* src, int64_t n, hipStream_t st);
+int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* out, int64_t* n_out, hipStream_t st);
+
+// ---- k_head.hip : fused upsample + argmax + metrics, CE gradient, phi-score confusion --------------------
+int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
+                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st);
+int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
+                   const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st);
+int launch_cross_confusion(const uint8_t* a, const uint8_t* b, int64_t n, const int32_t* lut /*[256] -> subset idx or -1*/,
+                           int K, int64_t* conf, hipStream_t st);
+
+}  // namespace ams

@@ -1,0 +1,263 @@
+"""Python handle over the C++/HIP student engine (ams_amd/csrc/engine.hip).
+
+PyTorch-ROCm is plumbing here: it owns the device arena (one ``torch.uint8`` tensor the engine carves up),
+the H2D/D2H copies and the stream; all arithmetic happens in libams_hip.so.  There is no CPU path: creating
+an engine without a GPU or without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hip
+from .spec import (BN_DECAY, BN_EPS_FROZEN, PIXEL_SCALE, Layer, StudentSpec, build_spec)
+from . import weights as W
+
+_ACT = {"none": hip.ACT_NONE, "relu": hip.ACT_RELU, "relu6": hip.ACT_RELU6}
+
+
+def _role(layer: Layer) -> int:
+    s = layer.scope
+    if s == "MobilenetV2/Conv":
+        return hip.ROLE_STEM
+    if s.endswith("/expand"):
+        return hip.ROLE_EXPAND
+    if s.endswith("/depthwise"):
+        return hip.ROLE_DEPTHWISE
+    if s.endswith("/project"):
+        return hip.ROLE_PROJECT
+    return {"image_pooling": hip.ROLE_POOL_CONV, "aspp0": hip.ROLE_ASPP, "concat_projection": hip.ROLE_CONCAT_PROJ,
+            "logits/semantic": hip.ROLE_LOGITS}[s]
+
+
+def layer_table(spec: StudentSpec):
+    """spec.py layer table -> C array of ams_layer_desc."""
+    arr = (hip.LayerDesc * len(spec.layers))()
+    for i, l in enumerate(spec.layers):
+        d = arr[i]
+        d.role = _role(l)
+        d.cin, d.cout, d.stride, d.rate = l.cin, l.cout, l.stride, l.rate
+        d.act = _ACT[l.act]
+        d.residual_from = l.residual_from or 0
+        d.w_off = spec.by_name[l.weight_name].offset
+        if l.bn_eps is not None:
+            d.bn_eps = l.bn_eps
+            d.gamma_off = spec.by_name[l.scope + "/BatchNorm/gamma:0"].offset
+            d.beta_off = spec.by_name[l.scope + "/BatchNorm/beta:0"].offset
+            d.mean_off = spec.by_name[l.scope + "/BatchNorm/moving_mean:0"].offset
+            d.var_off = spec.by_name[l.scope + "/BatchNorm/moving_variance:0"].offset
+        else:
+            d.bn_eps = -1.0
+            d.gamma_off = spec.by_name[l.scope + "/biases:0"].offset
+            d.beta_off = d.mean_off = d.var_off = 0
+    return arr
+
+
+class StudentEngine:
+    """One student network resident on one GPU."""
+
+    def __init__(self, class_indices: Sequence[int], height: int, width: Optional[int] = None, max_batch: int = 1,
+                 trainable: bool = False, num_classes: int = 19, device: str | torch.device = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise hip.AmsHipError("no GPU visible: the AMS student runs only on MI355X (no CPU fallback)")
+        self.lib = hip.lib()
+        self.device = torch.device(device)
+        self.spec = build_spec(num_classes)
+        self.height, self.width = int(height), int(width if width is not None else 2 * height)
+        self.max_batch = int(max_batch)
+        self.trainable = bool(trainable)
+        self.class_indices = [int(c) for c in class_indices]
+        self.K = len(self.class_indices)
+        cfg = hip.StudentConfig()
+        cfg.abi_version = hip.ABI_VERSION
+        cfg.height, cfg.width, cfg.max_batch = self.height, self.width, self.max_batch
+        cfg.num_classes, cfg.n_selected = num_classes, self.K
+        for i, c in enumerate(self.class_indices):
+            cfg.class_indices[i] = c
+        cfg.n_layers = len(self.spec.layers)
+        cfg.trainable = 1 if trainable else 0
+        cfg.act_dtype = hip.DT_F32
+        cfg.n_trainable, cfg.n_stats = self.spec.n_trainable, self.spec.n_stats
+        cfg.bn_decay, cfg.bn_eps_frozen, cfg.pixel_scale = BN_DECAY, BN_EPS_FROZEN, PIXEL_SCALE
+        self._cfg = cfg
+        self._layers = layer_table(self.spec)
+        need = C.c_size_t(0)
+        hip.check(self.lib.ams_student_arena_bytes(C.byref(cfg), self._layers, C.byref(need)), "ams_student_arena_bytes")
+        self.arena_bytes = int(need.value)
+        with torch.cuda.device(self.device):
+            self.arena = torch.zeros(self.arena_bytes, dtype=torch.uint8, device=self.device)
+            handle = C.c_void_p()
+            hip.check(self.lib.ams_student_create(C.byref(cfg), self._layers, C.c_void_p(self.arena.data_ptr()),
+                                                  self.arena_bytes, C.byref(handle)), "ams_student_create")
+        self._h = handle
+        self.params = self._view(hip.REGION_PARAMS, torch.float32)
+        self.stats = self._view(hip.REGION_STATS, torch.float32)
+        self.frozen_params = self._view(hip.REGION_FROZEN, torch.float32)
+        self.logits_lowres = self._view(hip.REGION_LOGITS, torch.float32)
+        self.bn_sync = self._view(hip.REGION_BN_SYNC, torch.float64)
+        if trainable:
+            self.grads = self._view(hip.REGION_GRADS, torch.float32)
+            self.adam_m = self._view(hip.REGION_ADAM_M, torch.float32)
+            self.adam_v = self._view(hip.REGION_ADAM_V, torch.float32)
+        h, w = C.c_int32(), C.c_int32()
+        hip.check(self.lib.ams_student_lowres_size(self._h, C.byref(h), C.byref(w)))
+        self.lowres = (h.value, w.value)
+        self._conf = torch.zeros(self.K * self.K, dtype=torch.int64, device=self.device)
+        self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._keepalive = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _view(self, region: int, dtype: torch.dtype) -> torch.Tensor:
+        off, n = C.c_size_t(), C.c_size_t()
+        hip.check(self.lib.ams_student_region(self._h, region, C.byref(off), C.byref(n)), "ams_student_region")
+        item = torch.empty((), dtype=dtype).element_size()
+        return self.arena[off.value:off.value + n.value * item].view(dtype)
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.ams_student_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _frames_to_device(self, frames) -> tuple:
+        """[B,H,W,3] uint8 or float array/tensor -> (device tensor, dtype code, B)."""
+        if isinstance(frames, torch.Tensor):
+            t = frames
+        else:
+            a = np.ascontiguousarray(frames)
+            if a.dtype != np.uint8:
+                a = a.astype(np.float32, copy=False)
+            t = torch.from_numpy(a)
+        if t.dtype not in (torch.uint8, torch.float32):
+            t = t.to(torch.float32)
+        assert t.dim() == 4 and tuple(t.shape[1:]) == (self.height, self.width, 3), \
+            "frames must be [B,%d,%d,3], got %s" % (self.height, self.width, tuple(t.shape))
+        assert 0 < t.shape[0] <= self.max_batch, "batch %d outside 1..%d" % (t.shape[0], self.max_batch)
+        t = t.to(self.device, non_blocking=True).contiguous()
+        return t, (hip.DT_U8 if t.dtype == torch.uint8 else hip.DT_F32), int(t.shape[0])
+
+    def _labels_to_device(self, labels, batch: int) -> torch.Tensor:
+        if isinstance(labels, torch.Tensor):
+            t = labels
+        else:
+            a = np.asarray(labels)
+            if a.dtype != np.uint8:
+                # tf.cast(labels, int32) truncates toward zero; ids outside 0..255 can never be selected -> 255
+                ai = a.astype(np.float32).astype(np.int64)
+                a = np.where((ai >= 0) & (ai < 255), ai, 255).astype(np.uint8)
+            t = torch.from_numpy(np.ascontiguousarray(a))
+        if t.dtype != torch.uint8:
+            ti = t.to(torch.int64)
+            t = torch.where((ti >= 0) & (ti < 255), ti, torch.full_like(ti, 255)).to(torch.uint8)
+        assert tuple(t.shape) == (batch, self.height, self.width), "labels must be [B,H,W], got %s" % (tuple(t.shape),)
+        return t.to(self.device, non_blocking=True).contiguous()
+
+    # ------------------------------------------------------------------ variables
+    def load_variables(self, variables: Dict[str, np.ndarray]) -> None:
+        """Assign every model variable present in ``variables`` (SaveHelper.restore_vars); Adam state untouched."""
+        tr = self.params.cpu().numpy()
+        st = self.stats.cpu().numpy()
+        for v in self.spec.trainable:
+            if v.name in variables:
+                tr[v.offset:v.offset + v.size] = np.asarray(variables[v.name], dtype=np.float32).reshape(-1)
+        for v in self.spec.stats:
+            if v.name in variables:
+                st[v.offset:v.offset + v.size] = np.asarray(variables[v.name], dtype=np.float32).reshape(-1)
+        self.params.copy_(torch.from_numpy(tr))
+        self.stats.copy_(torch.from_numpy(st))
+
+    def get_variables(self) -> Dict[str, np.ndarray]:
+        return W.unpack(self.spec, self.params.cpu().numpy(), self.stats.cpu().numpy())
+
+    def freeze(self) -> None:
+        """Device-side server->edge hand-off (replaces save_to_frozen_graph + reload)."""
+        hip.check(self.lib.ams_student_freeze(self._h, self._stream()), "ams_student_freeze")
+
+    # ------------------------------------------------------------------ compute
+    def predict(self, frames, mode: int = hip.MODE_FROZEN) -> torch.Tensor:
+        t, dt, b = self._frames_to_device(frames)
+        out = torch.empty((b, self.height, self.width), dtype=torch.int32, device=self.device)
+        hip.check(self.lib.ams_student_predict(self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(out.data_ptr()),
+                                               self._stream()), "ams_student_predict")
+        return out
+
+    def predict_with_metric(self, frames, labels_teacher, mode: int = hip.MODE_FROZEN):
+        """-> (labels int32 [B,H,W] (device), conf_mat int64 [K,K] (device), loss_sum_count f64[2] (device))."""
+        t, dt, b = self._frames_to_device(frames)
+        lab = self._labels_to_device(labels_teacher, b)
+        out = torch.empty((b, self.height, self.width), dtype=torch.int32, device=self.device)
+        conf = torch.empty(self.K * self.K, dtype=torch.int64, device=self.device)
+        loss = torch.empty(2, dtype=torch.float64, device=self.device)
+        hip.check(self.lib.ams_student_predict_with_metric(
+            self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()), C.c_void_p(out.data_ptr()),
+            C.c_void_p(conf.data_ptr()), C.c_void_p(loss.data_ptr()), self._stream()), "ams_student_predict_with_metric")
+        return out, conf.view(self.K, self.K), loss
+
+    def cross_confusion(self, labels_pair) -> torch.Tensor:
+        a = np.asarray(labels_pair)
+        assert a.shape[0] == 2
+        lab = self._labels_to_device(a.reshape(2, *a.shape[1:]), 2) if a.shape[1:] == (self.height, self.width) else None
+        assert lab is not None, "labels must be [2,H,W]"
+        conf = torch.empty(self.K * self.K, dtype=torch.int64, device=self.device)
+        hip.check(self.lib.ams_cross_confusion(self._h, C.c_void_p(lab.data_ptr()), self.height * self.width,
+                                               C.c_void_p(conf.data_ptr()), self._stream()), "ams_cross_confusion")
+        return conf.view(self.K, self.K)
+
+    def train_step(self, frames, labels_teacher, lr: float, mask: Optional[torch.Tensor] = None,
+                   allreduce=None, global_batch: Optional[int] = None) -> torch.Tensor:
+        """One Adam iteration; returns the device tensor f64[2] = (CE sum over valid pixels, valid pixel count).
+
+        ``allreduce``: optional callable(tensor) summing across ranks (data-parallel step)."""
+        assert self.trainable, "Can't train frozen graph!!!"
+        t, dt, b = self._frames_to_device(frames)
+        lab = self._labels_to_device(labels_teacher, b)
+        loss = torch.empty(2, dtype=torch.float64, device=self.device)
+        mptr = C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0)
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.numel() == self.spec.n_trainable and mask.device == self.arena.device
+        if allreduce is None:
+            hip.check(self.lib.ams_student_train_step(self._h, C.c_void_p(t.data_ptr()), dt, C.c_void_p(lab.data_ptr()), b,
+                                                      float(lr), mptr, C.c_void_p(loss.data_ptr()), self._stream()),
+                      "ams_student_train_step")
+            return loss
+        arena = self.arena
+
+        def _cb(_user, offset, count, dtype):
+            try:
+                if dtype == hip.DT_F64:
+                    view = arena[offset:offset + 8 * count].view(torch.float64)
+                else:
+                    view = arena[offset:offset + 4 * count].view(torch.float32)
+                allreduce(view)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                print("all-reduce callback failed:", e)
+                return 1
+
+        cb = hip.ALLREDUCE_CB(_cb)
+        hip.check(self.lib.ams_student_train_step_dp(self._h, C.c_void_p(t.data_ptr()), dt, C.c_void_p(lab.data_ptr()), b,
+                                                     int(global_batch or b), float(lr), mptr, C.c_void_p(loss.data_ptr()),
+                                                     cb, None, self._stream()), "ams_student_train_step_dp")
+        return loss
+
+    @property
+    def adam_step(self) -> int:
+        t = C.c_int64()
+        hip.check(self.lib.ams_student_get_adam_step(self._h, C.byref(t)))
+        return int(t.value)
+
+    @adam_step.setter
+    def adam_step(self, value: int) -> None:
+        hip.check(self.lib.ams_student_set_adam_step(self._h, int(value)))

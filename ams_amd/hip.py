@@ -1,0 +1,111 @@
+"""ctypes binding of libams_hip.so (C ABI in include/ams_hip.h).
+
+The product has no CPU fallback: if the library is missing or cannot be loaded, importing this module's
+``lib()`` raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C ams_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libams_hip.so"
+
+ABI_VERSION = 1
+
+# enums of include/ams_hip.h
+ROLE_STEM, ROLE_EXPAND, ROLE_DEPTHWISE, ROLE_PROJECT, ROLE_POOL_CONV, ROLE_ASPP, ROLE_CONCAT_PROJ, ROLE_LOGITS = range(8)
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+DT_F32, DT_U8, DT_BF16, DT_I32, DT_F64 = 0, 1, 2, 3, 4
+MODE_FROZEN, MODE_LIVE = 0, 1
+(REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
+ REGION_LOGITS) = range(8)
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("role", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("stride", C.c_int32),
+                ("rate", C.c_int32), ("act", C.c_int32), ("residual_from", C.c_int32), ("bn_eps", C.c_float),
+                ("w_off", C.c_int64), ("gamma_off", C.c_int64), ("beta_off", C.c_int64), ("mean_off", C.c_int64),
+                ("var_off", C.c_int64)]
+
+
+class StudentConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("max_batch", C.c_int32),
+                ("num_classes", C.c_int32), ("n_selected", C.c_int32), ("class_indices", C.c_int32 * 32),
+                ("n_layers", C.c_int32), ("trainable", C.c_int32), ("act_dtype", C.c_int32),
+                ("n_trainable", C.c_int64), ("n_stats", C.c_int64), ("bn_decay", C.c_float),
+                ("bn_eps_frozen", C.c_float), ("pixel_scale", C.c_float)]
+
+
+ALLREDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int32)
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes).  Every symbol declared in include/ams_hip.h appears here; tests check both ways.
+SIGNATURES = {
+    "ams_last_error": (C.c_char_p, []),
+    "ams_abi_version": (C.c_int, []),
+    "ams_device_info": (C.c_int, [C.c_char_p, _sz, C.POINTER(_i32), C.POINTER(_i64)]),
+    "ams_student_arena_bytes": (C.c_int, [C.POINTER(StudentConfig), C.POINTER(LayerDesc), C.POINTER(_sz)]),
+    "ams_student_create": (C.c_int, [C.POINTER(StudentConfig), C.POINTER(LayerDesc), _vp, _sz, C.POINTER(_vp)]),
+    "ams_student_destroy": (None, [_vp]),
+    "ams_student_region": (C.c_int, [_vp, _i32, C.POINTER(_sz), C.POINTER(_sz)]),
+    "ams_student_lowres_size": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ams_student_freeze": (C.c_int, [_vp, _vp]),
+    "ams_student_predict": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "ams_student_predict_with_metric": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ams_cross_confusion": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "ams_student_train_step": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _vp]),
+    "ams_student_train_step_dp": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, ALLREDUCE_CB, _vp, _vp]),
+    "ams_student_get_adam_step": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "ams_student_set_adam_step": (C.c_int, [_vp, _i64]),
+    "ams_pack_masked_fp16": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "ams_k_stem_conv": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _f32, _vp, _vp]),
+    "ams_k_depthwise3x3": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "ams_k_pointwise": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "ams_k_global_mean": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "ams_k_global_mean_scratch": (_sz, [_i32, _i32]),
+    "ams_k_upsample_argmax": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _i32, _vp, _vp, _vp,
+                                        _vp, _vp]),
+    "ams_k_ce_grad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "ams_k_pointwise_wgrad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "ams_k_pointwise_wgrad_scratch": (_sz, [_i64, _i32, _i32]),
+    "ams_k_depthwise3x3_dgrad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "ams_k_depthwise3x3_wgrad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "ams_k_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp]),
+}
+
+_lib = None
+
+
+class AmsHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libams_hip.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("AMS_HIP_LIB", str(LIB_PATH)))
+    if not path.exists():
+        raise AmsHipError(
+            "HIP library %s not found: the AMS student has no CPU fallback. Build it with "
+            "`make -C ams_amd/csrc` (hipcc --offload-arch=gfx950)." % path)
+    handle = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if handle.ams_abi_version() != ABI_VERSION:
+        raise AmsHipError("libams_hip.so ABI %d, binding expects %d" % (handle.ams_abi_version(), ABI_VERSION))
+    _lib = handle
+    return handle
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ams_last_error()
+        raise AmsHipError("%s failed (%d): %s" % (what or "libams_hip call", rc, msg.decode() if msg else "?"))

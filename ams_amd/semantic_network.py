@@ -1,0 +1,439 @@
+"""``SemanticNetwork`` — the drop-in boundary of the AMS hot path on MI355X.
+
+Mirrors the public surface of the reference class (SemanticNetwork.py:24-755): constructor arguments,
+method names, argument meaning, return types, assertion behaviour and the process-wide lock, so that the
+reference's edge/server loop (run.py) can use it unchanged.  Underneath, one ``StudentEngine`` (HIP) per
+instance replaces the tf.Session; there is no CPU fallback.
+
+Deliberate differences (all listed in INTEGRATION.md):
+  * ``<meta_dir>.pb`` written by ``save_to_frozen_graph`` is an ``AMSF`` container (weights + statistics),
+    not a TensorFlow GraphDef: the hand-off semantic (inference-mode BN with eps 1e-3 everywhere, trained
+    gamma/beta, moving statistics; reference utils/graph_utils.py:52-126) is the same, the bytes are not.
+  * ``infer`` / ``train_step`` aliases are added (BASELINE.json north-star names).
+  * per-iteration loss printing is off unless ``verbose=True`` (each print forces a device sync).
+"""
+from __future__ import annotations
+
+import io
+import os
+import random
+import threading
+import time
+from collections import deque
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import coord_masks, hip
+from .engine import StudentEngine
+from .utils import calculate_miou, colormap, mini_batch
+from .weights import load_npy
+
+FROZEN_MAGIC = b"AMSF\x01"
+
+
+class FrozenGraph:
+    """What the server ships to the edge: every model variable after training (reference: a GraphDef with the
+    variables folded to constants and BN rebound to inference mode, utils/graph_utils.py:79-126)."""
+
+    def __init__(self, variables: Dict[str, np.ndarray], class_indices, height: int, num_classes: int):
+        self.variables = variables
+        self.class_indices = [int(c) for c in class_indices]
+        self.height = int(height)
+        self.num_classes = int(num_classes)
+
+    def SerializeToString(self) -> bytes:
+        buf = io.BytesIO()
+        np.savez(buf, __class_indices=np.asarray(self.class_indices, dtype=np.int32),
+                 __height=np.asarray(self.height), __num_classes=np.asarray(self.num_classes),
+                 **{k.replace("/", "|"): v for k, v in self.variables.items()})
+        return FROZEN_MAGIC + buf.getvalue()
+
+    @staticmethod
+    def ParseFromString(data: bytes) -> "FrozenGraph":
+        if not data.startswith(FROZEN_MAGIC):
+            raise ValueError("not an AMSF frozen student (TensorFlow .pb files cannot be loaded by this build)")
+        z = np.load(io.BytesIO(data[len(FROZEN_MAGIC):]))
+        variables = {k.replace("|", "/"): z[k] for k in z.files if not k.startswith("__")}
+        return FrozenGraph(variables, z["__class_indices"].tolist(), int(z["__height"]), int(z["__num_classes"]))
+
+
+class SemanticNetwork(object):
+    OPT_FILTER = ['Adam', 'Momentum']
+    OP_FILTER = ['image_cache:0', 'global_step:0']
+    THREAD_SLEEP_INTERVAL = 1 / 1000.
+    TOTAL_CLASSES = 19
+    WHITE = np.array([255, 255, 255], dtype=np.uint8)
+    BLACK = np.array([0, 0, 0], dtype=np.uint8)
+
+    def __init__(self, meta_dir, class_weights_exp=None, height=None, gpu_id='0', frozen=False,
+                 scale=None, mini_batch_size=None, lr=None, mem_frac=1, coord_frac=0.1, cross_miou_compat=False,
+                 filter_out=None, over_ride_total_classes=None, **kwargs):
+        assert height is not None, "No height is given"
+        assert class_weights_exp is not None, "No class weights specified"
+        assert frozen or None not in [scale, mini_batch_size, lr], "Training parameters must be specified for " \
+                                                                   "non-frozen graph"
+        self.lr = lr
+        self.mini_batch_size = mini_batch_size
+        self.scale = scale
+        if over_ride_total_classes is not None:
+            self.TOTAL_CLASSES = over_ride_total_classes
+        self.coord_frac = coord_frac
+
+        self.class_weights_graph = class_weights_exp
+        self.class_indices_graph = np.where(self.class_weights_graph == 1)[0]
+        assert self.class_weights_graph.shape == (self.TOTAL_CLASSES, 1)
+        self.class_count = len(self.class_indices_graph)
+        assert self.class_indices_graph.shape == (self.class_count,)
+        assert self.class_count > 0
+        self.cross_miou_compat = cross_miou_compat
+
+        self.color_map_reduced_ = np.take(colormap(), self.class_indices_graph, axis=0)
+        ranks = np.cumsum(self.class_weights_graph).reshape(self.TOTAL_CLASSES) * \
+            self.class_weights_graph.reshape(self.TOTAL_CLASSES)
+        self.take_array = np.where(ranks != 0, ranks - 1, ranks).astype(int)
+        assert self.take_array.shape == (self.TOTAL_CLASSES,)
+
+        self.frozen = frozen
+        self.height = height
+        assert self.height > 0
+        self.meta_dir = meta_dir
+        self.process_lock = threading.Lock()
+        self.verbose = bool(kwargs.pop("verbose", False))
+        # kwargs the reference forwards to create_student_v3 (graph_utils.py:338-339); only the ones run.py can
+        # switch on are meaningful here
+        self.masked_gradients = bool(kwargs.pop("masked_gradients", False))
+        for dead in ("threshold", "map_misc", "test_mode"):
+            kwargs.pop(dead, None)
+        assert not kwargs.pop("train_biases_only", False), "train_biases_only is not supported"
+        assert not kwargs.pop("regularize", False), "regularize is not supported"
+        assert not kwargs.pop("soft_teacher", False), "soft_teacher is never fed by the reference and is not supported"
+        initial_variables = kwargs.pop("initial_variables", None)
+        frozen_graph = kwargs.pop("frozen_graph", None)
+        max_batch = kwargs.pop("max_batch", None)
+        assert not kwargs, "unknown arguments: %s" % sorted(kwargs)
+
+        device = "cuda:%d" % int(str(gpu_id).split(",")[0]) if not str(gpu_id).startswith("cuda") else str(gpu_id)
+        if torch.cuda.is_available() and int(device.split(":")[1]) >= torch.cuda.device_count():
+            device = "cuda:0"       # one process per GPU: the launcher already narrowed visibility (run.py:28)
+        if self.frozen:
+            if frozen_graph is None:
+                with open(meta_dir + ".pb", 'rb') as pb_file:
+                    frozen_graph = FrozenGraph.ParseFromString(pb_file.read())
+            self.engine = StudentEngine(self.class_indices_graph, self.height, 2 * self.height,
+                                        max_batch=int(max_batch or 1), trainable=False,
+                                        num_classes=self.TOTAL_CLASSES, device=device)
+            self.engine.load_variables(frozen_graph.variables)
+            self.engine.freeze()
+        else:
+            self.engine = StudentEngine(self.class_indices_graph, self.height, 2 * self.height,
+                                        max_batch=int(max_batch or max(int(mini_batch_size), 1)), trainable=True,
+                                        num_classes=self.TOTAL_CLASSES, device=device)
+            if filter_out is not None:
+                self.OPT_FILTER = list(self.OPT_FILTER) + list(filter_out)
+            self.filter = lambda elem: elem if all(
+                keyword not in elem for keyword in self.OPT_FILTER) and elem not in self.OP_FILTER else None
+            self._initial = initial_variables if initial_variables is not None else load_npy("%s.npy" % self.meta_dir)
+            self._restore_dict(self._initial)
+            self.mask = None
+            self.train_params = None
+            self.curr_mask = None
+            self.last_losses: List[float] = []
+        self._last_train_ms = 0.0
+
+    # ------------------------------------------------------------------ variables (SaveHelper semantics)
+    def _restore_dict(self, variables: Dict[str, np.ndarray]) -> None:
+        kept = {k: v for k, v in variables.items() if self.filter(k) is not None}
+        self.engine.load_variables(kept)
+
+    def restore_initial(self):
+        """Reload ``<meta_dir>.npy``; optimizer state (Adam moments, step count) is NOT reset."""
+        self._restore_dict(self._initial)
+
+    def restore(self, chk):
+        if isinstance(chk, str):
+            chk = load_npy(chk)
+        elif not isinstance(chk, dict):
+            raise SystemExit(1)
+        self._restore_dict(chk)
+
+    def get_vars(self):
+        out = self.engine.get_variables()
+        if not self.frozen:
+            m, v = self.engine.adam_m.cpu().numpy(), self.engine.adam_v.cpu().numpy()
+            for var in self.engine.spec.trainable:
+                stem = var.name[:-2]
+                out[stem + "/Adam:0"] = m[var.offset:var.offset + var.size].reshape(var.shape).copy()
+                out[stem + "/Adam_1:0"] = v[var.offset:var.offset + var.size].reshape(var.shape).copy()
+            t = self.engine.adam_step
+            out["beta1_power:0"] = np.float32(0.9 ** (t + 1))
+            out["beta2_power:0"] = np.float32(0.999 ** (t + 1))
+        return out
+
+    def _model_vars(self) -> Dict[str, np.ndarray]:
+        return self.engine.get_variables()
+
+    # ------------------------------------------------------------------ inference
+    def _mode(self) -> int:
+        return hip.MODE_FROZEN if self.frozen else hip.MODE_LIVE
+
+    def predict_input(self, frames):
+        self.process_lock.acquire()
+        try:
+            labels_ = self.engine.predict(frames, self._mode()).cpu().numpy()
+            assert labels_.shape == tuple(np.shape(frames)[:-1])
+        finally:
+            self.process_lock.release()
+        return labels_
+
+    infer = predict_input
+
+    def calc_cross_miou(self, labels):
+        assert not self.frozen or self.cross_miou_compat
+        assert labels.shape == (2, self.height, 2 * self.height)
+        self.process_lock.acquire()
+        try:
+            conf_mat_ = self.engine.cross_confusion(labels).cpu().numpy().astype(np.float64)
+            iou_ = calculate_miou(conf_mat_, nan=True)
+            miou_ = np.nanmean(iou_)
+        finally:
+            self.process_lock.release()
+        return conf_mat_, iou_, miou_
+
+    def predict_with_metric(self, frames, labels_teacher):
+        self.process_lock.acquire()
+        try:
+            labels_dev, conf_dev, loss_dev = self.engine.predict_with_metric(frames, labels_teacher, self._mode())
+            labels_student = labels_dev.cpu().numpy()
+            conf_mat_ = conf_dev.cpu().numpy().astype(np.float64)
+            ls = loss_dev.cpu().numpy()
+            loss_ = np.float32(ls[0] / ls[1]) if ls[1] > 0 else np.float32(np.nan)
+            assert labels_student.shape == tuple(np.shape(frames)[:-1])
+            iou_ = calculate_miou(conf_mat_, nan=True)
+            miou_ = np.nanmean(iou_)
+        finally:
+            self.process_lock.release()
+        return labels_student, conf_mat_, iou_, miou_, loss_
+
+    # ------------------------------------------------------------------ training
+    def train_with_deque(self, frame_deque, label_deque, num_of_iterations, train_strategy='full_model',
+                         keep_mask=False):
+        assert not self.frozen, "Can't train frozen graph!!!"
+        if not keep_mask:
+            self.mask = None
+        self.process_lock.acquire()
+        try:
+            batch_deque = deque()
+            batch_thr = threading.Thread(target=self._fill_batch, args=(batch_deque, frame_deque, label_deque,
+                                                                        num_of_iterations,))
+            batch_thr.start()
+            self._train(batch_deque, num_of_iterations, train_strategy)
+            batch_thr.join()
+        finally:
+            self.process_lock.release()
+
+    def train_step(self, frames, labels_teacher, train_strategy='full_model'):
+        """North-star alias: ONE optimisation step on an explicit batch; returns the loss (float)."""
+        assert not self.frozen, "Can't train frozen graph!!!"
+        with self.process_lock:
+            mask_dev = None
+            if 'coord_desc_' in train_strategy:
+                _before, train_mask_ = self.get_train_mask(train_strategy)
+                mask_dev = self._mask_to_device(train_mask_)
+            ls = self.engine.train_step(frames, labels_teacher, self.lr, mask_dev).cpu().numpy()
+        return float(ls[0] / ls[1]) if ls[1] > 0 else float("nan")
+
+    def _mask_to_device(self, train_mask_: Dict[str, np.ndarray]) -> torch.Tensor:
+        flat = np.empty(self.engine.spec.n_trainable, dtype=np.uint8)
+        for v in self.engine.spec.trainable:
+            flat[v.offset:v.offset + v.size] = np.asarray(train_mask_[v.name]).reshape(-1)
+        return torch.from_numpy(flat).to(self.engine.device)
+
+    def _train(self, batch_deque, num_of_iterations, train_strategy):
+        signal_deque = deque()
+        fill_thr = threading.Thread(target=self._fill_queue, args=(batch_deque, num_of_iterations, signal_deque))
+        fill_thr.start()
+
+        _before, train_mask_ = self.get_train_mask(train_strategy)
+        mask_dev = self._mask_to_device(train_mask_) if train_mask_ is not None else None
+        losses = []
+        t_phase = time.time()
+        for it in range(num_of_iterations):
+            staged = None
+            while staged is None:
+                try:
+                    staged = signal_deque.popleft()
+                except IndexError:
+                    time.sleep(self.THREAD_SLEEP_INTERVAL)
+            t1 = time.time()
+            frames_dev, labels_dev, ready = staged
+            torch.cuda.current_stream(self.engine.device).wait_event(ready)
+            loss_dev = self.engine.train_step(frames_dev, labels_dev, self.lr, mask_dev)
+            losses.append(loss_dev)
+            if self.verbose:
+                ls = loss_dev.cpu().numpy()
+                print('Loss is %.3f at iteration %d and took %.1f ms' % (ls[0] / max(ls[1], 1), it,
+                                                                         (time.time() - t1) * 1000.0))
+            if train_strategy == 'coord_desc_auto':
+                if it == 0 and self.mask is None:
+                    # derive the mask from the first step's |delta w|: keep the top coord_frac, roll back the rest
+                    _after = self._model_vars()
+                    names = [v.name for v in self.engine.spec.trainable]
+                    changes = np.concatenate([np.abs(_after[k] - _before[k]).reshape(-1) for k in names], axis=0)
+                    cut_threshold = np.percentile(changes, 100 * (1 - self.coord_frac))
+                    _combine = {}
+                    kept = total = 0
+                    for k in names:
+                        train_mask_[k] = np.abs(_after[k] - _before[k]) > cut_threshold
+                        kept += int(np.sum(train_mask_[k]))
+                        total += train_mask_[k].size
+                        _combine[k] = np.where(train_mask_[k], _after[k], _before[k])
+                    if self.verbose:
+                        print("Using auto mode, Training %.3f%% of variables" % (100 * kept / total))
+                    self._restore_dict(_combine)
+                    self.mask = train_mask_
+                    mask_dev = self._mask_to_device(train_mask_)
+        fill_thr.join()
+        stacked = torch.stack(losses).cpu().numpy() if losses else np.zeros((0, 2))
+        self.last_losses = [float(s / c) if c > 0 else float("nan") for s, c in stacked]
+        self._last_train_ms = (time.time() - t_phase) * 1000.0
+
+        _after_train = self._model_vars()
+        if 'coord_desc_' in train_strategy:
+            names = [v.name for v in self.engine.spec.trainable]
+            self.curr_mask = [np.asarray(train_mask_[k]) for k in names]
+            self.train_params = [_after_train[k] for k in names]
+        else:
+            self.train_params = [_after_train[k] for k in _after_train.keys()]
+            self.curr_mask = [np.ones_like(_after_train[k], dtype=bool) for k in _after_train.keys()]
+
+    def get_train_mask(self, train_strategy):
+        """Coordinate-descent masks (SemanticNetwork.py:302-669): dict variable name -> bool array, or None."""
+        if train_strategy == 'full_model':
+            return None, None
+        _before = {v.name: None for v in self.engine.spec.trainable}
+        shapes = {v.name: v.shape for v in self.engine.spec.trainable}
+        if train_strategy == 'coord_desc_auto':
+            _before = {k: v for k, v in self._model_vars().items() if k in shapes}
+            if self.mask is None:
+                train_mask_ = {k: np.ones(shapes[k], dtype=bool) for k in shapes}
+            else:
+                train_mask_ = self.mask
+            return _before, train_mask_
+        train_mask_ = coord_masks.build_mask(train_strategy, self.coord_frac, shapes)   # raises NameError if unknown
+        if self.verbose:
+            all_vars, train_vars_len = self.train_vars_count(train_mask_)
+            print("Using %s mode, Training %.3f%% of variables" % (train_strategy, 100 * train_vars_len / all_vars))
+        return _before, train_mask_
+
+    def train_vars_count(self, train_mask_):
+        all_vars = sum(m.size for m in train_mask_.values())
+        train_vars_len = sum(int(np.sum(m)) for m in train_mask_.values())
+        return all_vars, train_vars_len
+
+    def _fill_batch(self, batch_deque, frame_deque, label_deque, number_of_batches):
+        """Producer thread: sample mini-batches from the replay memory (utils.mini_batch contract).
+
+        Fast path (the only one run.py exercises: scale == [1], frames already at network size): draws the same
+        random numbers in the same order as ``mini_batch`` but gathers the uint8 frames directly instead of
+        materialising float64 copies (B x 12.6 MB per batch at 512x1024)."""
+        frames = list(frame_deque) if isinstance(frame_deque, deque) else frame_deque
+        labels = list(label_deque) if isinstance(label_deque, deque) else label_deque
+        crop = [self.height, self.height * 2]
+        fast = (list(self.scale) == [1] and all(f.shape[:2] == tuple(crop) for f in frames))
+        for _ in range(number_of_batches):
+            if fast:
+                picks = []
+                for _j in range(self.mini_batch_size):
+                    picks.append(np.random.choice(len(frames)))
+                    random.randint(0, 0)      # scale choice
+                    random.randint(0, 0)      # row offset  (slack is 0 when the frame already has the crop size)
+                    random.randint(0, 0)      # column offset
+                image_batch = np.stack([frames[p] for p in picks])
+                label_batch = np.stack([labels[p] for p in picks])
+            else:
+                ib, lb = mini_batch(frames, labels, crop, self.scale, self.mini_batch_size, 1, flip=False)
+                image_batch, label_batch = ib[0], lb[0]
+            assert np.shape(label_batch) == (self.mini_batch_size, self.height, self.height * 2)
+            assert np.shape(image_batch) == (self.mini_batch_size, self.height, self.height * 2, 3)
+            batch_deque.append({'frames': image_batch, 'labels': label_batch})
+
+    def _fill_queue(self, batch_deque, number_of_batches, signal_deque):
+        """Stager thread (the FIFO queue of the reference graph, capacity 200): H2D on a side stream."""
+        dev = self.engine.device
+        copy_stream = torch.cuda.Stream(device=dev)
+        for _ in range(number_of_batches):
+            batch = None
+            while batch is None:
+                try:
+                    batch = batch_deque.popleft()
+                except IndexError:
+                    time.sleep(self.THREAD_SLEEP_INTERVAL)
+            fr = batch['frames']
+            fr = fr if fr.dtype == np.uint8 else fr.astype(np.float32)
+            lb = batch['labels']
+            if lb.dtype != np.uint8:
+                li = lb.astype(np.float32).astype(np.int64)
+                lb = np.where((li >= 0) & (li < 255), li, 255).astype(np.uint8)
+            with torch.cuda.stream(copy_stream):
+                f_dev = torch.from_numpy(np.ascontiguousarray(fr)).pin_memory().to(dev, non_blocking=True)
+                l_dev = torch.from_numpy(np.ascontiguousarray(lb)).pin_memory().to(dev, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+            while len(signal_deque) >= 200:
+                time.sleep(self.THREAD_SLEEP_INTERVAL)
+            signal_deque.append((f_dev, l_dev, ready))
+
+    # ------------------------------------------------------------------ freeze / export
+    def get_frozen_graph(self):
+        return FrozenGraph(self._model_vars(), self.class_indices_graph, self.height, self.TOTAL_CLASSES)
+
+    def save_to_frozen_graph(self, save_dir):
+        graph_def = self.get_frozen_graph()
+        with open(save_dir + ".pb", 'wb') as pb_file:
+            pb_file.write(graph_def.SerializeToString())
+
+    def close_model(self):
+        self.engine.close()
+
+    # ------------------------------------------------------------------ visualisation helpers (NumPy only)
+    @staticmethod
+    def _blend(a, b):
+        return np.clip(np.rint(0.5 * a.astype(np.float32) + 0.5 * b.astype(np.float32)), 0, 255).astype(np.uint8)
+
+    def colorize(self, frame=None, label=None):
+        assert frame is not None or label is not None, "At least a label or frame must be given"
+        assert frame is None or frame.shape == (self.height, self.height * 2, 3)
+        if label is None:
+            label = self.predict_input(np.expand_dims(frame, axis=0))[0]
+        assert label.shape == (self.height, self.height * 2)
+        label_colored = self.color_map_reduced_[label]
+        if frame is not None:
+            return label_colored, self._blend(frame, label_colored)
+        return label_colored
+
+    def colorize_teacher(self, label, frame=None):
+        assert frame is None or frame.shape == (self.height, self.height * 2, 3)
+        assert label.shape == (self.height, self.height * 2)
+        label_colored = colormap()[label]
+        if frame is not None:
+            return label_colored, self._blend(frame, label_colored)
+        return label_colored
+
+    def cross_ignore(self, label_teacher, label_student=None, frame_student=None):
+        assert label_student is not None or frame_student is not None, \
+            "At least a label or frame from student must be given"
+        assert label_teacher.shape == (self.height, self.height * 2)
+        label_teacher_reduced = self.take_array[label_teacher]
+        if label_student is None:
+            label_student = self.predict_input(np.expand_dims(frame_student, axis=0))[0]
+        assert label_student.shape == (self.height, self.height * 2)
+        ignore_mask = np.where(np.expand_dims(label_teacher_reduced, axis=-1) == 0, self.WHITE, self.BLACK)
+        colorized_label_teacher = self.colorize(label=label_teacher_reduced)
+        cross_cond = np.logical_and(np.logical_not(ignore_mask[:, :, :1]),
+                                    np.expand_dims(np.not_equal(label_teacher_reduced, label_student), axis=-1))
+        cross_mask = np.where(cross_cond, colorized_label_teacher, self.BLACK)
+        assert ignore_mask.shape == cross_mask.shape
+        assert ignore_mask.shape == (self.height, self.height * 2, 3)
+        return cross_mask, ignore_mask

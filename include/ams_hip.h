@@ -1,0 +1,234 @@
+/*
+ * ams_hip.h — C ABI of the MI355X-native AMS student hot path (libams_hip.so).
+ *
+ * The reference (modelstreaming/ams) has NO native boundary: its hot path is a Python object,
+ * `SemanticNetwork` (reference SemanticNetwork.py:24), whose methods call `tf.Session.run` on a graph
+ * assembled by `create_student_v3` (reference utils/graph_utils.py:338-533).  This header is the seam
+ * a maintainer binds UNDER that class (ctypes stub in INTEGRATION.md): every entry point names the
+ * reference call it replaces.  Plain pointers and sizes only; all `*_dev` pointers are HIP device
+ * pointers owned by the caller (the Python host allocates them through PyTorch-ROCm); `stream` is a
+ * `hipStream_t` passed as `void*` (0 = the null stream).  All functions return 0 on success or a
+ * negative AMS_E_* code; `ams_last_error()` gives the message of the calling thread's last failure.
+ *
+ * Layouts: activations NHWC, dense; conv weights HWIO, depthwise weights HWC1 (TF layouts, so the
+ * reference's `.npy` weight dicts load without transposition); frames `[B,H,W,3]` RGB 0..255 as uint8
+ * or float32; label maps `[B,H,W]` (uint8 teacher ids in, int32 subset indices out).
+ */
+#ifndef AMS_HIP_H
+#define AMS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMS_ABI_VERSION 1
+
+enum {
+    AMS_OK = 0,
+    AMS_E_INVALID = -1,     /* bad argument (shape, dtype, mode, null pointer)           */
+    AMS_E_HIP = -2,         /* a HIP runtime call or kernel launch failed                 */
+    AMS_E_STATE = -3,       /* call not valid in this state (e.g. training a frozen net)  */
+    AMS_E_NOMEM = -4        /* arena too small                                            */
+};
+
+/* layer roles: how the engine wires a row of the layer table (ams_amd/spec.py -> Appendix A of SURVEY.md) */
+enum {
+    AMS_ROLE_STEM = 0,       /* MobilenetV2/Conv: dense 3x3 s2 on the normalised frame          */
+    AMS_ROLE_EXPAND = 1,     /* 1x1, BN, ReLU6                                                  */
+    AMS_ROLE_DEPTHWISE = 2,  /* 3x3 depthwise (stride 1/2, rate 1/2), BN, ReLU6                 */
+    AMS_ROLE_PROJECT = 3,    /* 1x1, BN, linear, optional residual add of the block input       */
+    AMS_ROLE_POOL_CONV = 4,  /* image_pooling: global mean -> 1x1 -> BN -> ReLU (per image)     */
+    AMS_ROLE_ASPP = 5,       /* aspp0: 1x1 -> BN -> ReLU                                        */
+    AMS_ROLE_CONCAT_PROJ = 6,/* concat_projection over [pool branch, aspp0] -> BN -> ReLU       */
+    AMS_ROLE_LOGITS = 7      /* logits/semantic: 1x1 + bias                                     */
+};
+enum { AMS_ACT_NONE = 0, AMS_ACT_RELU = 1, AMS_ACT_RELU6 = 2 };
+enum { AMS_DT_F32 = 0, AMS_DT_U8 = 1, AMS_DT_BF16 = 2, AMS_DT_I32 = 3, AMS_DT_F64 = 4 };
+enum {
+    AMS_MODE_FROZEN = 0,     /* BN with the statistics captured by ams_student_freeze, eps 1e-3 everywhere
+                                (reference utils/graph_utils.py:52-76, :362-369; the graph the edge runs) */
+    AMS_MODE_LIVE = 1        /* BN with batch statistics, per-layer eps (the live graph, is_training=True) */
+};
+
+/* one row of the layer table; offsets are in floats into the trainable / statistics arenas */
+typedef struct ams_layer_desc {
+    int32_t role;
+    int32_t cin, cout;
+    int32_t stride, rate;
+    int32_t act;
+    int32_t residual_from;   /* 1-based index of the layer whose output is added after BN, 0 = none */
+    float bn_eps;            /* < 0: no BN (bias instead) */
+    int64_t w_off;           /* weights    (trainable arena) */
+    int64_t gamma_off;       /* BN gamma   (trainable arena), or bias offset when bn_eps < 0 */
+    int64_t beta_off;        /* BN beta    (trainable arena) */
+    int64_t mean_off;        /* moving_mean     (statistics arena) */
+    int64_t var_off;         /* moving_variance (statistics arena) */
+} ams_layer_desc;
+
+typedef struct ams_student_config {
+    int32_t abi_version;     /* AMS_ABI_VERSION */
+    int32_t height, width;   /* frame size (reference: width = 2*height, run.py:71; not required here) */
+    int32_t max_batch;       /* largest B any call will pass */
+    int32_t num_classes;     /* 19 (Cityscapes) or 21 (VOC) */
+    int32_t n_selected;      /* K: size of the per-video class subset */
+    int32_t class_indices[32]; /* the K selected class ids, ascending (np.where(class_weights==1)) */
+    int32_t n_layers;
+    int32_t trainable;       /* 1: allocate activations/gradients/Adam state for ams_student_train_step */
+    int32_t act_dtype;       /* AMS_DT_F32 or AMS_DT_BF16: storage of inference activations */
+    int64_t n_trainable;     /* floats in the trainable arena (2 113 043 for Cityscapes) */
+    int64_t n_stats;         /* floats in the statistics arena (33 088) */
+    float bn_decay;          /* 0.9 (node BatchNorm/Const_2) */
+    float bn_eps_frozen;     /* 1e-3 */
+    float pixel_scale;       /* 1/127.5 as f32 (node mul_4/x) */
+} ams_student_config;
+
+typedef struct ams_student ams_student;
+
+/* arena regions addressable from the host side (ams_student_region) */
+enum {
+    AMS_REGION_PARAMS = 0,   /* trainable arena, f32[n_trainable], tf.trainable_variables() order      */
+    AMS_REGION_STATS = 1,    /* moving_mean / moving_variance, f32[n_stats]                             */
+    AMS_REGION_GRADS = 2,    /* d loss / d params, f32[n_trainable] (valid after a train step phase)    */
+    AMS_REGION_ADAM_M = 3,   /* f32[n_trainable]                                                         */
+    AMS_REGION_ADAM_V = 4,   /* f32[n_trainable]                                                         */
+    AMS_REGION_FROZEN = 5,   /* snapshot taken by ams_student_freeze: params followed by stats           */
+    AMS_REGION_BN_SYNC = 6,  /* per-layer BN partial sums exchanged across ranks in data-parallel steps  */
+    AMS_REGION_LOGITS = 7    /* low-resolution logits of the last forward, f32[B,h,w,num_classes]        */
+};
+
+const char* ams_last_error(void);
+int ams_abi_version(void);
+int ams_device_info(char* name_out, size_t name_cap, int32_t* n_cu, int64_t* hbm_bytes);
+
+/* ---- lifecycle: replaces SemanticNetwork.__init__ (SemanticNetwork.py:32-159) / create_student_v3 ------- */
+/* Bytes of device memory the engine needs for this configuration (activations, gradients, Adam, scratch). */
+int ams_student_arena_bytes(const ams_student_config* cfg, const ams_layer_desc* layers, size_t* bytes_out);
+/* Build the launch plan over caller-owned device memory `arena_dev` (>= arena_bytes, 256-byte aligned).
+ * Parameters are NOT initialised: write them through ams_student_region views, then call
+ * ams_student_freeze before the first AMS_MODE_FROZEN call. */
+int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* layers, void* arena_dev,
+                       size_t arena_bytes, ams_student** out);
+/* replaces SemanticNetwork.close_model (SemanticNetwork.py:716-717) */
+void ams_student_destroy(ams_student* s);
+/* byte offset into the arena and element count of a region */
+int ams_student_region(const ams_student* s, int32_t region, size_t* offset_bytes, size_t* n_elems);
+/* low-resolution feature size (h, w) = output stride 16 of the padded frame */
+int ams_student_lowres_size(const ams_student* s, int32_t* h, int32_t* w);
+
+/* ---- server -> edge hand-off: replaces save_to_frozen_graph / trim_graph_frozen / convert_batchnorms -----
+ * (SemanticNetwork.py:706-714, utils/graph_utils.py:52-126).  Snapshots params + moving statistics into the
+ * FROZEN region and folds every BN into (scale, shift) with eps = bn_eps_frozen.  Device-side, no protobuf. */
+int ams_student_freeze(ams_student* s, void* stream);
+
+/* ---- inference: replaces predict_input (SemanticNetwork.py:170-182), north-star `infer` ------------------
+ * frames_dev: [B,H,W,3] uint8 or float32; labels_out_dev: int32 [B,H,W], index into the K selected classes. */
+int ams_student_predict(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch,
+                        int32_t mode, int32_t* labels_out_dev, void* stream);
+
+/* ---- inference + metrics: replaces predict_with_metric (SemanticNetwork.py:196-213) ----------------------
+ * teacher_dev: uint8 [B,H,W] teacher class ids (ids outside the subset are ignored, weight 0).
+ * conf_mat_dev: int64 [K*K], rows = teacher, cols = student; OVERWRITTEN (the wrapper resets it per call).
+ * loss_dev: double[2] = {sum of per-pixel CE over valid pixels, number of valid pixels}; loss = [0]/[1]. */
+int ams_student_predict_with_metric(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch,
+                                    int32_t mode, const uint8_t* teacher_dev, int32_t* labels_out_dev,
+                                    int64_t* conf_mat_dev, double* loss_dev, void* stream);
+
+/* ---- phi-score: replaces calc_cross_miou's confusion matrix (SemanticNetwork.py:124-139, :184-194) -------
+ * labels_dev: uint8 [2,H,W] (before, after); conf_mat_dev: int64 [K*K] overwritten. */
+int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t n_pixels, int64_t* conf_mat_dev,
+                        void* stream);
+
+/* ---- one optimisation step: replaces sess.run({train, loss}) in _train (SemanticNetwork.py:253-260),
+ * north-star `train_step`.  forward (BN batch stats) -> masked mean CE over the K classes -> backward ->
+ * BN moving-average update (decay bn_decay) -> Adam (TF1 form, beta 0.9/0.999, eps 1e-8).
+ * mask_dev: NULL for 'full_model', else uint8[n_trainable]: entries with 0 are reverted after the Adam step
+ * while their moments still advance (utils/graph_utils.py:482-493).  loss_dev: double[2] as above (the loss of
+ * the forward pass, before the update).  Adam's step counter lives in the handle and is never reset. */
+int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
+                           int32_t batch, float lr, const uint8_t* mask_dev, double* loss_dev, void* stream);
+
+/* ---- data-parallel split of the same step (one process per GPU) -------------------------
+ * A sync callback is invoked on the host between phases whenever cross-rank sums are needed; it must
+ * all-reduce (sum) `count` float32 values at arena byte offset `offset_bytes` on `stream` order (the Python
+ * host wraps the arena in a torch tensor and calls torch.distributed.all_reduce -> RCCL).  With cb == NULL the
+ * step is the single-GPU step above.  Call sites: valid-pixel count (1 value), per-BN-layer (sum, sumsq)
+ * forward and (sum dy, sum dy*xhat) backward, and the flat gradient arena before Adam. */
+typedef int (*ams_allreduce_cb)(void* user, size_t offset_bytes, size_t count, int32_t dtype);
+int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t frames_dtype,
+                              const uint8_t* teacher_dev, int32_t batch, int32_t global_batch, float lr,
+                              const uint8_t* mask_dev, double* loss_dev, ams_allreduce_cb cb, void* user,
+                              void* stream);
+
+/* Adam step counter (t of SURVEY.md Appendix C.10); exposed so host-side checkpoints can carry it. */
+int ams_student_get_adam_step(const ams_student* s, int64_t* t);
+int ams_student_set_adam_step(ams_student* s, int64_t t);
+
+/* ---- model delta for the downlink: replaces the host loop of run.py:316-336 ------------------------------
+ * Casts the masked parameters to fp16 in trainable order: out_half_dev receives sum(mask) halves, and
+ * n_out_dev (int64) the count.  mask_dev NULL = all parameters. */
+int ams_pack_masked_fp16(const float* params_dev, const uint8_t* mask_dev, int64_t n, uint16_t* out_half_dev,
+                         int64_t* n_out_dev, void* stream);
+
+/* =====================================================================================================
+ * Kernel-level entry points.  Same kernels the engine launches, exposed one by one so that tests/ can
+ * check each against the oracle (SURVEY.md §4 test pyramid level 1).  x/y/... are device pointers.
+ * ===================================================================================================== */
+
+/* K1+K2: pad(127.5) -> x/127.5-1 -> dense 3x3 stride 2 SAME (3 -> cout) -> y*scale+shift -> act.
+ * scale/shift NULL: raw conv output.  stats_dev != NULL: also emit per-channel shifted (sum, sumsq) partials. */
+int ams_k_stem_conv(const void* frames, int32_t frames_dtype, int32_t B, int32_t H, int32_t W, const float* w /*[3,3,3,cout]*/,
+                    int32_t cout, const float* scale, const float* shift, int32_t act, float pixel_scale,
+                    float* y /*[B,Ho,Wo,cout]*/, void* stream);
+
+/* K3: depthwise 3x3, NHWC, SAME, stride 1|2, rate 1|2 -> y*scale+shift -> act (scale NULL: raw). */
+int ams_k_depthwise3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w /*[3,3,C,1]*/,
+                       int32_t stride, int32_t rate, const float* scale, const float* shift, int32_t act,
+                       float* y, void* stream);
+
+/* K4: 1x1 conv as GEMM: y[M,N] = act((x[M,K] @ w[K,N] + img_bias[row/rows_per_img]) * scale + shift) + res.
+ * Any of img_bias/scale/shift/res may be NULL.  trans_w != 0: w is given as [N,K] (dgrad). */
+int ams_k_pointwise(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w,
+                    const float* img_bias, int64_t rows_per_img, const float* scale, const float* shift,
+                    int32_t act, const float* res, float* y, void* stream);
+
+/* K7: global average pool [B,HW,C] -> [B,C] (two-stage, deterministic); scratch >= ams_k_global_mean_scratch floats. */
+int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,
+                      void* stream);
+size_t ams_k_global_mean_scratch(int32_t B, int32_t C);
+
+/* K9-K12: bilinear(align_corners) upsample of low-res logits to HxW fused with class gather, argmax and
+ * (when teacher != NULL) confusion matrix + CE loss sums.  Full-resolution logits are never written. */
+int ams_k_upsample_argmax(const float* logits /*[B,h,w,NC]*/, int32_t B, int32_t h, int32_t w, int32_t NC,
+                          const int32_t* class_idx_host, int32_t K, int32_t H, int32_t W, const uint8_t* teacher,
+                          int32_t* labels_out, int64_t* conf_mat, double* loss, void* stream);
+
+/* K11 backward: d loss / d low-res logits (zeros for unselected classes); loss_and_count_dev: the double[2]
+ * written by ams_k_upsample_argmax ([1] = number of valid pixels, the mean's denominator).
+ * class_idx_host (here and above): HOST array of the K selected class ids; it travels by value. */
+int ams_k_ce_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t NC, const int32_t* class_idx_host,
+                  int32_t K, int32_t H, int32_t W, const uint8_t* teacher, const double* loss_and_count_dev,
+                  float* dlogits, void* stream);
+
+/* K13: weight gradient of a 1x1 conv: dw[K,N] = x[M,K]^T @ dy[M,N]. scratch: >= ams_k_pointwise_wgrad_scratch floats */
+int ams_k_pointwise_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw,
+                          float* scratch, size_t scratch_floats, void* stream);
+size_t ams_k_pointwise_wgrad_scratch(int64_t M, int32_t K, int32_t N);
+
+/* K13: depthwise backward: dx (input gradient) and dw[3,3,C,1]. */
+int ams_k_depthwise3x3_dgrad(const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, const float* w,
+                             int32_t stride, int32_t rate, float* dx, void* stream);
+int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t H, int32_t W, int32_t C,
+                             int32_t stride, int32_t rate, float* dw, float* scratch, size_t scratch_floats,
+                             void* stream);
+
+/* K14-K16: fused Adam + coordinate-descent mask over a flat arena (TF1 Adam, Appendix C.10). */
+int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t,
+               float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMS_HIP_H */

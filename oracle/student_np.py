@@ -1,0 +1,162 @@
+"""Independent NumPy restatement of the student forward pass, metric path and Adam/EMA update.
+TEST INFRASTRUCTURE ONLY (see oracle/student_torch.py for the rules and the "parity unpinned" note).
+
+Written tap-by-tap with explicit slicing (no conv library), so that it shares no code with
+oracle/student_torch.py; tests/test_oracle_cpu.py requires the two to agree.  Cites:
+model.meta nodes via SURVEY.md Appendix A, TF op semantics via Appendix C, and reference
+utils/graph_utils.py:373-408 (class gather / argmax / CE), SemanticNetwork.py:96-115 (frozen metric
+path), utils/graph_utils.py:52-76 + :362-369 (frozen BN, eps 1e-3).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ams_amd import spec as S
+
+
+def _pad_same(x: np.ndarray, k: int, stride: int, rate: int) -> np.ndarray:
+    _, pt, pb = S.same_pad(x.shape[1], k, stride, rate)
+    _, pl, pr = S.same_pad(x.shape[2], k, stride, rate)
+    return np.pad(x, ((0, 0), (pt, pb), (pl, pr), (0, 0)))
+
+
+def conv3x3_dense(x, w, stride):
+    """NHWC dense conv, weights HWIO, SAME."""
+    b, h, wd, _ = x.shape
+    oh = S.same_pad(h, 3, stride, 1)[0]
+    ow = S.same_pad(wd, 3, stride, 1)[0]
+    xp = _pad_same(x, 3, stride, 1)
+    out = np.zeros((b, oh, ow, w.shape[3]), dtype=x.dtype)
+    for i in range(3):
+        for j in range(3):
+            patch = xp[:, i:i + (oh - 1) * stride + 1:stride, j:j + (ow - 1) * stride + 1:stride, :]
+            out += patch @ w[i, j]
+    return out
+
+
+def depthwise3x3(x, w, stride, rate):
+    """NHWC depthwise conv, weights [3,3,C,1], SAME; rate 2 == SpaceToBatchND/VALID/BatchToSpaceND."""
+    b, h, wd, c = x.shape
+    oh = S.same_pad(h, 3, stride, rate)[0]
+    ow = S.same_pad(wd, 3, stride, rate)[0]
+    xp = _pad_same(x, 3, stride, rate)
+    out = np.zeros((b, oh, ow, c), dtype=x.dtype)
+    for i in range(3):
+        for j in range(3):
+            r0, c0 = i * rate, j * rate
+            patch = xp[:, r0:r0 + (oh - 1) * stride + 1:stride, c0:c0 + (ow - 1) * stride + 1:stride, :]
+            out += patch * w[i, j, :, 0]
+    return out
+
+
+def batch_norm(x, gamma, beta, mean, var, eps):
+    return (x - mean) * (1.0 / np.sqrt(var + eps)) * gamma + beta
+
+
+def resize_bilinear_align_corners(x, out_h, out_w):
+    b, in_h, in_w, c = x.shape
+
+    def taps(n_in, n_out):
+        scale = np.float32((n_in - 1) / (n_out - 1)) if n_out > 1 else np.float32(0)
+        src = np.arange(n_out, dtype=np.float32) * scale
+        lo = np.floor(src).astype(np.int64)
+        return lo, np.minimum(lo + 1, n_in - 1), (src - lo).astype(x.dtype)
+
+    y0, y1, ty = taps(in_h, out_h)
+    x0, x1, tx = taps(in_w, out_w)
+    tx = tx[None, None, :, None]
+    ty = ty[None, :, None, None]
+    tl, tr = x[:, y0][:, :, x0], x[:, y0][:, :, x1]
+    bl, br = x[:, y1][:, :, x0], x[:, y1][:, :, x1]
+    top = tl + (tr - tl) * tx
+    bot = bl + (br - bl) * tx
+    return top + (bot - top) * ty
+
+
+def forward_lowres(variables: Dict[str, np.ndarray], frames: np.ndarray, mode: str = "frozen",
+                   num_classes: int = 19, dtype=np.float32, batch_stats: Optional[dict] = None) -> np.ndarray:
+    spec = S.build_spec(num_classes)
+    p = {k: np.asarray(v, dtype=dtype) for k, v in variables.items()}
+    x = np.asarray(frames, dtype=dtype)
+    x = np.pad(x, ((0, 0), (0, 1), (0, 1), (0, 0)), constant_values=S.PAD_VALUE)
+    x = x * dtype(np.float32(S.PIXEL_SCALE)) - dtype(1.0)
+
+    def bn_act(y, l):
+        g, bta = p[l.scope + "/BatchNorm/gamma:0"], p[l.scope + "/BatchNorm/beta:0"]
+        if mode == "frozen":
+            y = batch_norm(y, g, bta, p[l.scope + "/BatchNorm/moving_mean:0"],
+                           p[l.scope + "/BatchNorm/moving_variance:0"], dtype(S.BN_EPS_FROZEN))
+        else:
+            mu = y.mean(axis=(0, 1, 2))
+            var = ((y - mu) ** 2).mean(axis=(0, 1, 2))
+            if batch_stats is not None:
+                n = y.shape[0] * y.shape[1] * y.shape[2]
+                batch_stats[l.scope] = (mu, var * (n / max(n - 1, 1)))
+            y = batch_norm(y, g, bta, mu, var, dtype(l.bn_eps))
+        if l.act == "relu6":
+            y = np.clip(y, 0, 6)
+        elif l.act == "relu":
+            y = np.maximum(y, 0)
+        return y
+
+    outs = {0: x}
+    backbone = [l for l in spec.layers if l.scope.startswith("MobilenetV2")]
+    for l in backbone:
+        w = p[l.weight_name]
+        xin = outs[l.idx - 1]
+        if l.kind == "dw":
+            y = depthwise3x3(xin, w, l.stride, l.rate)
+        elif l.k == 3:
+            y = conv3x3_dense(xin, w, l.stride)
+        else:
+            y = xin @ w[0, 0]
+        y = bn_act(y, l)
+        if l.residual_from is not None:
+            y = y + outs[l.residual_from]
+        outs[l.idx] = y
+    feat = outs[backbone[-1].idx]
+    lp, la, lc, ll = spec.layers[-4:]
+    pool = bn_act(feat.mean(axis=(1, 2), keepdims=True) @ p[lp.weight_name][0, 0], lp)
+    pool = np.broadcast_to(pool, feat.shape[:3] + (pool.shape[-1],))
+    aspp = bn_act(feat @ p[la.weight_name][0, 0], la)
+    proj = bn_act(np.concatenate([pool, aspp], axis=-1) @ p[lc.weight_name][0, 0], lc)
+    return proj @ p[ll.weight_name][0, 0] + p[ll.scope + "/biases:0"]
+
+
+def predict_with_metric(variables, frames, labels_teacher, class_indices: Sequence[int], mode="frozen",
+                        num_classes: int = 19, dtype=np.float32):
+    """(labels int32 [B,H,W], conf_mat f64 [K,K], loss) — frozen metric path of SemanticNetwork.py:96-115."""
+    ci = np.asarray(class_indices)
+    k = len(ci)
+    low = forward_lowres(variables, frames, mode, num_classes, dtype)
+    full = resize_bilinear_align_corners(low, frames.shape[1], frames.shape[2])
+    z = full[..., ci]
+    pred = np.argmax(z, axis=-1).astype(np.int32)
+    lab = np.asarray(labels_teacher).astype(np.float32).astype(np.int32)
+    onehot = (lab[..., None] == np.arange(num_classes)).astype(dtype)     # out-of-range -> all-zero row
+    sel = onehot[..., ci]
+    target = np.argmax(sel, axis=-1)
+    weight = sel.sum(axis=-1)
+    cm = np.zeros((k, k), dtype=np.float64)
+    np.add.at(cm, (target.reshape(-1), pred.reshape(-1)), weight.reshape(-1).astype(np.float64))
+    zmax = z.max(axis=-1, keepdims=True)
+    lse = np.log(np.exp(z - zmax).sum(axis=-1)) + zmax[..., 0]
+    pixel = lse - (z * sel).sum(axis=-1)
+    valid = weight > 0
+    loss = float(pixel[valid].mean()) if valid.any() else float("nan")
+    return pred, cm, loss
+
+
+def adam_step(w, g, m, v, lr, beta1_power, beta2_power, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer dense apply (Appendix C.10). Returns (w, m, v)."""
+    lr_t = lr * np.sqrt(1.0 - beta2_power) / (1.0 - beta1_power)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    return w - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+def ema_update(moving, stat, decay=np.float32(S.BN_DECAY)):
+    """AssignMovingAvg: moving -= (moving - stat) * (1 - decay), all in f32."""
+    return moving - (moving - stat) * (np.float32(1.0) - np.float32(decay))

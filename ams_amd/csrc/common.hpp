@@ -12,6 +12,8 @@ namespace ams {
 
 // ---- error plumbing ------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+// per-launch profiling hook: launchers name their main kernel (as rocprofv3 prints it, minus namespace/arguments)
+void note_kernel(const char* name);
 
 #define AMS_CHECK_HIP(expr)                                                                   \
     do {                                                                                      \

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 
+#include <string>
 #include <vector>
 
 #include "kernels.hpp"
@@ -20,6 +21,31 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* last_error() { return g_err; }
+
+// ---- per-launch profiler (HIP events on the launch stream; bench.py's roofline leg) --------------------
+static thread_local const char* g_kname = nullptr;
+void note_kernel(const char* name) { if (!g_kname) g_kname = name; }
+
+struct ProfRec { std::string name; int layer; double bytes; hipEvent_t e0, e1; };
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void clear() {
+        for (auto& r : recs) { pool.push_back(r.e0); pool.push_back(r.e1); }
+        recs.clear();
+    }
+    ~Profiler() {
+        clear();
+        for (auto e : pool) if (e) (void)hipEventDestroy(e);
+    }
+};
 
 struct LayerRt {
     ams_layer_desc d;
@@ -77,6 +103,8 @@ struct ams_student {
     int64_t* conf_buf = nullptr;
     int64_t adam_t = 0;
     bool frozen_ready = false;
+    Profiler prof;
+    hipEvent_t prof_e0 = nullptr;
 };
 
 namespace ams {
@@ -238,6 +266,33 @@ static PwArgs pw_args(const float* x, int64_t M, int K, int ldx, const float* w,
 
 #define RUN(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+static inline void prof_begin(ams_student* s, hipStream_t st) {
+    g_kname = nullptr;
+    if (!s->prof.on) return;
+    s->prof_e0 = s->prof.get();
+    (void)hipEventRecord(s->prof_e0, st);
+}
+static inline void prof_end(ams_student* s, hipStream_t st, int layer, double bytes) {
+    if (!s->prof.on) return;
+    hipEvent_t e1 = s->prof.get();
+    (void)hipEventRecord(e1, st);
+    s->prof.recs.push_back(ProfRec{g_kname ? g_kname : "?", layer, bytes, s->prof_e0, e1});
+}
+// launch + profile: LAYER = 1-based layer index (0 = not tied to a layer), BYTES = algorithmic HBM bytes of the launch
+#define RUNK(LAYER, BYTES, expr)                                   \
+    do {                                                           \
+        prof_begin(s, st);                                         \
+        int _rc = (expr);                                          \
+        prof_end(s, st, (LAYER), (double)(BYTES));                 \
+        if (_rc) return _rc;                                       \
+    } while (0)
+
+// algorithmic bytes (f32 storage): every operand read once, every result written once
+static inline double pw_bytes(const PwArgs& a) {
+    return 4.0 * ((double)a.M * (a.K + a.N + (a.res ? a.N : 0)) + (double)a.Kw * a.N);
+}
+static inline double dw_bytes(const LayerRt& l, int B) { return 4.0 * ((double)B * (l.px_in + l.px_out) * l.d.cin + 9.0 * l.d.cin); }
+
 struct SyncCtx { ams_allreduce_cb cb; void* user; ams_student* s; };
 
 static int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream_t) {
@@ -257,8 +312,9 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
     int cur_i = 0;
     {
         LayerRt& l = s->L[1];
-        RUN(launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, l.fscale, l.fshift, l.d.act, c.pixel_scale,
-                        cur, st));
+        const double bytes = (double)B * c.height * c.width * 3 * (dtype == AMS_DT_U8 ? 1 : 4) + 4.0 * B * l.px_out * l.d.cout;
+        RUNK(1, bytes, launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, l.fscale, l.fshift, l.d.act,
+                                   c.pixel_scale, cur, st));
     }
     auto other = [&](int avoid0, int avoid1) { for (int k = 0; k < 4; ++k) if (k != avoid0 && k != avoid1) return k; return -1; };
     int i = 2;
@@ -272,15 +328,15 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             const int o = other(cur_i, -1);
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
-            RUN(launch_pointwise(a, st));
+            RUNK(i, pw_bytes(a), launch_pointwise(a, st));
             x = s->act[o]; x_i = o; ++i;
         }
         {
             LayerRt& l = s->L[i];
             AMS_REQUIRE(l.d.role == AMS_ROLE_DEPTHWISE, "engine: expected depthwise at layer %d", i);
             const int o = other(cur_i, x_i);
-            RUN(launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, l.fscale, l.fshift, l.d.act,
-                                 s->act[o], st));
+            RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, l.fscale,
+                                                     l.fshift, l.d.act, s->act[o], st));
             x = s->act[o]; x_i = o; ++i;
         }
         {
@@ -290,34 +346,34 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
             if (l.d.residual_from) { a.res = block_in; a.ldr = l.d.cout; }
-            RUN(launch_pointwise(a, st));
+            RUNK(i, pw_bytes(a), launch_pointwise(a, st));
             cur = s->act[o]; cur_i = o; ++i;
         }
     }
     // ---- head -------------------------------------------------------------------------------------------
     LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];
     const int64_t HW = (int64_t)s->h * s->w, M = (int64_t)B * HW;
-    RUN(launch_global_mean(cur, B, HW, lp.d.cin, s->pooled, s->scratch, st));
+    RUNK(s->iPool, 4.0 * M * lp.d.cin, launch_global_mean(cur, B, HW, lp.d.cin, s->pooled, s->scratch, st));
     {   // image_pooling conv + BN + ReLU on the pooled vector
         PwArgs a = pw_args(s->pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, s->pool_a, lp.d.cout);
         a.scale = lp.fscale; a.shift = lp.fshift; a.act = lp.d.act;
-        RUN(launch_pointwise(a, st));
+        RUNK(s->iPool, pw_bytes(a), launch_pointwise(a, st));
         // the broadcast pool branch enters concat_projection as a per-image bias: W_proj[0:256]^T . pool
         PwArgs b = pw_args(s->pool_a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, s->img_bias, lc.d.cout);
-        RUN(launch_pointwise(b, st));
+        RUNK(s->iProj, pw_bytes(b), launch_pointwise(b, st));
     }
     const int o1 = other(cur_i, -1), o2 = other(cur_i, o1);
     {
         PwArgs a = pw_args(cur, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, s->act[o1], la.d.cout);
         a.scale = la.fscale; a.shift = la.fshift; a.act = la.d.act;
-        RUN(launch_pointwise(a, st));
+        RUNK(s->iAspp, pw_bytes(a), launch_pointwise(a, st));
         PwArgs b = pw_args(s->act[o1], M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout,
                            s->act[o2], lc.d.cout);
         b.img_bias = s->img_bias; b.rows_per_img = HW; b.scale = lc.fscale; b.shift = lc.fshift; b.act = lc.d.act;
-        RUN(launch_pointwise(b, st));
+        RUNK(s->iProj, pw_bytes(b), launch_pointwise(b, st));
         PwArgs d = pw_args(s->act[o2], M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits, 32);
         d.shift = P + ll.d.gamma_off;      // biases
-        RUN(launch_pointwise(d, st));
+        RUNK(s->iLogits, pw_bytes(d), launch_pointwise(d, st));
     }
     return AMS_OK;
 }
@@ -329,13 +385,13 @@ static int bn_train(ams_student* s, LayerRt& l, int64_t M_local, double n_global
                     const float* res, hipStream_t st) {
     const ams_student_config& c = s->cfg;
     const float* center = s->stats + l.d.mean_off;       // shifted sums: moving_mean is a good, rank-identical centre
-    RUN(launch_colstats(l.z, M_local, l.d.cout, center, l.fsums, s->scratch, st));
+    RUNK(0, 4.0 * M_local * l.d.cout, launch_colstats(l.z, M_local, l.d.cout, center, l.fsums, s->scratch, st));
     RUN(sync_doubles(sc, l.fsums, 2 * (size_t)l.d.cout, st));
     const float omd = 1.0f - c.bn_decay;
     RUN(launch_bn_finalize(l.fsums, n_global, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
                            update_ema ? s->stats + l.d.mean_off : nullptr, update_ema ? s->stats + l.d.var_off : nullptr,
                            l.scale, l.shift, l.mean, l.rstd, st));
-    RUN(launch_bn_act(l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, res, l.a, st));
+    RUNK(0, 4.0 * M_local * l.d.cout * (res ? 3 : 2), launch_bn_act(l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, res, l.a, st));
     return AMS_OK;
 }
 
@@ -354,11 +410,11 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
         LayerRt& l = s->L[i];
         const float* x = s->L[i - 1].a;
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
-            RUN(launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, nullptr, nullptr, AMS_ACT_NONE,
-                                 l.z, st));
+            RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, nullptr, nullptr,
+                                                     AMS_ACT_NONE, l.z, st));
         } else {
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, l.z, l.d.cout);
-            RUN(launch_pointwise(a, st));
+            RUNK(0, pw_bytes(a), launch_pointwise(a, st));
         }
         const float* res = l.d.residual_from ? s->L[l.d.residual_from].a : nullptr;
         RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st));
@@ -369,22 +425,22 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
     RUN(launch_global_mean(feat, B, HW, lp.d.cin, s->pooled, s->scratch, st));
     {
         PwArgs a = pw_args(s->pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, lp.z, lp.d.cout);
-        RUN(launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
         RUN(bn_train(s, lp, B, (double)global_B, update_ema, sc, nullptr, st));     // statistics over the batch only
         PwArgs b = pw_args(lp.a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, s->img_bias, lc.d.cout);
-        RUN(launch_pointwise(b, st));
+        RUNK(0, pw_bytes(b), launch_pointwise(b, st));
     }
     {
         PwArgs a = pw_args(feat, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, la.z, la.d.cout);
-        RUN(launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
         RUN(bn_train(s, la, M, (double)global_B * HW, update_ema, sc, nullptr, st));
         PwArgs b = pw_args(la.a, M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout, lc.z, lc.d.cout);
         b.img_bias = s->img_bias; b.rows_per_img = HW;
-        RUN(launch_pointwise(b, st));
+        RUNK(0, pw_bytes(b), launch_pointwise(b, st));
         RUN(bn_train(s, lc, M, (double)global_B * HW, update_ema, sc, nullptr, st));
         PwArgs d = pw_args(lc.a, M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits, 32);
         d.shift = P + ll.d.gamma_off;
-        RUN(launch_pointwise(d, st));
+        RUNK(0, pw_bytes(d), launch_pointwise(d, st));
     }
     return AMS_OK;
 }
@@ -395,11 +451,13 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
 // BN backward of layer l given da (gradient wrt the layer's activated output): writes dz into s->dz, dgamma/dbeta into grads
 static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_local, double n_global, const SyncCtx* sc,
                        hipStream_t st) {
-    RUN(launch_bn_bwd_reduce(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch, st));
+    RUNK(0, 8.0 * M_local * l.d.cout,
+         launch_bn_bwd_reduce(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch, st));
     RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
     RUN(launch_bn_bwd_coef(l.bsums, n_global, l.d.cout, s->params + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC,
                            s->grads + l.d.gamma_off, s->grads + l.d.beta_off, st));
-    RUN(launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, s->dz, st));
+    RUNK(0, 12.0 * M_local * l.d.cout,
+         launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, s->dz, st));
     return AMS_OK;
 }
 
@@ -408,7 +466,8 @@ static int pw_wgrad(ams_student* s, const float* x, int ldx, int K, const float*
     WgArgs a;
     a.x = x; a.ldx = ldx; a.K = K; a.dy = dy; a.ldy = ldy; a.N = N; a.M = M; a.dw = dw;
     a.scratch = s->scratch; a.scratch_floats = s->scratch_floats;
-    return launch_pointwise_wgrad(a, st);
+    RUNK(0, 4.0 * ((double)M * (K + N) + (double)K * N), launch_pointwise_wgrad(a, st));
+    return AMS_OK;
 }
 
 // dx[M,K] = dy[M,N] @ w[K,N]^T (+ extras through the epilogue)
@@ -437,7 +496,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     {
         PwArgs a = dgrad_args(s->dlogits, M, 32, 32, P + ll.d.w_off, ll.d.cin, lc.da);
         a.Kw = NC; a.w_sn = NC;        // w is [cin][NC]; dlogits columns >= NC are zero
-        RUN(launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
     }
     // concat_projection
     RUN(bn_backward(s, lc, lc.da, M, nHW, sc, st));
@@ -446,14 +505,14 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     RUN(pw_wgrad(s, la.a, la.d.cout, la.d.cout, s->dz, lc.d.cout, lc.d.cout, M, G + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, st));
     {
         PwArgs a = dgrad_args(s->dz, M, lc.d.cout, lc.d.cout, Wc_bot, la.d.cout, la.da);
-        RUN(launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
     }
     // pool branch: the per-image bias collects the column sums of dz_proj
     RUN(launch_image_colsum(s->dz, B, HW, lc.d.cout, lc.d.cout, s->d_img_bias, s->scratch, st));
     RUN(pw_wgrad(s, lp.a, lp.d.cout, lp.d.cout, s->d_img_bias, lc.d.cout, lc.d.cout, B, G + lc.d.w_off, st));
     {
         PwArgs a = dgrad_args(s->d_img_bias, B, lc.d.cout, lc.d.cout, Wc_top, lp.d.cout, s->d_pool_a);
-        RUN(launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
     }
     {   // BN (over the batch) + ReLU of the pool branch; its dz goes to d_pool_z instead of s->dz (still in use? no: consumed)
         RUN(launch_bn_bwd_reduce(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.mean, lp.rstd, lp.bsums, s->scratch, st));
@@ -467,7 +526,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         RUN(launch_fill(s->tmp_c + 2048, lp.d.cin, (float)(1.0 / (double)HW), st));
         a.shift = s->tmp_c + 3072;
         RUN(launch_fill(s->tmp_c + 3072, lp.d.cin, 0.f, st));
-        RUN(launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
     }
     // aspp0: its input gradient also receives the pooled gradient, broadcast over the image
     LayerRt& lf = s->L[s->n_backbone];
@@ -476,7 +535,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     {
         PwArgs a = dgrad_args(s->dz, M, la.d.cout, la.d.cout, P + la.d.w_off, la.d.cin, lf.da);
         a.img_bias = s->d_pooled; a.rows_per_img = HW;
-        RUN(launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
     }
     // backbone, last layer to first
     for (int i = s->n_backbone; i >= 1; --i) {
@@ -490,9 +549,9 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         }
         LayerRt& prev = s->L[i - 1];
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
-            RUN(launch_depthwise_wgrad(prev.a, s->dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off, s->scratch,
-                                       s->scratch_floats, st));
-            RUN(launch_depthwise_dgrad(s->dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
+            RUNK(i, dw_bytes(l, B), launch_depthwise_wgrad(prev.a, s->dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off,
+                                                           s->scratch, s->scratch_floats, st));
+            RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(s->dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
         } else {
             RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, s->dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, st));
             PwArgs a = dgrad_args(s->dz, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, prev.da);
@@ -500,7 +559,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) {
                 a.res = s->L[i + 2].da; a.ldr = l.d.cin;
             }
-            RUN(launch_pointwise(a, st));
+            RUNK(0, pw_bytes(a), launch_pointwise(a, st));
         }
     }
     return AMS_OK;
@@ -680,6 +739,30 @@ int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frame
                            float lr, const uint8_t* mask_dev, double* loss_dev, void* stream) {
     return ams_student_train_step_dp(s, frames_dev, frames_dtype, teacher_dev, batch, batch, lr, mask_dev, loss_dev, nullptr, nullptr,
                                      stream);
+}
+
+int ams_student_profile(ams_student* s, int32_t enable) {
+    AMS_REQUIRE(s, "profile: null student");
+    AMS_CHECK_HIP(hipDeviceSynchronize());
+    s->prof.clear();
+    s->prof.on = enable != 0;
+    return AMS_OK;
+}
+
+int ams_student_profile_read(ams_student* s, char* buf, size_t cap, size_t* needed) {
+    AMS_REQUIRE(s && needed, "profile_read: null pointer");
+    AMS_CHECK_HIP(hipDeviceSynchronize());
+    std::string out;
+    char line[256];
+    for (auto& r : s->prof.recs) {
+        float ms = 0.f;
+        AMS_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        snprintf(line, sizeof(line), "%s\t%d\t%.6f\t%.0f\n", r.name.c_str(), r.layer, ms, r.bytes);
+        out += line;
+    }
+    *needed = out.size() + 1;
+    if (buf && cap >= out.size() + 1) memcpy(buf, out.c_str(), out.size() + 1);
+    return AMS_OK;
 }
 
 int ams_student_get_adam_step(const ams_student* s, int64_t* t) {

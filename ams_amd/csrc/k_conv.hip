@@ -87,6 +87,7 @@ int launch_stem(const void* frames, int dtype, int B, int H, int W, const float*
     const int64_t total = (int64_t)B * Ho * Wo * (cout / 8);
     const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
     const size_t lds = 27 * cout * sizeof(float);
+    note_kernel(dtype == AMS_DT_U8 ? "stem_conv_kernel<unsigned char>" : "stem_conv_kernel<float>");
     if (dtype == AMS_DT_U8)
         hipLaunchKernelGGL(stem_conv_kernel<uint8_t>, dim3(grid), dim3(256), lds, st, (const uint8_t*)frames, B, H, W, w, cout,
                            scale, shift, act, pixel_scale, y, Ho, Wo, pt, pl);
@@ -132,6 +133,7 @@ int launch_stem_im2col(const void* frames, int dtype, int B, int H, int W, float
     same_pad(W + 1, 3, 2, 1, &Wo, &pl);
     const int64_t total = (int64_t)B * Ho * Wo * 8;
     const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
+    note_kernel("stem_im2col_kernel");
     if (dtype == AMS_DT_U8)
         hipLaunchKernelGGL(stem_im2col_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, (const uint8_t*)frames, B, H, W,
                            pixel_scale, out, Ho, Wo, pt, pl);
@@ -222,6 +224,7 @@ int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w,
     AMS_REQUIRE((scale == nullptr) == (shift == nullptr), "depthwise: scale and shift come together");
     const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
     const int threads = g.CG * g.slots;
+    note_kernel(stride == 2 ? "dw3x3_fwd_kernel<2, 1>" : rate == 2 ? "dw3x3_fwd_kernel<1, 2>" : "dw3x3_fwd_kernel<1, 1>");
     if (stride == 1 && rate == 1)
         hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 1>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
     else if (stride == 2)
@@ -283,6 +286,7 @@ int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const fl
     if (rc) return rc;
     const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
     const int threads = g.CG * g.slots;
+    note_kernel(stride == 2 ? "dw3x3_dgrad_kernel<2, 1>" : rate == 2 ? "dw3x3_dgrad_kernel<1, 2>" : "dw3x3_dgrad_kernel<1, 1>");
     if (stride == 1 && rate == 1)
         hipLaunchKernelGGL((dw3x3_dgrad_kernel<1, 1>), dim3(nblocks), dim3(threads), 0, st, dy, w, dx, g, nblocks);
     else if (stride == 2)
@@ -368,6 +372,7 @@ int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W,
     const int threads = g.CG * g.slots;
     const size_t lds = (size_t)g.slots * 9 * C * sizeof(float);
     AMS_REQUIRE(lds <= 64 * 1024, "depthwise wgrad: LDS %zu too large", lds);
+    note_kernel(stride == 2 ? "dw3x3_wgrad_kernel<2, 1>" : rate == 2 ? "dw3x3_wgrad_kernel<1, 2>" : "dw3x3_wgrad_kernel<1, 1>");
     if (stride == 1 && rate == 1)
         hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, 1>), dim3(blocks), dim3(threads), lds, st, x, dy, scratch, g, ppb);
     else if (stride == 2)

@@ -134,12 +134,14 @@ size_t colstats_scratch(int64_t M, int C) { (void)M; return (size_t)kMaxChunks *
 
 int launch_colstats(const float* z, int64_t M, int C, const float* center, double* sums, float* scratch, hipStream_t st) {
     OpStats op{z, center};
+    note_kernel("col_reduce_kernel<2, OpStats>");
     return run_col_reduce<2, OpStats, double>(op, M, 1, C, C, 1.0, scratch, sums, st);
 }
 
 int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift,
                          int act, const float* mean, const float* rstd, double* sums, float* scratch, hipStream_t st) {
     OpBnBwd op{da, z, scale, shift, mean, rstd, act};
+    note_kernel("col_reduce_kernel<2, OpBnBwd>");
     return run_col_reduce<2, OpBnBwd, double>(op, M, 1, C, C, 1.0, scratch, sums, st);
 }
 
@@ -272,6 +274,7 @@ int launch_bn_act(const float* z, int64_t M, int C, const float* scale, const fl
                   float* a, hipStream_t st) {
     AMS_REQUIRE(C % 4 == 0, "bn_act: C=%d must be a multiple of 4", C);
     const int64_t n4 = M * C / 4;
+    note_kernel("bn_act_kernel");
     hipLaunchKernelGGL(bn_act_kernel, dim3(stream_grid(n4)), dim3(256), 0, st, z, n4, C / 4, scale, shift, act, res, a);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
@@ -299,6 +302,7 @@ int launch_bn_bwd_apply(const float* da, const float* z, int64_t M, int C, const
                         const float* coefA, const float* coefB, const float* coefC, float* dz, hipStream_t st) {
     AMS_REQUIRE(C % 4 == 0, "bn_bwd_apply: C=%d must be a multiple of 4", C);
     const int64_t n4 = M * C / 4;
+    note_kernel("bn_bwd_apply_kernel");
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, st, da, z, n4, C / 4, scale, shift, act, coefA,
                        coefB, coefC, dz);
     AMS_CHECK_LAUNCH();
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t, float b1,
                 float b2, float eps, hipStream_t st) {
+    note_kernel("adam_kernel");
     hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n)), dim3(256), 0, st, p, g, m, v, mask, n, lr_t, b1, b2, eps);
     AMS_CHECK_LAUNCH();
     return AMS_OK;

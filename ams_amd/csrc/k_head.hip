@@ -132,6 +132,7 @@ int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, con
         AMS_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double) * 2, st));
     }
     const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
+    note_kernel("upsample_argmax_kernel");
     hipLaunchKernelGGL(upsample_argmax_kernel, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, logits, g, ct, teacher, labels,
                        (unsigned long long*)conf, loss);
     AMS_CHECK_LAUNCH();
@@ -227,6 +228,7 @@ int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32
     AMS_REQUIRE(ldd >= NC && ldd <= 256, "ce_grad: ldd=%d must hold %d classes", ldd, NC);
     const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
     const dim3 grid(w, h, B);
+    note_kernel(K <= 8 ? "ce_grad_kernel<8>" : K <= 20 ? "ce_grad_kernel<20>" : "ce_grad_kernel<32>");
     if (K <= 8)
         hipLaunchKernelGGL(ce_grad_kernel<8>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd);
     else if (K <= 20)

@@ -15,6 +15,8 @@
 //     so for N <= 320 the activations are read once; wider N (expand layers, small K) re-reads a small A tile
 //     from L2, with the n-tiles of one m-tile placed on the same XCD by xcd_remap().
 //   * epilogue fuses per-image bias (pool branch), BN scale/shift, ReLU/ReLU6 and the residual add.
+#include <string>
+
 #include "kernels.hpp"
 
 namespace ams {
@@ -123,6 +125,8 @@ static int launch_pw_t(const PwArgs& a, hipStream_t st) {
     const int64_t n_tiles_m = cdiv64(a.M, 64 * RM);
     const int64_t nblocks = n_tiles_m * n_tiles_n;
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) { set_error("pointwise: bad grid %lld", (long long)nblocks); return AMS_E_INVALID; }
+    static const std::string nm = "pw_gemm_f32<" + std::to_string(RM) + ", " + std::to_string(NT) + ">";
+    note_kernel(nm.c_str());
     hipLaunchKernelGGL((pw_gemm_f32<RM, NT>), dim3((unsigned)nblocks), dim3(256), 0, st, a, n_tiles_n, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
@@ -271,6 +275,8 @@ static int launch_wg_t(const WgArgs& a, int splits, hipStream_t st) {
     const int tiles_k = cdiv(a.K, 16 * VA), tiles_n = cdiv(a.N, 16 * VB);
     int64_t rows = cdiv64(a.M, splits);
     rows = (rows + 3) / 4 * 4;
+    static const std::string nm = "pw_wgrad_f32<" + std::to_string(VA) + ", " + std::to_string(VB) + ">";
+    note_kernel(nm.c_str());
     hipLaunchKernelGGL((pw_wgrad_f32<VA, VB>), dim3(splits, tiles_k * tiles_n), dim3(256), 0, st, a, tiles_k, tiles_n, rows);
     AMS_CHECK_LAUNCH();
     return AMS_OK;

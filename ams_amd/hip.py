@@ -59,6 +59,8 @@ SIGNATURES = {
     "ams_cross_confusion": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "ams_student_train_step": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _vp]),
     "ams_student_train_step_dp": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, ALLREDUCE_CB, _vp, _vp]),
+    "ams_student_profile": (C.c_int, [_vp, _i32]),
+    "ams_student_profile_read": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "ams_student_get_adam_step": (C.c_int, [_vp, C.POINTER(_i64)]),
     "ams_student_set_adam_step": (C.c_int, [_vp, _i64]),
     "ams_pack_masked_fp16": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
@@ -94,6 +96,9 @@ def lib() -> C.CDLL:
         raise AmsHipError(
             "HIP library %s not found: the AMS student has no CPU fallback. Build it with "
             "`make -C ams_amd/csrc` (hipcc --offload-arch=gfx950)." % path)
+    # libams_hip.so needs libamdhip64.so.7; PyTorch-ROCm bundles its own copy under the same soname.  Whichever is
+    # loaded first serves both, and device pointers are only valid inside one runtime instance: load torch first.
+    import torch  # noqa: F401
     handle = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)          # AttributeError here = header/library mismatch: fail loudly

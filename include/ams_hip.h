@@ -162,6 +162,13 @@ int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t fr
                               const uint8_t* mask_dev, double* loss_dev, ams_allreduce_cb cb, void* user,
                               void* stream);
 
+/* ---- measurement hook (bench.py roofline leg) -----------------------------------------------------------
+ * With profiling enabled every kernel launch of the engine is bracketed by HIP events on the launch stream.
+ * ams_student_profile_read synchronises and writes one line per launch: "kernel\tlayer\tms\talgorithmic_bytes\n"
+ * (kernel named as rocprofv3 prints it, without namespace and argument list).  `needed` receives the size. */
+int ams_student_profile(ams_student* s, int32_t enable);
+int ams_student_profile_read(ams_student* s, char* buf, size_t cap, size_t* needed);
+
 /* Adam step counter (t of SURVEY.md Appendix C.10); exposed so host-side checkpoints can carry it. */
 int ams_student_get_adam_step(const ams_student* s, int64_t* t);
 int ams_student_set_adam_step(ams_student* s, int64_t t);

@@ -1,0 +1,276 @@
+"""Kernel-level parity: every HIP kernel, called through the C ABI, against the CPU oracle's op of the same name.
+
+Tolerances: f32 kernels vs an f64 evaluation of the same math — relative error <= 2e-5 of the output scale for
+GEMM-like reductions (f32 round-off grows ~sqrt(K)), exact equality for integer outputs (labels, confusion
+matrix).  Sizes are ragged on purpose (M not a multiple of the tile, odd spatial sizes, K=24, N=19).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ams_amd import hip, spec as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return hip.lib()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(DEV).contiguous()
+
+
+_KEEP = []
+
+
+def PD(a, dtype=torch.float32):
+    """device copy kept alive until the end of the test session (a bare PD(a) frees the tensor at once)."""
+    t = dev(a, dtype)
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return P(t)
+
+
+def rel_err(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------ pointwise
+@pytest.mark.parametrize("M,K,N", [(1000, 16, 96), (4097, 96, 24), (513, 24, 144), (2145, 960, 320), (2145, 160, 960),
+                                   (300, 320, 256), (77, 256, 19), (3, 320, 256), (70000, 32, 16), (2145, 576, 160),
+                                   (129 * 257, 144, 32), (2145, 384, 64)])
+def test_pointwise_forward(lib, M, K, N):
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    shift = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    xd, wd, sd, hd, rd = dev(x), dev(w), dev(scale), dev(shift), dev(res)
+    y = torch.empty((M, N), device=DEV)
+    hip.check(lib.ams_k_pointwise(P(xd), M, K, P(wd), N, 0, None, 1, P(sd), P(hd), hip.ACT_RELU6, P(rd), P(y), stream()))
+    want = np.clip((x.astype(np.float64) @ w.astype(np.float64)) * scale + shift, 0, 6) + res
+    assert rel_err(y.cpu().numpy(), want) < 2e-5
+    # plain product, no epilogue
+    hip.check(lib.ams_k_pointwise(P(xd), M, K, P(wd), N, 0, None, 1, None, None, hip.ACT_NONE, None, P(y), stream()))
+    assert rel_err(y.cpu().numpy(), x.astype(np.float64) @ w.astype(np.float64)) < 2e-5
+
+
+def test_pointwise_image_bias_and_transposed_weights(lib):
+    rng = np.random.default_rng(5)
+    B, HW, K, N = 3, 715, 256, 256
+    M = B * HW
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / 16).astype(np.float32)
+    bias = rng.standard_normal((B, N)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    shift = rng.standard_normal(N).astype(np.float32)
+    y = torch.empty((M, N), device=DEV)
+    hip.check(lib.ams_k_pointwise(PD(x), M, K, PD(w), N, 0, PD(bias), HW, PD(scale), PD(shift),
+                                  hip.ACT_RELU, None, P(y), stream()))
+    want = np.maximum((x.astype(np.float64) @ w + np.repeat(bias, HW, axis=0)) * scale + shift, 0)
+    assert rel_err(y.cpu().numpy(), want) < 2e-5
+    # dgrad form: y = x @ wt^T with wt stored [N_out, K_in] = the forward weight [K_fwd, N_fwd]
+    wt = (rng.standard_normal((96, K)) / 16).astype(np.float32)          # forward weight [K_fwd=96, N_fwd=256]
+    y2 = torch.empty((M, 96), device=DEV)
+    hip.check(lib.ams_k_pointwise(PD(x), M, K, PD(wt), 96, 1, None, 1, None, None, hip.ACT_NONE, None, P(y2), stream()))
+    assert rel_err(y2.cpu().numpy(), x.astype(np.float64) @ wt.T.astype(np.float64)) < 2e-5
+
+
+@pytest.mark.parametrize("M,K,N", [(5000, 16, 96), (4097, 96, 24), (2145 * 2, 960, 320), (2145, 160, 960), (3, 320, 256),
+                                   (33000, 32, 16), (2145, 256, 19), (9000, 27, 32), (70000, 144, 24)])
+def test_pointwise_wgrad(lib, M, K, N):
+    rng = np.random.default_rng(M * 3 + K + N)
+    ldx = 32 if K == 27 else K
+    x = rng.standard_normal((M, ldx)).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    n_scr = lib.ams_k_pointwise_wgrad_scratch(M, K, N)
+    scr = torch.empty(n_scr, device=DEV)
+    dw = torch.full((K, N), np.nan, device=DEV)
+    if ldx != K:
+        pytest.skip("padded leading dimension is exercised through the engine's stem path")
+    hip.check(lib.ams_k_pointwise_wgrad(PD(x), PD(dy), M, K, N, P(dw), P(scr), n_scr, stream()))
+    want = x[:, :K].astype(np.float64).T @ dy.astype(np.float64)
+    assert rel_err(dw.cpu().numpy(), want) < 3e-5
+    # deterministic: a second run gives the same bits
+    dw2 = torch.empty((K, N), device=DEV)
+    hip.check(lib.ams_k_pointwise_wgrad(PD(x), PD(dy), M, K, N, P(dw2), P(scr), n_scr, stream()))
+    assert torch.equal(dw, dw2)
+
+
+# ------------------------------------------------------------------------------------------------ stem
+@pytest.mark.parametrize("H,W,dtype", [(32, 64, np.uint8), (37, 50, np.float32), (64, 128, np.uint8)])
+def test_stem_conv(lib, H, W, dtype):
+    rng = np.random.default_rng(H)
+    B = 2
+    frames = rng.integers(0, 256, (B, H, W, 3)).astype(dtype)
+    if dtype == np.float32:
+        frames = frames + rng.random((B, H, W, 3)).astype(np.float32) * 0.5
+    w = (rng.standard_normal((3, 3, 3, 32)) * 0.3).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 32).astype(np.float32)
+    shift = rng.standard_normal(32).astype(np.float32)
+    Ho, Wo = S.same_pad(H + 1, 3, 2, 1)[0], S.same_pad(W + 1, 3, 2, 1)[0]
+    y = torch.empty((B, Ho, Wo, 32), device=DEV)
+    fd = torch.as_tensor(frames).to(DEV)
+    hip.check(lib.ams_k_stem_conv(P(fd), hip.DT_U8 if dtype == np.uint8 else hip.DT_F32, B, H, W, PD(w), 32, PD(scale),
+                                  PD(shift), hip.ACT_RELU6, S.PIXEL_SCALE, P(y), stream()))
+    x = torch.as_tensor(frames.astype(np.float32)).permute(0, 3, 1, 2)
+    x = F.pad(x, (0, 1, 0, 1), value=127.5) * np.float32(S.PIXEL_SCALE) - 1.0
+    _, pt, pb = S.same_pad(H + 1, 3, 2, 1)
+    _, pl, pr = S.same_pad(W + 1, 3, 2, 1)
+    ref = F.conv2d(F.pad(x.double(), (pl, pr, pt, pb)), torch.as_tensor(w).double().permute(3, 2, 0, 1), stride=2)
+    ref = torch.clamp(ref * torch.as_tensor(scale).view(1, -1, 1, 1) + torch.as_tensor(shift).view(1, -1, 1, 1), 0, 6)
+    assert rel_err(y.cpu().numpy(), ref.permute(0, 2, 3, 1).numpy()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ depthwise
+@pytest.mark.parametrize("H,W,Cn,stride,rate", [(33, 65, 32, 1, 1), (33, 65, 96, 2, 1), (17, 33, 960, 1, 2), (20, 31, 144, 2, 1),
+                                                (9, 9, 576, 1, 1), (12, 10, 192, 1, 2), (65, 129, 24, 1, 1), (8, 8, 384, 2, 1)])
+def test_depthwise_forward_and_backward(lib, H, W, Cn, stride, rate):
+    rng = np.random.default_rng(H * W + Cn)
+    B = 2
+    x = rng.standard_normal((B, H, W, Cn)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cn, 1)) * 0.4).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cn).astype(np.float32)
+    shift = rng.standard_normal(Cn).astype(np.float32)
+    Ho, pt, pb = S.same_pad(H, 3, stride, rate)
+    Wo, pl, pr = S.same_pad(W, 3, stride, rate)
+    xd, wd = dev(x), dev(w)
+    y = torch.empty((B, Ho, Wo, Cn), device=DEV)
+    hip.check(lib.ams_k_depthwise3x3(P(xd), B, H, W, Cn, P(wd), stride, rate, PD(scale), PD(shift), hip.ACT_RELU6, P(y),
+                                     stream()))
+    xt = torch.as_tensor(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.as_tensor(w).double().permute(2, 3, 0, 1).requires_grad_(True)
+    raw = F.conv2d(F.pad(xt, (pl, pr, pt, pb)), wt, stride=stride, dilation=rate, groups=Cn)
+    ref = torch.clamp(raw * torch.as_tensor(scale).view(1, -1, 1, 1) + torch.as_tensor(shift).view(1, -1, 1, 1), 0, 6)
+    assert rel_err(y.cpu().numpy(), ref.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    # raw output (training-mode forward)
+    hip.check(lib.ams_k_depthwise3x3(P(xd), B, H, W, Cn, P(wd), stride, rate, None, None, hip.ACT_NONE, P(y), stream()))
+    assert rel_err(y.cpu().numpy(), raw.detach().permute(0, 2, 3, 1).numpy()) < 1e-5
+    # backward
+    dy = rng.standard_normal((B, Ho, Wo, Cn)).astype(np.float32)
+    raw.backward(torch.as_tensor(dy).double().permute(0, 3, 1, 2))
+    dx = torch.empty((B, H, W, Cn), device=DEV)
+    hip.check(lib.ams_k_depthwise3x3_dgrad(PD(dy), B, H, W, Cn, P(wd), stride, rate, P(dx), stream()))
+    assert rel_err(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy()) < 1e-5
+    dw = torch.empty((3, 3, Cn, 1), device=DEV)
+    scr = torch.empty(1024 * 9 * Cn + 16, device=DEV)
+    hip.check(lib.ams_k_depthwise3x3_wgrad(P(xd), PD(dy), B, H, W, Cn, stride, rate, P(dw), P(scr), scr.numel(), stream()))
+    assert rel_err(dw.cpu().numpy(), wt.grad.permute(2, 3, 0, 1).numpy()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+def test_global_mean(lib):
+    rng = np.random.default_rng(0)
+    B, HW, Cn = 3, 2145, 320
+    x = rng.standard_normal((B, HW, Cn)).astype(np.float32) + 0.5
+    y = torch.empty((B, Cn), device=DEV)
+    n = lib.ams_k_global_mean_scratch(B, Cn)
+    scr = torch.empty(n, device=DEV)
+    hip.check(lib.ams_k_global_mean(PD(x), B, HW, Cn, P(y), P(scr), n, stream()))
+    assert rel_err(y.cpu().numpy(), x.astype(np.float64).mean(axis=1)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ head
+def _np_bilinear(x, H, W):
+    from oracle.student_np import resize_bilinear_align_corners
+    return resize_bilinear_align_corners(x, H, W)
+
+
+@pytest.mark.parametrize("h,w,H,W,cls", [(5, 9, 64, 128, [0, 1, 2, 10, 11, 13]), (3, 5, 32, 64, [2, 8, 9, 10, 11, 13]),
+                                         (9, 17, 128, 256, list(range(19))), (4, 7, 50, 90, [0, 15])])
+def test_upsample_argmax_metrics_and_ce_grad(lib, h, w, H, W, cls):
+    rng = np.random.default_rng(h * w)
+    B, NC, K = 2, 19, len(cls)
+    logits = (rng.standard_normal((B, h, w, NC)) * 2).astype(np.float32)
+    teacher = rng.integers(0, 19, (B, H, W)).astype(np.uint8)
+    teacher[rng.random((B, H, W)) < 0.1] = 255
+    ci = (C.c_int32 * K)(*cls)
+    ld, td = dev(logits), torch.as_tensor(teacher).to(DEV)
+    labels = torch.empty((B, H, W), dtype=torch.int32, device=DEV)
+    conf = torch.empty(K * K, dtype=torch.int64, device=DEV)
+    loss = torch.empty(2, dtype=torch.float64, device=DEV)
+    hip.check(lib.ams_k_upsample_argmax(P(ld), B, h, w, NC, ci, K, H, W, P(td), P(labels), P(conf), P(loss), stream()))
+    full = _np_bilinear(logits, H, W)[..., cls]                       # f32, same unfused lerp order as the kernel
+    want_lab = np.argmax(full, axis=-1)
+    assert np.array_equal(labels.cpu().numpy(), want_lab)              # bit-exact label map
+    lut = np.full(256, -1)
+    lut[cls] = np.arange(K)
+    tgt = lut[teacher]
+    valid = tgt >= 0
+    cm = np.zeros((K, K), dtype=np.int64)
+    np.add.at(cm, (tgt[valid], want_lab[valid]), 1)
+    assert np.array_equal(conf.cpu().numpy().reshape(K, K), cm)
+    z = full.astype(np.float64)
+    lse = np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1)) + z.max(-1)
+    pix = lse - np.take_along_axis(z, np.maximum(tgt, 0)[..., None], -1)[..., 0]
+    got = loss.cpu().numpy()
+    assert got[1] == valid.sum()
+    assert got[0] / got[1] == pytest.approx(pix[valid].mean(), rel=1e-5)
+    # labels only (no teacher): same labels, metric buffers untouched
+    labels2 = torch.empty_like(labels)
+    hip.check(lib.ams_k_upsample_argmax(P(ld), B, h, w, NC, ci, K, H, W, None, P(labels2), None, None, stream()))
+    assert torch.equal(labels, labels2)
+    # ---- gradient of the masked mean CE wrt the low-res logits
+    from oracle.student_torch import resize_bilinear_align_corners
+    lt = torch.as_tensor(logits).double().requires_grad_(True)
+    zf = resize_bilinear_align_corners(lt, H, W)[..., cls]
+    lse_t = torch.logsumexp(zf, -1)
+    picked = torch.gather(zf, -1, torch.as_tensor(np.maximum(tgt, 0))[..., None])[..., 0]
+    ((lse_t - picked)[torch.as_tensor(valid)]).mean().backward()
+    dl = torch.full((B, h, w, NC), np.nan, device=DEV)
+    hip.check(lib.ams_k_ce_grad(P(ld), B, h, w, NC, ci, K, H, W, P(td), P(loss), P(dl), stream()))
+    assert rel_err(dl.cpu().numpy(), lt.grad.numpy()) < 2e-5
+    unsel = [c for c in range(NC) if c not in cls]
+    assert np.all(dl.cpu().numpy()[..., unsel] == 0)
+
+
+def test_upsample_all_ignored_gives_zero_count(lib):
+    B, h, w, H, W, NC = 1, 3, 5, 32, 64, 19
+    cls = [0, 1]
+    ci = (C.c_int32 * 2)(*cls)
+    logits = dev(np.random.default_rng(0).standard_normal((B, h, w, NC)))
+    teacher = torch.full((B, H, W), 255, dtype=torch.uint8, device=DEV)
+    labels = torch.empty((B, H, W), dtype=torch.int32, device=DEV)
+    conf = torch.ones(4, dtype=torch.int64, device=DEV)
+    loss = torch.ones(2, dtype=torch.float64, device=DEV)
+    hip.check(lib.ams_k_upsample_argmax(P(logits), B, h, w, NC, ci, 2, H, W, P(teacher), P(labels), P(conf), P(loss), stream()))
+    assert conf.sum().item() == 0 and loss.cpu().tolist() == [0.0, 0.0]
+
+
+# ------------------------------------------------------------------------------------------------ Adam
+def test_adam_matches_tf1_form(lib):
+    from oracle.student_np import adam_step
+    rng = np.random.default_rng(1)
+    n = 100003
+    p, g = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32) * 0.01
+    m, v = rng.standard_normal(n).astype(np.float32) * 0.01, rng.random(n).astype(np.float32) * 1e-4
+    mask = (rng.random(n) < 0.3).astype(np.uint8)
+    b1p, b2p, lr = 0.9 ** 3, 0.999 ** 3, 1e-3
+    lr_t = lr * np.sqrt(1 - b2p) / (1 - b1p)
+    pd, gd, md, vd = dev(p), dev(g), dev(m), dev(v)
+    hip.check(lib.ams_k_adam(P(pd), P(gd), P(md), P(vd), PD(mask, torch.uint8), n, float(lr_t), 0.9, 0.999, 1e-8, stream()))
+    wn, mn, vn = adam_step(p.astype(np.float64), g.astype(np.float64), m.astype(np.float64), v.astype(np.float64), lr, b1p, b2p)
+    assert rel_err(md.cpu().numpy(), mn) < 1e-6 and rel_err(vd.cpu().numpy(), vn) < 1e-6
+    got = pd.cpu().numpy()
+    assert np.array_equal(got[mask == 0], p[mask == 0])                # reverted entries keep their bits
+    assert np.abs(got[mask == 1] - wn[mask == 1]).max() < 1e-6

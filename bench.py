@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the AMS student hot path on MI355X (contract: see README / DESIGN.md §measurement).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): student inference only, 512x1024 synthetic video, frames resident in HBM
+as uint8 when the timed region starts.  One step = one pass of the hot path (frozen student forward + fused
+upsample/argmax -> int32 label maps) over one batch of --batch frames per GPU.  value = frames/s over all GPUs.
+Extra legs on the same JSON line:
+  distill_steps_per_sec : config[2]'s fine-tune step (B=8 frames, BN batch statistics, backward, Adam), timed apart
+  roofline              : dominant kernel of the inference step, HIP events on the launch stream over a profiled replay
+  cpu_baseline          : the CPU oracle (PyTorch-CPU restatement, all host cores) on a bounded sample, rank 0 / N=1
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from ams_amd import hip, spec as S, synth, weights as Wt  # noqa: E402
+from ams_amd.engine import StudentEngine  # noqa: E402
+
+CI = [0, 1, 2, 10, 11, 13]          # exp 25 (Cityscapes) class subset, reference exp_configs.py:86-89
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def read_profile(eng):
+    need = C.c_size_t(0)
+    hip.check(eng.lib.ams_student_profile_read(eng._h, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value + 16)
+    hip.check(eng.lib.ams_student_profile_read(eng._h, buf, len(buf), C.byref(need)))
+    rows = []
+    for line in buf.value.decode().splitlines():
+        name, layer, ms, nbytes = line.split("\t")
+        rows.append((name, int(layer), float(ms), float(nbytes)))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world
+
+    H, B = args.height, args.batch
+    spec = S.build_spec()
+    W0 = Wt.synthetic_weights(spec, seed=0)
+    video = synth.SyntheticVideo(H, max(B, args.train_batch), CI, seed=rank)
+    frames_np, labels_np = video.clip()
+    frames = torch.from_numpy(frames_np[:B]).to(dev)          # uint8 [B,H,2H,3] resident in HBM
+
+    eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False, device=dev)
+    eng.load_variables(W0)
+    eng.freeze()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        eng.predict(frames)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.predict(frames)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fps = n_gpus * B * args.steps / elapsed
+    checksum = int(out.sum().item())
+
+    # ---- latency mode: one frame per call (what the edge loop of run.py:400-423 does) ---------------------------
+    one = frames[:1].contiguous()
+    for _ in range(3):
+        eng.predict(one)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    n1 = max(10, args.steps)
+    for _ in range(n1):
+        eng.predict(one)
+    torch.cuda.synchronize(dev)
+    fps_b1 = n1 / (time.perf_counter() - t1)
+
+    # ---- roofline leg: profiled replay of the same step ----------------------------------------------------------
+    roofline = None
+    kernels = {}
+    if not args.no_profile and rank == 0:
+        hip.check(eng.lib.ams_student_profile(eng._h, 1))
+        n_prof = min(args.steps, 5)
+        for _ in range(n_prof):
+            eng.predict(frames)
+        rows = read_profile(eng)
+        hip.check(eng.lib.ams_student_profile(eng._h, 0))
+        agg = defaultdict(lambda: [0, 0.0, 0.0])
+        for name, layer, ms, nbytes in rows:
+            a = agg[name]
+            a[0] += 1
+            a[1] += ms
+            a[2] += nbytes
+        total_ms = sum(a[1] for a in agg.values())
+        for name, (cnt, ms, nbytes) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            kernels[name] = {"launches": cnt, "avg_us": round(1e3 * ms / cnt, 2), "share": round(ms / total_ms, 4),
+                             "alg_GBps": round(nbytes / ms / 1e6, 1)}
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        cnt, ms, nbytes = dom[1]
+        achieved = nbytes / ms / 1e6          # bytes / ms -> GB/s
+        roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(1e3 * ms / cnt, 2), "launches": cnt,
+                    "alg_bytes_per_launch": round(nbytes / cnt),
+                    "step_kernel_ms": round(total_ms / n_prof, 3),
+                    "note": "HIP events on the launch stream around every kernel of a profiled replay of the timed step; "
+                            "algorithmic bytes = f32 operands read once + results written once (DESIGN.md)"}
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+
+    # ---- config[2] leg: one 8-frame fine-tune step --------------------------------------------------------------
+    distill = None
+    if not args.no_train:
+        TB = args.train_batch
+        teng = StudentEngine(CI, H, 2 * H, max_batch=TB, trainable=True, device=dev)
+        teng.load_variables(W0)
+        tf = torch.from_numpy(frames_np[:TB]).to(dev)
+        tl = torch.from_numpy(labels_np[:TB]).to(dev)
+        allreduce = None
+        if dist is not None:
+            def allreduce(t):  # noqa: E306
+                dist.all_reduce(t)
+        for _ in range(2):
+            teng.train_step(tf, tl, 1e-3, allreduce=allreduce, global_batch=TB * n_gpus)
+        barrier()
+        ts = time.perf_counter()
+        n_train = max(3, min(args.steps, 10))
+        for _ in range(n_train):
+            loss = teng.train_step(tf, tl, 1e-3, allreduce=allreduce, global_batch=TB * n_gpus)
+        barrier()
+        tt = time.perf_counter() - ts
+        if dist is not None:
+            t = torch.tensor([tt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tt = float(t.item())
+        ls = loss.cpu().numpy()
+        distill = {"steps_per_sec": round(n_train / tt, 3), "ms_per_step": round(1e3 * tt / n_train, 3), "batch_per_gpu": TB,
+                   "global_batch": TB * n_gpus, "mode": "dp-allreduce+syncbn" if dist is not None else "single",
+                   "loss": round(float(ls[0] / max(ls[1], 1)), 5)}
+        teng.close()
+        del teng
+
+    # ---- CPU baseline leg: the oracle on the host cores (rank 0, N = 1 only) ----------------------------------------
+    cpu = None
+    if not args.no_cpu and rank == 0 and n_gpus == 1:
+        from oracle.student_torch import StudentOracle
+        # PyTorch-CPU oversubscribes badly on very wide hosts (256 hardware threads: 55 s per frame); 32 threads is the
+        # fastest setting measured on the GPU box, and `cores` reports the threads actually used
+        cores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(cores)
+        oracle = StudentOracle(W0, CI)
+        sample = frames_np[:1].astype(np.float32)
+        oracle.predict(sample)                           # warm-up
+        tc = time.perf_counter()
+        n_cpu = 0
+        while time.perf_counter() - tc < 12.0 and n_cpu < 16:
+            oracle.predict(frames_np[n_cpu % len(frames_np)][None].astype(np.float32))
+            n_cpu += 1
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": round(n_cpu / tcpu, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "%d frames of the same %dx%d synthetic clip, one at a time, PyTorch-CPU f32 restatement "
+                         "(oracle/student_torch.py) with %d threads; stand-in for the reference's TF1 CPU path, which "
+                         "cannot run here (TF 1.15 absent)" % (n_cpu, H, 2 * H, torch.get_num_threads())}
+
+    if rank == 0:
+        result = {
+            "metric": "frames/sec student infer (DeeplabV3+MobileNetV2, 512x1024) + distill-steps/sec",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "student infer only, %dx%d synthetic clip, frozen BN, uint8 frames resident in HBM, "
+                                   "int32 label maps out (BASELINE.json configs[1])" % (H, 2 * H),
+                       "frames_per_step_per_gpu": B, "class_subset": CI, "weights": "synthetic seed 0",
+                       "parallelism": "replicas x%d (no collective on the inference path)" % n_gpus},
+            "frames_per_sec_batch1": round(fps_b1, 2),
+            "distill": distill,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+            "labels_checksum": checksum,
+        }
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""Data-parallel plumbing for the fine-tune step: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).
+
+Only the fine-tune step has an exchange; inference and independent students are replicas with
+no collective.  The HIP engine calls back into ``ArenaAllReduce`` at every point where full-batch semantics
+need cross-rank sums:
+  * per BN layer, forward : (sum(z-c), sum((z-c)^2))   2*C float64   -> SyncBN statistics over the global batch
+  * loss                  : (CE sum, valid-pixel count) 2 float64    -> the mean's denominator is global
+  * per BN layer, backward: (sum dy, sum dy*xhat)       2*C float64
+  * gradients             : the flat trainable arena    2 113 043 float32 (8.45 MB), once, before Adam
+Every rank then applies the identical Adam update to identical weights, as the reference's single-process step
+would on the concatenated batch.  The 8.45 MB gradient message is one flat buffer by construction (the engine
+trains in a flat arena), so there is exactly one bandwidth-bound collective per step; the BN messages (<= 15 KB)
+are latency-bound and sequentially dependent (108 per step) — see DESIGN.md for what that costs on xGMI.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from . import hip
+
+
+def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None):
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun's contract).
+
+    Returns (rank, world_size, local_rank).  With WORLD_SIZE unset or 1 no process group is created."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kwargs = {}
+        if backend == "nccl" and device is not None:
+            kwargs["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, local_rank
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced shard [begin, end) of n_items for this rank (earlier ranks take the remainder)."""
+    base, rem = divmod(n_items, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+class ArenaAllReduce:
+    """The engine's ``ams_allreduce_cb``: sum ``count`` elements at byte ``offset`` of the arena across ranks.
+
+    ``reduce_fn`` defaults to ``torch.distributed.all_reduce`` on ``group``.  Instances count calls and bytes so
+    tests and DESIGN.md can state what a step exchanges."""
+
+    def __init__(self, arena: torch.Tensor, group=None, reduce_fn: Optional[Callable[[torch.Tensor], None]] = None):
+        assert arena.dtype == torch.uint8 and arena.dim() == 1
+        self.arena = arena
+        self.group = group
+        self.reduce_fn = reduce_fn
+        self.calls = 0
+        self.bytes = 0
+        self.error: Optional[BaseException] = None
+
+    def view(self, offset: int, count: int, dtype_code: int) -> torch.Tensor:
+        if dtype_code == hip.DT_F64:
+            return self.arena[offset:offset + 8 * count].view(torch.float64)
+        if dtype_code == hip.DT_F32:
+            return self.arena[offset:offset + 4 * count].view(torch.float32)
+        raise ValueError("all-reduce of dtype code %d is not part of the ABI" % dtype_code)
+
+    def __call__(self, _user, offset, count, dtype_code) -> int:
+        try:
+            t = self.view(int(offset), int(count), int(dtype_code))
+            if self.reduce_fn is not None:
+                self.reduce_fn(t)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self.calls += 1
+            self.bytes += t.numel() * t.element_size()
+            return 0
+        except BaseException as e:  # noqa: BLE001  (must not propagate through the C frame)
+            self.error = e
+            return 1

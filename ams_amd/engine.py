@@ -219,7 +219,8 @@ class StudentEngine:
                    allreduce=None, global_batch: Optional[int] = None) -> torch.Tensor:
         """One Adam iteration; returns the device tensor f64[2] = (CE sum over valid pixels, valid pixel count).
 
-        ``allreduce``: optional callable(tensor) summing across ranks (data-parallel step)."""
+        ``allreduce``: an ``ams_amd.dist.ArenaAllReduce`` or a callable(tensor) summing in place across ranks
+        (data-parallel step); ``global_batch`` = frames over all ranks."""
         assert self.trainable, "Can't train frozen graph!!!"
         t, dt, b = self._frames_to_device(frames)
         lab = self._labels_to_device(labels_teacher, b)
@@ -232,24 +233,15 @@ class StudentEngine:
                                                       float(lr), mptr, C.c_void_p(loss.data_ptr()), self._stream()),
                       "ams_student_train_step")
             return loss
-        arena = self.arena
-
-        def _cb(_user, offset, count, dtype):
-            try:
-                if dtype == hip.DT_F64:
-                    view = arena[offset:offset + 8 * count].view(torch.float64)
-                else:
-                    view = arena[offset:offset + 4 * count].view(torch.float32)
-                allreduce(view)
-                return 0
-            except Exception as e:  # noqa: BLE001
-                print("all-reduce callback failed:", e)
-                return 1
-
-        cb = hip.ALLREDUCE_CB(_cb)
-        hip.check(self.lib.ams_student_train_step_dp(self._h, C.c_void_p(t.data_ptr()), dt, C.c_void_p(lab.data_ptr()), b,
-                                                     int(global_batch or b), float(lr), mptr, C.c_void_p(loss.data_ptr()),
-                                                     cb, None, self._stream()), "ams_student_train_step_dp")
+        from .dist import ArenaAllReduce
+        reducer = allreduce if isinstance(allreduce, ArenaAllReduce) else ArenaAllReduce(self.arena, reduce_fn=allreduce)
+        cb = hip.ALLREDUCE_CB(reducer)
+        rc = self.lib.ams_student_train_step_dp(self._h, C.c_void_p(t.data_ptr()), dt, C.c_void_p(lab.data_ptr()), b,
+                                                int(global_batch or b), float(lr), mptr, C.c_void_p(loss.data_ptr()),
+                                                cb, None, self._stream())
+        if reducer.error is not None:
+            raise reducer.error
+        hip.check(rc, "ams_student_train_step_dp")
         return loss
 
     @property

@@ -1,0 +1,85 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/ams_hip.h declares (no compute calls here)."""
+import re
+import subprocess
+
+import pytest
+
+from ams_amd import hip
+
+
+def _header_functions(root):
+    text = (root / "include" / "ams_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(ams_[a-z0-9_]+)\s*\(", text))
+    names -= {"ams_allreduce_cb"}
+    return names
+
+
+def test_header_binding_and_library_agree(golden_dir):
+    root = golden_dir.parent.parent
+    declared = _header_functions(root)
+    assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
+    lib = hip.lib()                                  # loads on a CPU-only host; raises if a symbol is missing
+    out = subprocess.run(["nm", "-D", "--defined-only", str(hip.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (ams_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert exported - declared == set(), "library exports undeclared symbols: %s" % (exported - declared)
+    assert lib.ams_abi_version() == hip.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    # ams_layer_desc: 7 x int32, float, 5 x int64 ; ams_student_config: see header
+    assert C.sizeof(hip.LayerDesc) == 7 * 4 + 4 + 5 * 8
+    assert C.sizeof(hip.StudentConfig) == (6 + 32 + 3) * 4 + 4 + 2 * 8 + 3 * 4 + 4      # incl. padding before/after the int64 pair
+    assert hip.StudentConfig.n_trainable.offset % 8 == 0
+
+
+def test_arena_size_query_runs_without_gpu():
+    """ams_student_arena_bytes is pure host arithmetic: it must work here and scale with batch / trainable."""
+    import ctypes as C
+    from ams_amd import spec as S
+    from ams_amd.engine import layer_table
+    from ams_amd.spec import BN_DECAY, BN_EPS_FROZEN, PIXEL_SCALE
+    lib = hip.lib()
+    sp = S.build_spec()
+
+    def need(batch, trainable, height=512):
+        cfg = hip.StudentConfig()
+        cfg.abi_version = hip.ABI_VERSION
+        cfg.height, cfg.width, cfg.max_batch = height, 2 * height, batch
+        cfg.num_classes, cfg.n_selected = 19, 6
+        for i, c in enumerate([0, 1, 2, 10, 11, 13]):
+            cfg.class_indices[i] = c
+        cfg.n_layers, cfg.trainable, cfg.act_dtype = len(sp.layers), trainable, hip.DT_F32
+        cfg.n_trainable, cfg.n_stats = sp.n_trainable, sp.n_stats
+        cfg.bn_decay, cfg.bn_eps_frozen, cfg.pixel_scale = BN_DECAY, BN_EPS_FROZEN, PIXEL_SCALE
+        n = C.c_size_t()
+        hip.check(lib.ams_student_arena_bytes(C.byref(cfg), layer_table(sp), C.byref(n)))
+        return n.value
+
+    frozen1, frozen8, train8 = need(1, 0), need(8, 0), need(8, 1)
+    assert 200e6 < frozen1 < 400e6            # 4 ping-pong buffers of the largest layer (50.6 MB) + weights
+    assert frozen8 > 4 * frozen1
+    assert 8e9 < train8 < 12e9                # z, a, da for all 55 layers at B=8, 512x1024 (~1.05 GB per frame)
+    # bad configuration -> error code + message, no crash
+    cfg = hip.StudentConfig()
+    n = C.c_size_t()
+    assert lib.ams_student_arena_bytes(C.byref(cfg), layer_table(sp), C.byref(n)) == -1
+    assert b"ABI version" in lib.ams_last_error()
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ams_amd.engine import StudentEngine
+    with pytest.raises(hip.AmsHipError):
+        StudentEngine([0, 1], 32)
+
+
+def test_product_never_touches_the_oracle(golden_dir):
+    root = golden_dir.parent.parent
+    for path in (root / "ams_amd").rglob("*.py"):
+        src = path.read_text()
+        assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), path

@@ -9,125 +9,268 @@
 //   * A (activations) never touches LDS: each lane loads float4 = 4 consecutive k of one row straight to VGPRs;
 //     16 lanes x 16 B = one 64-byte row segment, 4 such rows per MFMA.  The contraction index may be permuted
 //     freely as long as A and B agree, so MFMA step j consumes k = 4*(lane>>4) + j of a 16-wide chunk.
-//   * B (weights, <= 1.2 MB, L2 resident) is staged per 32-k chunk into LDS with row pitch 16*NT+4 floats
-//     (pitch % 8 == 4 makes the two 16-lane halves of a ds_read_b32 group hit disjoint banks).
-//   * one block = 4 waves x RM x 16 rows; all NT*16 columns of the n-tile accumulate in registers (<= 80 f32),
-//     so for N <= 320 the activations are read once; wider N (expand layers, small K) re-reads a small A tile
-//     from L2, with the n-tiles of one m-tile placed on the same XCD by xcd_remap().
-//   * epilogue fuses per-image bias (pool branch), BN scale/shift, ReLU/ReLU6 and the residual add.
+//   * B (weights, <= 1.2 MB, L2 resident) lives in LDS with row pitch 16*NT+4 floats (pitch % 8 == 4 makes the two
+//     16-lane halves of a ds_read_b32 group hit disjoint banks): the whole panel for streaming layers (variant S,
+//     persistent waves, no barrier in the loop), 32-k stages double-buffered for late layers (variant L).
+//   * MFMA operand roles are swapped (weights = A, activations = B) so each lane ends up with 4 consecutive output
+//     channels of one pixel: the epilogue (per-image bias, BN scale/shift, ReLU/ReLU6, residual, store) is float4.
 #include <string>
 
 #include "kernels.hpp"
 
 namespace ams {
 
+// ---------------------------------------------------------------------------------------------------------
+// Operand roles are SWAPPED in the MFMA (a = weights, b = activations): the 16x16 result then has the output
+// channel along the accumulator registers (row = 4*(lane>>4) + i) and the pixel along lanes (col = lane & 15),
+// so every lane owns 4 consecutive output channels of one pixel and the epilogue is float4 loads/stores
+// (scale, shift, per-image bias, residual, result) instead of four scalar stores per tile.
+// ---------------------------------------------------------------------------------------------------------
 template <int RM, int NT>
-__global__ __launch_bounds__(256) void pw_gemm_f32(PwArgs a, int n_tiles_n, unsigned nblocks) {
+__device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x4 (&acc)[RM][NT], int64_t m_base, int n0, int l15, int q) {
+    const bool y_vec = (a.ldy & 3) == 0, r_vec = (a.ldr & 3) == 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n4 = n0 + 16 * t + 4 * q;
+        if (n4 >= a.N) continue;
+        const bool full = n4 + 3 < a.N;
+        float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (full) {
+            if (a.scale) { const float4 v = ld4(a.scale + n4); sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w; }
+            if (a.shift) { const float4 v = ld4(a.shift + n4); sh[0] = v.x; sh[1] = v.y; sh[2] = v.z; sh[3] = v.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n4 + i < a.N) { if (a.scale) sc[i] = a.scale[n4 + i]; if (a.shift) sh[i] = a.shift[n4 + i]; }
+        }
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const int64_t m = m_base + r * 16 + l15;
+            if (m >= a.M) continue;
+            float v[4] = {acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]};
+            if (a.img_bias) {
+                const float* bp = a.img_bias + (m / a.rows_per_img) * a.N + n4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n4 + i < a.N) v[i] += bp[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i] * sc[i] + sh[i], a.act);
+            if (a.res) {
+                const float* rp = a.res + m * a.ldr + n4;
+                if (full && r_vec) { const float4 rv = ld4(rp); v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w; }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (n4 + i < a.N) v[i] += rp[i];
+                }
+            }
+            float* yp = a.y + m * a.ldy + n4;
+            if (full && y_vec) st4(yp, make_float4(v[0], v[1], v[2], v[3]));
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n4 + i < a.N) yp[i] = v[i];
+            }
+        }
+    }
+}
+
+// one 16-k chunk: 4 MFMA k-steps x NT column tiles x RM row groups; sB points at this lane's (k = 4q, n = l15) element
+template <int RM, int NT, int PITCH>
+__device__ __forceinline__ void pw_chunk(f32x4 (&acc)[RM][NT], const float4 (&av)[RM], const float* sB) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float xv[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) xv[r] = j == 0 ? av[r].x : j == 1 ? av[r].y : j == 2 ? av[r].z : av[r].w;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float wv = sB[j * PITCH + 16 * t];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv[r], acc[r][t], 0, 0, 0);
+        }
+    }
+}
+
+// stage w[k0 .. k0+rows) x [n0 .. n0+16*NT) into LDS (row pitch PITCH), zero-filled outside Kw x N
+template <int NT, int PITCH>
+__device__ __forceinline__ void pw_stage_w(const PwArgs& a, float* dst, int k0, int rows, int n0, int tid, int nthreads) {
+    const int cols = 16 * NT;
+    if (a.w_sn == 1) {
+        for (int e = tid; e < rows * cols; e += nthreads) {
+            const int kk = e / cols, nn = e - kk * cols;
+            float v = 0.f;
+            if (k0 + kk < a.Kw && n0 + nn < a.N) v = a.w[(int64_t)(k0 + kk) * a.w_sk + (n0 + nn)];
+            dst[kk * PITCH + nn] = v;
+        }
+    } else {                                      // transposed use (dgrad): k is the contiguous index in memory
+        for (int e = tid; e < rows * cols; e += nthreads) {
+            const int nn = e / rows, kk = e - nn * rows;
+            float v = 0.f;
+            if (k0 + kk < a.Kw && n0 + nn < a.N) v = a.w[(int64_t)(k0 + kk) * a.w_sk + (int64_t)(n0 + nn) * a.w_sn];
+            dst[kk * PITCH + nn] = v;
+        }
+    }
+}
+
+// ---- variant S: streaming layers (huge M, small K x N).  The whole weight panel of this column tile stays in LDS for
+// the block's lifetime; every wave walks its own 16*RM-row groups (grid-stride), no barrier after the prologue, and
+// the A fragment of the NEXT (row group, k chunk) is in flight while the current one feeds the matrix pipe.
+template <int RM, int NT>
+__global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, int64_t n_groups) {
+    constexpr int PITCH = 16 * NT + 4;
+    extern __shared__ __attribute__((aligned(16))) float sW[];          // [Kpad][PITCH]
+    const int tile_n = blockIdx.y;
+    const int n0 = tile_n * 16 * NT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int K = a.K, n_chunks = (K + 15) / 16;
+    pw_stage_w<NT, PITCH>(a, sW, 0, n_chunks * 16, n0, tid, 256);
+    __syncthreads();
+
+    const int64_t wave_stride = (int64_t)gridDim.x * 4;
+    int64_t g = (int64_t)blockIdx.x * 4 + wave;
+    if (g >= n_groups) return;
+    auto row_ptr = [&](int64_t grp, int r) {
+        int64_t m = grp * (16 * RM) + r * 16 + l15;
+        if (m > a.M - 1) m = a.M - 1;
+        return a.x + m * (int64_t)a.ldx + 4 * q;
+    };
+    float4 a_cur[RM], a_nxt[RM];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < RM; ++r) a_cur[r] = (4 * q < K) ? ld4(row_ptr(g, r)) : zero4;
+    f32x4 acc[RM][NT];
+    while (g < n_groups) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int64_t g_next = g + wave_stride;
+        for (int c = 0; c < n_chunks; ++c) {
+            // prefetch: next chunk of this group, or chunk 0 of the next group
+            if (c + 1 < n_chunks) {
+                const bool ok = (c + 1) * 16 + 4 * q < K;
+#pragma unroll
+                for (int r = 0; r < RM; ++r) a_nxt[r] = ok ? ld4(row_ptr(g, r) + (c + 1) * 16) : zero4;
+            } else if (g_next < n_groups) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r) a_nxt[r] = (4 * q < K) ? ld4(row_ptr(g_next, r)) : zero4;
+            }
+            pw_chunk<RM, NT, PITCH>(acc, a_cur, sW + (c * 16 + 4 * q) * PITCH + l15);
+#pragma unroll
+            for (int r = 0; r < RM; ++r) a_cur[r] = a_nxt[r];
+        }
+        pw_epilogue<RM, NT>(a, acc, g * (16 * RM), n0, l15, q);
+        g = g_next;
+    }
+}
+
+// ---- variant L: late layers (M = B*33*65 rows, K and/or N in the hundreds).  One (64*RM) x (16*NT) tile per block,
+// K walked in 32-wide stages whose weight panel is double-buffered in LDS: the next stage's panel travels
+// global -> registers while the current one is consumed, and is written to the other buffer before the single barrier.
+template <int RM, int NT>
+__global__ __launch_bounds__(256) void pw_gemm_f32_l(PwArgs a, int n_tiles_n, unsigned nblocks) {
     constexpr int BK = 32;
     constexpr int PITCH = 16 * NT + 4;
-    __shared__ float sW[BK * PITCH];
-
+    constexpr int NREG = (BK * 16 * NT + 255) / 256;              // staged elements per thread
+    __shared__ float sW[2][BK * PITCH];
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     const int tile_n = lb % n_tiles_n;
     const int64_t tile_m = lb / n_tiles_n;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int l15 = lane & 15, q = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int n0 = tile_n * 16 * NT;
     const int64_t m_base = tile_m * (64 * RM) + wave * (16 * RM);
+    const int K = a.K, n_chunks = (K + 15) / 16, n_stages = (n_chunks + 1) / 2;
+    constexpr int cols = 16 * NT;
+    const bool n_contig = a.w_sn == 1;
 
+    float wreg[NREG];
+    auto load_stage = [&](int s) {
+        const int k0 = s * BK;
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) {
+            const int e = tid + u * 256;
+            int kk, nn;
+            if (n_contig) { kk = e / cols; nn = e - kk * cols; } else { nn = e / BK; kk = e - nn * BK; }
+            float v = 0.f;
+            if (e < BK * cols && k0 + kk < a.Kw && n0 + nn < a.N)
+                v = a.w[(int64_t)(k0 + kk) * a.w_sk + (int64_t)(n0 + nn) * a.w_sn];
+            wreg[u] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) {
+            const int e = tid + u * 256;
+            int kk, nn;
+            if (n_contig) { kk = e / cols; nn = e - kk * cols; } else { nn = e / BK; kk = e - nn * BK; }
+            if (e < BK * cols) sW[buf][kk * PITCH + nn] = wreg[u];
+        }
+    };
+
+    const float* arow[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        int64_t m = m_base + r * 16 + l15;
+        if (m > a.M - 1) m = a.M - 1;
+        arow[r] = a.x + m * (int64_t)a.ldx + 4 * q;
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a_cur[RM], a_nxt[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) a_cur[r] = (4 * q < K) ? ld4(arow[r]) : zero4;
     f32x4 acc[RM][NT];
 #pragma unroll
     for (int r = 0; r < RM; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* arow[RM];
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < n_stages; ++s) {
+        if (s + 1 < n_stages) load_stage(s + 1);
 #pragma unroll
-    for (int r = 0; r < RM; ++r) {
-        int64_t m = m_base + r * 16 + l15;
-        if (m > a.M - 1) m = a.M - 1;                 // clamp: rows past M are computed but never stored
-        arow[r] = a.x + m * (int64_t)a.ldx + 4 * q;
-    }
-
-    const int K = a.K;
-    const int n_chunks = (K + 15) / 16;
-    float4 a_cur[RM], a_nxt[RM];
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * s + h;
+            if (c < n_chunks) {
+                const bool ok = c + 1 < n_chunks && (c + 1) * 16 + 4 * q < K;
 #pragma unroll
-    for (int r = 0; r < RM; ++r) a_cur[r] = (4 * q < K) ? ld4(arow[r]) : make_float4(0.f, 0.f, 0.f, 0.f);
-
-    for (int c = 0; c < n_chunks; ++c) {
-        if ((c & 1) == 0) {
-            __syncthreads();
-            // stage w[k0 .. k0+32) x [n0 .. n0+16*NT) ; zero-fill outside K x N
-            const int k0 = c * 16;
-            for (int e = tid; e < BK * 16 * NT; e += 256) {
-                int kk, nn;
-                if (a.w_sn == 1) { kk = e / (16 * NT); nn = e % (16 * NT); }     // n contiguous in memory
-                else             { nn = e / BK;        kk = e % BK; }             // k contiguous (transposed use)
-                float v = 0.f;
-                if (k0 + kk < a.Kw && n0 + nn < a.N) v = a.w[(int64_t)(k0 + kk) * a.w_sk + (int64_t)(n0 + nn) * a.w_sn];
-                sW[kk * PITCH + nn] = v;
-            }
-            __syncthreads();
-        }
-        // prefetch the next 16-k chunk of A while this one feeds the matrix pipe
-        const int kn = (c + 1) * 16 + 4 * q;
+                for (int r = 0; r < RM; ++r) a_nxt[r] = ok ? ld4(arow[r] + (c + 1) * 16) : zero4;
+                pw_chunk<RM, NT, PITCH>(acc, a_cur, &sW[s & 1][(h * 16 + 4 * q) * PITCH + l15]);
 #pragma unroll
-        for (int r = 0; r < RM; ++r)
-            a_nxt[r] = (c + 1 < n_chunks && kn < K) ? ld4(arow[r] + (c + 1) * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-
-        const float* sB = sW + ((c & 1) * 16 + 4 * q) * PITCH + l15;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float av[RM];
-#pragma unroll
-            for (int r = 0; r < RM; ++r) av[r] = j == 0 ? a_cur[r].x : j == 1 ? a_cur[r].y : j == 2 ? a_cur[r].z : a_cur[r].w;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float b = sB[j * PITCH + 16 * t];
-#pragma unroll
-                for (int r = 0; r < RM; ++r)
-                    acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], b, acc[r][t], 0, 0, 0);
+                for (int r = 0; r < RM; ++r) a_cur[r] = a_nxt[r];
             }
         }
-#pragma unroll
-        for (int r = 0; r < RM; ++r) a_cur[r] = a_nxt[r];
+        if (s + 1 < n_stages) store_stage((s + 1) & 1);
+        __syncthreads();
     }
-
-    // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg --------------------
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = n0 + 16 * t + l15;
-        if (n >= a.N) continue;
-        const float sc = a.scale ? a.scale[n] : 1.f;
-        const float sh = a.shift ? a.shift[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < RM; ++r) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t m = m_base + r * 16 + 4 * q + i;
-                if (m >= a.M) continue;
-                float v = acc[r][t][i];
-                if (a.img_bias) v += a.img_bias[(m / a.rows_per_img) * a.N + n];
-                v = v * sc + sh;
-                v = apply_act(v, a.act);
-                if (a.res) v += a.res[m * a.ldr + n];
-                a.y[m * a.ldy + n] = v;
-            }
-        }
-    }
+    pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q);
 }
 
 template <int RM, int NT>
-static int launch_pw_t(const PwArgs& a, hipStream_t st) {
+static int launch_pw_l(const PwArgs& a, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
-    const int64_t n_tiles_m = cdiv64(a.M, 64 * RM);
-    const int64_t nblocks = n_tiles_m * n_tiles_n;
+    const int64_t nblocks = cdiv64(a.M, 64 * RM) * n_tiles_n;
     if (nblocks <= 0 || nblocks > 0x7fffffffLL) { set_error("pointwise: bad grid %lld", (long long)nblocks); return AMS_E_INVALID; }
-    static const std::string nm = "pw_gemm_f32<" + std::to_string(RM) + ", " + std::to_string(NT) + ">";
+    static const std::string nm = "pw_gemm_f32_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_f32<RM, NT>), dim3((unsigned)nblocks), dim3(256), 0, st, a, n_tiles_n, (unsigned)nblocks);
+    hipLaunchKernelGGL((pw_gemm_f32_l<RM, NT>), dim3((unsigned)nblocks), dim3(256), 0, st, a, n_tiles_n, (unsigned)nblocks);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+template <int RM, int NT>
+static int launch_pw_s(const PwArgs& a, hipStream_t st) {
+    constexpr int PITCH = 16 * NT + 4;
+    const int n_tiles_n = cdiv(a.N, 16 * NT);
+    const int64_t n_groups = cdiv64(a.M, 16 * RM);
+    const size_t lds = (size_t)((a.K + 15) / 16 * 16) * PITCH * sizeof(float);
+    int64_t blocks = cdiv64(n_groups, 4);
+    // persistent: a few blocks per CU, as many as the LDS panel allows
+    const int per_cu = lds > 48 * 1024 ? 2 : lds > 24 * 1024 ? 4 : 6;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ">";
+    note_kernel(nm.c_str());
+    hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, a, n_tiles_n, n_groups);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -137,27 +280,47 @@ int launch_pointwise(const PwArgs& a, hipStream_t st) {
     AMS_REQUIRE(a.Kw > 0 && a.Kw <= a.K, "pointwise: Kw=%d must be in 1..K=%d", a.Kw, a.K);
     AMS_REQUIRE(a.K % 4 == 0 && a.ldx % 4 == 0, "pointwise: K (%d) and ldx (%d) must be multiples of 4", a.K, a.ldx);
     AMS_REQUIRE((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "pointwise: x must be 16-byte aligned");
-    // pick the n-tile width: the narrowest instantiation that covers N in one tile, else the widest useful one
     const int n16 = cdiv(a.N, 16);
-    // small M (head at batch 1, pool branch): prefer more, narrower tiles so the chip is not left idle
-    const bool small_m = a.M < 64 * 256;
-    if (n16 <= 1) return launch_pw_t<2, 1>(a, st);
-    if (n16 <= 2) return launch_pw_t<2, 2>(a, st);
-    if (small_m) {
-        if (n16 <= 4) return launch_pw_t<1, 4>(a, st);
-        if (n16 % 5 == 0) return launch_pw_t<1, 5>(a, st);
-        if (n16 % 6 == 0) return launch_pw_t<1, 6>(a, st);
-        return launch_pw_t<1, 4>(a, st);
+    const int kpad = (a.K + 15) / 16 * 16;
+    // ---- streaming variant: weight panel resident in LDS (<= 56 KB), plenty of rows --------------------------
+    if (a.M >= 32768) {
+        int nt = n16 <= 12 ? n16 : (n16 % 12 == 0 ? 12 : n16 % 10 == 0 ? 10 : n16 % 8 == 0 ? 8 : 6);
+        if (nt == 7) nt = 8; if (nt == 11) nt = 12;
+        if ((size_t)kpad * (16 * nt + 4) * 4 <= 56 * 1024) {
+            switch (nt) {
+                case 1: return launch_pw_s<2, 1>(a, st);
+                case 2: return launch_pw_s<2, 2>(a, st);
+                case 3: return launch_pw_s<2, 3>(a, st);
+                case 4: return launch_pw_s<2, 4>(a, st);
+                case 5: return launch_pw_s<2, 5>(a, st);
+                case 6: return launch_pw_s<2, 6>(a, st);
+                case 8: return launch_pw_s<2, 8>(a, st);
+                case 9: return launch_pw_s<2, 9>(a, st);
+                case 10: return launch_pw_s<1, 10>(a, st);
+                case 12: return launch_pw_s<1, 12>(a, st);
+                default: break;
+            }
+        }
     }
-    if (n16 <= 4) return launch_pw_t<2, 4>(a, st);
-    if (n16 <= 6) return launch_pw_t<2, 6>(a, st);
-    if (n16 <= 9) return launch_pw_t<2, 9>(a, st);
-    if (n16 <= 10) return launch_pw_t<2, 10>(a, st);
-    if (n16 <= 12) return launch_pw_t<1, 12>(a, st);
-    if (n16 <= 16) return launch_pw_t<1, 16>(a, st);
-    if (n16 <= 20) return launch_pw_t<1, 20>(a, st);
-    if (n16 % 20 == 0) return launch_pw_t<1, 20>(a, st);     // 960 = 3 x 320
-    return launch_pw_t<1, 12>(a, st);                          // 384 = 2 x 192, 576 = 3 x 192
+    // ---- tiled variant: pick the column-tile width (in 16s) that wastes least while giving the chip >= ~3 blocks per CU
+    int best_nt = 1, best_rm = 1;
+    double best = -1;
+    for (int nt = 6; nt >= 1; --nt)
+        for (int rm = 2; rm >= 1; --rm) {
+            const int tn = cdiv(n16, nt);
+            const double blocks = (double)cdiv64(a.M, 64 * rm) * tn;
+            const double useful = (double)n16 / (tn * nt);                      // fraction of computed columns that exist
+            const double fill = blocks >= 768 ? 1.0 : blocks / 768.0;           // parallelism
+            const double reuse = 0.85 + 0.15 * (nt * rm) / 12.0;                // bigger tiles re-read less
+            const double score = useful * fill * reuse;
+            if (score > best) { best = score; best_nt = nt; best_rm = rm; }
+        }
+#define PW_L(RM_, NT_) if (best_rm == RM_ && best_nt == NT_) return launch_pw_l<RM_, NT_>(a, st);
+    PW_L(2, 6) PW_L(2, 5) PW_L(2, 4) PW_L(2, 3) PW_L(2, 2) PW_L(2, 1)
+    PW_L(1, 6) PW_L(1, 5) PW_L(1, 4) PW_L(1, 3) PW_L(1, 2) PW_L(1, 1)
+#undef PW_L
+    set_error("pointwise: no tile configuration");
+    return AMS_E_INVALID;
 }
 
 // =========================================================================================================

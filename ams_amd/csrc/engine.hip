@@ -58,6 +58,9 @@ struct LayerRt {
     double *fsums = nullptr, *bsums = nullptr;      // [2][cout] each, inside the BN_SYNC region
     // training activations (max_batch images each)
     float *z = nullptr, *a = nullptr, *da = nullptr;
+    // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
+    uint16_t *whi = nullptr, *wlo = nullptr;
+    int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
 };
 
 struct Carver {
@@ -103,6 +106,7 @@ struct ams_student {
     int64_t* conf_buf = nullptr;
     int64_t adam_t = 0;
     bool frozen_ready = false;
+    int matmul_mode = AMS_MATMUL_SPLIT_BF16;   // frozen inference, late layers
     Profiler prof;
     hipEvent_t prof_e0 = nullptr;
 };
@@ -143,6 +147,17 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
         l.cA = cv.take<float>(l.d.cout);
         l.cB = cv.take<float>(l.d.cout);
         l.cC = cv.take<float>(l.d.cout);
+    }
+    for (int i = 2; i <= c.n_layers; ++i) {
+        LayerRt& l = s->L[i];
+        const int role = l.d.role;
+        if (role == AMS_ROLE_DEPTHWISE || role == AMS_ROLE_POOL_CONV) continue;
+        int K = l.d.cin;
+        l.split_k0 = 0;
+        if (role == AMS_ROLE_CONCAT_PROJ) { l.split_k0 = s->L[s->iPool].d.cout; K = l.d.cin - l.split_k0; }
+        l.Kp = (K + 31) / 32 * 32;
+        l.whi = cv.take<uint16_t>((size_t)l.d.cout * l.Kp);
+        l.wlo = cv.take<uint16_t>((size_t)l.d.cout * l.Kp);
     }
     // BN sync region: loss (2 doubles) then per layer fwd sums [2][C], bwd sums [2][C]
     s->bn_sync_doubles = 2 + 4 * sum_c;
@@ -302,6 +317,15 @@ static int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream_t) {
     return AMS_OK;
 }
 
+// frozen 1x1 layer: late layers (few rows, wide K/N: matrix-pipe bound) go through the split-bf16 kernel
+static int frozen_pointwise(ams_student* s, int layer, const PwArgs& a, hipStream_t st) {
+    const LayerRt& l = s->L[layer];
+    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && l.whi && a.M < 32768 && a.K >= 32 && a.K % 8 == 0 && a.M >= 256;
+    if (split) RUNK(layer, pw_bytes(a), launch_pointwise_split(a, l.whi, l.wlo, l.Kp, st));
+    else RUNK(layer, pw_bytes(a), launch_pointwise(a, st));
+    return AMS_OK;
+}
+
 // =======================================================================================================
 // frozen inference (BN folded; what the edge device runs)
 // =======================================================================================================
@@ -328,7 +352,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             const int o = other(cur_i, -1);
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
-            RUNK(i, pw_bytes(a), launch_pointwise(a, st));
+            RUN(frozen_pointwise(s, i, a, st));
             x = s->act[o]; x_i = o; ++i;
         }
         {
@@ -346,7 +370,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
             if (l.d.residual_from) { a.res = block_in; a.ldr = l.d.cout; }
-            RUNK(i, pw_bytes(a), launch_pointwise(a, st));
+            RUN(frozen_pointwise(s, i, a, st));
             cur = s->act[o]; cur_i = o; ++i;
         }
     }
@@ -366,14 +390,14 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
     {
         PwArgs a = pw_args(cur, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, s->act[o1], la.d.cout);
         a.scale = la.fscale; a.shift = la.fshift; a.act = la.d.act;
-        RUNK(s->iAspp, pw_bytes(a), launch_pointwise(a, st));
+        RUN(frozen_pointwise(s, s->iAspp, a, st));
         PwArgs b = pw_args(s->act[o1], M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout,
                            s->act[o2], lc.d.cout);
         b.img_bias = s->img_bias; b.rows_per_img = HW; b.scale = lc.fscale; b.shift = lc.fshift; b.act = lc.d.act;
-        RUNK(s->iProj, pw_bytes(b), launch_pointwise(b, st));
+        RUN(frozen_pointwise(s, s->iProj, b, st));
         PwArgs d = pw_args(s->act[o2], M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits, 32);
         d.shift = P + ll.d.gamma_off;      // biases
-        RUNK(s->iLogits, pw_bytes(d), launch_pointwise(d, st));
+        RUN(frozen_pointwise(s, s->iLogits, d, st));
     }
     return AMS_OK;
 }
@@ -656,6 +680,12 @@ int ams_student_freeze(ams_student* s, void* stream) {
         RUN(launch_bn_fold(s->fparams + l.d.gamma_off, s->fparams + l.d.beta_off, s->fstats + l.d.mean_off, s->fstats + l.d.var_off,
                            s->cfg.bn_eps_frozen, l.d.cout, l.fscale, l.fshift, st));
     }
+    for (int i = 2; i <= s->cfg.n_layers; ++i) {
+        LayerRt& l = s->L[i];
+        if (!l.whi) continue;
+        const int K = l.d.cin - l.split_k0;
+        RUN(launch_split_weights(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whi, l.wlo, st));
+    }
     s->frozen_ready = true;
     return AMS_OK;
 }
@@ -741,6 +771,17 @@ int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frame
                                      stream);
 }
 
+int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
+    AMS_REQUIRE(s, "set_option: null student");
+    if (option == AMS_OPT_MATMUL) {
+        AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16, "set_option: unknown matmul mode %d", value);
+        s->matmul_mode = value;
+        return AMS_OK;
+    }
+    set_error("set_option: unknown option %d", option);
+    return AMS_E_INVALID;
+}
+
 int ams_student_profile(ams_student* s, int32_t enable) {
     AMS_REQUIRE(s, "profile: null student");
     AMS_CHECK_HIP(hipDeviceSynchronize());
@@ -802,6 +843,20 @@ int ams_k_pointwise(const float* x, int64_t M, int32_t K, const float* w, int32_
     a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
     if (scale && !shift) { set_error("pointwise: scale without shift"); return AMS_E_INVALID; }
     return launch_pointwise(a, (hipStream_t)stream);
+}
+
+int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, int32_t N, const float* scale, const float* shift,
+                          int32_t act, const float* res, float* y, uint16_t* panels, size_t panel_elems, void* stream) {
+    const int Kp = (K + 31) / 32 * 32;
+    AMS_REQUIRE(panels && panel_elems >= (size_t)2 * N * Kp, "pointwise_split: panel scratch too small (need %zu)", (size_t)2 * N * Kp);
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t* hi = panels;
+    uint16_t* lo = panels + (size_t)N * Kp;
+    RUN(launch_split_weights(w, N, 1, K, N, Kp, hi, lo, st));
+    PwArgs a = pw_args(x, M, K, K, w, N, y, N);
+    a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
+    if (scale && !shift) { set_error("pointwise_split: scale without shift"); return AMS_E_INVALID; }
+    return launch_pointwise_split(a, hi, lo, Kp, st);
 }
 
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

@@ -76,6 +76,81 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const TIn* __restrict__ 
     }
 }
 
+// MFMA form of the same layer (cout = 32): the 3x3x3 receptive field is a K = 27 (padded to 32) contraction, i.e. a
+// [pixels, 32] x [32, 32] GEMM whose A operand is gathered straight from the uint8 frame.  Exact f32 MFMA with the
+// operand roles swapped as in k_pointwise.hip: lane (p = lane & 15, q = lane >> 4) supplies taps k = 16c + 4q + j of
+// pixel p and ends up owning output channels 16t + 4q .. +3 of that pixel (float4 epilogue).  8 byte-gathers and
+// 16 MFMAs per 16 pixels instead of 27 gathers and 864 scalar FMAs per pixel.
+template <typename TIn>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const TIn* __restrict__ frames, int B, int H, int W,
+                                                        const float* __restrict__ wgt, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, int act, float ps,
+                                                        float* __restrict__ y, int Ho, int Wo, int pt, int pl, int64_t n_groups) {
+    constexpr int PITCH = 36, RM = 2, NT = 2;
+    __shared__ float sW[32 * PITCH];
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+        const int kk = e >> 5, nn = e & 31;
+        sW[kk * PITCH + nn] = kk < 27 ? wgt[kk * 32 + nn] : 0.f;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    // this lane's 8 taps: k = 16c + 4q + j  ->  (dy, dx, ch); k >= 27 are padding
+    int tdy[8], tdx[8], tch[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = 16 * (u >> 2) + 4 * q + (u & 3);
+        const int tap = k / 3;
+        tch[u] = k < 27 ? k - tap * 3 : -1;
+        tdy[u] = tap / 3;
+        tdx[u] = tap - tdy[u] * 3;
+    }
+    const int64_t total_px = (int64_t)B * Ho * Wo;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < n_groups; g += (int64_t)gridDim.x * 4) {
+        f32x4 acc[RM][NT];
+        float v[RM][8];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            int64_t p = g * (16 * RM) + r * 16 + l15;
+            if (p > total_px - 1) p = total_px - 1;
+            const int ox = (int)(p % Wo);
+            const int64_t t2 = p / Wo;
+            const int oy = (int)(t2 % Ho), b = (int)(t2 / Ho);
+            const TIn* img = frames + (int64_t)b * H * W * 3;
+            const int iy0 = oy * 2 - pt, ix0 = ox * 2 - pl;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[r][u] = tch[u] >= 0 ? norm_frame_value(img, H, W, iy0 + tdy[u], ix0 + tdx[u], tch[u], ps) : 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* sB = sW + (16 * (u >> 2) + 4 * q + (u & 3)) * PITCH + l15;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float wv = sB[16 * t];
+#pragma unroll
+                for (int r = 0; r < RM; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[r][u], acc[r][t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n4 = 16 * t + 4 * q;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (scale) { sc = ld4(scale + n4); sh = ld4(shift + n4); }
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                const int64_t p = g * (16 * RM) + r * 16 + l15;
+                if (p >= total_px) continue;
+                float4 o;
+                o.x = apply_act(acc[r][t][0] * sc.x + sh.x, act); o.y = apply_act(acc[r][t][1] * sc.y + sh.y, act);
+                o.z = apply_act(acc[r][t][2] * sc.z + sh.z, act); o.w = apply_act(acc[r][t][3] * sc.w + sh.w, act);
+                st4(y + p * 32 + n4, o);
+            }
+        }
+    }
+}
+
 int launch_stem(const void* frames, int dtype, int B, int H, int W, const float* w, int cout, const float* scale,
                 const float* shift, int act, float pixel_scale, float* y, hipStream_t st) {
     AMS_REQUIRE(cout % 8 == 0 && cout <= 256, "stem: cout %d must be a multiple of 8", cout);
@@ -84,6 +159,20 @@ int launch_stem(const void* frames, int dtype, int B, int H, int W, const float*
     int Ho, Wo, pt, pl;
     same_pad(H + 1, 3, 2, 1, &Ho, &pt);
     same_pad(W + 1, 3, 2, 1, &Wo, &pl);
+    if (cout == 32) {
+        const int64_t n_groups = cdiv64((int64_t)B * Ho * Wo, 32);
+        int64_t grid = cdiv64(n_groups, 4);
+        if (grid > 256 * 8) grid = 256 * 8;
+        note_kernel(dtype == AMS_DT_U8 ? "stem_mfma_kernel<unsigned char>" : "stem_mfma_kernel<float>");
+        if (dtype == AMS_DT_U8)
+            hipLaunchKernelGGL(stem_mfma_kernel<uint8_t>, dim3((unsigned)grid), dim3(256), 0, st, (const uint8_t*)frames, B, H, W, w,
+                               scale, shift, act, pixel_scale, y, Ho, Wo, pt, pl, n_groups);
+        else
+            hipLaunchKernelGGL(stem_mfma_kernel<float>, dim3((unsigned)grid), dim3(256), 0, st, (const float*)frames, B, H, W, w,
+                               scale, shift, act, pixel_scale, y, Ho, Wo, pt, pl, n_groups);
+        AMS_CHECK_LAUNCH();
+        return AMS_OK;
+    }
     const int64_t total = (int64_t)B * Ho * Wo * (cout / 8);
     const int grid = (int)(cdiv64(total, 256) < 8192 ? cdiv64(total, 256) : 8192);
     const size_t lds = 27 * cout * sizeof(float);
@@ -190,7 +279,7 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
     float* yb = y + (int64_t)b * g.Ho * g.Wo * g.C + c0;
     const int oy0 = ty * g.TH;
-#pragma unroll 1
+#pragma unroll 2
     for (int r = 0; r < g.TH; ++r) {
         const int oy = oy0 + r;
         if (oy >= g.Ho) break;

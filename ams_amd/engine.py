@@ -181,6 +181,10 @@ class StudentEngine:
     def get_variables(self) -> Dict[str, np.ndarray]:
         return W.unpack(self.spec, self.params.cpu().numpy(), self.stats.cpu().numpy())
 
+    def set_matmul_mode(self, mode: int) -> None:
+        """hip.MATMUL_F32 (exact) or hip.MATMUL_SPLIT_BF16 (default; late-layer products via 3 bf16 MFMAs, ~1e-5 rel)."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_MATMUL, int(mode)), "ams_student_set_option")
+
     def freeze(self) -> None:
         """Device-side server->edge hand-off (replaces save_to_frozen_graph + reload)."""
         hip.check(self.lib.ams_student_freeze(self._h, self._stream()), "ams_student_freeze")

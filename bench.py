@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-layers", action="store_true", help="print the per-launch profile of one step to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +125,11 @@ def main():
             eng.predict(frames)
         rows = read_profile(eng)
         hip.check(eng.lib.ams_student_profile(eng._h, 0))
+        if args.dump_layers:
+            per = len(rows) // n_prof
+            for name, layer, ms, nbytes in rows[-per:]:
+                print("%3d %-28s %8.1f us %8.1f GB/s %10.0f KB" % (layer, name, 1e3 * ms, nbytes / ms / 1e6, nbytes / 1e3),
+                      file=sys.stderr)
         agg = defaultdict(lambda: [0, 0.0, 0.0])
         for name, layer, ms, nbytes in rows:
             a = agg[name]

@@ -162,6 +162,16 @@ int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t fr
                               const uint8_t* mask_dev, double* loss_dev, ams_allreduce_cb cb, void* user,
                               void* stream);
 
+/* ---- options -----------------------------------------------------------------------------------------------
+ * AMS_OPT_MATMUL selects how FROZEN inference forms the 1x1-conv products of the late layers (rows < 32768):
+ *   AMS_MATMUL_F32        exact f32 MFMA (v_mfma_f32_16x16x4_f32), bit-for-bit an f32 fma chain
+ *   AMS_MATMUL_SPLIT_BF16 (default) f32 data split into bf16 hi+lo, 3 bf16 MFMAs per product group, f32 accumulate:
+ *                         <= 2^-16 relative per product (~1e-5 on a layer output), 5x the matrix throughput.
+ * Training and the live graph always use exact f32. */
+enum { AMS_OPT_MATMUL = 1 };
+enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1 };
+int ams_student_set_option(ams_student* s, int32_t option, int32_t value);
+
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------------------------------
  * With profiling enabled every kernel launch of the engine is bracketed by HIP events on the launch stream.
  * ams_student_profile_read synchronises and writes one line per launch: "kernel\tlayer\tms\talgorithmic_bytes\n"
@@ -200,6 +210,12 @@ int ams_k_depthwise3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t 
 int ams_k_pointwise(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w,
                     const float* img_bias, int64_t rows_per_img, const float* scale, const float* shift,
                     int32_t act, const float* res, float* y, void* stream);
+
+/* K4, split-bf16 form (see AMS_MATMUL_SPLIT_BF16): y = act((x @ w) * scale + shift) + res with w [K,N] f32 split on the
+ * fly into bf16 hi/lo panels held in `panels` (uint16, >= 2*N*roundup(K,32) elements).  K % 8 == 0. */
+int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, int32_t N, const float* scale,
+                          const float* shift, int32_t act, const float* res, float* y, uint16_t* panels,
+                          size_t panel_elems, void* stream);
 
 /* K7: global average pool [B,HW,C] -> [B,C] (two-stage, deterministic); scratch >= ams_k_global_mean_scratch floats. */
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

@@ -96,6 +96,28 @@ def test_pointwise_image_bias_and_transposed_weights(lib):
     assert rel_err(y2.cpu().numpy(), x.astype(np.float64) @ wt.T.astype(np.float64)) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(2145, 960, 320), (17160, 160, 960), (2145, 384, 64), (4290, 576, 160), (2145, 256, 19),
+                                   (1000, 64, 384), (300, 320, 256), (2145, 24 * 8, 32)])
+def test_pointwise_split_bf16(lib, M, K, N):
+    """bf16x3 product: error budget 2^-16 per product -> ~1e-5 of the output scale; must beat plain bf16 (4e-3) by far."""
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    shift = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    Kp = (K + 31) // 32 * 32
+    panels = torch.zeros(2 * N * Kp, dtype=torch.int16, device=DEV)
+    y = torch.empty((M, N), device=DEV)
+    hip.check(lib.ams_k_pointwise_split(PD(x), M, K, PD(w), N, PD(scale), PD(shift), hip.ACT_RELU6, PD(res), P(y), P(panels),
+                                        panels.numel(), stream()))
+    want = np.clip((x.astype(np.float64) @ w.astype(np.float64)) * scale + shift, 0, 6) + res
+    assert rel_err(y.cpu().numpy(), want) < 5e-5
+    hip.check(lib.ams_k_pointwise_split(PD(x), M, K, PD(w), N, None, None, hip.ACT_NONE, None, P(y), P(panels),
+                                        panels.numel(), stream()))
+    assert rel_err(y.cpu().numpy(), x.astype(np.float64) @ w.astype(np.float64)) < 5e-5
+
+
 @pytest.mark.parametrize("M,K,N", [(5000, 16, 96), (4097, 96, 24), (2145 * 2, 960, 320), (2145, 160, 960), (3, 320, 256),
                                    (33000, 32, 16), (2145, 256, 19), (9000, 27, 32), (70000, 144, 24)])
 def test_pointwise_wgrad(lib, M, K, N):

@@ -51,11 +51,13 @@ def _check_labels(got, oracle_logits_sel, tol):
     return bad.mean()
 
 
-@pytest.mark.parametrize("H,B", [(64, 2), (48, 3)])
-def test_frozen_inference_matches_oracle(W0, H, B):
+@pytest.mark.parametrize("H,B,matmul", [(64, 2, hip.MATMUL_F32), (48, 3, hip.MATMUL_F32), (64, 2, hip.MATMUL_SPLIT_BF16),
+                                        (128, 2, hip.MATMUL_SPLIT_BF16)])
+def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     frames, labels = synth.SyntheticVideo(H, B, CI, seed=3).clip()
     eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
     eng.load_variables(W0)
+    eng.set_matmul_mode(matmul)
     eng.freeze()
     o = _oracle(W0)
     with torch.no_grad():

@@ -477,9 +477,11 @@ static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_lo
                        hipStream_t st) {
     RUNK(0, 8.0 * M_local * l.d.cout,
          launch_bn_bwd_reduce(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch, st));
+    // gamma/beta gradients from this rank's own sums: the gradient all-reduce adds the ranks up exactly once
+    RUN(launch_bn_param_grads(l.bsums, l.d.cout, s->grads + l.d.gamma_off, s->grads + l.d.beta_off, st));
     RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
     RUN(launch_bn_bwd_coef(l.bsums, n_global, l.d.cout, s->params + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC,
-                           s->grads + l.d.gamma_off, s->grads + l.d.beta_off, st));
+                           nullptr, nullptr, st));
     RUNK(0, 12.0 * M_local * l.d.cout,
          launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, s->dz, st));
     return AMS_OK;
@@ -540,9 +542,10 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     }
     {   // BN (over the batch) + ReLU of the pool branch; its dz goes to d_pool_z instead of s->dz (still in use? no: consumed)
         RUN(launch_bn_bwd_reduce(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.mean, lp.rstd, lp.bsums, s->scratch, st));
+        RUN(launch_bn_param_grads(lp.bsums, lp.d.cout, G + lp.d.gamma_off, G + lp.d.beta_off, st));
         RUN(sync_doubles(sc, lp.bsums, 2 * (size_t)lp.d.cout, st));
         RUN(launch_bn_bwd_coef(lp.bsums, (double)global_B, lp.d.cout, P + lp.d.gamma_off, lp.mean, lp.rstd, lp.cA, lp.cB, lp.cC,
-                               G + lp.d.gamma_off, G + lp.d.beta_off, st));
+                               nullptr, nullptr, st));
         RUN(launch_bn_bwd_apply(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.cA, lp.cB, lp.cC, s->d_pool_z, st));
         RUN(pw_wgrad(s, s->pooled, lp.d.cin, lp.d.cin, s->d_pool_z, lp.d.cout, lp.d.cout, B, G + lp.d.w_off, st));
         PwArgs a = dgrad_args(s->d_pool_z, B, lp.d.cout, lp.d.cout, P + lp.d.w_off, lp.d.cin, s->d_pooled);

@@ -235,6 +235,20 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, double n, in
     if (dgamma) { dgamma[c] = (float)sdyx; dbeta[c] = (float)sdy; }
 }
 
+// dgamma = sum(dy * xhat), dbeta = sum(dy) from the LOCAL sums (data-parallel ranks add theirs up in the gradient all-reduce)
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)sums[c];
+    dgamma[c] = (float)sums[C + c];
+}
+
+int launch_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, hipStream_t st) {
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums, C, dgamma, dbeta);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 int launch_bn_bwd_coef(const double* sums, double n, int C, const float* gamma, const float* mean, const float* rstd,
                        float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta, hipStream_t st) {
     hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, sums, n, C, gamma, mean, rstd, coefA, coefB,

@@ -82,6 +82,7 @@ int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, cons
 // per-channel (A,B,C) with dz = A*dy + B + C*z; also writes dgamma, dbeta
 int launch_bn_bwd_coef(const double* sums, double n, int C, const float* gamma, const float* mean, const float* rstd,
                        float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta, hipStream_t st);
+int launch_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, hipStream_t st);
 int launch_bn_bwd_apply(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift, int act,
                         const float* coefA, const float* coefB, const float* coefC, float* dz, hipStream_t st);
 // plain column sums over rows (bias gradient): out[c] = sum_m x[m, c]

@@ -66,9 +66,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AMS_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_gpus = world
 
@@ -164,8 +165,8 @@ def main():
         tl = torch.from_numpy(labels_np[:TB]).to(dev)
         allreduce = None
         if dist is not None:
-            def allreduce(t):  # noqa: E306
-                dist.all_reduce(t)
+            from ams_amd.dist import ArenaAllReduce
+            allreduce = ArenaAllReduce(teng.arena)
         for _ in range(2):
             teng.train_step(tf, tl, 1e-3, allreduce=allreduce, global_batch=TB * n_gpus)
         barrier()

@@ -254,3 +254,53 @@ def test_semantic_network_surface(W0, tmp_path):
     assert col.shape == (H, 2 * H, 3)
     net.close_model()
     edge.close_model()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# data-parallel fine-tune step on the real engine: 2 ranks (gloo, both on cuda:0) x 2 frames == 1 rank x 4 frames
+# ---------------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, tmp):
+    import os
+    import torch.distributed as dist
+    from ams_amd.dist import ArenaAllReduce, init_from_env, shard_bounds
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_from_env("gloo")
+    W0 = Wt.synthetic_weights(S.build_spec(), seed=0)
+    frames, labels = synth.SyntheticVideo(64, 4, CI, seed=9).clip()
+    b, e = shard_bounds(4, rank, world)
+    eng = StudentEngine(CI, 64, 128, max_batch=2, trainable=True)
+    eng.load_variables(W0)
+    red = ArenaAllReduce(eng.arena)
+    ls = eng.train_step(frames[b:e], labels[b:e], 1e-3, allreduce=red, global_batch=4).cpu().numpy()
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(os.path.join(tmp, "dp_grads.npy"), eng.grads.cpu().numpy())
+        np.save(os.path.join(tmp, "dp_params.npy"), eng.params.cpu().numpy())
+        np.save(os.path.join(tmp, "dp_stats.npy"), eng.stats.cpu().numpy())
+        np.save(os.path.join(tmp, "dp_loss.npy"), ls)
+        np.save(os.path.join(tmp, "dp_calls.npy"), np.array([red.calls, red.bytes]))
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_single_process(W0, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    frames, labels = synth.SyntheticVideo(64, 4, CI, seed=9).clip()
+    eng = StudentEngine(CI, 64, 128, max_batch=4, trainable=True)
+    eng.load_variables(W0)
+    ls = eng.train_step(frames, labels, 1e-3).cpu().numpy()
+    dp_ls = np.load(tmp_path / "dp_loss.npy")
+    assert dp_ls[1] == ls[1] and dp_ls[0] == pytest.approx(ls[0], rel=1e-6)      # global CE sum and valid count
+    g, dg = eng.grads.cpu().numpy().astype(np.float64), np.load(tmp_path / "dp_grads.npy").astype(np.float64)
+    cos = float(g @ dg / (np.linalg.norm(g) * np.linalg.norm(dg)))
+    assert cos > 0.99999, cos
+    assert rel(np.load(tmp_path / "dp_stats.npy"), eng.stats.cpu().numpy()) < 1e-5    # SyncBN: same moving averages
+    calls, nbytes = np.load(tmp_path / "dp_calls.npy")
+    assert calls == 54 * 2 + 2                     # BN fwd + BN bwd per layer, loss, gradients
+    assert nbytes > 4 * eng.spec.n_trainable
+    eng.close()

@@ -259,10 +259,14 @@ static int dw_geom(int B, int H, int W, int C, int stride, int rate, bool over_i
     return AMS_OK;
 }
 
-template <int S, int R>
+// Forward: a thread owns one output column (4 channels) and TH consecutive output rows.  All distinct input taps of
+// the TH rows ((TH-1)*S + 2*R + 1 input rows x 3 columns) are requested up front — independent loads, nothing
+// serialised — and each is used by every output row it belongs to (4.5 loads per output for stride 1 instead of 9).
+template <int S, int R, int TH>
 __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         int act, float* __restrict__ y, DwGeom g, unsigned nblocks) {
+    constexpr int NR = (TH - 1) * S + 2 * R + 1;           // input rows touched by TH output rows
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     const int tx = lb % g.tiles_x;
     const int ty = (lb / g.tiles_x) % g.tiles_y;
@@ -271,33 +275,44 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     const int ox = tx * g.slots + slot;
     if (slot >= g.slots || ox >= g.Wo) return;
     const int c0 = cg * 4;
+    const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
+    float* yb = y + (int64_t)b * g.Ho * g.Wo * g.C + c0;
+    const int oy0 = ty * TH;
+    const int iy0 = oy0 * S - g.pt;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ixs[3];
+    bool okx[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ixs[j] = ox * S - g.pl + j * R; okx[j] = ixs[j] >= 0 && ixs[j] < g.W; }
+    float4 in[NR][3];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+        // rows that no output row of this thread uses (rate 2: every other one is still used by the odd outputs) are all needed
+        const int iy = iy0 + rr;
+        const bool oky = iy >= 0 && iy < g.H && (oy0 + (rr / S)) < g.Ho + 2 * R;
+        const float* rp = xb + (int64_t)iy * g.W * g.C;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) in[rr][j] = (oky && okx[j]) ? ld4(rp + (int64_t)ixs[j] * g.C) : zero4;
+    }
     float4 wv[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + k * g.C + c0);
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4;
     if (scale) { sc = ld4(scale + c0); sh = ld4(shift + c0); }
-    const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
-    float* yb = y + (int64_t)b * g.Ho * g.Wo * g.C + c0;
-    const int oy0 = ty * g.TH;
-#pragma unroll 2
-    for (int r = 0; r < g.TH; ++r) {
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
         const int oy = oy0 + r;
         if (oy >= g.Ho) break;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc = zero4;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int iy = oy * S - g.pt + i * R;
-            if (iy < 0 || iy >= g.H) continue;
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int ix = ox * S - g.pl + j * R;
-                if (ix < 0 || ix >= g.W) continue;
-                const float4 v = ld4(xb + ((int64_t)iy * g.W + ix) * g.C);
+                const float4 v = in[r * S + i * R][j];
                 const float4 w4 = wv[i * 3 + j];
                 acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
                 acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
             }
-        }
         float4 o;
         o.x = apply_act(acc.x * sc.x + sh.x, act); o.y = apply_act(acc.y * sc.y + sh.y, act);
         o.z = apply_act(acc.z * sc.z + sh.z, act); o.w = apply_act(acc.w * sc.w + sh.w, act);
@@ -311,15 +326,17 @@ int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w,
     int rc = dw_geom(B, H, W, C, stride, rate, false, &g);
     if (rc) return rc;
     AMS_REQUIRE((scale == nullptr) == (shift == nullptr), "depthwise: scale and shift come together");
+    constexpr int TH1 = 4, TH2 = 3, THR = 4;
+    g.tiles_y = cdiv(g.Ho, stride == 2 ? TH2 : rate == 2 ? THR : TH1);
     const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
     const int threads = g.CG * g.slots;
-    note_kernel(stride == 2 ? "dw3x3_fwd_kernel<2, 1>" : rate == 2 ? "dw3x3_fwd_kernel<1, 2>" : "dw3x3_fwd_kernel<1, 1>");
+    note_kernel(stride == 2 ? "dw3x3_fwd_kernel<2, 1, 3>" : rate == 2 ? "dw3x3_fwd_kernel<1, 2, 4>" : "dw3x3_fwd_kernel<1, 1, 4>");
     if (stride == 1 && rate == 1)
-        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 1>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 1, TH1>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
     else if (stride == 2)
-        hipLaunchKernelGGL((dw3x3_fwd_kernel<2, 1>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<2, 1, TH2>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
     else
-        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 2>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 2, THR>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

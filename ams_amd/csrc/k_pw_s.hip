@@ -1,0 +1,128 @@
+// 1x1 convolutions, streaming variant (huge M, small K x N): see k_pointwise.hip for the overview.
+#include "pw_common.hpp"
+
+namespace ams {
+
+// ---- variant S: streaming layers (huge M, small K x N).  The whole weight panel of this column tile stays in LDS for
+// the block's lifetime; every wave walks its own 16*RM-row groups (grid-stride), no barrier after the prologue, and
+// the A fragment of the NEXT (row group, k chunk) is in flight while the current one feeds the matrix pipe.
+template <int RM, int NT, int EPI>
+__global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, int64_t n_groups) {
+    constexpr int PITCH = 16 * NT + 4;
+    extern __shared__ __attribute__((aligned(16))) float sW[];          // [Kpad][PITCH] then scale[16NT], shift[16NT]
+    const int tile_n = blockIdx.y;
+    const int n0 = tile_n * 16 * NT;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int K = a.K, n_chunks = (K + 15) / 16;
+    float* sSc = sW + n_chunks * 16 * PITCH;
+    float* sSh = sSc + 16 * NT;
+    float* sOut = sSh + 16 * NT + wave * (16 * (16 * NT + 4));
+    pw_stage_w<NT, PITCH>(a, sW, 0, n_chunks * 16, n0, tid, 256);
+    pw_stage_affine<NT>(a, sSc, sSh, n0, tid, 256);
+    __syncthreads();
+
+    const int64_t wave_stride = (int64_t)gridDim.x * 4;
+    int64_t g = (int64_t)blockIdx.x * 4 + wave;
+    if (g >= n_groups) return;
+    auto row_ptr = [&](int64_t grp, int r) {
+        int64_t m = grp * (16 * RM) + r * 16 + l15;
+        if (m > a.M - 1) m = a.M - 1;
+        return a.x + m * (int64_t)a.ldx + 4 * q;
+    };
+    float4 a_cur[RM], a_nxt[RM];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < RM; ++r) a_cur[r] = (4 * q < K) ? ld4(row_ptr(g, r)) : zero4;
+    f32x4 acc[RM][NT];
+    while (g < n_groups) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int64_t g_next = g + wave_stride;
+        for (int c = 0; c < n_chunks; ++c) {
+            // prefetch: next chunk of this group, or chunk 0 of the next group
+            if (c + 1 < n_chunks) {
+                const bool ok = (c + 1) * 16 + 4 * q < K;
+#pragma unroll
+                for (int r = 0; r < RM; ++r) a_nxt[r] = ok ? ld4(row_ptr(g, r) + (c + 1) * 16) : zero4;
+            } else if (g_next < n_groups) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r) a_nxt[r] = (4 * q < K) ? ld4(row_ptr(g_next, r)) : zero4;
+            }
+            pw_chunk<RM, NT, PITCH>(acc, a_cur, sW + (c * 16 + 4 * q) * PITCH + l15);
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                a_cur[r] = a_nxt[r];
+                // Pin the hand-over HERE, ahead of the epilogue's stores.  vmcnt retires in order and counts stores, and
+                // hipcc waits vmcnt(0) on a loop-carried load: left to itself it parks that wait at the top of the next
+                // iteration, i.e. behind this group's 12 freshly issued stores — every group then pays a full store round
+                // trip with the matrix pipe idle (measured: 18 % MFMA busy, SQ_WAIT_INST_ANY 40 % of wave cycles).
+                asm volatile("" : "+v"(a_cur[r].x), "+v"(a_cur[r].y), "+v"(a_cur[r].z), "+v"(a_cur[r].w));
+            }
+        }
+        pw_epilogue_t<RM, NT, EPI>(a, acc, g * (16 * RM), n0, lane, sSc, sSh, sOut);      // host guarantees N, ldy, ldr % 4 == 0
+        g = g_next;
+    }
+}
+
+template <int RM, int NT, int EPI>
+static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
+    constexpr int PITCH = 16 * NT + 4;
+    const int n_tiles_n = cdiv(a.N, 16 * NT);
+    const int64_t n_groups = cdiv64(a.M, 16 * RM);
+    const size_t lds = ((size_t)((a.K + 15) / 16 * 16) * PITCH + 32 * NT + 4 * 16 * (16 * NT + 4)) * sizeof(float);
+    int64_t blocks = cdiv64(n_groups, 4);
+    // persistent grid: exactly the blocks that are co-resident (work is pre-partitioned by grid-stride, so any block that
+    // has to wait for a slot would run its whole share on a half-empty chip)
+    static int per_cu_cache = -1;
+    static size_t per_cu_lds = 0;
+    if (per_cu_cache < 0 || per_cu_lds != lds) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pw_gemm_f32_s<RM, NT, EPI>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+        per_cu_cache = nb;
+        per_cu_lds = lds;
+    }
+    int per_cu = per_cu_cache;
+    if (const char* e = getenv("AMS_PW_PERCU")) per_cu = atoi(e);          // tuning knob (tools/bench_kernel.py)
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    if (lds > 64 * 1024)
+        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_f32_s<RM, NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ">";
+    note_kernel(nm.c_str());
+    hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT, EPI>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, a, n_tiles_n, n_groups);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+template <int RM, int NT>
+static int launch_pw_s(const PwArgs& a, hipStream_t st) {
+    return a.res ? launch_pw_s_e<RM, NT, EPI_RES>(a, st) : launch_pw_s_e<RM, NT, EPI_PLAIN>(a, st);
+}
+
+// returns AMS_OK and sets *handled when the streaming variant applies (weight panel <= 56 KB, vector-friendly layout)
+int launch_pointwise_stream(const PwArgs& a, int force_rm, int force_nt, bool* handled, hipStream_t st) {
+    *handled = false;
+    const int epi = pw_pick_epi(a);
+    if (epi != EPI_PLAIN && epi != EPI_RES) return AMS_OK;
+    const int n16 = cdiv(a.N, 16);
+    const int kpad = (a.K + 15) / 16 * 16;
+    int nt = n16;
+    if (n16 > 6) { const int parts = cdiv(n16, 6); nt = cdiv(n16, parts); }     // column tiles of at most 6 x 16
+    if (force_nt > 0) nt = force_nt;
+    if ((size_t)kpad * (16 * nt + 4) * 4 > 56 * 1024) return AMS_OK;
+    *handled = true;
+    switch (nt) {
+        case 1: return launch_pw_s<2, 1>(a, st);
+        case 2: return launch_pw_s<2, 2>(a, st);
+        case 3: return launch_pw_s<2, 3>(a, st);
+        case 4: return launch_pw_s<2, 4>(a, st);
+        case 5: return launch_pw_s<2, 5>(a, st);
+        case 6: return launch_pw_s<2, 6>(a, st);
+        default: break;
+    }
+    *handled = false;
+    return AMS_OK;
+}
+
+}  // namespace ams

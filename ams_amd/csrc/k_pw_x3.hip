@@ -1,0 +1,190 @@
+// 1x1 convolutions, split-bf16 ("bf16x3") variant for frozen late layers: see k_pointwise.hip for the overview.
+#include "pw_common.hpp"
+
+namespace ams {
+
+// =========================================================================================================
+// Split-bf16 ("bf16x3") late-layer GEMM.  f32 activations stay f32 in HBM; inside the kernel every operand is split
+// into bf16 hi + bf16 lo (16 significand bits together) and the product is formed as hi*hi + lo*hi + hi*lo on the
+// bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, f32 accumulate): 3 instructions per 32 k instead of 8 f32-MFMA
+// instructions of twice the latency (the f32-input MFMA runs at 1/16 of the bf16 rate on gfx950).  Dropped terms are
+// <= 2^-16 relative per product, i.e. ~1e-5 on a layer output — two orders inside the 1e-3 logit tolerance.  The
+// weights are split once per ams_student_freeze into [N][Kp] hi / lo panels (k contiguous, Kp = K rounded up to 32).
+// =========================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ void split_w_kernel(const float* __restrict__ w, int64_t sk, int64_t sn, int K, int N, int Kp,
+                               unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Kp) return;
+    const int n = (int)(i / Kp), k = (int)(i % Kp);
+    const float v = k < K ? w[k * sk + n * sn] : 0.f;
+    const unsigned short h = bf16_rne_bits(v);
+    const float hf = __uint_as_float((unsigned)h << 16);
+    hi[i] = h;
+    lo[i] = bf16_rne_bits(v - hf);
+}
+
+int launch_split_weights(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st) {
+    const int64_t n = (int64_t)N * Kp;
+    hipLaunchKernelGGL(split_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, sk, sn, K, N, Kp, hi, lo);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// 8 consecutive f32 -> bf16x8 hi and lo
+__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& hi, bf16x8& lo) {
+    const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)f[j];
+        hi[j] = h;
+        lo[j] = (__bf16)(f[j] - (float)h);
+    }
+}
+
+template <int RM, int NT, int EPI>
+__global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ whi,
+                                                        const unsigned short* __restrict__ wlo, int Kp, int n_tiles_n,
+                                                        unsigned nblocks) {
+    constexpr int PITCH = 40;                        // bf16 elements per LDS row: 80 B, conflict-free for ds_read_b128
+    constexpr int ROWS = 16 * NT;
+    constexpr int NPIECE = 2 * ROWS * 4;             // 16-byte pieces per stage (hi + lo panels, 32 k = 4 pieces per row)
+    constexpr int NREG = (NPIECE + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned short sW[2][2][ROWS * PITCH];     // [buffer][hi/lo]
+    __shared__ __attribute__((aligned(16))) float sSc[16 * NT], sSh[16 * NT];
+    __shared__ __attribute__((aligned(16))) float sOutAll[EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4)];
+    const unsigned lb = xcd_remap(blockIdx.x, nblocks);
+    const int tile_n = lb % n_tiles_n;
+    const int64_t tile_m = lb / n_tiles_n;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int n0 = tile_n * ROWS;
+    const int64_t m_base = tile_m * (64 * RM) + wave * (16 * RM);
+    const int K = a.K, n_stages = Kp / 32;
+
+    uint4 wreg[NREG];
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) {
+            const int e = tid + u * 256;
+            const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (e < NPIECE && n0 + n < a.N)
+                v = *reinterpret_cast<const uint4*>((which ? wlo : whi) + (int64_t)(n0 + n) * Kp + s * 32 + part * 8);
+            wreg[u] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) {
+            const int e = tid + u * 256;
+            const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
+            if (e < NPIECE) *reinterpret_cast<uint4*>(&sW[buf][which][n * PITCH + part * 8]) = wreg[u];
+        }
+    };
+
+    const float* arow[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        int64_t m = m_base + r * 16 + l15;
+        if (m > a.M - 1) m = a.M - 1;
+        arow[r] = a.x + m * (int64_t)a.ldx + 8 * q;
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a_cur[RM][2], a_nxt[RM][2];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        const bool ok = 8 * q < K;
+        a_cur[r][0] = ok ? ld4(arow[r]) : zero4;
+        a_cur[r][1] = ok ? ld4(arow[r] + 4) : zero4;
+    }
+    f32x4 acc[RM][NT];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_stage(0);
+    pw_stage_affine<NT>(a, sSc, sSh, n0, tid, 256);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < n_stages; ++s) {
+        if (s + 1 < n_stages) {
+            load_stage(s + 1);
+            const bool ok = (s + 1) * 32 + 8 * q < K;
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                a_nxt[r][0] = ok ? ld4(arow[r] + (s + 1) * 32) : zero4;
+                a_nxt[r][1] = ok ? ld4(arow[r] + (s + 1) * 32 + 4) : zero4;
+            }
+        }
+        bf16x8 xh[RM], xl[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) split8(a_cur[r][0], a_cur[r][1], xh[r], xl[r]);
+        const unsigned short* bh = &sW[s & 1][0][l15 * PITCH + 8 * q];
+        const unsigned short* bl = &sW[s & 1][1][l15 * PITCH + 8 * q];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(bh + t * 16 * PITCH);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(bl + t * 16 * PITCH);
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[r], acc[r][t], 0, 0, 0);
+                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[r], acc[r][t], 0, 0, 0);
+                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[r], acc[r][t], 0, 0, 0);
+            }
+        }
+        if (s + 1 < n_stages) {
+            store_stage((s + 1) & 1);
+#pragma unroll
+            for (int r = 0; r < RM; ++r) { a_cur[r][0] = a_nxt[r][0]; a_cur[r][1] = a_nxt[r][1]; }
+        }
+        __syncthreads();
+    }
+    if (EPI == EPI_GENERIC) pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q, sSc, sSh);
+    else pw_epilogue_t<RM, NT, EPI>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)));
+}
+
+template <int RM, int NT, int EPI>
+static int launch_pw_x3_e(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+    const int n_tiles_n = cdiv(a.N, 16 * NT);
+    const int64_t nblocks = cdiv64(a.M, 64 * RM) * n_tiles_n;
+    static const std::string nm = "pw_gemm_bf16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ">";
+    note_kernel(nm.c_str());
+    hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI>), dim3((unsigned)nblocks), dim3(256), 0, st, a, whi, wlo, Kp, n_tiles_n,
+                       (unsigned)nblocks);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+template <int RM, int NT>
+static int launch_pw_x3(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+    switch (pw_pick_epi(a)) {
+        case EPI_PLAIN: return launch_pw_x3_e<RM, NT, EPI_PLAIN>(a, whi, wlo, Kp, st);
+        case EPI_RES: return launch_pw_x3_e<RM, NT, EPI_RES>(a, whi, wlo, Kp, st);
+        case EPI_BIAS: return launch_pw_x3_e<RM, NT, EPI_BIAS>(a, whi, wlo, Kp, st);
+        default: return launch_pw_x3_e<RM, NT, EPI_GENERIC>(a, whi, wlo, Kp, st);
+    }
+}
+
+// y = epilogue(x @ w) with w given as pre-split bf16 hi/lo panels [N][Kp]; requires K % 8 == 0
+int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+    AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0 && Kp % 32 == 0 && Kp >= a.K, "pointwise_split: bad problem");
+    AMS_REQUIRE(a.K % 8 == 0 && a.ldx % 4 == 0, "pointwise_split: K (%d) must be a multiple of 8", a.K);
+    int rm, nt;
+    pw_pick_tile(a.M, a.N, &rm, &nt);
+#define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, whi, wlo, Kp, st);
+    PW_X(2, 6) PW_X(2, 5) PW_X(2, 4) PW_X(2, 3) PW_X(2, 2) PW_X(2, 1)
+    PW_X(1, 6) PW_X(1, 5) PW_X(1, 4) PW_X(1, 3) PW_X(1, 2) PW_X(1, 1)
+#undef PW_X
+    set_error("pointwise_split: no tile configuration");
+    return AMS_E_INVALID;
+}
+
+}  // namespace ams

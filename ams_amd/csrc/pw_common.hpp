@@ -1,0 +1,249 @@
+// Device pieces shared by the pointwise (1x1 conv) GEMM kernels: epilogues, MFMA chunk, weight-panel staging.
+#pragma once
+#include <stdlib.h>
+
+#include <string>
+
+#include "kernels.hpp"
+
+namespace ams {
+
+// ---------------------------------------------------------------------------------------------------------
+// Operand roles are SWAPPED in the MFMA (a = weights, b = activations): the 16x16 result then has the output
+// channel along the accumulator registers (row = 4*(lane>>4) + i) and the pixel along lanes (col = lane & 15),
+// so every lane owns 4 consecutive output channels of one pixel and the epilogue is float4 loads/stores
+// (scale, shift, per-image bias, residual, result) instead of four scalar stores per tile.
+// ---------------------------------------------------------------------------------------------------------
+// BN scale / shift of this column tile are staged in LDS once per block (sSc, sSh: 16*NT floats each, identity where
+// absent) and the residual / per-image-bias operands of a whole row group are requested before any of them is used:
+// the epilogue then costs one memory round trip per row group instead of one per 16-column tile.
+template <int NT>
+__device__ __forceinline__ void pw_stage_affine(const PwArgs& a, float* sSc, float* sSh, int n0, int tid, int nthreads) {
+    for (int e = tid; e < 16 * NT; e += nthreads) {
+        const int n = n0 + e;
+        sSc[e] = (a.scale && n < a.N) ? a.scale[n] : 1.f;
+        sSh[e] = (a.shift && n < a.N) ? a.shift[n] : 0.f;
+    }
+}
+
+template <int RM, int NT>
+__device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x4 (&acc)[RM][NT], int64_t m_base, int n0, int l15, int q,
+                                            const float* sSc, const float* sSh) {
+    const bool y_vec = (a.ldy & 3) == 0, r_vec = (a.ldr & 3) == 0, n_vec = (a.N & 3) == 0;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        const int64_t m = m_base + r * 16 + l15;
+        if (m >= a.M) continue;
+        float4 add[NT];                                   // residual + per-image bias contributions, gathered first
+        bool has_add = false;
+        if (a.res || a.img_bias) {
+            has_add = true;
+            const float* rp = a.res ? a.res + m * a.ldr : nullptr;
+            const float* bp = a.img_bias ? a.img_bias + (m / a.rows_per_img) * a.N : nullptr;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n4 = n0 + 16 * t + 4 * q;
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), bv = rv;
+                if (n4 + 3 < a.N) {
+                    if (rp) rv = r_vec ? ld4(rp + n4) : make_float4(rp[n4], rp[n4 + 1], rp[n4 + 2], rp[n4 + 3]);
+                    if (bp) bv = n_vec ? ld4(bp + n4) : make_float4(bp[n4], bp[n4 + 1], bp[n4 + 2], bp[n4 + 3]);
+                } else if (n4 < a.N) {
+                    float tr[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (n4 + i < a.N) { if (rp) tr[i] = rp[n4 + i]; if (bp) tb[i] = bp[n4 + i]; }
+                    rv = make_float4(tr[0], tr[1], tr[2], tr[3]);
+                    bv = make_float4(tb[0], tb[1], tb[2], tb[3]);
+                }
+                add[t] = rv;
+                // the bias enters BEFORE scale/shift: fold it into the accumulator now
+                acc[r][t][0] += bv.x; acc[r][t][1] += bv.y; acc[r][t][2] += bv.z; acc[r][t][3] += bv.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c4 = 16 * t + 4 * q, n4 = n0 + c4;
+            if (n4 >= a.N) continue;
+            const float4 sc = ld4(sSc + c4), sh = ld4(sSh + c4);
+            float4 v;
+            v.x = apply_act(acc[r][t][0] * sc.x + sh.x, a.act); v.y = apply_act(acc[r][t][1] * sc.y + sh.y, a.act);
+            v.z = apply_act(acc[r][t][2] * sc.z + sh.z, a.act); v.w = apply_act(acc[r][t][3] * sc.w + sh.w, a.act);
+            if (has_add && a.res) { v.x += add[t].x; v.y += add[t].y; v.z += add[t].z; v.w += add[t].w; }
+            float* yp = a.y + m * a.ldy + n4;
+            if (n4 + 3 < a.N && y_vec) st4(yp, v);
+            else {
+                const float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (n4 + i < a.N) yp[i] = o[i];
+            }
+        }
+    }
+}
+
+// Coalesced form of the epilogue: the MFMA result leaves a lane with 4 channels of ONE pixel, i.e. a wave-level store
+// touches 16 different rows in 64-byte pieces (measured: 32-byte L1->L2 write requests, 4x the request count of a
+// linear store).  Here each 16-row x 16*NT-column slab goes through a per-wave LDS staging buffer and is written back
+// row-major: consecutive lanes hold consecutive float4 of a row, so stores (and the residual loads) are full lines.
+// All global loads of a slab (per-image bias, residual) are issued together with clamped addresses and no branches, so
+// the slab costs one memory round trip.  Requires N, ldy (and ldr) multiples of 4 and N >= 4.
+// sOut: this wave's buffer, 16 x (16*NT + 4) floats.
+enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_BIAS = 2, EPI_GENERIC = 3 };
+
+template <int RM, int NT, int EPI>
+__device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][NT], int64_t m_base, int n0, int lane,
+                                              const float* sSc, const float* sSh, float* sOut) {
+    constexpr int OP = 16 * NT + 4;
+    constexpr int V4 = 4 * NT;                 // float4 per slab row
+    const int l15 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        const int64_t m0 = m_base + r * 16;
+        if (EPI == EPI_BIAS) {                 // added before scale/shift; row = this lane's pixel
+            int64_t m = m0 + l15;
+            if (m > a.M - 1) m = a.M - 1;
+            const float* bp = a.img_bias + (m / a.rows_per_img) * a.N;
+            float4 bv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int n4 = n0 + 16 * t + 4 * q;
+                if (n4 > a.N - 4) n4 = a.N - 4;
+                bv[t] = ld4(bp + n4);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { acc[r][t][0] += bv[t].x; acc[r][t][1] += bv[t].y; acc[r][t][2] += bv[t].z; acc[r][t][3] += bv[t].w; }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c4 = 16 * t + 4 * q;
+            const float4 sc = ld4(sSc + c4), sh = ld4(sSh + c4);
+            float4 v;
+            v.x = apply_act(acc[r][t][0] * sc.x + sh.x, a.act); v.y = apply_act(acc[r][t][1] * sc.y + sh.y, a.act);
+            v.z = apply_act(acc[r][t][2] * sc.z + sh.z, a.act); v.w = apply_act(acc[r][t][3] * sc.w + sh.w, a.act);
+            st4(sOut + l15 * OP + c4, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float4 rv[NT];
+        if (EPI == EPI_RES) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int f = lane + 64 * u;
+                const int row = f / V4;
+                int col = n0 + (f - row * V4) * 4;
+                int64_t m = m0 + row;
+                if (m > a.M - 1) m = a.M - 1;
+                if (col > a.N - 4) col = a.N - 4;
+                rv[u] = ld4(a.res + m * a.ldr + col);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int f = lane + 64 * u;
+            const int row = f / V4, c4 = (f - row * V4) * 4;
+            const int64_t m = m0 + row;
+            float4 v = ld4(sOut + row * OP + c4);
+            if (EPI == EPI_RES) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
+            if (m < a.M && n0 + c4 < a.N) st4(a.y + m * a.ldy + n0 + c4, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// which epilogue a problem can use
+static inline int pw_pick_epi(const PwArgs& a) {
+    const bool vec_ok = a.N >= 4 && (a.N & 3) == 0 && (a.ldy & 3) == 0 && (!a.res || (a.ldr & 3) == 0);
+    if (!vec_ok || (a.res && a.img_bias)) return EPI_GENERIC;
+    return a.res ? EPI_RES : a.img_bias ? EPI_BIAS : EPI_PLAIN;
+}
+
+// column-tile width (in 16s) and rows per wave for the tiled kernels: least padding waste while giving the chip >= ~3
+// blocks per CU
+static inline void pw_pick_tile(int64_t M, int N, int* rm_out, int* nt_out) {
+    const int n16 = cdiv(N, 16);
+    int best_nt = 1, best_rm = 1;
+    double best = -1;
+    for (int nt = 6; nt >= 1; --nt)
+        for (int rm = 2; rm >= 1; --rm) {
+            const int tn = cdiv(n16, nt);
+            const double blocks = (double)cdiv64(M, 64 * rm) * tn;
+            const double useful = (double)n16 / (tn * nt);
+            const double fill = blocks >= 768 ? 1.0 : blocks / 768.0;
+            const double reuse = 0.85 + 0.15 * (nt * rm) / 12.0;
+            const double score = useful * fill * reuse;
+            if (score > best) { best = score; best_nt = nt; best_rm = rm; }
+        }
+    *rm_out = best_rm;
+    *nt_out = best_nt;
+}
+
+// one 16-k chunk: 4 MFMA k-steps x NT column tiles x RM row groups; sB points at this lane's (k = 4q, n = l15) element
+template <int RM, int NT, int PITCH>
+__device__ __forceinline__ void pw_chunk(f32x4 (&acc)[RM][NT], const float4 (&av)[RM], const float* sB) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float xv[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) xv[r] = j == 0 ? av[r].x : j == 1 ? av[r].y : j == 2 ? av[r].z : av[r].w;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float wv = sB[j * PITCH + 16 * t];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv[r], acc[r][t], 0, 0, 0);
+        }
+    }
+}
+
+// stage w[k0 .. k0+rows) x [n0 .. n0+16*NT) into LDS (row pitch PITCH), zero-filled outside Kw x N.
+// Loads are issued in batches of U independent requests before any LDS store, so a panel costs a few L2 round trips
+// instead of one per element (the panel is re-staged by every block: it must not serialise).
+template <int NT, int PITCH>
+__device__ __forceinline__ void pw_stage_w(const PwArgs& a, float* dst, int k0, int rows, int n0, int tid, int nthreads) {
+    constexpr int cols = 16 * NT;
+    constexpr int U = 8;
+    if (a.w_sn == 1 && (a.N & 3) == 0 && (a.w_sk & 3) == 0) {
+        constexpr int c4 = cols / 4;
+        const int pieces = rows * c4;
+        for (int base = tid; base < pieces; base += nthreads * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * nthreads;
+                const int kk = e / c4, nn = (e - kk * c4) * 4;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < pieces && k0 + kk < a.Kw && n0 + nn < a.N) v[u] = ld4(a.w + (int64_t)(k0 + kk) * a.w_sk + (n0 + nn));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = base + u * nthreads;
+                const int kk = e / c4, nn = (e - kk * c4) * 4;
+                if (e < pieces) st4(dst + kk * PITCH + nn, v[u]);
+            }
+        }
+        return;
+    }
+    const int total = rows * cols;
+    const bool n_contig = a.w_sn == 1;
+    for (int base = tid; base < total; base += nthreads * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * nthreads;
+            int kk, nn;
+            if (n_contig) { kk = e / cols; nn = e - kk * cols; } else { nn = e / rows; kk = e - nn * rows; }
+            v[u] = 0.f;
+            if (e < total && k0 + kk < a.Kw && n0 + nn < a.N) v[u] = a.w[(int64_t)(k0 + kk) * a.w_sk + (int64_t)(n0 + nn) * a.w_sn];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = base + u * nthreads;
+            int kk, nn;
+            if (n_contig) { kk = e / cols; nn = e - kk * cols; } else { nn = e / rows; kk = e - nn * rows; }
+            if (e < total) dst[kk * PITCH + nn] = v[u];
+        }
+    }
+}
+
+}  // namespace ams

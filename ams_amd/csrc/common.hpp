@@ -57,10 +57,11 @@ static inline void same_pad(int in, int k, int stride, int rate, int* out, int* 
 constexpr int kNumXcd = 8;   // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
 
 // ---- device helpers --------------------------------------------------------------------------------
+// branch-free: the activation is a clamp to [lo, hi] with wave-uniform bounds (scalar selects, two VALU ops per value)
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == AMS_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
-    if (act == AMS_ACT_RELU) return fmaxf(v, 0.f);
-    return v;
+    const float lo = act == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f;
+    const float hi = act == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+    return fminf(fmaxf(v, lo), hi);
 }
 
 // XCD-aware block remap: consecutive *logical* ids land on the same XCD (same private L2), so blocks that

@@ -22,47 +22,54 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
     __syncthreads();
 
     const int64_t wave_stride = (int64_t)gridDim.x * 4;
-    int64_t g = (int64_t)blockIdx.x * 4 + wave;
-    if (g >= n_groups) return;
-    auto row_ptr = [&](int64_t grp, int r) {
-        int64_t m = grp * (16 * RM) + r * 16 + l15;
-        if (m > a.M - 1) m = a.M - 1;
-        return a.x + m * (int64_t)a.ldx + 4 * q;
+    const int64_t g_first = (int64_t)blockIdx.x * 4 + wave;
+    if (g_first >= n_groups) return;
+    const int64_t my_groups = (n_groups - 1 - g_first) / wave_stride + 1;
+    const int64_t n_items = my_groups * n_chunks;              // (row group, 16-k chunk) pairs walked by this wave
+
+    // branch-free operand fetch: addresses are clamped into the tensor (rows to M-1, the k offset to K-4) and lanes
+    // whose k range lies beyond K are zeroed by a select, so the loop body has no exec-masked VMEM and hipcc can keep
+    // the prefetch in flight across the MFMAs (an exec-masked load makes it fall back to s_waitcnt vmcnt(0)).
+    auto fetch = [&](int64_t grp, int c, float4 (&dst)[RM]) {
+        int koff = c * 16 + 4 * q;
+        const bool ok = koff < K;
+        if (koff > K - 4) koff = K - 4;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            int64_t m = grp * (16 * RM) + r * 16 + l15;
+            if (m > a.M - 1) m = a.M - 1;
+            const float4 v = ld4(a.x + m * (int64_t)a.ldx + koff);
+            dst[r] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
     };
     float4 a_cur[RM], a_nxt[RM];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < RM; ++r) a_cur[r] = (4 * q < K) ? ld4(row_ptr(g, r)) : zero4;
+    fetch(g_first, 0, a_cur);
     f32x4 acc[RM][NT];
-    while (g < n_groups) {
+    int64_t g = g_first;
+    int c = 0;
+    for (int64_t it = 0; it < n_items; ++it) {
+        // next item: next chunk of this group, else chunk 0 of the wave's next group (clamped on the very last item)
+        int cn = c + 1;
+        int64_t gn = g;
+        if (cn == n_chunks) { cn = 0; gn = g + wave_stride; if (gn >= n_groups) gn = g; }
+        fetch(gn, cn, a_nxt);
+        if (c == 0) {
 #pragma unroll
-        for (int r = 0; r < RM; ++r)
+            for (int r = 0; r < RM; ++r)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int64_t g_next = g + wave_stride;
-        for (int c = 0; c < n_chunks; ++c) {
-            // prefetch: next chunk of this group, or chunk 0 of the next group
-            if (c + 1 < n_chunks) {
-                const bool ok = (c + 1) * 16 + 4 * q < K;
-#pragma unroll
-                for (int r = 0; r < RM; ++r) a_nxt[r] = ok ? ld4(row_ptr(g, r) + (c + 1) * 16) : zero4;
-            } else if (g_next < n_groups) {
-#pragma unroll
-                for (int r = 0; r < RM; ++r) a_nxt[r] = (4 * q < K) ? ld4(row_ptr(g_next, r)) : zero4;
-            }
-            pw_chunk<RM, NT, PITCH>(acc, a_cur, sW + (c * 16 + 4 * q) * PITCH + l15);
-#pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                a_cur[r] = a_nxt[r];
-                // Pin the hand-over HERE, ahead of the epilogue's stores.  vmcnt retires in order and counts stores, and
-                // hipcc waits vmcnt(0) on a loop-carried load: left to itself it parks that wait at the top of the next
-                // iteration, i.e. behind this group's 12 freshly issued stores — every group then pays a full store round
-                // trip with the matrix pipe idle (measured: 18 % MFMA busy, SQ_WAIT_INST_ANY 40 % of wave cycles).
-                asm volatile("" : "+v"(a_cur[r].x), "+v"(a_cur[r].y), "+v"(a_cur[r].z), "+v"(a_cur[r].w));
-            }
+                for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        pw_epilogue_t<RM, NT, EPI>(a, acc, g * (16 * RM), n0, lane, sSc, sSh, sOut);      // host guarantees N, ldy, ldr % 4 == 0
-        g = g_next;
+        pw_chunk<RM, NT, PITCH>(acc, a_cur, sW + (c * 16 + 4 * q) * PITCH + l15);
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            a_cur[r] = a_nxt[r];
+            // Hand the prefetched fragment over HERE, ahead of the epilogue's stores: vmcnt retires in order and counts
+            // stores, so a wait placed after them would sit behind a full store round trip with the matrix pipe idle.
+            asm volatile("" : "+v"(a_cur[r].x), "+v"(a_cur[r].y), "+v"(a_cur[r].z), "+v"(a_cur[r].w));
+        }
+        if (c == n_chunks - 1) pw_epilogue_t<RM, NT, EPI>(a, acc, g * (16 * RM), n0, lane, sSc, sSh, sOut);
+        c = cn;
+        g = gn;
     }
 }
 

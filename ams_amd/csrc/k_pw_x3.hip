@@ -179,6 +179,7 @@ int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t*
     AMS_REQUIRE(a.K % 8 == 0 && a.ldx % 4 == 0, "pointwise_split: K (%d) must be a multiple of 8", a.K);
     int rm, nt;
     pw_pick_tile(a.M, a.N, &rm, &nt);
+    if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &rm, &nt);       // tuning knob
 #define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, whi, wlo, Kp, st);
     PW_X(2, 6) PW_X(2, 5) PW_X(2, 4) PW_X(2, 3) PW_X(2, 2) PW_X(2, 1)
     PW_X(1, 6) PW_X(1, 5) PW_X(1, 4) PW_X(1, 3) PW_X(1, 2) PW_X(1, 1)

@@ -159,24 +159,19 @@ static inline int pw_pick_epi(const PwArgs& a) {
     return a.res ? EPI_RES : a.img_bias ? EPI_BIAS : EPI_PLAIN;
 }
 
-// column-tile width (in 16s) and rows per wave for the tiled kernels: least padding waste while giving the chip >= ~3
-// blocks per CU
+// Column-tile width (in 16s) and row groups per wave for the tiled kernels.  Rule distilled from a sweep over the
+// late-layer shapes on MI355X (tools/bench_kernel.py, AMS_PWX_FORCE): 64-wide tiles when they divide N, else 80, 48, 32;
+// 96-wide tiles lose to LDS pressure; two row groups per wave only when that still leaves >= 2 blocks per CU.
 static inline void pw_pick_tile(int64_t M, int N, int* rm_out, int* nt_out) {
-    const int n16 = cdiv(N, 16);
-    int best_nt = 1, best_rm = 1;
-    double best = -1;
-    for (int nt = 6; nt >= 1; --nt)
-        for (int rm = 2; rm >= 1; --rm) {
-            const int tn = cdiv(n16, nt);
-            const double blocks = (double)cdiv64(M, 64 * rm) * tn;
-            const double useful = (double)n16 / (tn * nt);
-            const double fill = blocks >= 768 ? 1.0 : blocks / 768.0;
-            const double reuse = 0.85 + 0.15 * (nt * rm) / 12.0;
-            const double score = useful * fill * reuse;
-            if (score > best) { best = score; best_nt = nt; best_rm = rm; }
-        }
-    *rm_out = best_rm;
-    *nt_out = best_nt;
+    int nt;
+    if (N % 64 == 0) nt = 4;
+    else if (N % 80 == 0) nt = 5;
+    else if (N % 48 == 0) nt = 3;
+    else if (N % 32 == 0) nt = 2;
+    else nt = N <= 16 ? 1 : N <= 32 ? 2 : N <= 48 ? 3 : 4;
+    const int tiles_n = cdiv(N, 16 * nt);
+    *rm_out = (cdiv64(M, 128) * tiles_n >= 512) ? 2 : 1;
+    *nt_out = nt;
 }
 
 // one 16-k chunk: 4 MFMA k-steps x NT column tiles x RM row groups; sB points at this lane's (k = 4q, n = l15) element

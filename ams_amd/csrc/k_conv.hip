@@ -280,19 +280,29 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     const int oy0 = ty * TH;
     const int iy0 = oy0 * S - g.pt;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int ixs[3];
+    int ixc[3];
     bool okx[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { ixs[j] = ox * S - g.pl + j * R; okx[j] = ixs[j] >= 0 && ixs[j] < g.W; }
+    for (int j = 0; j < 3; ++j) {
+        const int ix = ox * S - g.pl + j * R;
+        okx[j] = ix >= 0 && ix < g.W;
+        ixc[j] = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
+    }
     float4 in[NR][3];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
         // rows that no output row of this thread uses (rate 2: every other one is still used by the odd outputs) are all needed
         const int iy = iy0 + rr;
-        const bool oky = iy >= 0 && iy < g.H && (oy0 + (rr / S)) < g.Ho + 2 * R;
-        const float* rp = xb + (int64_t)iy * g.W * g.C;
+        const bool oky = iy >= 0 && iy < g.H;
+        const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+        const float* rp = xb + (int64_t)iyc * g.W * g.C;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) in[rr][j] = (oky && okx[j]) ? ld4(rp + (int64_t)ixs[j] * g.C) : zero4;
+        for (int j = 0; j < 3; ++j) {
+            // clamped address + select instead of a guarded load: no exec-masked VMEM, all taps stay in flight together
+            const float4 v = ld4(rp + (int64_t)ixc[j] * g.C);
+            const bool ok = oky && okx[j];
+            in[rr][j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
     }
     float4 wv[9];
 #pragma unroll
@@ -366,19 +376,19 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int ny = iy + g.pt - i * R;
-            if (ny < 0 || (S == 2 && (ny & 1))) continue;
-            const int oy = ny / S;
-            if (oy >= g.Ho) continue;
+            const bool oky = ny >= 0 && !(S == 2 && (ny & 1)) && ny / S < g.Ho;
+            int oy = ny < 0 ? 0 : ny / S;
+            if (oy > g.Ho - 1) oy = g.Ho - 1;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int nx = ix + g.pl - j * R;
-                if (nx < 0 || (S == 2 && (nx & 1))) continue;
-                const int ox = nx / S;
-                if (ox >= g.Wo) continue;
-                const float4 v = ld4(dyb + ((int64_t)oy * g.Wo + ox) * g.C);
+                const bool ok = oky && nx >= 0 && !(S == 2 && (nx & 1)) && nx / S < g.Wo;
+                int ox = nx < 0 ? 0 : nx / S;
+                if (ox > g.Wo - 1) ox = g.Wo - 1;
+                const float4 v = ld4(dyb + ((int64_t)oy * g.Wo + ox) * g.C);      // clamped address, masked by select
                 const float4 w4 = wv[i * 3 + j];
-                acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
-                acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
+                acc.x = fmaf(ok ? v.x : 0.f, w4.x, acc.x); acc.y = fmaf(ok ? v.y : 0.f, w4.y, acc.y);
+                acc.z = fmaf(ok ? v.z : 0.f, w4.z, acc.z); acc.w = fmaf(ok ? v.w : 0.f, w4.w, acc.w);
             }
         }
         st4(dxb + ((int64_t)iy * g.W + ix) * g.C, acc);
@@ -421,23 +431,26 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restric
     if (p_end > total) p_end = total;
     if (slot < g.slots) {
         for (int64_t p = p_begin + slot; p < p_end; p += g.slots) {
-            const int ox = (int)(p % g.Wo);
-            const int oy = (int)((p / g.Wo) % g.Ho);
-            const int b = (int)(p / ((int64_t)g.Wo * g.Ho));
+            const int pi = (int)p;                                   // B*Ho*Wo < 2^31 (checked on the host)
+            const int ox = pi % g.Wo;
+            const int t2 = pi / g.Wo;
+            const int oy = t2 % g.Ho, b = t2 / g.Ho;
             const float4 d = ld4(dy + p * g.C + c0);
             const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int iy = oy * S - g.pt + i * R;
-                if (iy < 0 || iy >= g.H) continue;
+                const bool oky = iy >= 0 && iy < g.H;
+                const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int ix = ox * S - g.pl + j * R;
-                    if (ix < 0 || ix >= g.W) continue;
-                    const float4 v = ld4(xb + ((int64_t)iy * g.W + ix) * g.C);
+                    const bool ok = oky && ix >= 0 && ix < g.W;
+                    const int ixc = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
+                    const float4 v = ld4(xb + ((int64_t)iyc * g.W + ixc) * g.C);   // clamped address, masked by select
                     float4& a = acc[i * 3 + j];
-                    a.x = fmaf(v.x, d.x, a.x); a.y = fmaf(v.y, d.y, a.y);
-                    a.z = fmaf(v.z, d.z, a.z); a.w = fmaf(v.w, d.w, a.w);
+                    a.x = fmaf(ok ? v.x : 0.f, d.x, a.x); a.y = fmaf(ok ? v.y : 0.f, d.y, a.y);
+                    a.z = fmaf(ok ? v.z : 0.f, d.z, a.z); a.w = fmaf(ok ? v.w : 0.f, d.w, a.w);
                 }
             }
         }
@@ -474,6 +487,7 @@ int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W,
     const int64_t total = (int64_t)B * g.Ho * g.Wo;
     const int blocks = dw_wgrad_blocks(total);
     AMS_REQUIRE(scratch_floats >= (size_t)blocks * 9 * C, "depthwise wgrad: scratch too small");
+    AMS_REQUIRE(total < 0x7fffffffLL, "depthwise wgrad: too many pixels");
     const int64_t ppb = cdiv64(total, blocks);
     const int threads = g.CG * g.slots;
     const size_t lds = (size_t)g.slots * 9 * C * sizeof(float);

@@ -22,7 +22,7 @@ static ColGeom col_geom(int64_t rows_per_group, int groups, int C, int ldx, int 
     ColGeom g;
     g.C = C; g.CG = C / 4; g.ldx = ldx; g.groups = groups; g.rows_per_group = rows_per_group;
     g.slots = 256 / g.CG < 1 ? 1 : 256 / g.CG;
-    int64_t chunks = cdiv64(rows_per_group, (int64_t)g.slots * 8);      // >= 8 rows per thread
+    int64_t chunks = cdiv64(rows_per_group, (int64_t)g.slots * 16);     // >= 16 rows per thread
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
     g.chunks = (int)chunks;
@@ -30,11 +30,13 @@ static ColGeom col_geom(int64_t rows_per_group, int groups, int C, int ldx, int 
     return g;
 }
 
+// Each functor: prepare(c0) caches this thread's per-channel constants once; operator() maps one row to (q0, q1).
 struct OpStats {          // q0 = z - center, q1 = (z - center)^2
     const float* z; const float* center;
+    float4 c;
+    __device__ __forceinline__ void prepare(int c0) { c = center ? ld4(center + c0) : make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
         const float4 v = ld4(z + row * ld + c0);
-        const float4 c = center ? ld4(center + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         q0 = make_float4(v.x - c.x, v.y - c.y, v.z - c.z, v.w - c.w);
         q1 = make_float4(q0.x * q0.x, q0.y * q0.y, q0.z * q0.z, q0.w * q0.w);
     }
@@ -48,9 +50,10 @@ __device__ __forceinline__ float act_grad_mask(float y, int act) {
 
 struct OpBnBwd {          // q0 = dy, q1 = dy * xhat ; dy = da * act'(z*scale+shift), xhat = (z-mean)*rstd
     const float* da; const float* z; const float* scale; const float* shift; const float* mean; const float* rstd; int act;
+    float4 sc, sh, mu, rs;
+    __device__ __forceinline__ void prepare(int c0) { sc = ld4(scale + c0); sh = ld4(shift + c0); mu = ld4(mean + c0); rs = ld4(rstd + c0); }
     __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
         const float4 g = ld4(da + row * ld + c0), v = ld4(z + row * ld + c0);
-        const float4 sc = ld4(scale + c0), sh = ld4(shift + c0), mu = ld4(mean + c0), rs = ld4(rstd + c0);
         q0.x = g.x * act_grad_mask(v.x * sc.x + sh.x, act); q0.y = g.y * act_grad_mask(v.y * sc.y + sh.y, act);
         q0.z = g.z * act_grad_mask(v.z * sc.z + sh.z, act); q0.w = g.w * act_grad_mask(v.w * sc.w + sh.w, act);
         q1.x = q0.x * (v.x - mu.x) * rs.x; q1.y = q0.y * (v.y - mu.y) * rs.y;
@@ -60,6 +63,7 @@ struct OpBnBwd {          // q0 = dy, q1 = dy * xhat ; dy = da * act'(z*scale+sh
 
 struct OpSum {            // q0 = x
     const float* x;
+    __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
         q0 = ld4(x + row * ld + c0);
         q1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -77,8 +81,21 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(Op op, ColGeom g, float
     if (r_end > g.rows_per_group) r_end = g.rows_per_group;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     if (slot < g.slots) {
+        op.prepare(c0);
         const int64_t base = (int64_t)group * g.rows_per_group;
-        for (int64_t r = r_begin + slot; r < r_end; r += g.slots) {
+        int64_t r = r_begin + slot;
+        // 4 rows in flight per thread: the loads are independent, the adds keep the original row order
+        for (; r + 3 * g.slots < r_end; r += 4 * g.slots) {
+            float4 q0[4], q1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) op(base + r + u * g.slots, c0, g.ldx, q0[u], q1[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0.x += q0[u].x; a0.y += q0[u].y; a0.z += q0[u].z; a0.w += q0[u].w;
+                if (NQ > 1) { a1.x += q1[u].x; a1.y += q1[u].y; a1.z += q1[u].z; a1.w += q1[u].w; }
+            }
+        }
+        for (; r < r_end; r += g.slots) {
             float4 q0, q1;
             op(base + r, c0, g.ldx, q0, q1);
             a0.x += q0.x; a0.y += q0.y; a0.z += q0.z; a0.w += q0.w;
@@ -96,25 +113,34 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(Op op, ColGeom g, float
     }
 }
 
-// second stage: out[group][q][c] = alpha * sum_chunk part[group][chunk][q][c]   (f64 accumulation, ascending chunk order)
+// second stage: out[group][e] = alpha * sum_chunk part[group][chunk][e], e = (q, c) flattened.  One block sums 16
+// columns: thread t owns column (t & 15) and every 16th chunk starting at (t >> 4); the 16 per-thread f64 partials of a
+// column are then added in a fixed order, so the result does not depend on scheduling.
 template <typename TOut>
-__global__ void col_finalize_kernel(const float* __restrict__ part, int chunks, int per_group /* NQ*C */, int groups,
-                                    double alpha, TOut* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per_group * groups) return;
-    const int group = i / per_group, e = i % per_group;
-    const float* p = part + (int64_t)group * chunks * per_group + e;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int k = 0;
-    for (; k + 3 < chunks; k += 4) {
-        s0 += p[(int64_t)k * per_group]; s1 += p[(int64_t)(k + 1) * per_group];
-        s2 += p[(int64_t)(k + 2) * per_group]; s3 += p[(int64_t)(k + 3) * per_group];
+__global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ part, int chunks, int per_group /* NQ*C */,
+                                                           int groups, double alpha, TOut* __restrict__ out) {
+    __shared__ double sacc[16][17];
+    const int col16 = blockIdx.x, group = blockIdx.y;
+    const int e = col16 * 16 + (threadIdx.x & 15), kpart = threadIdx.x >> 4;
+    double s = 0.0;
+    if (e < per_group) {
+        const float* p = part + (int64_t)group * chunks * per_group + e;
+        double s0 = 0, s1 = 0;
+        int k = kpart;
+        for (; k + 16 < chunks; k += 32) { s0 += p[(int64_t)k * per_group]; s1 += p[(int64_t)(k + 16) * per_group]; }
+        if (k < chunks) s0 += p[(int64_t)k * per_group];
+        s = s0 + s1;
     }
-    for (; k < chunks; ++k) s0 += p[(int64_t)k * per_group];
-    out[i] = (TOut)(((s0 + s1) + (s2 + s3)) * alpha);
+    sacc[kpart][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && col16 * 16 + threadIdx.x < per_group) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sacc[k][threadIdx.x];
+        out[(int64_t)group * per_group + col16 * 16 + threadIdx.x] = (TOut)(t * alpha);
+    }
 }
 
-constexpr int kMaxChunks = 256;
+constexpr int kMaxChunks = 1024;
 
 template <int NQ, class Op, typename TOut>
 static int run_col_reduce(Op op, int64_t rows_per_group, int groups, int C, int ldx, double alpha, float* scratch, TOut* out,
@@ -124,8 +150,8 @@ static int run_col_reduce(Op op, int64_t rows_per_group, int groups, int C, int 
     const size_t lds = (size_t)g.slots * NQ * C * sizeof(float);
     hipLaunchKernelGGL((col_reduce_kernel<NQ, Op>), dim3(g.chunks, groups), dim3(g.CG * g.slots), lds, st, op, g, scratch);
     AMS_CHECK_LAUNCH();
-    const int n = NQ * C * groups;
-    hipLaunchKernelGGL((col_finalize_kernel<TOut>), dim3(cdiv(n, 128)), dim3(128), 0, st, scratch, g.chunks, NQ * C, groups, alpha, out);
+    hipLaunchKernelGGL((col_finalize_kernel<TOut>), dim3(cdiv(NQ * C, 16), groups), dim3(256), 0, st, scratch, g.chunks, NQ * C, groups,
+                       alpha, out);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -133,14 +159,14 @@ static int run_col_reduce(Op op, int64_t rows_per_group, int groups, int C, int 
 size_t colstats_scratch(int64_t M, int C) { (void)M; return (size_t)kMaxChunks * 2 * C; }
 
 int launch_colstats(const float* z, int64_t M, int C, const float* center, double* sums, float* scratch, hipStream_t st) {
-    OpStats op{z, center};
+    OpStats op{z, center, {}};
     note_kernel("col_reduce_kernel<2, OpStats>");
     return run_col_reduce<2, OpStats, double>(op, M, 1, C, C, 1.0, scratch, sums, st);
 }
 
 int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift,
                          int act, const float* mean, const float* rstd, double* sums, float* scratch, hipStream_t st) {
-    OpBnBwd op{da, z, scale, shift, mean, rstd, act};
+    OpBnBwd op{da, z, scale, shift, mean, rstd, act, {}, {}, {}, {}};
     note_kernel("col_reduce_kernel<2, OpBnBwd>");
     return run_col_reduce<2, OpBnBwd, double>(op, M, 1, C, C, 1.0, scratch, sums, st);
 }
@@ -348,21 +374,33 @@ int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mas
     return AMS_OK;
 }
 
-__global__ void reduce_splits_kernel(const float* __restrict__ part, int splits, int64_t n, float* __restrict__ out) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < splits; k += 4) {
-        s0 += part[(int64_t)k * n + i]; s1 += part[(int64_t)(k + 1) * n + i];
-        s2 += part[(int64_t)(k + 2) * n + i]; s3 += part[(int64_t)(k + 3) * n + i];
+// out[i] = sum_k part[k*n + i].  One block per 16 outputs: thread t owns output (t & 15) and every 16th split starting
+// at (t >> 4); the 16 f64 partials of an output are added in a fixed order (deterministic, and ~16x shorter dependent
+// load chains than one thread per output: with ~1000 splits the serial form cost > 100 us per call).
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, int splits, int64_t n,
+                                                            float* __restrict__ out) {
+    __shared__ double sacc[16][17];
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+    const int kpart = threadIdx.x >> 4;
+    double s = 0.0;
+    if (i < n) {
+        double s0 = 0, s1 = 0;
+        int k = kpart;
+        for (; k + 16 < splits; k += 32) { s0 += part[(int64_t)k * n + i]; s1 += part[(int64_t)(k + 16) * n + i]; }
+        if (k < splits) s0 += part[(int64_t)k * n + i];
+        s = s0 + s1;
     }
-    for (; k < splits; ++k) s0 += part[(int64_t)k * n + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    sacc[kpart][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && (int64_t)blockIdx.x * 16 + threadIdx.x < n) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sacc[k][threadIdx.x];
+        out[(int64_t)blockIdx.x * 16 + threadIdx.x] = (float)t;
+    }
 }
 
 int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, splits, n, out);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, splits, n, out);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

@@ -50,20 +50,20 @@ struct VecLd;
 template <>
 struct VecLd<4> {
     static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[4]) {
-        float4 v = ok ? ld4(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        const float4 v = ld4(p);
+        o[0] = ok ? v.x : 0.f; o[1] = ok ? v.y : 0.f; o[2] = ok ? v.z : 0.f; o[3] = ok ? v.w : 0.f;
     }
 };
 template <>
 struct VecLd<2> {
     static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[2]) {
-        float2 v = ok ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
-        o[0] = v.x; o[1] = v.y;
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        o[0] = ok ? v.x : 0.f; o[1] = ok ? v.y : 0.f;
     }
 };
 template <>
 struct VecLd<1> {
-    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[1]) { o[0] = ok ? *p : 0.f; }
+    static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[1]) { const float v = *p; o[0] = ok ? v : 0.f; }
 };
 
 template <int VA, int VB>
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32(WgArgs a, int tiles_k, int t
 
     const int ka = k0 + VA * l15, nb = n0 + VB * l15;
     const bool ka_ok = ka < a.K, nb_ok = nb < a.N;        // K, N are multiples of VA / VB for the chosen instantiation
+    const int kac = ka_ok ? ka : 0, nbc = nb_ok ? nb : 0;
     // each wave takes every 4th group of 4 pixels; 2 groups in flight for latency hiding
     // (loop bounds are wave-uniform: an MFMA must be issued by the whole wave)
     for (int64_t mg = m_begin + wave * 4; mg < m_end; mg += 32) {
@@ -95,8 +96,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32(WgArgs a, int tiles_k, int t
         for (int h = 0; h < 2; ++h) {
             const int64_t mm = mg + q + h * 16;
             const bool ok = mm < m_end;
-            VecLd<VA>::ld(a.x + mm * (int64_t)a.ldx + ka, ok && ka_ok, xa[h]);
-            VecLd<VB>::ld(a.dy + mm * (int64_t)a.ldy + nb, ok && nb_ok, yb[h]);
+            const int64_t mc = ok ? mm : m_end - 1;                    // clamped row, zeroed by select: no exec-masked loads
+            VecLd<VA>::ld(a.x + mc * (int64_t)a.ldx + kac, ok && ka_ok, xa[h]);
+            VecLd<VB>::ld(a.dy + mc * (int64_t)a.ldy + nbc, ok && nb_ok, yb[h]);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)

@@ -465,8 +465,13 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restric
     }
 }
 
-static int dw_wgrad_blocks(int64_t total_px) {
-    int64_t blocks = cdiv64(total_px, 256);
+// blocks of the depthwise weight-gradient pass: ~8 pixels per thread, at most 1024 blocks (the partials are reduced by
+// a second kernel).  slots = pixel columns per block (256 / (C/4)): wide layers have ONE, so the block count must not be
+// derived from a fixed pixels-per-block figure (that left the 960-channel layers with 68 blocks on 256 CUs).
+static int dw_wgrad_blocks(int64_t total_px, int C) {
+    const int cg = C / 4;
+    const int slots = 256 / cg < 1 ? 1 : 256 / cg;
+    int64_t blocks = cdiv64(total_px, (int64_t)slots * 8);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -476,7 +481,7 @@ size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate)
     int Ho, Wo, p;
     same_pad(H, 3, stride, rate, &Ho, &p);
     same_pad(W, 3, stride, rate, &Wo, &p);
-    return (size_t)dw_wgrad_blocks((int64_t)B * Ho * Wo) * 9 * C;
+    return (size_t)dw_wgrad_blocks((int64_t)B * Ho * Wo, C) * 9 * C;
 }
 
 int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
@@ -485,7 +490,7 @@ int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W,
     int rc = dw_geom(B, H, W, C, stride, rate, false, &g);
     if (rc) return rc;
     const int64_t total = (int64_t)B * g.Ho * g.Wo;
-    const int blocks = dw_wgrad_blocks(total);
+    const int blocks = dw_wgrad_blocks(total, C);
     AMS_REQUIRE(scratch_floats >= (size_t)blocks * 9 * C, "depthwise wgrad: scratch too small");
     AMS_REQUIRE(total < 0x7fffffffLL, "depthwise wgrad: too many pixels");
     const int64_t ppb = cdiv64(total, blocks);

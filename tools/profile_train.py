@@ -30,3 +30,7 @@ tot = sum(a[1] for a in agg.values())
 print("train step kernels: %.2f ms over %d launches" % (tot, len(rows)))
 for k, (n, ms, nb) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-28s %4d launches %8.3f ms %5.1f%%  %7.0f MB %6.0f GB/s" % (k, n, ms, 100 * ms / tot, nb / 1e6, nb / ms / 1e6))
+if len(sys.argv) > 3:
+    for name, layer, ms, nb in rows:
+        if sys.argv[3] in name:
+            print("%3d %-30s %8.1f us %7.0f GB/s %8.0f KB" % (layer, name, 1e3 * ms, nb / ms / 1e6, nb / 1e3))

@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TIn* __restrict__ 
         float v[RM][8];
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
-            int64_t p = g * (16 * RM) + r * 16 + l15;
-            if (p > total_px - 1) p = total_px - 1;
-            const int ox = (int)(p % Wo);
-            const int64_t t2 = p / Wo;
-            const int oy = (int)(t2 % Ho), b = (int)(t2 / Ho);
+            int p = (int)(g * (16 * RM)) + r * 16 + l15;                // total_px < 2^31 (checked on the host): 32-bit decode
+            if (p > (int)total_px - 1) p = (int)total_px - 1;
+            const int ox = p % Wo;
+            const int t2 = p / Wo;
+            const int oy = t2 % Ho, b = t2 / Ho;
             const TIn* img = frames + (int64_t)b * H * W * 3;
             const int iy0 = oy * 2 - pt, ix0 = ox * 2 - pl;
 #pragma unroll
@@ -160,6 +160,7 @@ int launch_stem(const void* frames, int dtype, int B, int H, int W, const float*
     same_pad(H + 1, 3, 2, 1, &Ho, &pt);
     same_pad(W + 1, 3, 2, 1, &Wo, &pl);
     if (cout == 32) {
+        AMS_REQUIRE((int64_t)B * Ho * Wo < 0x7fffffffLL, "stem: too many pixels");
         const int64_t n_groups = cdiv64((int64_t)B * Ho * Wo, 32);
         int64_t grid = cdiv64(n_groups, 4);
         if (grid > 256 * 8) grid = 256 * 8;

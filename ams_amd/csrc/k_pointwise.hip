@@ -21,11 +21,50 @@ namespace ams {
 int launch_pointwise_stream(const PwArgs& a, int force_rm, int force_nt, bool* handled, hipStream_t st);
 int launch_pointwise_tiled(const PwArgs& a, int force_rm, int force_nt, hipStream_t st);
 
+// M <= 16 rows (the pooled vector of the image-pooling branch: one row per image).  A tiled MFMA kernel would run a
+// single block through K/32 barrier-separated stages (~17 us of pure latency); here every output element is one thread
+// walking K with coalesced weight reads, 4 partial sums in flight.
+__global__ __launch_bounds__(256) void pw_small_m_kernel(PwArgs a) {
+    // block = one row m x 16 output columns; thread (n = t & 15, part = t >> 4) sums every 16th k, then a fixed-order
+    // LDS reduction over the 16 parts (deterministic)
+    __shared__ float sacc[16][17];
+    const int n = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    const int m = blockIdx.y;
+    float s0 = 0.f, s1 = 0.f;
+    if (n < a.N) {
+        const float* xr = a.x + (int64_t)m * a.ldx;
+        const float* wp = a.w + (int64_t)n * a.w_sn;
+        int k = part;
+        for (; k + 16 < a.Kw; k += 32) {
+            s0 = fmaf(xr[k], wp[(int64_t)k * a.w_sk], s0);
+            s1 = fmaf(xr[k + 16], wp[(int64_t)(k + 16) * a.w_sk], s1);
+        }
+        if (k < a.Kw) s0 = fmaf(xr[k], wp[(int64_t)k * a.w_sk], s0);
+    }
+    sacc[part][threadIdx.x & 15] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 16 && n < a.N) {
+        float v = 0.f;
+        for (int p = 0; p < 16; ++p) v += sacc[p][threadIdx.x];
+        if (a.img_bias) v += a.img_bias[(m / a.rows_per_img) * a.N + n];
+        v = v * (a.scale ? a.scale[n] : 1.f) + (a.shift ? a.shift[n] : 0.f);
+        v = apply_act(v, a.act);
+        if (a.res) v += a.res[(int64_t)m * a.ldr + n];
+        a.y[(int64_t)m * a.ldy + n] = v;
+    }
+}
+
 int launch_pointwise(const PwArgs& a, hipStream_t st) {
     AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0, "pointwise: empty problem M=%lld K=%d N=%d", (long long)a.M, a.K, a.N);
     AMS_REQUIRE(a.Kw > 0 && a.Kw <= a.K, "pointwise: Kw=%d must be in 1..K=%d", a.Kw, a.K);
     AMS_REQUIRE(a.K % 4 == 0 && a.ldx % 4 == 0, "pointwise: K (%d) and ldx (%d) must be multiples of 4", a.K, a.ldx);
     AMS_REQUIRE((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "pointwise: x must be 16-byte aligned");
+    if (a.M <= 16) {
+        note_kernel("pw_small_m_kernel");
+        hipLaunchKernelGGL(pw_small_m_kernel, dim3(cdiv(a.N, 16), (unsigned)a.M), dim3(256), 0, st, a);
+        AMS_CHECK_LAUNCH();
+        return AMS_OK;
+    }
     char force = 0;
     int frm = 0, fnt = 0;
     if (const char* e = getenv("AMS_PW_FORCE")) sscanf(e, "%c,%d,%d", &force, &frm, &fnt);     // tuning knob: "<s|l>,<RM>,<NT>"

@@ -116,6 +116,28 @@ def main():
     torch.cuda.synchronize(dev)
     fps_b1 = n1 / (time.perf_counter() - t1)
 
+    # ---- the same two loops replayed from a hipGraph (one launch per step instead of ~60) -------------------------
+    graph_fps = graph_fps_b1 = None
+    try:
+        gp = eng.graphed_predict(B)
+        gp1 = eng.graphed_predict(1)
+        for g_, fr_, n_, key in ((gp, frames, args.steps, "b"), (gp1, one, n1, "b1")):
+            for _ in range(3):
+                g_(fr_)
+            torch.cuda.synchronize(dev)
+            tg = time.perf_counter()
+            for _ in range(n_):
+                lab_g = g_(fr_)
+            torch.cuda.synchronize(dev)
+            rate = n_ * fr_.shape[0] / (time.perf_counter() - tg)
+            if key == "b":
+                graph_fps = rate
+                assert int(lab_g.sum().item()) == checksum, "graph replay changed the label maps"
+            else:
+                graph_fps_b1 = rate
+    except Exception as e:  # noqa: BLE001
+        print("hipGraph leg skipped:", e, file=sys.stderr)
+
     # ---- roofline leg: profiled replay of the same step ----------------------------------------------------------
     roofline = None
     kernels = {}
@@ -220,6 +242,9 @@ def main():
                        "frames_per_step_per_gpu": B, "class_subset": CI, "weights": "synthetic seed 0",
                        "parallelism": "replicas x%d (no collective on the inference path)" % n_gpus},
             "frames_per_sec_batch1": round(fps_b1, 2),
+            "hipgraph": {"frames_per_sec": round(graph_fps, 2) if graph_fps else None,
+                         "frames_per_sec_batch1": round(graph_fps_b1, 2) if graph_fps_b1 else None,
+                         "note": "same step captured once with torch.cuda.graph and replayed; single GPU, not the headline"},
             "distill": distill,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -18,10 +18,17 @@ __device__ __forceinline__ float load_px(const TIn* p) { return (float)(*p); }
 
 template <typename TIn>
 __device__ __forceinline__ float norm_frame_value(const TIn* img, int H, int W, int iy, int ix, int ch, float ps) {
-    // coordinates are in the 127.5-padded (H+1)x(W+1) image; outside of it: SAME zero padding
-    if (iy < 0 || ix < 0 || iy > H || ix > W) return 0.f;
-    float raw = (iy == H || ix == W) ? 127.5f : load_px(img + ((int64_t)iy * W + ix) * 3 + ch);
-    return __fsub_rn(__fmul_rn(raw, ps), 1.0f);      // two roundings like the graph's Mul then Sub (no FMA contraction)
+    // coordinates are in the 127.5-padded (H+1)x(W+1) image; outside of it: SAME zero padding.
+    // Branch-free (clamped address + selects): a guarded load would be an exec-masked VMEM op that hipcc waits for
+    // with vmcnt(0), serialising the taps.
+    const bool inside = iy >= 0 && ix >= 0 && iy <= H && ix <= W;
+    const bool pad = iy >= H || ix >= W;
+    const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    const int ixc = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+    float raw = load_px(img + ((int64_t)iyc * W + ixc) * 3 + ch);
+    raw = pad ? 127.5f : raw;
+    const float v = __fsub_rn(__fmul_rn(raw, ps), 1.0f);     // two roundings like the graph's Mul then Sub (no FMA contraction)
+    return inside ? v : 0.f;
 }
 
 template <typename TIn>
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TIn* __restrict__ 
                                                         float* __restrict__ y, int Ho, int Wo, int pt, int pl, int64_t n_groups) {
     constexpr int PITCH = 36, RM = 2, NT = 2;
     __shared__ float sW[32 * PITCH];
+    __shared__ __attribute__((aligned(16))) float sOut[4 * 16 * 36];
     for (int e = threadIdx.x; e < 32 * 32; e += 256) {
         const int kk = e >> 5, nn = e & 31;
         sW[kk * PITCH + nn] = kk < 27 ? wgt[kk * 32 + nn] : 0.f;
@@ -119,7 +127,10 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TIn* __restrict__ 
             const int iy0 = oy * 2 - pt, ix0 = ox * 2 - pl;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                v[r][u] = tch[u] >= 0 ? norm_frame_value(img, H, W, iy0 + tdy[u], ix0 + tdx[u], tch[u], ps) : 0.f;
+                {
+                    const float t = norm_frame_value(img, H, W, iy0 + tdy[u], ix0 + tdx[u], tch[u] < 0 ? 0 : tch[u], ps);
+                    v[r][u] = tch[u] >= 0 ? t : 0.f;
+                }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -133,20 +144,35 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TIn* __restrict__ 
                 for (int r = 0; r < RM; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, v[r][u], acc[r][t], 0, 0, 0);
             }
         }
+        // epilogue: BN + activation, then through a per-wave LDS slab so that the 16 pixels x 128 B of a row group leave
+        // as 2 KB of consecutive float4 (a lane's MFMA result is 4 channels of ONE pixel: direct stores would hit 16
+        // different lines in 64-byte pieces)
+        float* slab = sOut + wave * (16 * 36);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n4 = 16 * t + 4 * q;
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (scale) { sc = ld4(scale + n4); sh = ld4(shift + n4); }
+        for (int r = 0; r < RM; ++r) {
 #pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                const int64_t p = g * (16 * RM) + r * 16 + l15;
-                if (p >= total_px) continue;
+            for (int t = 0; t < NT; ++t) {
+                const int n4 = 16 * t + 4 * q;
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (scale) { sc = ld4(scale + n4); sh = ld4(shift + n4); }
                 float4 o;
                 o.x = apply_act(acc[r][t][0] * sc.x + sh.x, act); o.y = apply_act(acc[r][t][1] * sc.y + sh.y, act);
                 o.z = apply_act(acc[r][t][2] * sc.z + sh.z, act); o.w = apply_act(acc[r][t][3] * sc.w + sh.w, act);
-                st4(y + p * 32 + n4, o);
+                st4(slab + l15 * 36 + n4, o);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int64_t p0 = g * (16 * RM) + r * 16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int f = lane + 64 * u, row = f >> 3, c4 = (f & 7) * 4;
+                const float4 o = ld4(slab + row * 36 + c4);
+                if (p0 + row < total_px) st4(y + (p0 + row) * 32 + c4, o);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 }

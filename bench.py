@@ -237,6 +237,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "precision_note": "f32 storage and accumulation everywhere; products of the late 1x1 layers (rows < 32768) are formed "
+                              "as 3 bf16 MFMAs on hi/lo splits of the f32 operands (<= 2^-16 relative per product; AMS_MATMUL_F32 "
+                              "selects exact f32 MFMA); parity vs the f32 oracle: logits < 1e-3 rel (tests/test_gpu_network.py)",
             "config": {"workload": "student infer only, %dx%d synthetic clip, frozen BN, uint8 frames resident in HBM, "
                                    "int32 label maps out (BASELINE.json configs[1])" % (H, 2 * H),
                        "frames_per_step_per_gpu": B, "class_subset": CI, "weights": "synthetic seed 0",

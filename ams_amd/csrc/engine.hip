@@ -107,6 +107,8 @@ struct ams_student {
     int64_t adam_t = 0;
     bool frozen_ready = false;
     int matmul_mode = AMS_MATMUL_SPLIT_BF16;   // frozen inference, late layers
+    int fuse_expand_dw = 1;                    // frozen inference, expand + depthwise in one kernel: 0 never, 1 where it
+                                               // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
     hipEvent_t prof_e0 = nullptr;
 };
@@ -347,6 +349,19 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
         const float* block_in = cur;
         const float* x = cur;
         int x_i = cur_i;
+        if (s->fuse_expand_dw && s->L[i].d.role == AMS_ROLE_EXPAND && i + 1 <= s->n_backbone &&
+            s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
+            expand_dw_supported(s->L[i].d.cin, s->L[i].d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate) &&
+            (s->fuse_expand_dw >= 2 || s->L[i].d.cin <= 24 || s->L[i + 1].d.stride == 2)) {
+            // expand + depthwise in one kernel: the 6x-expanded tensor stays in LDS
+            LayerRt& le = s->L[i];
+            LayerRt& ld = s->L[i + 1];
+            const int o = other(cur_i, -1);
+            const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin + ld.px_out * ld.d.cout) + (double)le.d.cin * le.d.cout + 9.0 * ld.d.cin);
+            RUNK(i + 1, bytes, launch_expand_dw(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
+                                                P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act, s->act[o], st));
+            x = s->act[o]; x_i = o; i += 2;
+        } else {
         if (s->L[i].d.role == AMS_ROLE_EXPAND) {
             LayerRt& l = s->L[i];
             const int o = other(cur_i, -1);
@@ -362,6 +377,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, l.fscale,
                                                      l.fshift, l.d.act, s->act[o], st));
             x = s->act[o]; x_i = o; ++i;
+        }
         }
         {
             LayerRt& l = s->L[i];
@@ -781,6 +797,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         s->matmul_mode = value;
         return AMS_OK;
     }
+    if (option == AMS_OPT_FUSE_EXPAND_DW) {
+        s->fuse_expand_dw = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return AMS_OK;
+    }
     set_error("set_option: unknown option %d", option);
     return AMS_E_INVALID;
 }
@@ -860,6 +880,14 @@ int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, 
     a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
     if (scale && !shift) { set_error("pointwise_split: scale without shift"); return AMS_E_INVALID; }
     return launch_pointwise_split(a, hi, lo, Kp, st);
+}
+
+int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
+                    const float* shift_e, int32_t Cexp, const float* w_dw, int32_t stride, int32_t rate, const float* scale_d,
+                    const float* shift_d, float* y, void* stream) {
+    if (!expand_dw_supported(Cin, Cexp, stride, rate)) { set_error("expand_dw: unsupported shape"); return AMS_E_INVALID; }
+    return launch_expand_dw(x, B, H, W, Cin, w_exp, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, stride, rate, scale_d, shift_d,
+                            AMS_ACT_RELU6, y, (hipStream_t)stream);
 }
 
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

@@ -54,6 +54,12 @@ size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate)
 int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
                            float* dw, float* scratch, size_t scratch_floats, hipStream_t st);
 
+// ---- k_expand_dw.hip : fused expand (1x1+BN+ReLU6) -> depthwise 3x3 (+BN+ReLU6), frozen inference ------------
+bool expand_dw_supported(int Cin, int Cexp, int stride, int rate);
+int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e,
+                     int Cexp, const float* w_dw, int stride, int rate, const float* sc_d, const float* sh_d, int act_d, float* y,
+                     hipStream_t st);
+
 // ---- k_elementwise.hip : BN pieces, pooling, reductions, Adam ------------------------------------------
 // per-image column reductions; scratch >= image_colsum_scratch(B, C) floats
 size_t image_colsum_scratch(int B, int C);

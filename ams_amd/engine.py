@@ -185,6 +185,11 @@ class StudentEngine:
         """hip.MATMUL_F32 (exact) or hip.MATMUL_SPLIT_BF16 (default; late-layer products via 3 bf16 MFMAs, ~1e-5 rel)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_MATMUL, int(mode)), "ams_student_set_option")
 
+    def set_fuse_expand_dw(self, on: int) -> None:
+        """Frozen inference, expand + depthwise of a block as one kernel: 0 never, 1 (default) the blocks where it is
+        measured faster, 2 every supported block."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_EXPAND_DW, int(on)), "ams_student_set_option")
+
     def freeze(self) -> None:
         """Device-side server->edge hand-off (replaces save_to_frozen_graph + reload)."""
         hip.check(self.lib.ams_student_freeze(self._h, self._stream()), "ams_student_freeze")

@@ -168,7 +168,7 @@ int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t fr
  *   AMS_MATMUL_SPLIT_BF16 (default) f32 data split into bf16 hi+lo, 3 bf16 MFMAs per product group, f32 accumulate:
  *                         <= 2^-16 relative per product (~1e-5 on a layer output), 5x the matrix throughput.
  * Training and the live graph always use exact f32. */
-enum { AMS_OPT_MATMUL = 1 };
+enum { AMS_OPT_MATMUL = 1, AMS_OPT_FUSE_EXPAND_DW = 2 /* 0 never, 1 (default) blocks where the fused kernel is faster, 2 every supported block */ };
 enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1 };
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value);
 
@@ -216,6 +216,13 @@ int ams_k_pointwise(const float* x, int64_t M, int32_t K, const float* w, int32_
 int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, int32_t N, const float* scale,
                           const float* shift, int32_t act, const float* res, float* y, uint16_t* panels,
                           size_t panel_elems, void* stream);
+
+/* K4+K3 fused (frozen inference): y = relu6(bn_d(dw3x3(relu6(bn_e(x @ w_exp))))) for an inverted-residual block whose
+ * input has Cin <= 64 channels; the expanded tensor never reaches HBM.  x [B,H,W,Cin], w_exp [Cin,Cexp], w_dw [3,3,Cexp,1],
+ * y [B,Ho,Wo,Cexp] (SAME, stride 1|2, rate 1).  Cexp % 32 == 0 or % 48 == 0. */
+int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
+                    const float* shift_e, int32_t Cexp, const float* w_dw, int32_t stride, int32_t rate, const float* scale_d,
+                    const float* shift_d, float* y, void* stream);
 
 /* K7: global average pool [B,HW,C] -> [B,C] (two-stage, deterministic); scratch >= ams_k_global_mean_scratch floats. */
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

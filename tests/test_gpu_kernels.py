@@ -200,6 +200,27 @@ def test_depthwise_forward_and_backward(lib, H, W, Cn, stride, rate):
     assert rel_err(dw.cpu().numpy(), wt.grad.permute(2, 3, 0, 1).numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,Cin,Cexp,stride", [(33, 65, 16, 96, 2), (40, 37, 24, 144, 1), (33, 65, 24, 144, 2), (29, 50, 32, 192, 1),
+                                                 (17, 17, 64, 384, 1), (65, 129, 16, 96, 1)])
+def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):
+    rng = np.random.default_rng(H + Cin)
+    B = 2
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    we = (rng.standard_normal((Cin, Cexp)) / np.sqrt(Cin)).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, Cexp, 1)) * 0.4).astype(np.float32)
+    se, sd = rng.uniform(0.5, 1.5, Cexp).astype(np.float32), rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
+    he, hd = rng.standard_normal(Cexp).astype(np.float32), rng.standard_normal(Cexp).astype(np.float32)
+    Ho, pt, pb = S.same_pad(H, 3, stride, 1)
+    Wo, pl, pr = S.same_pad(W, 3, stride, 1)
+    y = torch.full((B, Ho, Wo, Cexp), np.nan, device=DEV)
+    hip.check(lib.ams_k_expand_dw(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), stride, 1, PD(sd), PD(hd), P(y), stream()))
+    e = np.clip((x.astype(np.float64) @ we.astype(np.float64)) * se + he, 0, 6)
+    et = torch.as_tensor(e).permute(0, 3, 1, 2)
+    raw = F.conv2d(F.pad(et, (pl, pr, pt, pb)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), stride=stride, groups=Cexp)
+    ref = torch.clamp(raw * torch.as_tensor(sd).view(1, -1, 1, 1) + torch.as_tensor(hd).view(1, -1, 1, 1), 0, 6)
+    assert rel_err(y.cpu().numpy(), ref.permute(0, 2, 3, 1).numpy()) < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------ pooling
 def test_global_mean(lib):
     rng = np.random.default_rng(0)

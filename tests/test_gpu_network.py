@@ -58,6 +58,7 @@ def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
     eng.load_variables(W0)
     eng.set_matmul_mode(matmul)
+    eng.set_fuse_expand_dw(2 if matmul == hip.MATMUL_SPLIT_BF16 else 0)   # 2: every supported block fused; 0: layer-by-layer plan
     eng.freeze()
     o = _oracle(W0)
     with torch.no_grad():

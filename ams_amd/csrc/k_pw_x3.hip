@@ -12,6 +12,7 @@ namespace ams {
 // weights are split once per ams_student_freeze into [N][Kp] hi / lo panels (k contiguous, Kp = K rounded up to 32).
 // =========================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // native vector: stays in registers where HIP's uint4 struct may not
 
 __device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
     unsigned u = __float_as_uint(f);
@@ -49,7 +50,12 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
     }
 }
 
-template <int RM, int NT, int EPI>
+// D = stages of the activation operand in flight per lane (registers).  One stage is 32 k = 128 B per row; with a
+// single stage ahead the kernel is HBM-latency-bound (per CU only blocks x RM x 8 KB outstanding: ~2 TB/s by Little's
+// law), so long-K layers run D = 4.  The stage loop is unrolled by D so the ring is statically indexed; the stage count
+// is rounded up to a multiple of D and the surplus stages multiply zeros (all loads are branch-free: clamped address +
+// select, so the compiler never needs vmcnt(0) for a guarded load).
+template <int RM, int NT, int EPI, int D>
 __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ whi,
                                                         const unsigned short* __restrict__ wlo, int Kp, int n_tiles_n,
                                                         unsigned nblocks) {
@@ -67,25 +73,30 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned
     const int n0 = tile_n * ROWS;
     const int64_t m_base = tile_m * (64 * RM) + wave * (16 * RM);
     const int K = a.K, n_stages = Kp / 32;
+    const int n_iter = (n_stages + D - 1) / D * D;
 
-    uint4 wreg[NREG];
-    auto load_stage = [&](int s) {
+    // vmcnt retires in order: a wait for the weight pieces of the next stage would also drain every older activation
+    // load, so the weight pieces ride the same D-deep ring and are waited for at the same age.
+    u32x4 wring[D][NREG];
+    auto load_stage = [&](int s, u32x4 (&wreg)[NREG]) {
+        if (s > n_stages - 1) s = n_stages - 1;
 #pragma unroll
         for (int u = 0; u < NREG; ++u) {
-            const int e = tid + u * 256;
+            const int e = tid + u * 256 < NPIECE ? tid + u * 256 : NPIECE - 1;     // surplus lanes repeat the last piece
             const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (e < NPIECE && n0 + n < a.N)
-                v = *reinterpret_cast<const uint4*>((which ? wlo : whi) + (int64_t)(n0 + n) * Kp + s * 32 + part * 8);
-            wreg[u] = v;
+            int nn = n0 + n;
+            if (nn > a.N - 1) nn = a.N - 1;
+            // columns >= N repeat column N-1: they are never stored.  No select here: hipcc would turn it back into an
+            // exec-masked branch around the load, and a masked load costs a vmcnt(0)
+            wreg[u] = *reinterpret_cast<const u32x4*>((which & 1 ? wlo : whi) + (int64_t)nn * Kp + s * 32 + part * 8);
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, const u32x4 (&wreg)[NREG]) {
 #pragma unroll
         for (int u = 0; u < NREG; ++u) {
-            const int e = tid + u * 256;
+            const int e = tid + u * 256 < NPIECE ? tid + u * 256 : NPIECE - 1;
             const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
-            if (e < NPIECE) *reinterpret_cast<uint4*>(&sW[buf][which][n * PITCH + part * 8]) = wreg[u];
+            *reinterpret_cast<u32x4*>(&sW[buf][which][n * PITCH + part * 8]) = wreg[u];
         }
     };
 
@@ -94,15 +105,24 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned
     for (int r = 0; r < RM; ++r) {
         int64_t m = m_base + r * 16 + l15;
         if (m > a.M - 1) m = a.M - 1;
-        arow[r] = a.x + m * (int64_t)a.ldx + 8 * q;
+        arow[r] = a.x + m * (int64_t)a.ldx;
     }
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 a_cur[RM][2], a_nxt[RM][2];
+    float4 abuf[D][RM][2];
+    auto load_a = [&](int s, float4 (&dst)[RM][2]) {
+        // k >= K repeats the last 8 k of the row: the weight panels are zero there (split_w_kernel pads to Kp)
+        int koff = s * 32 + 8 * q;
+        if (koff > K - 8) koff = K - 8;
 #pragma unroll
-    for (int r = 0; r < RM; ++r) {
-        const bool ok = 8 * q < K;
-        a_cur[r][0] = ok ? ld4(arow[r]) : zero4;
-        a_cur[r][1] = ok ? ld4(arow[r] + 4) : zero4;
+        for (int r = 0; r < RM; ++r) {
+            dst[r][0] = ld4(arow[r] + koff);
+            dst[r][1] = ld4(arow[r] + koff + 4);
+        }
+    };
+    load_stage(0, wring[0]);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        if (d > 0) load_stage(d, wring[d]);
+        load_a(d, abuf[d]);
     }
     f32x4 acc[RM][NT];
 #pragma unroll
@@ -110,57 +130,60 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_stage(0);
     pw_stage_affine<NT>(a, sSc, sSh, n0, tid, 256);
-    store_stage(0);
+    store_stage(0, wring[0]);
     __syncthreads();
-    for (int s = 0; s < n_stages; ++s) {
-        if (s + 1 < n_stages) {
-            load_stage(s + 1);
-            const bool ok = (s + 1) * 32 + 8 * q < K;
+    for (int s0 = 0; s0 < n_iter; s0 += D) {
 #pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                a_nxt[r][0] = ok ? ld4(arow[r] + (s + 1) * 32) : zero4;
-                a_nxt[r][1] = ok ? ld4(arow[r] + (s + 1) * 32 + 4) : zero4;
+        for (int d = 0; d < D; ++d) {
+            const int s = s0 + d;
+            load_stage(s + D - 1, wring[(d + D - 1) % D]);
+            load_a(s + D - 1, abuf[(d + D - 1) % D]);
+            if (s < n_stages) {                       // block-uniform: surplus stages of the rounded-up loop only move data
+                bf16x8 xh[RM], xl[RM];
+#pragma unroll
+                for (int r = 0; r < RM; ++r) split8(abuf[d][r][0], abuf[d][r][1], xh[r], xl[r]);
+                const unsigned short* bh = &sW[d & 1][0][l15 * PITCH + 8 * q];
+                const unsigned short* bl = &sW[d & 1][1][l15 * PITCH + 8 * q];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(bh + t * 16 * PITCH);
+                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(bl + t * 16 * PITCH);
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) {
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[r], acc[r][t], 0, 0, 0);
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[r], acc[r][t], 0, 0, 0);
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[r], acc[r][t], 0, 0, 0);
+                    }
+                }
             }
+            store_stage((d + 1) & 1, wring[(d + 1) % D]);
+            __syncthreads();
         }
-        bf16x8 xh[RM], xl[RM];
-#pragma unroll
-        for (int r = 0; r < RM; ++r) split8(a_cur[r][0], a_cur[r][1], xh[r], xl[r]);
-        const unsigned short* bh = &sW[s & 1][0][l15 * PITCH + 8 * q];
-        const unsigned short* bl = &sW[s & 1][1][l15 * PITCH + 8 * q];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(bh + t * 16 * PITCH);
-            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(bl + t * 16 * PITCH);
-#pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[r], acc[r][t], 0, 0, 0);
-                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[r], acc[r][t], 0, 0, 0);
-                acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[r], acc[r][t], 0, 0, 0);
-            }
-        }
-        if (s + 1 < n_stages) {
-            store_stage((s + 1) & 1);
-#pragma unroll
-            for (int r = 0; r < RM; ++r) { a_cur[r][0] = a_nxt[r][0]; a_cur[r][1] = a_nxt[r][1]; }
-        }
-        __syncthreads();
     }
     if (EPI == EPI_GENERIC) pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q, sSc, sSh);
     else pw_epilogue_t<RM, NT, EPI>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)));
 }
 
-template <int RM, int NT, int EPI>
-static int launch_pw_x3_e(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+template <int RM, int NT, int EPI, int D>
+static int launch_pw_x3_d(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     const int64_t nblocks = cdiv64(a.M, 64 * RM) * n_tiles_n;
-    static const std::string nm = "pw_gemm_bf16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ">";
+    static const std::string nm = "pw_gemm_bf16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " +
+                                  std::to_string(D) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI>), dim3((unsigned)nblocks), dim3(256), 0, st, a, whi, wlo, Kp, n_tiles_n,
+    hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI, D>), dim3((unsigned)nblocks), dim3(256), 0, st, a, whi, wlo, Kp, n_tiles_n,
                        (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
+}
+
+template <int RM, int NT, int EPI>
+static int launch_pw_x3_e(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+    static const int force_d = getenv("AMS_PWX_DEPTH") ? atoi(getenv("AMS_PWX_DEPTH")) : 0;      // tuning knob
+    const int d = force_d ? force_d : 2;      // measured: D = 4 is no faster (the stage loop is bound by the LDS hand-over, not HBM latency)
+    if (d >= 4) return launch_pw_x3_d<RM, NT, EPI, 4>(a, whi, wlo, Kp, st);
+    return launch_pw_x3_d<RM, NT, EPI, 2>(a, whi, wlo, Kp, st);
 }
 
 template <int RM, int NT>

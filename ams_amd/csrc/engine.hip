@@ -93,6 +93,7 @@ struct ams_student {
     float *fparams = nullptr, *fstats = nullptr;      // frozen snapshot
     double* bn_sync = nullptr; size_t bn_sync_doubles = 0;
     float* logits = nullptr;         // [B,h,w,32]
+    uint16_t* panel_scratch = nullptr; size_t panel_elems = 0;   // live (training) weights split per launch: hi | lo
     float* dlogits = nullptr;
     float* act[4] = {nullptr, nullptr, nullptr, nullptr};   // inference ping-pong pool
     size_t act_elems = 0;
@@ -198,6 +199,19 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
     }
     s->scratch_floats = sc;
     s->scratch = cv.take<float>(sc);
+    if (c.trainable) {
+        // one panel buffer for the live split-bf16 GEMMs (forward and dgrad orientation): the stream orders split -> GEMM
+        size_t pe = 0;
+        for (int i = 2; i <= c.n_layers; ++i) {
+            const LayerRt& l = s->L[i];
+            if (l.d.role == AMS_ROLE_DEPTHWISE) continue;
+            const size_t f = (size_t)l.d.cout * ((l.d.cin + 31) / 32 * 32), b = (size_t)l.d.cin * ((l.d.cout + 31) / 32 * 32);
+            if (3 * f > pe) pe = 3 * f;
+            if (3 * b > pe) pe = 3 * b;
+        }
+        s->panel_elems = pe;
+        s->panel_scratch = cv.take<uint16_t>(pe);
+    }
     if (c.trainable) {
         s->dlogits = cv.take<float>((size_t)B * s->h * s->w * 32);
         s->d_img_bias = cv.take<float>((size_t)B * aspp_c);
@@ -317,6 +331,23 @@ static int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream_t) {
     const int rc = sc->cb(sc->user, (size_t)((char*)p - sc->s->arena), n, AMS_DT_F64);
     if (rc) { set_error("all-reduce callback failed (%d)", rc); return AMS_E_STATE; }
     return AMS_OK;
+}
+
+// live (training) 1x1 layer or its input gradient: same split-bf16 rule as the frozen path, the weights are split right
+// before the launch because they change every step (one small kernel; the panels live in one shared scratch buffer)
+static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
+    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && s->panel_scratch && a.M < 32768 && a.M >= 256 && a.K >= 32 &&
+                       a.K % 8 == 0 && a.Kw == a.K && a.ldx % 4 == 0;
+    if (!split) return launch_pointwise(a, st);
+    // three-part split (6 MFMAs, f32-level products): gradients amplify product error ~1e5 x on this graph, the two-part
+    // split of the frozen path would put the step outside the f32 error class
+    const int Kp = (a.K + 31) / 32 * 32;
+    const size_t plane = (size_t)a.N * Kp;
+    AMS_REQUIRE(3 * plane <= s->panel_elems, "live_pointwise: panel scratch too small");
+    uint16_t* p0 = s->panel_scratch;
+    int rc = launch_split_weights3(a.w, a.w_sk, a.w_sn, a.K, a.N, Kp, p0, p0 + plane, p0 + 2 * plane, st);
+    if (rc) return rc;
+    return launch_pointwise_split3(a, p0, p0 + plane, p0 + 2 * plane, Kp, st);
 }
 
 // frozen 1x1 layer: late layers (few rows, wide K/N: matrix-pipe bound) go through the split-bf16 kernel
@@ -454,7 +485,7 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
                                                      AMS_ACT_NONE, l.z, st));
         } else {
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, l.z, l.d.cout);
-            RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+            RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         }
         const float* res = l.d.residual_from ? s->L[l.d.residual_from].a : nullptr;
         RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st));
@@ -465,22 +496,22 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
     RUN(launch_global_mean(feat, B, HW, lp.d.cin, s->pooled, s->scratch, st));
     {
         PwArgs a = pw_args(s->pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, lp.z, lp.d.cout);
-        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         RUN(bn_train(s, lp, B, (double)global_B, update_ema, sc, nullptr, st));     // statistics over the batch only
         PwArgs b = pw_args(lp.a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, s->img_bias, lc.d.cout);
-        RUNK(0, pw_bytes(b), launch_pointwise(b, st));
+        RUNK(0, pw_bytes(b), live_pointwise(s, b, st));
     }
     {
         PwArgs a = pw_args(feat, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, la.z, la.d.cout);
-        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         RUN(bn_train(s, la, M, (double)global_B * HW, update_ema, sc, nullptr, st));
         PwArgs b = pw_args(la.a, M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout, lc.z, lc.d.cout);
         b.img_bias = s->img_bias; b.rows_per_img = HW;
-        RUNK(0, pw_bytes(b), launch_pointwise(b, st));
+        RUNK(0, pw_bytes(b), live_pointwise(s, b, st));
         RUN(bn_train(s, lc, M, (double)global_B * HW, update_ema, sc, nullptr, st));
         PwArgs d = pw_args(lc.a, M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits, 32);
         d.shift = P + ll.d.gamma_off;
-        RUNK(0, pw_bytes(d), launch_pointwise(d, st));
+        RUNK(0, pw_bytes(d), live_pointwise(s, d, st));
     }
     return AMS_OK;
 }
@@ -538,7 +569,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     {
         PwArgs a = dgrad_args(s->dlogits, M, 32, 32, P + ll.d.w_off, ll.d.cin, lc.da);
         a.Kw = NC; a.w_sn = NC;        // w is [cin][NC]; dlogits columns >= NC are zero
-        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
     // concat_projection
     RUN(bn_backward(s, lc, lc.da, M, nHW, sc, st));
@@ -547,14 +578,14 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     RUN(pw_wgrad(s, la.a, la.d.cout, la.d.cout, s->dz, lc.d.cout, lc.d.cout, M, G + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, st));
     {
         PwArgs a = dgrad_args(s->dz, M, lc.d.cout, lc.d.cout, Wc_bot, la.d.cout, la.da);
-        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
     // pool branch: the per-image bias collects the column sums of dz_proj
     RUN(launch_image_colsum(s->dz, B, HW, lc.d.cout, lc.d.cout, s->d_img_bias, s->scratch, st));
     RUN(pw_wgrad(s, lp.a, lp.d.cout, lp.d.cout, s->d_img_bias, lc.d.cout, lc.d.cout, B, G + lc.d.w_off, st));
     {
         PwArgs a = dgrad_args(s->d_img_bias, B, lc.d.cout, lc.d.cout, Wc_top, lp.d.cout, s->d_pool_a);
-        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
     {   // BN (over the batch) + ReLU of the pool branch; its dz goes to d_pool_z instead of s->dz (still in use? no: consumed)
         RUN(launch_bn_bwd_reduce(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.mean, lp.rstd, lp.bsums, s->scratch, st));
@@ -569,7 +600,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         RUN(launch_fill(s->tmp_c + 2048, lp.d.cin, (float)(1.0 / (double)HW), st));
         a.shift = s->tmp_c + 3072;
         RUN(launch_fill(s->tmp_c + 3072, lp.d.cin, 0.f, st));
-        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
     // aspp0: its input gradient also receives the pooled gradient, broadcast over the image
     LayerRt& lf = s->L[s->n_backbone];
@@ -578,7 +609,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     {
         PwArgs a = dgrad_args(s->dz, M, la.d.cout, la.d.cout, P + la.d.w_off, la.d.cin, lf.da);
         a.img_bias = s->d_pooled; a.rows_per_img = HW;
-        RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
     // backbone, last layer to first
     for (int i = s->n_backbone; i >= 1; --i) {
@@ -602,7 +633,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) {
                 a.res = s->L[i + 2].da; a.ldr = l.d.cin;
             }
-            RUNK(0, pw_bytes(a), launch_pointwise(a, st));
+            RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         }
     }
     return AMS_OK;

@@ -20,33 +20,58 @@ __device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
     return (unsigned short)(u >> 16);
 }
 
+// parts: hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid); `lo` may be null (two-part split).  Three parts hold all
+// 24 significand bits of v exactly.
 __global__ void split_w_kernel(const float* __restrict__ w, int64_t sk, int64_t sn, int K, int N, int Kp,
-                               unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+                               unsigned short* __restrict__ hi, unsigned short* __restrict__ mid, unsigned short* __restrict__ lo) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= (int64_t)N * Kp) return;
     const int n = (int)(i / Kp), k = (int)(i % Kp);
     const float v = k < K ? w[k * sk + n * sn] : 0.f;
     const unsigned short h = bf16_rne_bits(v);
-    const float hf = __uint_as_float((unsigned)h << 16);
+    const float r1 = v - __uint_as_float((unsigned)h << 16);
+    const unsigned short m = bf16_rne_bits(r1);
     hi[i] = h;
-    lo[i] = bf16_rne_bits(v - hf);
+    mid[i] = m;
+    if (lo) lo[i] = bf16_rne_bits(r1 - __uint_as_float((unsigned)m << 16));
 }
 
 int launch_split_weights(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st) {
     const int64_t n = (int64_t)N * Kp;
-    hipLaunchKernelGGL(split_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, sk, sn, K, N, Kp, hi, lo);
+    hipLaunchKernelGGL(split_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, sk, sn, K, N, Kp, hi, lo, (unsigned short*)nullptr);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
 
-// 8 consecutive f32 -> bf16x8 hi and lo
-__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& hi, bf16x8& lo) {
+int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* mid, uint16_t* lo,
+                          hipStream_t st) {
+    const int64_t n = (int64_t)N * Kp;
+    hipLaunchKernelGGL(split_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, sk, sn, K, N, Kp, hi, mid, lo);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// 8 consecutive f32 -> bf16x8 parts (hi, mid, lo): successive bf16 roundings of the remainder.  Plain named vectors (an
+// array of vectors filled element-wise lands in scratch memory).
+__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& p0, bf16x8& p1) {
     const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const __bf16 h = (__bf16)f[j];
-        hi[j] = h;
-        lo[j] = (__bf16)(f[j] - (float)h);
+        p0[j] = h;
+        p1[j] = (__bf16)(f[j] - (float)h);
+    }
+}
+__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+    const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)f[j];
+        const float r1 = f[j] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        p0[j] = h;
+        p1[j] = m;
+        p2[j] = (__bf16)(r1 - (float)m);
     }
 }
 
@@ -55,15 +80,17 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
 // law), so long-K layers run D = 4.  The stage loop is unrolled by D so the ring is statically indexed; the stage count
 // is rounded up to a multiple of D and the surplus stages multiply zeros (all loads are branch-free: clamped address +
 // select, so the compiler never needs vmcnt(0) for a guarded load).
-template <int RM, int NT, int EPI, int D>
-__global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ whi,
-                                                        const unsigned short* __restrict__ wlo, int Kp, int n_tiles_n,
-                                                        unsigned nblocks) {
+// NP = 2: products hi*hi + lo*hi + hi*lo (3 MFMAs per 32 k, ~1e-5 relative: frozen inference).
+// NP = 3: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (6 MFMAs; the dropped terms are <= 2^-24 relative, i.e. f32
+// rounding level: training, where the gradient is ~1e5 x more sensitive to product error than the logits are).
+template <int RM, int NT, int EPI, int D, int NP>
+__global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
+                                                        int Kp, int n_tiles_n, unsigned nblocks) {
     constexpr int PITCH = 40;                        // bf16 elements per LDS row: 80 B, conflict-free for ds_read_b128
     constexpr int ROWS = 16 * NT;
-    constexpr int NPIECE = 2 * ROWS * 4;             // 16-byte pieces per stage (hi + lo panels, 32 k = 4 pieces per row)
+    constexpr int NPIECE = NP * ROWS * 4;            // 16-byte pieces per stage (NP panels, 32 k = 4 pieces per row)
     constexpr int NREG = (NPIECE + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned short sW[2][2][ROWS * PITCH];     // [buffer][hi/lo]
+    __shared__ __attribute__((aligned(16))) unsigned short sW[2][NP][ROWS * PITCH];    // [buffer][part]
     __shared__ __attribute__((aligned(16))) float sSc[16 * NT], sSh[16 * NT];
     __shared__ __attribute__((aligned(16))) float sOutAll[EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4)];
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
@@ -88,7 +115,8 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned
             if (nn > a.N - 1) nn = a.N - 1;
             // columns >= N repeat column N-1: they are never stored.  No select here: hipcc would turn it back into an
             // exec-masked branch around the load, and a masked load costs a vmcnt(0)
-            wreg[u] = *reinterpret_cast<const u32x4*>((which & 1 ? wlo : whi) + (int64_t)nn * Kp + s * 32 + part * 8);
+            // part p of the panels starts at w0 + p * plane (one base pointer: a select between pointers becomes a stack table)
+            wreg[u] = *reinterpret_cast<const u32x4*>(w0 + which * plane + (int64_t)nn * Kp + s * 32 + part * 8);
         }
     };
     auto store_stage = [&](int buf, const u32x4 (&wreg)[NREG]) {
@@ -140,20 +168,31 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned
             load_stage(s + D - 1, wring[(d + D - 1) % D]);
             load_a(s + D - 1, abuf[(d + D - 1) % D]);
             if (s < n_stages) {                       // block-uniform: surplus stages of the rounded-up loop only move data
-                bf16x8 xh[RM], xl[RM];
+                bf16x8 x0[RM], x1[RM], x2[RM];
 #pragma unroll
-                for (int r = 0; r < RM; ++r) split8(abuf[d][r][0], abuf[d][r][1], xh[r], xl[r]);
-                const unsigned short* bh = &sW[d & 1][0][l15 * PITCH + 8 * q];
-                const unsigned short* bl = &sW[d & 1][1][l15 * PITCH + 8 * q];
+                for (int r = 0; r < RM; ++r) {
+                    if (NP == 3) split8(abuf[d][r][0], abuf[d][r][1], x0[r], x1[r], x2[r]);
+                    else split8(abuf[d][r][0], abuf[d][r][1], x0[r], x1[r]);
+                }
+                const unsigned short* bw = &sW[d & 1][0][l15 * PITCH + 8 * q];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(bh + t * 16 * PITCH);
-                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(bl + t * 16 * PITCH);
+                    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(bw + t * 16 * PITCH);
+                    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(bw + (ROWS * PITCH) + t * 16 * PITCH);
+                    if (NP == 3) {           // smallest terms first
+                        const bf16x8 q2 = *reinterpret_cast<const bf16x8*>(bw + 2 * (ROWS * PITCH) + t * 16 * PITCH);
+#pragma unroll
+                        for (int r = 0; r < RM; ++r) {
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2, x0[r], acc[r][t], 0, 0, 0);
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, x2[r], acc[r][t], 0, 0, 0);
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, x1[r], acc[r][t], 0, 0, 0);
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < RM; ++r) {
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[r], acc[r][t], 0, 0, 0);
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[r], acc[r][t], 0, 0, 0);
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[r], acc[r][t], 0, 0, 0);
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, x0[r], acc[r][t], 0, 0, 0);
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, x1[r], acc[r][t], 0, 0, 0);
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, x0[r], acc[r][t], 0, 0, 0);
                     }
                 }
             }
@@ -165,50 +204,63 @@ __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned
     else pw_epilogue_t<RM, NT, EPI>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)));
 }
 
-template <int RM, int NT, int EPI, int D>
-static int launch_pw_x3_d(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+struct SplitPanels { const uint16_t* base; int64_t plane; int np; };     // part p at base + p * plane
+
+template <int RM, int NT, int EPI, int D, int NP>
+static int launch_pw_x3_d(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     const int64_t nblocks = cdiv64(a.M, 64 * RM) * n_tiles_n;
-    static const std::string nm = "pw_gemm_bf16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " +
-                                  std::to_string(D) + ">";
+    static const std::string nm = std::string(NP == 3 ? "pw_gemm_bf16x6_l<" : "pw_gemm_bf16x3_l<") + std::to_string(RM) + ", " +
+                                  std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(D) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI, D>), dim3((unsigned)nblocks), dim3(256), 0, st, a, whi, wlo, Kp, n_tiles_n,
-                       (unsigned)nblocks);
+    hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI, D, NP>), dim3((unsigned)nblocks), dim3(256), 0, st, a, w.base, w.plane, Kp,
+                       n_tiles_n, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
 
 template <int RM, int NT, int EPI>
-static int launch_pw_x3_e(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
-    static const int force_d = getenv("AMS_PWX_DEPTH") ? atoi(getenv("AMS_PWX_DEPTH")) : 0;      // tuning knob
-    const int d = force_d ? force_d : 2;      // measured: D = 4 is no faster (the stage loop is bound by the LDS hand-over, not HBM latency)
-    if (d >= 4) return launch_pw_x3_d<RM, NT, EPI, 4>(a, whi, wlo, Kp, st);
-    return launch_pw_x3_d<RM, NT, EPI, 2>(a, whi, wlo, Kp, st);
+static int launch_pw_x3_e(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
+    // D = 4 is no faster (measured): the stage loop is bound by the LDS hand-over of the weight pieces, not by HBM latency
+    if (w.np == 3) return launch_pw_x3_d<RM, NT, EPI, 2, 3>(a, w, Kp, st);
+    return launch_pw_x3_d<RM, NT, EPI, 2, 2>(a, w, Kp, st);
 }
 
 template <int RM, int NT>
-static int launch_pw_x3(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+static int launch_pw_x3(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
     switch (pw_pick_epi(a)) {
-        case EPI_PLAIN: return launch_pw_x3_e<RM, NT, EPI_PLAIN>(a, whi, wlo, Kp, st);
-        case EPI_RES: return launch_pw_x3_e<RM, NT, EPI_RES>(a, whi, wlo, Kp, st);
-        case EPI_BIAS: return launch_pw_x3_e<RM, NT, EPI_BIAS>(a, whi, wlo, Kp, st);
-        default: return launch_pw_x3_e<RM, NT, EPI_GENERIC>(a, whi, wlo, Kp, st);
+        case EPI_PLAIN: return launch_pw_x3_e<RM, NT, EPI_PLAIN>(a, w, Kp, st);
+        case EPI_RES: return launch_pw_x3_e<RM, NT, EPI_RES>(a, w, Kp, st);
+        case EPI_BIAS: return launch_pw_x3_e<RM, NT, EPI_BIAS>(a, w, Kp, st);
+        default: return launch_pw_x3_e<RM, NT, EPI_GENERIC>(a, w, Kp, st);
     }
 }
 
-// y = epilogue(x @ w) with w given as pre-split bf16 hi/lo panels [N][Kp]; requires K % 8 == 0
-int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
     AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0 && Kp % 32 == 0 && Kp >= a.K, "pointwise_split: bad problem");
     AMS_REQUIRE(a.K % 8 == 0 && a.ldx % 4 == 0, "pointwise_split: K (%d) must be a multiple of 8", a.K);
     int rm, nt;
     pw_pick_tile(a.M, a.N, &rm, &nt);
     if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &rm, &nt);       // tuning knob
-#define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, whi, wlo, Kp, st);
+#define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, w, Kp, st);
     PW_X(2, 6) PW_X(2, 5) PW_X(2, 4) PW_X(2, 3) PW_X(2, 2) PW_X(2, 1)
     PW_X(1, 6) PW_X(1, 5) PW_X(1, 4) PW_X(1, 3) PW_X(1, 2) PW_X(1, 1)
 #undef PW_X
     set_error("pointwise_split: no tile configuration");
     return AMS_E_INVALID;
+}
+
+// y = epilogue(x @ w) with w given as pre-split bf16 hi/lo panels [N][Kp]; requires K % 8 == 0
+int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
+    const SplitPanels w = {whi, (int64_t)(wlo - whi), 2};
+    return launch_pointwise_parts(a, w, Kp, st);
+}
+
+// the same with three-part panels (hi, mid, lo): f32-level accuracy at 6 bf16 MFMAs per 32 k
+int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t* wmid, const uint16_t* wlo, int Kp, hipStream_t st) {
+    AMS_REQUIRE(wlo - wmid == wmid - whi, "pointwise_split3: the three panels must be equally spaced");
+    const SplitPanels w = {whi, (int64_t)(wmid - whi), 3};
+    return launch_pointwise_parts(a, w, Kp, st);
 }
 
 }  // namespace ams

@@ -29,6 +29,9 @@ int launch_pointwise(const PwArgs& a, hipStream_t st);
 // split-bf16 (hi + lo) late-layer variant: weights pre-split into [N][Kp] bf16 panels, Kp = K rounded up to 32
 int launch_split_weights(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st);
 int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st);
+int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* mid, uint16_t* lo,
+                          hipStream_t st);
+int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t* wmid, const uint16_t* wlo, int Kp, hipStream_t st);
 
 // dw[K,N] = x[M,K]^T @ dy[M,N];  scratch holds the per-split partial products.
 struct WgArgs {

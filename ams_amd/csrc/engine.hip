@@ -539,6 +539,7 @@ static int pw_wgrad(ams_student* s, const float* x, int ldx, int K, const float*
     WgArgs a;
     a.x = x; a.ldx = ldx; a.K = K; a.dy = dy; a.ldy = ldy; a.N = N; a.M = M; a.dw = dw;
     a.scratch = s->scratch; a.scratch_floats = s->scratch_floats;
+    a.allow_split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16;
     RUNK(0, 4.0 * ((double)M * (K + N) + (double)K * N), launch_pointwise_wgrad(a, st));
     return AMS_OK;
 }
@@ -944,10 +945,18 @@ int ams_k_ce_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t 
 
 size_t ams_k_pointwise_wgrad_scratch(int64_t M, int32_t K, int32_t N) { return pointwise_wgrad_scratch(M, K, N); }
 
+int ams_k_pointwise_wgrad_split(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw, float* scratch,
+                                size_t scratch_floats, void* stream) {
+    if (!pointwise_wgrad_x6_applies(M, K, N, K, N)) { set_error("pointwise_wgrad_split: shape M=%lld K=%d N=%d not supported", (long long)M, K, N); return AMS_E_INVALID; }
+    WgArgs a;
+    a.x = x; a.ldx = K; a.K = K; a.dy = dy; a.ldy = N; a.N = N; a.M = M; a.dw = dw; a.scratch = scratch; a.scratch_floats = scratch_floats; a.allow_split = 1;
+    return launch_pointwise_wgrad(a, (hipStream_t)stream);
+}
+
 int ams_k_pointwise_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw, float* scratch,
                           size_t scratch_floats, void* stream) {
     WgArgs a;
-    a.x = x; a.ldx = K; a.K = K; a.dy = dy; a.ldy = N; a.N = N; a.M = M; a.dw = dw; a.scratch = scratch; a.scratch_floats = scratch_floats;
+    a.x = x; a.ldx = K; a.K = K; a.dy = dy; a.ldy = N; a.N = N; a.M = M; a.dw = dw; a.scratch = scratch; a.scratch_floats = scratch_floats; a.allow_split = 0;
     return launch_pointwise_wgrad(a, (hipStream_t)stream);
 }
 

@@ -125,11 +125,19 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
     double s = 0.0;
     if (e < per_group) {
         const float* p = part + (int64_t)group * chunks * per_group + e;
-        double s0 = 0, s1 = 0;
+        // 8 loads in flight per thread (the loop is latency-bound)
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int k = kpart;
+        for (; k + 112 < chunks; k += 128) {
+            const float v0 = p[(int64_t)k * per_group], v1 = p[(int64_t)(k + 16) * per_group];
+            const float v2 = p[(int64_t)(k + 32) * per_group], v3 = p[(int64_t)(k + 48) * per_group];
+            const float v4 = p[(int64_t)(k + 64) * per_group], v5 = p[(int64_t)(k + 80) * per_group];
+            const float v6 = p[(int64_t)(k + 96) * per_group], v7 = p[(int64_t)(k + 112) * per_group];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
         for (; k + 16 < chunks; k += 32) { s0 += p[(int64_t)k * per_group]; s1 += p[(int64_t)(k + 16) * per_group]; }
         if (k < chunks) s0 += p[(int64_t)k * per_group];
-        s = s0 + s1;
+        s = (s0 + s1) + (s2 + s3);
     }
     sacc[kpart][threadIdx.x & 15] = s;
     __syncthreads();

@@ -186,7 +186,10 @@ static int wgrad_splits(int64_t M, int K, int N) {
     return (int)want;
 }
 
-size_t pointwise_wgrad_scratch(int64_t M, int K, int N) { return (size_t)wgrad_splits(M, K, N) * K * N; }
+size_t pointwise_wgrad_scratch(int64_t M, int K, int N) {
+    const size_t f32 = (size_t)wgrad_splits(M, K, N) * K * N, x6 = (size_t)wgrad_x6_splits(M, K, N) * K * N;
+    return f32 > x6 ? f32 : x6;
+}
 
 template <int VA, int VB>
 static int launch_wg_t(const WgArgs& a, int splits, hipStream_t st) {
@@ -202,6 +205,14 @@ static int launch_wg_t(const WgArgs& a, int splits, hipStream_t st) {
 
 int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st) {
     AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0, "wgrad: empty problem");
+    if (a.allow_split && pointwise_wgrad_x6_applies(a.M, a.K, a.N, a.ldx, a.ldy)) {
+        const int sp = wgrad_x6_splits(a.M, a.K, a.N);
+        AMS_REQUIRE(a.scratch_floats >= (size_t)sp * a.K * a.N, "wgrad: scratch too small (%zu < %zu)", a.scratch_floats,
+                    (size_t)sp * a.K * a.N);
+        int rc = launch_pointwise_wgrad_x6(a, sp, st);
+        if (rc) return rc;
+        return launch_reduce_splits(a.scratch, sp, (int64_t)a.K * a.N, a.dw, st);
+    }
     const int splits = wgrad_splits(a.M, a.K, a.N);
     AMS_REQUIRE(a.scratch_floats >= (size_t)splits * a.K * a.N, "wgrad: scratch too small (%zu < %zu)", a.scratch_floats,
                 (size_t)splits * a.K * a.N);

@@ -40,7 +40,11 @@ struct WgArgs {
     int64_t M;
     float* dw;             // [K, N] dense
     float* scratch; size_t scratch_floats;
+    int allow_split;       // != 0: layers where the f32 MFMA kernel is matrix-pipe bound may use the 3-part bf16 kernel
 };
+bool pointwise_wgrad_x6_applies(int64_t M, int K, int N, int ldx, int ldy);
+int wgrad_x6_splits(int64_t M, int K, int N);
+int launch_pointwise_wgrad_x6(const WgArgs& a, int splits, hipStream_t st);
 size_t pointwise_wgrad_scratch(int64_t M, int K, int N);
 int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st);
 

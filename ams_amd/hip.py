@@ -80,6 +80,7 @@ SIGNATURES = {
     "ams_k_ce_grad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ams_k_pointwise_wgrad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_pointwise_wgrad_scratch": (_sz, [_i64, _i32, _i32]),
+    "ams_k_pointwise_wgrad_split": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_depthwise3x3_dgrad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ams_k_depthwise3x3_wgrad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp]),

@@ -246,6 +246,11 @@ int ams_k_ce_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t 
 int ams_k_pointwise_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw,
                           float* scratch, size_t scratch_floats, void* stream);
 size_t ams_k_pointwise_wgrad_scratch(int64_t M, int32_t K, int32_t N);
+/* K13b: the same on the bf16 matrix pipe with both operands split into three bf16 parts (six products, f32-level
+ * accuracy): the kernel the fine-tune step uses for its late layers (few pixels, many channel pairs).  Requires
+ * 1024 <= M <= 32768, K and N multiples of 4, K*N >= 4096 (AMS_E_INVALID otherwise). */
+int ams_k_pointwise_wgrad_split(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw,
+                                float* scratch, size_t scratch_floats, void* stream);
 
 /* K13: depthwise backward: dx (input gradient) and dw[3,3,C,1]. */
 int ams_k_depthwise3x3_dgrad(const float* dy, int32_t B, int32_t H, int32_t W, int32_t C, const float* w,

@@ -139,6 +139,36 @@ def test_pointwise_wgrad(lib, M, K, N):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("M,K,N", [(16384, 960, 160), (2048, 64, 384), (4160, 384, 64), (1500, 576, 96), (1024, 320, 256),
+                                   (3000, 144, 24 * 4), (2080, 256, 20)])
+def test_pointwise_wgrad_split(lib, M, K, N):
+    """3-part bf16 split on the matrix pipe (transpose reads from LDS): f32-level accuracy, deterministic, ragged M / N."""
+    rng = np.random.default_rng(M + K + N)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.1, 4.0, (1, K))).astype(np.float32)
+    dy = (rng.standard_normal((M, N)) * 1e-3).astype(np.float32)
+    n_scr = lib.ams_k_pointwise_wgrad_scratch(M, K, N)
+    scr = torch.empty(n_scr, device=DEV)
+    dw = torch.full((K, N), np.nan, device=DEV)
+    hip.check(lib.ams_k_pointwise_wgrad_split(PD(x), PD(dy), M, K, N, P(dw), P(scr), n_scr, stream()))
+    want = x.astype(np.float64).T @ dy.astype(np.float64)
+    got = dw.cpu().numpy()
+    assert np.isfinite(got).all()
+    # against the exact-f32 MFMA kernel's own bar (3e-5): the split must be in the same class
+    assert rel_err(got, want) < 3e-5
+    f32 = torch.empty((K, N), device=DEV)
+    hip.check(lib.ams_k_pointwise_wgrad(PD(x), PD(dy), M, K, N, P(f32), P(scr), n_scr, stream()))
+    assert rel_err(got, want) <= 2 * rel_err(f32.cpu().numpy(), want) + 1e-6
+    dw2 = torch.empty((K, N), device=DEV)
+    hip.check(lib.ams_k_pointwise_wgrad_split(PD(x), PD(dy), M, K, N, P(dw2), P(scr), n_scr, stream()))
+    assert torch.equal(dw, dw2)
+
+
+def test_pointwise_wgrad_split_rejects_small_problems(lib):
+    scr = torch.empty(1024, device=DEV)
+    z = torch.zeros(16, device=DEV)
+    assert lib.ams_k_pointwise_wgrad_split(P(z), P(z), 64, 16, 16, P(z), P(scr), 1024, stream()) == -1
+
+
 # ------------------------------------------------------------------------------------------------ stem
 @pytest.mark.parametrize("H,W,dtype", [(32, 64, np.uint8), (37, 50, np.float32), (64, 128, np.uint8)])
 def test_stem_conv(lib, H, W, dtype):

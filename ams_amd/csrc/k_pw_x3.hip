@@ -210,8 +210,9 @@ template <int RM, int NT, int EPI, int D, int NP>
 static int launch_pw_x3_d(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     const int64_t nblocks = cdiv64(a.M, 64 * RM) * n_tiles_n;
-    static const std::string nm = std::string(NP == 3 ? "pw_gemm_bf16x6_l<" : "pw_gemm_bf16x3_l<") + std::to_string(RM) + ", " +
-                                  std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(D) + ">";
+    // the kernel's own symbol (rocprofv3 reports the same text); NP = 3 is the six-product "x6" training variant
+    static const std::string nm = "pw_gemm_bf16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) +
+                                  ", " + std::to_string(D) + ", " + std::to_string(NP) + ">";
     note_kernel(nm.c_str());
     hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI, D, NP>), dim3((unsigned)nblocks), dim3(256), 0, st, a, w.base, w.plane, Kp,
                        n_tiles_n, (unsigned)nblocks);

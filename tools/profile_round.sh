@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round artefacts on the GPU box (repo root): full bench JSON, rocprofv3 kernel-trace summary of the timed inference loop
+# and of one fine-tune leg, PMC traffic passes.  usage: bash tools/profile_round.sh <tag>   -> gpurun_out/<tag>_*
+tag=${1:-rXX}
+python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf gpurun_out/prof_$tag
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag/infer -o p -- python3 bench.py --only-timed --steps 20 --warmup 3 > gpurun_out/${tag}_prof_infer.log 2>&1
+db=$(find gpurun_out/prof_$tag/infer -name "*.db" | head -1)
+python3 tools/rocpd_stats.py "$db" gpurun_out/${tag}_infer_kernel_stats.csv
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag/train -o p -- python3 tools/profile_train.py 8 512 > gpurun_out/${tag}_prof_train.log 2>&1
+db=$(find gpurun_out/prof_$tag/train -name "*.db" | head -1)
+python3 tools/rocpd_stats.py "$db" gpurun_out/${tag}_train_kernel_stats.csv
+bash tools/pmc_traffic.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
+rm -rf gpurun_out/prof_$tag gpurun_out/pmc_$tag
+head -5 gpurun_out/${tag}_infer_kernel_stats.csv

@@ -456,12 +456,20 @@ static int bn_train(ams_student* s, LayerRt& l, int64_t M_local, double n_global
                     const float* res, hipStream_t st) {
     const ams_student_config& c = s->cfg;
     const float* center = s->stats + l.d.mean_off;       // shifted sums: moving_mean is a good, rank-identical centre
-    RUNK(0, 4.0 * M_local * l.d.cout, launch_colstats(l.z, M_local, l.d.cout, center, l.fsums, s->scratch, st));
-    RUN(sync_doubles(sc, l.fsums, 2 * (size_t)l.d.cout, st));
     const float omd = 1.0f - c.bn_decay;
-    RUN(launch_bn_finalize(l.fsums, n_global, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
-                           update_ema ? s->stats + l.d.mean_off : nullptr, update_ema ? s->stats + l.d.var_off : nullptr,
-                           l.scale, l.shift, l.mean, l.rstd, st));
+    float* mm = update_ema ? s->stats + l.d.mean_off : nullptr;
+    float* mv = update_ema ? s->stats + l.d.var_off : nullptr;
+    if (!sc || !sc->cb) {
+        // no cross-rank sum between the statistics and their use: the reduction's second stage finishes the BN arithmetic
+        RUNK(0, 4.0 * M_local * l.d.cout,
+             launch_colstats_bn(l.z, M_local, l.d.cout, center, l.fsums, s->scratch, n_global, s->params + l.d.gamma_off,
+                                s->params + l.d.beta_off, l.d.bn_eps, omd, mm, mv, l.scale, l.shift, l.mean, l.rstd, st));
+    } else {
+        RUNK(0, 4.0 * M_local * l.d.cout, launch_colstats(l.z, M_local, l.d.cout, center, l.fsums, s->scratch, st));
+        RUN(sync_doubles(sc, l.fsums, 2 * (size_t)l.d.cout, st));
+        RUN(launch_bn_finalize(l.fsums, n_global, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
+                               mm, mv, l.scale, l.shift, l.mean, l.rstd, st));
+    }
     RUNK(0, 4.0 * M_local * l.d.cout * (res ? 3 : 2), launch_bn_act(l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, res, l.a, st));
     return AMS_OK;
 }
@@ -522,13 +530,20 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
 // BN backward of layer l given da (gradient wrt the layer's activated output): writes dz into s->dz, dgamma/dbeta into grads
 static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_local, double n_global, const SyncCtx* sc,
                        hipStream_t st) {
-    RUNK(0, 8.0 * M_local * l.d.cout,
-         launch_bn_bwd_reduce(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch, st));
-    // gamma/beta gradients from this rank's own sums: the gradient all-reduce adds the ranks up exactly once
-    RUN(launch_bn_param_grads(l.bsums, l.d.cout, s->grads + l.d.gamma_off, s->grads + l.d.beta_off, st));
-    RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
-    RUN(launch_bn_bwd_coef(l.bsums, n_global, l.d.cout, s->params + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC,
-                           nullptr, nullptr, st));
+    if (!sc || !sc->cb) {
+        RUNK(0, 8.0 * M_local * l.d.cout,
+             launch_bn_bwd_reduce_coef(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch,
+                                       n_global, s->params + l.d.gamma_off, l.cA, l.cB, l.cC, s->grads + l.d.gamma_off,
+                                       s->grads + l.d.beta_off, st));
+    } else {
+        RUNK(0, 8.0 * M_local * l.d.cout,
+             launch_bn_bwd_reduce(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch, st));
+        // gamma/beta gradients from this rank's own sums: the gradient all-reduce adds the ranks up exactly once
+        RUN(launch_bn_param_grads(l.bsums, l.d.cout, s->grads + l.d.gamma_off, s->grads + l.d.beta_off, st));
+        RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
+        RUN(launch_bn_bwd_coef(l.bsums, n_global, l.d.cout, s->params + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC,
+                               nullptr, nullptr, st));
+    }
     RUNK(0, 12.0 * M_local * l.d.cout,
          launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, s->dz, st));
     return AMS_OK;

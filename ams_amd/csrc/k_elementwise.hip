@@ -148,6 +148,77 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
     }
 }
 
+// Second stage fused with the per-channel BN arithmetic (single-GPU path: no all-reduce sits between the sums and their
+// use).  part is [chunks][2][C]; a block of 512 threads owns 16 channels: thread t = (q = t >> 8, kpart = (t >> 4) & 15, col = t & 15).
+struct BnFwdFin {
+    double n; const float* center; const float* gamma; const float* beta; float eps, one_minus_decay;
+    float *moving_mean, *moving_var, *scale, *shift, *save_mean, *save_rstd;
+    __device__ void operator()(int c, int /*C*/, double s0, double s1) const {
+        const double ctr = center ? (double)center[c] : 0.0;
+        const double d1 = s0 / n, d2 = s1 / n;
+        double var = d2 - d1 * d1;
+        if (var < 0) var = 0;
+        const float mean = (float)(ctr + d1);
+        const float varf = (float)var;
+        const float rstd = 1.0f / sqrtf(varf + eps);
+        const float sc = gamma[c] * rstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - mean * sc;
+        if (save_mean) { save_mean[c] = mean; save_rstd[c] = rstd; }
+        if (moving_mean) {
+            const float unbiased = (float)(var * (n / (n > 1.5 ? n - 1.0 : 1.0)));
+            moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * one_minus_decay;
+            moving_var[c] = moving_var[c] - (moving_var[c] - unbiased) * one_minus_decay;
+        }
+    }
+};
+struct BnBwdFin {
+    double n; const float* gamma; const float* mean; const float* rstd;
+    float *coefA, *coefB, *coefC, *dgamma, *dbeta;
+    __device__ void operator()(int c, int /*C*/, double sdy, double sdyx) const {
+        const double A = (double)gamma[c] * rstd[c];
+        const double k = A * (sdyx / n) * rstd[c];
+        coefA[c] = (float)A;
+        coefC[c] = (float)(-k);
+        coefB[c] = (float)(-A * (sdy / n) + k * mean[c]);
+        dgamma[c] = (float)sdyx;
+        dbeta[c] = (float)sdy;
+    }
+};
+
+template <class Fin>
+__global__ __launch_bounds__(512) void col_finalize_bn_kernel(const float* __restrict__ part, int chunks, int C,
+                                                              double* __restrict__ sums, Fin fin) {
+    __shared__ double sacc[2][16][17];
+    const int col = threadIdx.x & 15, kpart = (threadIdx.x >> 4) & 15, q = threadIdx.x >> 8;
+    const int c = blockIdx.x * 16 + col;
+    double s = 0.0;
+    if (c < C) {
+        const int64_t per = 2 * (int64_t)C;
+        const float* p = part + (int64_t)q * C + c;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int k = kpart;
+        for (; k + 112 < chunks; k += 128) {          // 8 loads in flight
+            const float v0 = p[(int64_t)k * per], v1 = p[(int64_t)(k + 16) * per];
+            const float v2 = p[(int64_t)(k + 32) * per], v3 = p[(int64_t)(k + 48) * per];
+            const float v4 = p[(int64_t)(k + 64) * per], v5 = p[(int64_t)(k + 80) * per];
+            const float v6 = p[(int64_t)(k + 96) * per], v7 = p[(int64_t)(k + 112) * per];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
+        for (; k < chunks; k += 16) s0 += p[(int64_t)k * per];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sacc[q][kpart][col] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = 0; k < 16; ++k) { t0 += sacc[0][k][col]; t1 += sacc[1][k][col]; }
+        sums[c] = t0;
+        sums[C + c] = t1;
+        fin(c, C, t0, t1);
+    }
+}
+
 constexpr int kMaxChunks = 1024;
 
 template <int NQ, class Op, typename TOut>
@@ -170,6 +241,38 @@ int launch_colstats(const float* z, int64_t M, int C, const float* center, doubl
     OpStats op{z, center, {}};
     note_kernel("col_reduce_kernel<2, OpStats>");
     return run_col_reduce<2, OpStats, double>(op, M, 1, C, C, 1.0, scratch, sums, st);
+}
+
+template <class Op, class Fin>
+static int run_col_reduce_bn(Op op, int64_t M, int C, float* scratch, double* sums, Fin fin, hipStream_t st) {
+    AMS_REQUIRE(C % 4 == 0 && C / 4 <= 256, "column reduce: C=%d must be a multiple of 4 (<= 1024)", C);
+    const ColGeom g = col_geom(M, 1, C, C, kMaxChunks);
+    const size_t lds = (size_t)g.slots * 2 * C * sizeof(float);
+    hipLaunchKernelGGL((col_reduce_kernel<2, Op>), dim3(g.chunks, 1), dim3(g.CG * g.slots), lds, st, op, g, scratch);
+    AMS_CHECK_LAUNCH();
+    hipLaunchKernelGGL((col_finalize_bn_kernel<Fin>), dim3(cdiv(C, 16)), dim3(512), 0, st, scratch, g.chunks, C, sums, fin);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// launch_colstats + launch_bn_finalize in two launches instead of three (no cross-rank sum in between)
+int launch_colstats_bn(const float* z, int64_t M, int C, const float* center, double* sums, float* scratch, double n,
+                       const float* gamma, const float* beta, float eps, float one_minus_decay, float* moving_mean,
+                       float* moving_var, float* scale, float* shift, float* save_mean, float* save_rstd, hipStream_t st) {
+    OpStats op{z, center, {}};
+    note_kernel("col_reduce_kernel<2, OpStats>");
+    const BnFwdFin fin{n, center, gamma, beta, eps, one_minus_decay, moving_mean, moving_var, scale, shift, save_mean, save_rstd};
+    return run_col_reduce_bn(op, M, C, scratch, sums, fin, st);
+}
+
+// launch_bn_bwd_reduce + launch_bn_param_grads + launch_bn_bwd_coef in two launches instead of four
+int launch_bn_bwd_reduce_coef(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift, int act,
+                              const float* mean, const float* rstd, double* sums, float* scratch, double n, const float* gamma,
+                              float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta, hipStream_t st) {
+    OpBnBwd op{da, z, scale, shift, mean, rstd, act, {}, {}, {}, {}};
+    note_kernel("col_reduce_kernel<2, OpBnBwd>");
+    const BnBwdFin fin{n, gamma, mean, rstd, coefA, coefB, coefC, dgamma, dbeta};
+    return run_col_reduce_bn(op, M, C, scratch, sums, fin, st);
 }
 
 int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift,

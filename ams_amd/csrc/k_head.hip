@@ -45,17 +45,20 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
     const bool metric = teacher != nullptr;
     if (metric)
         for (int e = threadIdx.x; e < g.K * g.K; e += blockDim.x) s_conf[e] = 0;
-    const int y = blockIdx.y, b = blockIdx.z;
+    const int b = blockIdx.z;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y0, y1; float ty;
-    src_tap(y, g.sy, g.h, y0, y1, ty);
     if (metric) __syncthreads();
     float my_loss = 0.f;
     int my_cnt = 0;
-    if (x < g.W) {
-        int x0, x1; float tx;
-        src_tap(x, g.sx, g.w, x0, x1, tx);
-        const float* base = logits + (int64_t)b * g.h * g.w * g.ld;
+    int x0 = 0, x1 = 0; float tx = 0.f;
+    if (x < g.W) src_tap(x, g.sx, g.w, x0, x1, tx);
+    const float* base = logits + (int64_t)b * g.h * g.w * g.ld;
+    // a block walks rows blockIdx.y, blockIdx.y + gridDim.y, ...: the confusion counts and the loss leave the block once
+    // (the global atomics on a handful of addresses were the cost of the metric path with one row per block)
+    for (int y = blockIdx.y; y < g.H; y += gridDim.y) {
+        if (x >= g.W) break;
+        int y0, y1; float ty;
+        src_tap(y, g.sy, g.h, y0, y1, ty);
         const float* ptl = base + ((int64_t)y0 * g.w + x0) * g.ld;
         const float* ptr = base + ((int64_t)y0 * g.w + x1) * g.ld;
         const float* pbl = base + ((int64_t)y1 * g.w + x0) * g.ld;
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
         }
         if (labels) labels[pix] = arg;
         if (target >= 0) {
-            my_loss = (zmax + __logf(ssum)) - zt;
-            my_cnt = 1;
+            my_loss += (zmax + __logf(ssum)) - zt;
+            my_cnt += 1;
             atomicAdd(&s_conf[target * g.K + arg], 1);
         }
     }
@@ -133,7 +136,8 @@ int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, con
     }
     const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
     note_kernel("upsample_argmax_kernel");
-    hipLaunchKernelGGL(upsample_argmax_kernel, dim3(cdiv(W, 256), H, B), dim3(256), 0, st, logits, g, ct, teacher, labels,
+    const int rows_y = teacher ? (H < 32 ? H : 32) : H;          // metric path: 32 row-walkers per column strip and image
+    hipLaunchKernelGGL(upsample_argmax_kernel, dim3(cdiv(W, 256), rows_y, B), dim3(256), 0, st, logits, g, ct, teacher, labels,
                        (unsigned long long*)conf, loss);
     AMS_CHECK_LAUNCH();
     return AMS_OK;

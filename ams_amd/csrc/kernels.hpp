@@ -96,6 +96,13 @@ int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, cons
 int launch_bn_bwd_coef(const double* sums, double n, int C, const float* gamma, const float* mean, const float* rstd,
                        float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta, hipStream_t st);
 int launch_bn_param_grads(const double* sums, int C, float* dgamma, float* dbeta, hipStream_t st);
+// single-GPU fusions of the above: the second reduction stage also does the per-channel arithmetic
+int launch_colstats_bn(const float* z, int64_t M, int C, const float* center, double* sums, float* scratch, double n,
+                       const float* gamma, const float* beta, float eps, float one_minus_decay, float* moving_mean,
+                       float* moving_var, float* scale, float* shift, float* save_mean, float* save_rstd, hipStream_t st);
+int launch_bn_bwd_reduce_coef(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift, int act,
+                              const float* mean, const float* rstd, double* sums, float* scratch, double n, const float* gamma,
+                              float* coefA, float* coefB, float* coefC, float* dgamma, float* dbeta, hipStream_t st);
 int launch_bn_bwd_apply(const float* da, const float* z, int64_t M, int C, const float* scale, const float* shift, int act,
                         const float* coefA, const float* coefB, const float* coefC, float* dz, hipStream_t st);
 // plain column sums over rows (bias gradient): out[c] = sum_m x[m, c]

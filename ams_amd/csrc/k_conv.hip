@@ -441,32 +441,49 @@ int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const fl
 }
 
 // weight gradient: dw[i,j,c] = sum_{b,oy,ox} x[b, oy*S-pt+i*R, ox*S-pl+j*R, c] * dy[b,oy,ox,c]
-// each block owns a contiguous chunk of output pixels; per-thread 9 x float4 accumulators; the block's column
-// slots are reduced through LDS in fixed order and the chunk partials by launch_reduce_splits (deterministic).
+// A thread owns 4 channels and walks work items = (image, group of TH = 4 output rows, output column): the
+// (TH-1)*S + 2R + 1 input rows that the group touches are each loaded once (3 taps per row) and feed up to 3 output
+// rows, so an item costs NU*3 + 4 vector loads for 4 pixels instead of 10 per pixel (the tap re-reads were saturating
+// L2, not HBM).  All loads of an item are requested up front, branch-free (clamped address + select).  A block owns a
+// contiguous range of items; its pixel slots are added through LDS in a fixed order and the block partials by
+// launch_reduce_splits (deterministic).
 template <int S, int R>
 __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          float* __restrict__ part, DwGeom g, int64_t px_per_block) {
+                                                          float* __restrict__ part, DwGeom g, int64_t items_per_block) {
+    constexpr int TH = 4;
+    constexpr int NU = (TH - 1) * S + 2 * R + 1;                    // distinct input rows of an item
     extern __shared__ __attribute__((aligned(16))) float sred[];   // [slots][9][C]
     const int cg = threadIdx.x % g.CG, slot = threadIdx.x / g.CG;
     const int c0 = cg * 4;
     float4 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t total = (int64_t)g.B * g.Ho * g.Wo;
-    const int64_t p_begin = blockIdx.x * px_per_block;
-    int64_t p_end = p_begin + px_per_block;
+    const int tiles_y = (g.Ho + TH - 1) / TH;
+    const int64_t total = (int64_t)g.B * tiles_y * g.Wo;
+    const int64_t p_begin = blockIdx.x * items_per_block;
+    int64_t p_end = p_begin + items_per_block;
     if (p_end > total) p_end = total;
     if (slot < g.slots) {
         for (int64_t p = p_begin + slot; p < p_end; p += g.slots) {
-            const int pi = (int)p;                                   // B*Ho*Wo < 2^31 (checked on the host)
+            const int pi = (int)p;                                   // < 2^31 (checked on the host)
             const int ox = pi % g.Wo;
             const int t2 = pi / g.Wo;
-            const int oy = t2 % g.Ho, b = t2 / g.Ho;
-            const float4 d = ld4(dy + p * g.C + c0);
-            const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
+            const int ty = t2 % tiles_y, b = t2 / tiles_y;
+            const int oy0 = ty * TH;
+            float4 d[TH];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int iy = oy * S - g.pt + i * R;
+            for (int r = 0; r < TH; ++r) {
+                const int oy = oy0 + r;
+                const int oyc = oy < g.Ho ? oy : g.Ho - 1;
+                const float4 v = ld4(dy + (((int64_t)b * g.Ho + oyc) * g.Wo + ox) * g.C + c0);
+                const bool ok = oy < g.Ho;
+                d[r] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            }
+            const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
+            float4 xv[NU][3];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int iy = oy0 * S - g.pt + u;
                 const bool oky = iy >= 0 && iy < g.H;
                 const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
 #pragma unroll
@@ -474,12 +491,25 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restric
                     const int ix = ox * S - g.pl + j * R;
                     const bool ok = oky && ix >= 0 && ix < g.W;
                     const int ixc = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
-                    const float4 v = ld4(xb + ((int64_t)iyc * g.W + ixc) * g.C);   // clamped address, masked by select
-                    float4& a = acc[i * 3 + j];
-                    a.x = fmaf(ok ? v.x : 0.f, d.x, a.x); a.y = fmaf(ok ? v.y : 0.f, d.y, a.y);
-                    a.z = fmaf(ok ? v.z : 0.f, d.z, a.z); a.w = fmaf(ok ? v.w : 0.f, d.w, a.w);
+                    const float4 v = ld4(xb + ((int64_t)iyc * g.W + ixc) * g.C);
+                    xv[u][j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    // input row u is tap row i of output row r iff u = r*S + i*R
+                    if ((u - i * R) >= 0 && (u - i * R) % S == 0 && (u - i * R) / S < TH) {
+                        const float4 dd = d[(u - i * R) / S];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            float4& a = acc[i * 3 + j];
+                            a.x = fmaf(xv[u][j].x, dd.x, a.x); a.y = fmaf(xv[u][j].y, dd.y, a.y);
+                            a.z = fmaf(xv[u][j].z, dd.z, a.z); a.w = fmaf(xv[u][j].w, dd.w, a.w);
+                        }
+                    }
+                }
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) st4(sred + ((int64_t)slot * 9 + k) * g.C + c0, acc[k]);
@@ -495,10 +525,14 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_kernel(const float* __restric
 // blocks of the depthwise weight-gradient pass: ~8 pixels per thread, at most 1024 blocks (the partials are reduced by
 // a second kernel).  slots = pixel columns per block (256 / (C/4)): wide layers have ONE, so the block count must not be
 // derived from a fixed pixels-per-block figure (that left the 960-channel layers with 68 blocks on 256 CUs).
-static int dw_wgrad_blocks(int64_t total_px, int C) {
+static int dw_wgrad_blocks(int64_t total_items, int C) {
     const int cg = C / 4;
     const int slots = 256 / cg < 1 ? 1 : 256 / cg;
-    int64_t blocks = cdiv64(total_px, (int64_t)slots * 8);
+    int64_t blocks = cdiv64(total_items, (int64_t)slots * 2);      // ~2 items (8 pixels) per thread
+    // every block writes a 9 x C partial that the second stage reads back: keep that below ~1/4 of the x + dy traffic
+    // (4 pixels per item, 2 tensors: partial bytes <= items * 4 * 2 * C / 4  ->  blocks <= items * 2 / 9)
+    const int64_t by_traffic = total_items * 2 / 9 > 1 ? total_items * 2 / 9 : 1;
+    if (blocks > by_traffic) blocks = by_traffic;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -508,7 +542,7 @@ size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate)
     int Ho, Wo, p;
     same_pad(H, 3, stride, rate, &Ho, &p);
     same_pad(W, 3, stride, rate, &Wo, &p);
-    return (size_t)dw_wgrad_blocks((int64_t)B * Ho * Wo, C) * 9 * C;
+    return (size_t)dw_wgrad_blocks((int64_t)B * ((Ho + 3) / 4) * Wo, C) * 9 * C;
 }
 
 int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
@@ -516,14 +550,21 @@ int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W,
     DwGeom g;
     int rc = dw_geom(B, H, W, C, stride, rate, false, &g);
     if (rc) return rc;
-    const int64_t total = (int64_t)B * g.Ho * g.Wo;
-    const int blocks = dw_wgrad_blocks(total, C);
+    const int64_t total = (int64_t)B * ((g.Ho + 3) / 4) * g.Wo;      // work items: 4 output rows x 1 column
+    int blocks = dw_wgrad_blocks(total, C);
     AMS_REQUIRE(scratch_floats >= (size_t)blocks * 9 * C, "depthwise wgrad: scratch too small");
     AMS_REQUIRE(total < 0x7fffffffLL, "depthwise wgrad: too many pixels");
-    const int64_t ppb = cdiv64(total, blocks);
     const int threads = g.CG * g.slots;
     const size_t lds = (size_t)g.slots * 9 * C * sizeof(float);
     AMS_REQUIRE(lds <= 64 * 1024, "depthwise wgrad: LDS %zu too large", lds);
+    // the items are dealt out up front, so a grid a little larger than what is co-resident costs a whole second round:
+    // never launch more blocks than fit at once
+    const void* fn = stride == 2 ? (const void*)dw3x3_wgrad_kernel<2, 1> : rate == 2 ? (const void*)dw3x3_wgrad_kernel<1, 2>
+                                                                                   : (const void*)dw3x3_wgrad_kernel<1, 1>;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    const int64_t ppb = cdiv64(total, blocks);
     note_kernel(stride == 2 ? "dw3x3_wgrad_kernel<2, 1>" : rate == 2 ? "dw3x3_wgrad_kernel<1, 2>" : "dw3x3_wgrad_kernel<1, 1>");
     if (stride == 1 && rate == 1)
         hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, 1>), dim3(blocks), dim3(threads), lds, st, x, dy, scratch, g, ppb);

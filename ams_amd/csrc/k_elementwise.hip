@@ -284,6 +284,7 @@ int launch_bn_bwd_reduce(const float* da, const float* z, int64_t M, int C, cons
 
 int launch_colsum(const float* x, int64_t M, int C, int ldx, float* out, float* scratch, hipStream_t st) {
     OpSum op{x};
+    note_kernel("col_reduce_kernel<1, OpSum>");
     return run_col_reduce<1, OpSum, float>(op, M, 1, C, ldx, 1.0, scratch, out, st);
 }
 
@@ -291,6 +292,7 @@ int launch_colsum(const float* x, int64_t M, int C, int ldx, float* out, float* 
 static int image_colsum_impl(const float* x, int B, int64_t HW, int C, int ldx, double alpha, float* out, float* scratch,
                              hipStream_t st) {
     OpSum op{x};
+    note_kernel("col_reduce_kernel<1, OpSum>");
     return run_col_reduce<1, OpSum, float>(op, HW, B, C, ldx, alpha, scratch, out, st);
 }
 

@@ -126,11 +126,11 @@ def main():
     checksum = int(out.sum().item())
 
     if args.only_timed:
-        if rank == 0:
-            print(json.dumps({"value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-                              "labels_checksum": checksum, "note": "--only-timed: no other leg was run"}))
         if dist is not None:
             dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                              "labels_checksum": checksum, "note": "--only-timed: no other leg was run"}), flush=True)
         return
 
     # ---- latency mode: one frame per call (what the edge loop of run.py:400-423 does) ---------------------------
@@ -284,9 +284,16 @@ def main():
             "kernels": kernels,
             "labels_checksum": checksum,
         }
-        print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line must be the last thing on stdout: RCCL's banner sits in the C stdio buffer until it is flushed
+        try:
+            C.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -108,6 +108,9 @@ struct ams_student {
     int64_t adam_t = 0;
     bool frozen_ready = false;
     int matmul_mode = AMS_MATMUL_SPLIT_BF16;   // frozen inference, late layers
+    int fuse_dw_project = 0;                   // frozen inference: depthwise + project in one kernel on the stride-16 blocks.
+                                               // Off by default: measured equal to the two kernels at B = 8 (LDS-read bound:
+                                               // 60 b128 reads per wave and 32 channels) and slower at B = 1 (45 blocks)
     int fuse_expand_dw = 1;                    // frozen inference, expand + depthwise in one kernel: 0 never, 1 where it
                                                // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
@@ -404,6 +407,22 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
         {
             LayerRt& l = s->L[i];
             AMS_REQUIRE(l.d.role == AMS_ROLE_DEPTHWISE, "engine: expected depthwise at layer %d", i);
+            LayerRt& lpj = s->L[i + 1];
+            if (s->fuse_dw_project && s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && i + 1 <= s->n_backbone &&
+                lpj.d.role == AMS_ROLE_PROJECT && lpj.whi && (int64_t)B * l.px_out < 32768 && (int64_t)B * l.px_out >= 256 &&
+                lpj.Kp == l.d.cin && dw_project_supported(l.d.cin, lpj.d.cout, l.d.stride, l.d.rate)) {
+                // depthwise + project in one kernel (split-bf16 GEMM that computes its own operand): d never reaches HBM
+                const int o = other(cur_i, x_i);
+                PwArgs a = pw_args(nullptr, (int64_t)B * lpj.px_in, lpj.d.cin, lpj.d.cin, P + lpj.d.w_off, lpj.d.cout, s->act[o], lpj.d.cout);
+                a.scale = lpj.fscale; a.shift = lpj.fshift; a.act = lpj.d.act;
+                if (lpj.d.residual_from) { a.res = block_in; a.ldr = lpj.d.cout; }
+                const double bytes = 4.0 * ((double)B * (l.px_in * l.d.cin + lpj.px_out * lpj.d.cout * (a.res ? 2 : 1)) +
+                                            (double)lpj.d.cin * lpj.d.cout + 9.0 * l.d.cin);
+                RUNK(i + 1, bytes, launch_dw_project(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, l.fscale, l.fshift, l.d.act, a,
+                                                     lpj.whi, lpj.wlo, lpj.Kp, st));
+                cur = s->act[o]; cur_i = o; i += 2;
+                continue;
+            }
             const int o = other(cur_i, x_i);
             RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, l.fscale,
                                                      l.fshift, l.d.act, s->act[o], st));
@@ -844,6 +863,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         s->matmul_mode = value;
         return AMS_OK;
     }
+    if (option == AMS_OPT_FUSE_DW_PROJECT) {
+        s->fuse_dw_project = value != 0;
+        return AMS_OK;
+    }
     if (option == AMS_OPT_FUSE_EXPAND_DW) {
         s->fuse_expand_dw = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
@@ -927,6 +950,21 @@ int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, 
     a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
     if (scale && !shift) { set_error("pointwise_split: scale without shift"); return AMS_E_INVALID; }
     return launch_pointwise_split(a, hi, lo, Kp, st);
+}
+
+int ams_k_dw_project(const float* e, int32_t B, int32_t H, int32_t W, int32_t Cc, const float* w_dw, int32_t rate, const float* scale_d,
+                     const float* shift_d, const float* w_proj, int32_t N, const float* scale_p, const float* shift_p,
+                     const float* res, float* y, uint16_t* panels, size_t panel_elems, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!dw_project_supported(Cc, N, 1, rate)) { set_error("dw_project: unsupported shape C=%d N=%d rate=%d", Cc, N, rate); return AMS_E_INVALID; }
+    AMS_REQUIRE(panels && panel_elems >= (size_t)2 * N * Cc, "dw_project: panel scratch too small (need %zu)", (size_t)2 * N * Cc);
+    uint16_t* hi = panels;
+    uint16_t* lo = panels + (size_t)N * Cc;
+    RUN(launch_split_weights(w_proj, N, 1, Cc, N, Cc, hi, lo, st));
+    PwArgs a = pw_args(nullptr, (int64_t)B * H * W, Cc, Cc, w_proj, N, y, N);
+    a.scale = scale_p; a.shift = shift_p; a.act = AMS_ACT_NONE;
+    if (res) { a.res = res; a.ldr = N; }
+    return launch_dw_project(e, B, H, W, Cc, w_dw, rate, scale_d, shift_d, AMS_ACT_RELU6, a, hi, lo, Cc, st);
 }
 
 int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,

@@ -42,6 +42,10 @@ struct WgArgs {
     float* scratch; size_t scratch_floats;
     int allow_split;       // != 0: layers where the f32 MFMA kernel is matrix-pipe bound may use the 3-part bf16 kernel
 };
+// fused depthwise 3x3 (+BN+act) -> project 1x1 (+BN, +residual), frozen inference, split-bf16 GEMM (k_dw_project.hip)
+bool dw_project_supported(int C, int N, int stride, int rate);
+int launch_dw_project(const float* e, int B, int H, int W, int C, const float* w_dw, int rate, const float* sc_d, const float* sh_d,
+                      int act_d, const PwArgs& p, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st);
 bool pointwise_wgrad_x6_applies(int64_t M, int K, int N, int ldx, int ldy);
 int wgrad_x6_splits(int64_t M, int K, int N);
 int launch_pointwise_wgrad_x6(const WgArgs& a, int splits, hipStream_t st);

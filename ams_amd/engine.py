@@ -185,6 +185,11 @@ class StudentEngine:
         """hip.MATMUL_F32 (exact) or hip.MATMUL_SPLIT_BF16 (default; late-layer products via 3 bf16 MFMAs, ~1e-5 rel)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_MATMUL, int(mode)), "ams_student_set_option")
 
+    def set_fuse_dw_project(self, on: bool) -> None:
+        """Frozen inference: depthwise + project of the stride-16 blocks as one kernel (default off: measured no faster than
+        the two kernels; split-bf16 mode only)."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DW_PROJECT, int(bool(on))), "ams_student_set_option")
+
     def set_fuse_expand_dw(self, on: int) -> None:
         """Frozen inference, expand + depthwise of a block as one kernel: 0 never, 1 (default) the blocks where it is
         measured faster, 2 every supported block."""

@@ -168,7 +168,9 @@ int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t fr
  *   AMS_MATMUL_SPLIT_BF16 (default) f32 data split into bf16 hi+lo, 3 bf16 MFMAs per product group, f32 accumulate:
  *                         <= 2^-16 relative per product (~1e-5 on a layer output), 5x the matrix throughput.
  * Training and the live graph always use exact f32. */
-enum { AMS_OPT_MATMUL = 1, AMS_OPT_FUSE_EXPAND_DW = 2 /* 0 never, 1 (default) blocks where the fused kernel is faster, 2 every supported block */ };
+enum { AMS_OPT_FUSE_DW_PROJECT = 3 /* frozen inference: 1 = depthwise + project of the stride-16 blocks in one kernel (needs
+                                      AMS_MATMUL_SPLIT_BF16), 0 (default) separate kernels: measured no faster */,
+       AMS_OPT_MATMUL = 1, AMS_OPT_FUSE_EXPAND_DW = 2 /* 0 never, 1 (default) blocks where the fused kernel is faster, 2 every supported block */ };
 enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1 };
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value);
 
@@ -223,6 +225,14 @@ int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, 
 int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
                     const float* shift_e, int32_t Cexp, const float* w_dw, int32_t stride, int32_t rate, const float* scale_d,
                     const float* shift_d, float* y, void* stream);
+
+/* K3+K4 fused (frozen inference): y = bn_p(relu6(bn_d(dw3x3(e))) @ w_proj) (+ res) — the depthwise output never reaches
+ * HBM; the product uses the two-part bf16 split of ams_k_pointwise_split.  e [B,H,W,C] (C % 32 == 0), w_dw [3,3,C,1],
+ * stride 1, rate 1|2, w_proj [C,N] with N % 16 == 0 and N/16 in {1..6, 8, 10} or a multiple of 10 or 8 of those; res/y
+ * [B,H,W,N]; panels: scratch of >= 2*N*C uint16. */
+int ams_k_dw_project(const float* e, int32_t B, int32_t H, int32_t W, int32_t C, const float* w_dw, int32_t rate,
+                     const float* scale_d, const float* shift_d, const float* w_proj, int32_t N, const float* scale_p,
+                     const float* shift_p, const float* res, float* y, uint16_t* panels, size_t panel_elems, void* stream);
 
 /* K7: global average pool [B,HW,C] -> [B,C] (two-stage, deterministic); scratch >= ams_k_global_mean_scratch floats. */
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

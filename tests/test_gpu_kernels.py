@@ -251,6 +251,34 @@ def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):
     assert rel_err(y.cpu().numpy(), ref.permute(0, 2, 3, 1).numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,C_,N,rate,res", [(33, 65, 384, 64, 1, True), (33, 65, 576, 160, 1, False), (9, 17, 960, 160, 2, True),
+                                                (5, 9, 960, 320, 2, False), (17, 33, 384, 96, 1, False), (4, 16, 64, 16, 1, True)])
+def test_fused_depthwise_project(lib, H, W, C_, N, rate, res):
+    """Depthwise + project in one kernel vs f64: ragged tiles (33x65 is not a multiple of 4x16), both rates, residual."""
+    rng = np.random.default_rng(H + C_ + N)
+    B = 2
+    e = np.clip(rng.standard_normal((B, H, W, C_)) * 2 + 1, 0, 6).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, C_, 1)) * 0.4).astype(np.float32)
+    sd, hd = rng.uniform(0.5, 1.5, C_).astype(np.float32), rng.standard_normal(C_).astype(np.float32)
+    wp = (rng.standard_normal((C_, N)) / np.sqrt(C_)).astype(np.float32)
+    sp, hp = rng.uniform(0.5, 1.5, N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((B, H, W, N)).astype(np.float32) if res else None
+    y = torch.full((B, H, W, N), np.nan, device=DEV)
+    panels = torch.zeros(2 * N * C_, dtype=torch.int16, device=DEV)
+    rd = dev(r) if res else None
+    hip.check(lib.ams_k_dw_project(PD(e), B, H, W, C_, PD(wd), rate, PD(sd), PD(hd), PD(wp), N, PD(sp), PD(hp),
+                                   P(rd) if res else None, P(y), P(panels), panels.numel(), stream()))
+    et = torch.as_tensor(e).double().permute(0, 3, 1, 2)
+    raw = F.conv2d(F.pad(et, (rate, rate, rate, rate)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), dilation=rate, groups=C_)
+    d = torch.clamp(raw * torch.as_tensor(sd).view(1, -1, 1, 1) + torch.as_tensor(hd).view(1, -1, 1, 1), 0, 6).permute(0, 2, 3, 1).numpy()
+    want = (d @ wp.astype(np.float64)) * sp + hp
+    if res:
+        want = want + r
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < 5e-5          # two-part bf16 split: ~1e-5 relative
+
+
 # ------------------------------------------------------------------------------------------------ pooling
 def test_global_mean(lib):
     rng = np.random.default_rng(0)

@@ -59,6 +59,7 @@ def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     eng.load_variables(W0)
     eng.set_matmul_mode(matmul)
     eng.set_fuse_expand_dw(2 if matmul == hip.MATMUL_SPLIT_BF16 else 0)   # 2: every supported block fused; 0: layer-by-layer plan
+    eng.set_fuse_dw_project(matmul == hip.MATMUL_SPLIT_BF16)              # the optional depthwise+project kernel too
     eng.freeze()
     o = _oracle(W0)
     with torch.no_grad():

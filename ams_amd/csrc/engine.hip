@@ -336,11 +336,18 @@ static int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream_t) {
     return AMS_OK;
 }
 
+// Split-bf16 pays where the exact-f32 kernels are matrix-pipe bound (f32-input MFMA = 157 TFLOP/s against ~5 TB/s of HBM:
+// ~31 FLOP per byte): few rows (the streaming kernel needs >= 32768), a weight panel too large for the streaming kernel,
+// or an arithmetic intensity 2KN / 4(K+N) of 20 FLOP/B and more (64 -> 384 and wider, at any batch size).
+static bool split_pays(const PwArgs& a) {
+    if (a.K < 32 || a.K % 8 != 0 || a.M < 256) return false;
+    return a.M < 32768 || !pointwise_stream_applies(a) || (int64_t)a.K * a.N >= 40 * (int64_t)(a.K + a.N);
+}
+
 // live (training) 1x1 layer or its input gradient: same split-bf16 rule as the frozen path, the weights are split right
 // before the launch because they change every step (one small kernel; the panels live in one shared scratch buffer)
 static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
-    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && s->panel_scratch && a.M < 32768 && a.M >= 256 && a.K >= 32 &&
-                       a.K % 8 == 0 && a.Kw == a.K && a.ldx % 4 == 0;
+    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && s->panel_scratch && split_pays(a) && a.Kw == a.K && a.ldx % 4 == 0;
     if (!split) return launch_pointwise(a, st);
     // three-part split (6 MFMAs, f32-level products): gradients amplify product error ~1e5 x on this graph, the two-part
     // split of the frozen path would put the step outside the f32 error class
@@ -356,7 +363,7 @@ static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
 // frozen 1x1 layer: late layers (few rows, wide K/N: matrix-pipe bound) go through the split-bf16 kernel
 static int frozen_pointwise(ams_student* s, int layer, const PwArgs& a, hipStream_t st) {
     const LayerRt& l = s->L[layer];
-    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && l.whi && a.M < 32768 && a.K >= 32 && a.K % 8 == 0 && a.M >= 256;
+    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && l.whi && split_pays(a);
     if (split) RUNK(layer, pw_bytes(a), launch_pointwise_split(a, l.whi, l.wlo, l.Kp, st));
     else RUNK(layer, pw_bytes(a), launch_pointwise(a, st));
     return AMS_OK;

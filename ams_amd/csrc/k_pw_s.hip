@@ -107,17 +107,27 @@ static int launch_pw_s(const PwArgs& a, hipStream_t st) {
     return a.res ? launch_pw_s_e<RM, NT, EPI_RES>(a, st) : launch_pw_s_e<RM, NT, EPI_PLAIN>(a, st);
 }
 
-// returns AMS_OK and sets *handled when the streaming variant applies (weight panel <= 56 KB, vector-friendly layout)
-int launch_pointwise_stream(const PwArgs& a, int force_rm, int force_nt, bool* handled, hipStream_t st) {
-    *handled = false;
+// column-tile width (in 16s) of the streaming variant, or 0 when it does not apply (weight panel of the tile > 56 KB, or
+// an epilogue it does not implement)
+static int pw_stream_nt(const PwArgs& a, int force_nt) {
     const int epi = pw_pick_epi(a);
-    if (epi != EPI_PLAIN && epi != EPI_RES) return AMS_OK;
+    if (epi != EPI_PLAIN && epi != EPI_RES) return 0;
     const int n16 = cdiv(a.N, 16);
     const int kpad = (a.K + 15) / 16 * 16;
     int nt = n16;
     if (n16 > 6) { const int parts = cdiv(n16, 6); nt = cdiv(n16, parts); }     // column tiles of at most 6 x 16
     if (force_nt > 0) nt = force_nt;
-    if ((size_t)kpad * (16 * nt + 4) * 4 > 56 * 1024) return AMS_OK;
+    if ((size_t)kpad * (16 * nt + 4) * 4 > 56 * 1024) return 0;
+    return nt;
+}
+
+bool pointwise_stream_applies(const PwArgs& a) { return pw_stream_nt(a, 0) > 0; }
+
+// returns AMS_OK and sets *handled when the streaming variant applies (weight panel <= 56 KB, vector-friendly layout)
+int launch_pointwise_stream(const PwArgs& a, int force_rm, int force_nt, bool* handled, hipStream_t st) {
+    *handled = false;
+    const int nt = pw_stream_nt(a, force_nt);
+    if (nt == 0) return AMS_OK;
     *handled = true;
     switch (nt) {
         case 1: return launch_pw_s<2, 1>(a, st);

@@ -25,6 +25,7 @@ struct PwArgs {
     int ldy;
 };
 int launch_pointwise(const PwArgs& a, hipStream_t st);
+bool pointwise_stream_applies(const PwArgs& a);     // the persistent streaming variant (small K x N) can take this problem
 
 // split-bf16 (hi + lo) late-layer variant: weights pre-split into [N][Kp] bf16 panels, Kp = K rounded up to 32
 int launch_split_weights(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st);

@@ -52,8 +52,9 @@ def pmc_traffic(kernel, batch, height):
     exact.  Both were re-checked on kernels of known size in this library's access patterns (profiles/*_pmc_calib*:
     1 GiB copy 0.500 / 1.000, depthwise 0.500 / 1.000).  The passes are valid for the default workload only."""
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith("_pmc_traffic.json"))
-    if not files or batch != 8 or height != 512:
+    tag = "_b%d_pmc_traffic.json" % batch              # the passes are valid for the batch they were collected at
+    files = sorted(f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith(tag))
+    if not files or height != 512:
         return {"traffic": None}
     table = json.load(open(os.path.join(here, "profiles", files[-1])))
     for name, v in table.items():
@@ -70,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (throughput saturates at ~24; 8: 5.1 k, 32: 5.5 k frames/s)")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--train-batch", type=int, default=8)
     ap.add_argument("--no-train", action="store_true")

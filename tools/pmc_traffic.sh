@@ -5,7 +5,7 @@
 # writes gpurun_out/pmc_<tag>/{fetch,write}/...counter_collection.csv and gpurun_out/pmc_traffic_<tag>.json
 tag=$1; shift
 args=("$@")
-[ ${#args[@]} -eq 0 ] && args=(--steps 3 --warmup 1 --only-timed)
+[ ${#args[@]} -eq 0 ] && args=(--steps 3 --warmup 1 --only-timed)      # default batch of bench.py
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmc_$tag
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag/fetch -o p -- python3 bench.py "${args[@]}" > gpurun_out/pmc_${tag}_fetch.log 2>&1

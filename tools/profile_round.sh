@@ -11,6 +11,6 @@ python3 tools/rocpd_stats.py "$db" gpurun_out/${tag}_infer_kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag/train -o p -- python3 tools/profile_train.py 8 512 > gpurun_out/${tag}_prof_train.log 2>&1
 db=$(find gpurun_out/prof_$tag/train -name "*.db" | head -1)
 python3 tools/rocpd_stats.py "$db" gpurun_out/${tag}_train_kernel_stats.csv
-bash tools/pmc_traffic.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
+bash tools/pmc_traffic.sh $tag > gpurun_out/${tag}_pmc.log 2>&1      # -> gpurun_out/pmc_traffic_$tag.json (copy to profiles/<round>_b<batch>_pmc_traffic.json)
 rm -rf gpurun_out/prof_$tag gpurun_out/pmc_$tag
 head -5 gpurun_out/${tag}_infer_kernel_stats.csv

@@ -959,6 +959,11 @@ int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, 
     return launch_pointwise_split(a, hi, lo, Kp, st);
 }
 
+int ams_ingest_resize_u8(const uint8_t* src, int32_t Hs, int32_t Ws, int32_t Cn, int32_t mode, int32_t swap_rb, uint8_t* dst, int32_t H,
+                         int32_t W, void* stream) {
+    return launch_resize_u8(src, Hs, Ws, Cn, mode, swap_rb, dst, H, W, (hipStream_t)stream);
+}
+
 int ams_k_dw_project(const float* e, int32_t B, int32_t H, int32_t W, int32_t Cc, const float* w_dw, int32_t rate, const float* scale_d,
                      const float* shift_d, const float* w_proj, int32_t N, const float* scale_p, const float* shift_p,
                      const float* res, float* y, uint16_t* panels, size_t panel_elems, void* stream) {

@@ -53,6 +53,9 @@ int launch_pointwise_wgrad_x6(const WgArgs& a, int splits, hipStream_t st);
 size_t pointwise_wgrad_scratch(int64_t M, int K, int N);
 int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st);
 
+// ---- k_ingest.hip : frame / label resize on the device (run.py:179-183)
+int launch_resize_u8(const uint8_t* src, int Hs, int Ws, int C, int mode, int swap_rb, uint8_t* dst, int H, int W, hipStream_t st);
+
 // ---- k_conv.hip : stem and depthwise ------------------------------------------------------------------
 int launch_stem(const void* frames, int dtype, int B, int H, int W, const float* w, int cout, const float* scale,
                 const float* shift, int act, float pixel_scale, float* y, hipStream_t st);

@@ -185,6 +185,19 @@ class StudentEngine:
         """hip.MATMUL_F32 (exact) or hip.MATMUL_SPLIT_BF16 (default; late-layer products via 3 bf16 MFMAs, ~1e-5 rel)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_MATMUL, int(mode)), "ams_student_set_option")
 
+    def pack_masked_fp16(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Masked trainable parameters as fp16, compacted in trainable order, on the device (the value part of the downlink
+        delta, reference run.py:330-332).  mask: uint8 [n_trainable] on the device, None = all.  -> int16 view of the halves."""
+        n = self.spec.n_trainable
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.numel() == n and mask.device == self.arena.device
+        out = torch.empty(n, dtype=torch.int16, device=self.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        hip.check(self.lib.ams_pack_masked_fp16(C.c_void_p(self.params.data_ptr()), C.c_void_p(mask.data_ptr()) if mask is not None else None,
+                                                n, C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()), self._stream()),
+                  "ams_pack_masked_fp16")
+        return out[:int(cnt.item())]
+
     def set_fuse_dw_project(self, on: bool) -> None:
         """Frozen inference: depthwise + project of the stride-16 blocks as one kernel (default off: measured no faster than
         the two kernels; split-bf16 mode only)."""

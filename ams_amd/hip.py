@@ -21,6 +21,7 @@ ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 DT_F32, DT_U8, DT_BF16, DT_I32, DT_F64 = 0, 1, 2, 3, 4
 MODE_FROZEN, MODE_LIVE = 0, 1
 OPT_MATMUL = 1
+RESIZE_NEAREST, RESIZE_LINEAR = 0, 1
 OPT_FUSE_EXPAND_DW = 2
 OPT_FUSE_DW_PROJECT = 3
 MATMUL_F32, MATMUL_SPLIT_BF16 = 0, 1
@@ -73,6 +74,7 @@ SIGNATURES = {
     "ams_k_depthwise3x3": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ams_k_pointwise": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "ams_k_pointwise_split": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ams_ingest_resize_u8": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "ams_k_dw_project": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ams_k_expand_dw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ams_k_global_mean": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _sz, _vp]),

@@ -56,6 +56,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--compress_uplink", action="store_true")
     p.add_argument("--no_restore", action="store_true")
     p.add_argument("--save_pic", action="store_true")
+    p.add_argument("--gpu_ingest", action="store_true",
+                   help="resize / BGR->RGB of frames and labels on the GPU (extra flag; reference: cv2 on the host)")
     p.add_argument("--enable_ASR", action="store_true")
     p.add_argument("--enable_ATR", action="store_true")
     p.add_argument("--train_strategy", default="full_model",
@@ -121,13 +123,26 @@ def open_source(flags) -> Tuple[FrameSource, int]:
     return DirectorySource(spec, flags.gt_video), vid_num
 
 
-def _to_size(frame: np.ndarray, label: np.ndarray, size: List[int]) -> Tuple[np.ndarray, np.ndarray]:
-    """cv2.resize(frame, (2H, H)) [bilinear] and cv2.resize(label, ..., INTER_NEAREST) (run.py:179-183, :415-421)."""
+def _to_size(frame: np.ndarray, label: np.ndarray, size: List[int], ingest=None):
+    """cv2.resize(frame, (2H, H)) [bilinear] and cv2.resize(label, ..., INTER_NEAREST) (run.py:179-183, :415-421).
+
+    ``ingest`` (an ``ams_amd.ingest.FrameIngest``, flag ``--gpu_ingest``) does both on the device: the raw uint8 frame is
+    what crosses PCIe and the results stay there (``SemanticNetwork`` takes device tensors); frames that already have the
+    network's size pass through untouched either way."""
     if frame.shape[:2] != (size[0], size[1]):
-        frame = resize_linear(frame, size[1], size[0])
+        frame = ingest.frame(frame, size[0], size[1]) if ingest is not None else resize_linear(frame, size[1], size[0])
     if label.shape[:2] != (size[0], size[1]):
-        label = resize_nearest(label, size[1], size[0])
+        label = ingest.label(label, size[0], size[1]) if ingest is not None else resize_nearest(label, size[1], size[0])
     return frame, label
+
+
+def _batch1(x):
+    """np.expand_dims(x, 0) for host arrays and device tensors alike."""
+    return x.unsqueeze(0) if hasattr(x, "unsqueeze") else np.expand_dims(x, axis=0)
+
+
+def _host(x) -> np.ndarray:
+    return x.cpu().numpy() if hasattr(x, "cpu") else x
 
 
 class Context:
@@ -136,6 +151,10 @@ class Context:
         self.size = [flags.height, flags.height * 2]
         self.source, self.vid_num = open_source(flags)
         self.length = flags.length or (len(self.source) // self.source.fps)
+        self.ingest = None
+        if getattr(flags, "gpu_ingest", False):
+            from .ingest import FrameIngest
+            self.ingest = FrameIngest("cuda:%s" % flags.gpu)
         ck = flags.student_checkpoint
         self.initial_variables = None
         if ck.startswith("synthetic"):
@@ -205,7 +224,8 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
             frames_chosen, labels_chosen = choose_frames(frame_label_bucket, send_rate)
             size_images = 0.0
             for fr, label in zip(frames_chosen, labels_chosen):
-                fr, label_resized = _to_size(fr, label, ctx.size)
+                fr, label_resized = _to_size(fr, label, ctx.size, ctx.ingest)
+                fr, label_resized = _host(fr), _host(label_resized)       # the replay memory lives on the host
                 if map_coco is not None:
                     label_resized = map_coco[label_resized]
                 frame_memory.append(fr)
@@ -245,14 +265,8 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
             train_ms.append(1000 * (time.time() - t1))
             print("Training for %d iterations took %d ms!!!" % (FLAGS.iter, train_ms[-1]))
             # model delta on the downlink: packed mask bits + masked parameters as fp16, gzip -9 (run.py:316-336)
-            payload = bytearray()
-            full_size = 0
-            for val in semantic_network.curr_mask:
-                payload += np.packbits(val.flatten()).tobytes()
-                full_size += val.size
-            for p_ind in range(len(semantic_network.train_params)):
-                assert semantic_network.train_params[p_ind].shape == semantic_network.curr_mask[p_ind].shape
-                payload += semantic_network.train_params[p_ind][semantic_network.curr_mask[p_ind]].astype(np.float16).tobytes()
+            payload = semantic_network.delta_payload()          # value part gathered + cast to fp16 on the device
+            full_size = sum(val.size for val in semantic_network.curr_mask)
             with open(save_dir + '_mask.dat', 'wb') as f:
                 f.write(payload)
             with gzip.open(save_dir + '_mask.dat.gz', 'wb', compresslevel=9) as f:
@@ -300,10 +314,9 @@ def infer_output(ctx: Context, inf_start, inf_end, gpu_id, run_label, gt_path, e
                 semantic_network.close_model()
             semantic_network = SemanticNetwork(meta_dir=save_dir + "_final", class_weights_exp=class_weights(exp_num),
                                                height=FLAGS.height, gpu_id=gpu_id, mem_frac=1, frozen=True)
-        frame, gt_frame = _to_size(*ctx.source.read(i), ctx.size)
+        frame, gt_frame = _to_size(*ctx.source.read(i), ctx.size, ctx.ingest)
         t0 = time.time()
-        labels_, conf_mat_, _, miou_, loss_ = semantic_network.predict_with_metric(np.expand_dims(frame, axis=0),
-                                                                                   np.expand_dims(gt_frame, axis=0))
+        labels_, conf_mat_, _, miou_, loss_ = semantic_network.predict_with_metric(_batch1(frame), _batch1(gt_frame))
         t_infer += time.time() - t0
         loss_s.append(loss_)
         miou_cats.append(np.array(conf_mat_))

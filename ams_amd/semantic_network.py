@@ -182,7 +182,7 @@ class SemanticNetwork(object):
         self.process_lock.acquire()
         try:
             labels_ = self.engine.predict(frames, self._mode()).cpu().numpy()
-            assert labels_.shape == tuple(np.shape(frames)[:-1])
+            assert labels_.shape == tuple(frames.shape[:-1] if hasattr(frames, 'shape') else np.shape(frames)[:-1])
         finally:
             self.process_lock.release()
         return labels_
@@ -209,7 +209,7 @@ class SemanticNetwork(object):
             conf_mat_ = conf_dev.cpu().numpy().astype(np.float64)
             ls = loss_dev.cpu().numpy()
             loss_ = np.float32(ls[0] / ls[1]) if ls[1] > 0 else np.float32(np.nan)
-            assert labels_student.shape == tuple(np.shape(frames)[:-1])
+            assert labels_student.shape == tuple(frames.shape[:-1] if hasattr(frames, 'shape') else np.shape(frames)[:-1])
             iou_ = calculate_miou(conf_mat_, nan=True)
             miou_ = np.nanmean(iou_)
         finally:
@@ -307,6 +307,31 @@ class SemanticNetwork(object):
         else:
             self.train_params = [_after_train[k] for k in _after_train.keys()]
             self.curr_mask = [np.ones_like(_after_train[k], dtype=bool) for k in _after_train.keys()]
+
+    def delta_payload(self) -> bytes:
+        """The downlink model delta of reference run.py:316-336 as bytes: per variable ``np.packbits(mask.flatten())``, then
+        per variable the masked parameters as fp16.  Under the coordinate-descent strategies (``train_params`` = the
+        trainable variables, in arena order) the value part is gathered and cast on the device by ``ams_pack_masked_fp16``;
+        otherwise (``full_model``: every model variable incl. BN statistics) it is the reference's host loop."""
+        assert self.curr_mask is not None and self.train_params is not None, "no training phase has run yet"
+        payload = bytearray()
+        for val in self.curr_mask:
+            payload += np.packbits(val.flatten()).tobytes()
+        trainable = self.engine.spec.trainable
+        on_device = len(self.curr_mask) == len(trainable) and all(m.size == v.size for m, v in zip(self.curr_mask, trainable))
+        if on_device:
+            flat = np.concatenate([m.reshape(-1) for m in self.curr_mask]).astype(np.uint8)
+            self.process_lock.acquire()
+            try:
+                halves = self.engine.pack_masked_fp16(torch.from_numpy(flat).to(self.engine.device))
+                payload += halves.cpu().numpy().tobytes()
+            finally:
+                self.process_lock.release()
+        else:
+            for p_, m_ in zip(self.train_params, self.curr_mask):
+                assert p_.shape == m_.shape
+                payload += p_[m_].astype(np.float16).tobytes()
+        return bytes(payload)
 
     def get_train_mask(self, train_strategy):
         """Coordinate-descent masks (SemanticNetwork.py:302-669): dict variable name -> bool array, or None."""

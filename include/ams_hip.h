@@ -234,6 +234,13 @@ int ams_k_dw_project(const float* e, int32_t B, int32_t H, int32_t W, int32_t C,
                      const float* scale_d, const float* shift_d, const float* w_proj, int32_t N, const float* scale_p,
                      const float* shift_p, const float* res, float* y, uint16_t* panels, size_t panel_elems, void* stream);
 
+/* Frame ingest (reference run.py:179-183, :415-421: cv2.resize of the decoded frame to [H, 2H] + BGR->RGB; INTER_NEAREST for
+ * the teacher label map).  src [Hs,Ws,C] uint8 -> dst [H,W,C] uint8, both device memory.  mode AMS_RESIZE_NEAREST |
+ * AMS_RESIZE_LINEAR (half-pixel centres, edge clamp, round half to even); swap_rb != 0 reverses the 3 channels. */
+enum { AMS_RESIZE_NEAREST = 0, AMS_RESIZE_LINEAR = 1 };
+int ams_ingest_resize_u8(const uint8_t* src, int32_t Hs, int32_t Ws, int32_t C, int32_t mode, int32_t swap_rb, uint8_t* dst,
+                         int32_t H, int32_t W, void* stream);
+
 /* K7: global average pool [B,HW,C] -> [B,C] (two-stage, deterministic); scratch >= ams_k_global_mean_scratch floats. */
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,
                       void* stream);

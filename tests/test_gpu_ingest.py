@@ -1,0 +1,49 @@
+"""Frame ingest on the device against the host restatement of cv2.resize (ams_amd/utils.py): bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from ams_amd import utils as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ing():
+    from ams_amd.ingest import FrameIngest
+    return FrameIngest("cuda:0")
+
+
+@pytest.mark.parametrize("src,dst", [((1208, 1920), (512, 1024)), ((1080, 1920), (256, 512)), ((100, 200), (256, 512)),
+                                     ((513, 1025), (512, 1024)), ((37, 53), (37, 53)), ((7, 5), (64, 128))])
+def test_frame_resize_matches_host_restatement(ing, src, dst):
+    rng = np.random.default_rng(src[0] + dst[1])
+    img = rng.integers(0, 256, (src[0], src[1], 3), dtype=np.uint8)
+    want = U.resize_linear(img, dst[1], dst[0])
+    got = ing.frame(img, dst[0], dst[1]).cpu().numpy()
+    assert got.dtype == np.uint8 and got.shape == want.shape
+    assert np.array_equal(got, want)
+    # BGR -> RGB on the way (cv2.cvtColor(..., COLOR_BGR2RGB) after the resize commutes with it)
+    got_swapped = ing.frame(img, dst[0], dst[1], bgr=True).cpu().numpy()
+    assert np.array_equal(got_swapped, want[..., ::-1])
+
+
+@pytest.mark.parametrize("src,dst", [((1208, 1920), (512, 1024)), ((1024, 2048), (512, 1024)), ((33, 65), (512, 1024)), ((50, 90), (50, 90))])
+def test_label_resize_is_nearest(ing, src, dst):
+    rng = np.random.default_rng(src[0])
+    lab = rng.integers(0, 20, src, dtype=np.uint8)
+    lab[rng.random(src) < 0.05] = 255
+    want = U.resize_nearest(lab, dst[1], dst[0])
+    got = ing.label(lab, dst[0], dst[1]).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_device_tensor_input_and_extremes(ing):
+    img = torch.zeros((64, 64, 3), dtype=torch.uint8, device="cuda:0")
+    img[::2] = 255
+    out = ing.frame(img, 32, 32)
+    assert out.is_cuda and out.shape == (32, 32, 3)
+    want = U.resize_linear(img.cpu().numpy(), 32, 32)
+    assert np.array_equal(out.cpu().numpy(), want)
+    with pytest.raises(AssertionError):
+        ing.frame(np.zeros((4, 4, 3), np.float32), 8, 8)

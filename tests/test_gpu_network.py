@@ -306,3 +306,24 @@ def test_data_parallel_step_equals_single_process(W0, tmp_path):
     assert calls == 54 * 2 + 2                     # BN fwd + BN bwd per layer, loss, gradients
     assert nbytes > 4 * eng.spec.n_trainable
     eng.close()
+
+
+def test_delta_payload_matches_reference_host_loop(W0):
+    """Downlink delta (run.py:316-336): mask bits + masked parameters as fp16.  The device gather/cast must produce the
+    bytes of the reference's per-variable host loop, for a coordinate-descent mask and for the full model."""
+    H = 64
+    frames, labels = synth.SyntheticVideo(H, 4, CI, seed=2).clip()
+    for strategy in ("coord_desc_rand", "full_model"):
+        net = SemanticNetwork("unused", class_weights_exp=exp_configs.class_weights(25), height=H, scale=[1], mini_batch_size=2, lr=1e-3,
+                              coord_frac=0.1, masked_gradients=strategy != "full_model", initial_variables=W0)
+        np.random.seed(3)
+        random.seed(3)
+        net.train_with_deque(deque(frames), deque(labels), 2, strategy)
+        want = bytearray()
+        for val in net.curr_mask:
+            want += np.packbits(val.flatten()).tobytes()
+        for p_, m_ in zip(net.train_params, net.curr_mask):
+            want += p_[m_].astype(np.float16).tobytes()
+        got = net.delta_payload()
+        assert got == bytes(want), strategy
+        net.close_model()

@@ -1,5 +1,7 @@
 """BASELINE.json configs[0] as plumbing: 64 synthetic 256x512 frames through the run.py-style scheduler (server
 fine-tune phases + edge inference with metric), on the HIP path."""
+import random
+
 import numpy as np
 import pytest
 
@@ -43,3 +45,32 @@ def test_event_times_follow_reference_formula():
     flags.initial_fill = True
     flags.memory_len = 160
     assert R.event_times(flags, 200) == [0, 180]
+
+
+def test_directory_source_with_gpu_ingest_equals_host_resize(tmp_path):
+    """Frames stored at another resolution (as decoded video would be): --gpu_ingest resizes frames (bilinear) and labels
+    (nearest) on the device and hands device tensors to SemanticNetwork; the per-frame results equal the host-resize run."""
+    import glob
+    from ams_amd import synth
+    H, fps, seconds = 64, 30, 3
+    frames, labels = synth.SyntheticVideo(96, fps * seconds, [0, 1, 2, 10, 11, 13], seed=5).clip()      # 96x192 source
+    src = tmp_path / "25-clip"
+    src.mkdir()
+    for i in range(len(frames)):
+        np.save(src / ("frame_%06d.npy" % i), frames[i])
+        np.save(src / ("gt_%06d.npy" % i), labels[i])
+    outs = {}
+    for tag, extra in (("host", []), ("dev", ["--gpu_ingest"])):
+        out = str(tmp_path / ("out_" + tag)) + "/"
+        np.random.seed(11)        # mini_batch draws from the global generators, as the reference's does
+        random.seed(11)
+        R.main(["--input_video", str(src), "--gt_video", str(src), "--student_checkpoint", "synthetic:0", "--output_dir", out,
+                "--gpu", "0", "--mode", "simple", "--height", str(H), "--batch_size", "2", "--iter", "2", "--send_period", "1",
+                "--train_period", "1", "--first_train_time", "1", "--memory_len", "2", "--length", str(seconds)] + extra)
+        outs[tag] = out
+    a = np.load(glob.glob(outs["host"] + "*_mioucats.npy")[0])
+    b = np.load(glob.glob(outs["dev"] + "*_mioucats.npy")[0])
+    assert a.shape == (fps * seconds, 6, 6) and np.array_equal(a, b)
+    la = np.load(glob.glob(outs["host"] + "*_loss.npy")[0])
+    lb = np.load(glob.glob(outs["dev"] + "*_loss.npy")[0])
+    np.testing.assert_allclose(la, lb, rtol=1e-5)

@@ -111,6 +111,7 @@ struct ams_student {
     int fuse_dw_project = 0;                   // frozen inference: depthwise + project in one kernel on the stride-16 blocks.
                                                // Off by default: measured equal to the two kernels at B = 8 (LDS-read bound:
                                                // 60 b128 reads per wave and 32 channels) and slower at B = 1 (45 blocks)
+    int fuse_first_block = 1;                  // frozen inference: stem + depthwise + project of the first block in one kernel
     int fuse_expand_dw = 1;                    // frozen inference, expand + depthwise in one kernel: 0 never, 1 where it
                                                // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
@@ -377,14 +378,28 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
     const float* P = s->fparams;
     float* cur = s->act[0];
     int cur_i = 0;
+    int i = 2;
     {
         LayerRt& l = s->L[1];
-        const double bytes = (double)B * c.height * c.width * 3 * (dtype == AMS_DT_U8 ? 1 : 4) + 4.0 * B * l.px_out * l.d.cout;
-        RUNK(1, bytes, launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, l.fscale, l.fshift, l.d.act,
-                                   c.pixel_scale, cur, st));
+        LayerRt& ld = s->L[2];
+        LayerRt& lj = s->L[3];
+        const double in_bytes = (double)B * c.height * c.width * 3 * (dtype == AMS_DT_U8 ? 1 : 4);
+        if (s->fuse_first_block && s->n_backbone >= 3 && l.d.cout == 32 && ld.d.role == AMS_ROLE_DEPTHWISE && ld.d.cin == 32 &&
+            ld.d.stride == 1 && ld.d.rate == 1 && lj.d.role == AMS_ROLE_PROJECT && lj.d.cin == 32 && lj.d.cout == 16 &&
+            !lj.d.residual_from) {
+            // stem + depthwise + project of the first block in one kernel: the 32-channel half-resolution tensor stays in LDS
+            const double bytes = in_bytes + 4.0 * B * lj.px_out * lj.d.cout + 4.0 * (27 * 32 + 9 * 32 + 32 * 16);
+            RUNK(3, bytes, launch_first_block(frames, dtype, B, c.height, c.width, c.pixel_scale, P + l.d.w_off, l.fscale, l.fshift,
+                                              l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
+                                              lj.fshift, lj.d.act, cur, st));
+            i = 4;
+        } else {
+            const double bytes = in_bytes + 4.0 * B * l.px_out * l.d.cout;
+            RUNK(1, bytes, launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, l.fscale, l.fshift, l.d.act,
+                                       c.pixel_scale, cur, st));
+        }
     }
     auto other = [&](int avoid0, int avoid1) { for (int k = 0; k < 4; ++k) if (k != avoid0 && k != avoid1) return k; return -1; };
-    int i = 2;
     while (i <= s->n_backbone) {
         // one inverted-residual block: [expand] -> depthwise -> project (+ block input)
         const float* block_in = cur;
@@ -868,6 +883,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     if (option == AMS_OPT_MATMUL) {
         AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16, "set_option: unknown matmul mode %d", value);
         s->matmul_mode = value;
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_FUSE_FIRST_BLOCK) {
+        s->fuse_first_block = value != 0;
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_DW_PROJECT) {

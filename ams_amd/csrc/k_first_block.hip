@@ -1,0 +1,229 @@
+// First block of the backbone in one kernel (frozen inference): frame -> pad 127.5 -> x/127.5-1 -> stem 3x3 s2 (3->32) + BN
+// + ReLU6 -> depthwise 3x3 (32) + BN + ReLU6 -> project 1x1 (32->16) + BN  (layers 1-3, MobilenetV2/Conv and
+// MobilenetV2/expanded_conv).
+//
+// Layer by layer this is the largest traffic item of the network: the 32-channel half-resolution tensor (16.9 MB per
+// 512x1024 frame) is written by the stem, read and written by the depthwise conv and read by the project GEMM — 67 MB per
+// frame against 1.6 MB in and 8.4 MB out.  Here a block owns an 8 x 16 tile of output pixels:
+//   phase 1  stem on the tile + 1-pixel halo (10 x 18 positions; zeros outside the feature map = the depthwise conv's
+//            SAME padding): the 27-tap receptive field gathered from the uint8 frame as the MFMA operand (exact f32,
+//            K = 27 -> 32), BN + ReLU6, result in LDS;
+//   phase 2  depthwise 3x3 from LDS, 4 output rows per work unit through a sliding register window, tap weights in
+//            registers, BN + ReLU6, result in LDS;
+//   phase 3  project 32 -> 16 as 8 MFMAs per 16 pixels from LDS, BN, float4 stores (16 channels = 64 B per pixel, 16
+//            consecutive pixels per lane group: full lines without a transpose).
+// Arithmetic per element is the same as in the three separate kernels (same tap order, same MFMA chunking).
+#include "pw_common.hpp"
+
+namespace ams {
+
+struct FirstBlockArgs {
+    const void* frames; int B, H, W;        // [B,H,W,3] uint8 or float
+    float ps;                               // pixel scale 1/127.5
+    const float* w_stem;                    // [27][32]
+    const float* sc_s; const float* sh_s;   // folded BN of the stem
+    const float* w_dw;                      // [9][32]
+    const float* sc_d; const float* sh_d;
+    const float* w_pj;                      // [32][16]
+    const float* sc_p; const float* sh_p;
+    int act_s, act_d, act_p;
+    float* y;                               // [B,Ho,Wo,16]
+    int Ho, Wo, pt, pl;                     // stem output size and its SAME padding on the 127.5-padded frame
+    int tiles_x, tiles_y;
+};
+
+template <typename TIn>
+__device__ __forceinline__ float fb_frame_value(const TIn* img, int H, int W, int iy, int ix, int ch, float ps) {
+    // coordinates in the 127.5-padded (H+1) x (W+1) image; outside of it the stem's SAME zero padding (see k_conv.hip)
+    const bool inside = iy >= 0 && ix >= 0 && iy <= H && ix <= W;
+    const bool pad = iy >= H || ix >= W;
+    const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    const int ixc = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+    float raw = (float)img[((int64_t)iyc * W + ixc) * 3 + ch];
+    raw = pad ? 127.5f : raw;
+    const float v = __fsub_rn(__fmul_rn(raw, ps), 1.0f);
+    return inside ? v : 0.f;
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsigned nblocks) {
+    constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
+    constexpr int NRG = (NPIX + 15) / 16;             // 12 row groups of stem positions
+    constexpr int P = 36;                             // pitch of the 32-channel rows (stride 144 B: conflict-free b128 passes)
+    constexpr int PW = 20;                            // pitch of the project weight rows
+    __shared__ __attribute__((aligned(16))) float sW[28 * P];          // stem weights [k][n]; row 27 = zeros for the padding taps
+    __shared__ __attribute__((aligned(16))) float sS[NPIX * P];        // stem output tile (three blocks per CU: 52.7 KB)
+    __shared__ __attribute__((aligned(16))) float sD[TH * TW * P];     // depthwise output tile
+    __shared__ __attribute__((aligned(16))) float sDw[9 * 32];
+    __shared__ __attribute__((aligned(16))) float sWp[32 * PW];
+    __shared__ __attribute__((aligned(16))) float sAff[32 * 4 + 16 * 2];      // sc_s, sh_s, sc_d, sh_d, sc_p, sh_p
+
+    const unsigned lb = xcd_remap(blockIdx.x, nblocks);
+    const int tx = lb % a.tiles_x;
+    unsigned t1 = lb / a.tiles_x;
+    const int ty = t1 % a.tiles_y;
+    const int b = t1 / a.tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    for (int e = tid; e < 28 * 32; e += 256) {
+        const int kk = e >> 5, nn = e & 31;
+        sW[kk * P + nn] = kk < 27 ? a.w_stem[kk * 32 + nn] : 0.f;
+    }
+    for (int e = tid; e < 9 * 32; e += 256) sDw[e] = a.w_dw[e];
+    for (int e = tid; e < 32 * 16; e += 256) sWp[(e >> 4) * PW + (e & 15)] = a.w_pj[e];
+    if (tid < 32) {
+        sAff[tid] = a.sc_s[tid]; sAff[32 + tid] = a.sh_s[tid]; sAff[64 + tid] = a.sc_d[tid]; sAff[96 + tid] = a.sh_d[tid];
+    } else if (tid < 48) {
+        sAff[128 + tid - 32] = a.sc_p[tid - 32]; sAff[144 + tid - 32] = a.sh_p[tid - 32];
+    }
+
+    // ---- phase 1: stem over the halo tile.  This lane's 8 taps: k = 16c + 4q + j -> (dy, dx, channel); k >= 27 padding
+    int tdy[8], tdx[8], tch[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = 16 * (u >> 2) + 4 * q + (u & 3);
+        const int tap = k / 3;
+        tch[u] = k < 27 ? k - tap * 3 : -1;
+        tdy[u] = tap / 3;
+        tdx[u] = tap - tdy[u] * 3;
+    }
+    const TIn* img = reinterpret_cast<const TIn*>(a.frames) + (int64_t)b * a.H * a.W * 3;
+    constexpr int MRG = (NRG + 3) / 4;
+    float v[MRG][8];
+    bool live[MRG];
+#pragma unroll
+    for (int i = 0; i < MRG; ++i) {
+        int rg = wave + 4 * i;
+        if (rg > NRG - 1) rg = NRG - 1;
+        const int m = rg * 16 + l15;
+        const int ty_i = m / IW, tx_i = m - ty_i * IW;
+        const int sy = oy0 - 1 + ty_i, sx = ox0 - 1 + tx_i;              // position in the stem's output map
+        live[i] = m < NPIX && sy >= 0 && sy < a.Ho && sx >= 0 && sx < a.Wo;
+        const int iy0 = sy * 2 - a.pt, ix0 = sx * 2 - a.pl;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = fb_frame_value(img, a.H, a.W, iy0 + tdy[u], ix0 + tdx[u], tch[u] < 0 ? 0 : tch[u], a.ps);
+            v[i][u] = tch[u] >= 0 ? t : 0.f;
+        }
+    }
+    __syncthreads();                                                      // weights and coefficients are staged
+#pragma unroll
+    for (int i = 0; i < MRG; ++i) {
+        const int rg = wave + 4 * i;
+        if (rg < NRG) {                                                   // wave-uniform
+            f32x4 acc[2];
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = 16 * (u >> 2) + 4 * q + (u & 3);
+                const float* sB = sW + (k < 27 ? k : 27) * P + l15;
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[0], v[i][u], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[16], v[i][u], acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int n4 = 16 * t + 4 * q;
+                const float4 sc = ld4(sAff + n4), sh = ld4(sAff + 32 + n4);
+                float4 o;
+                o.x = live[i] ? apply_act(acc[t][0] * sc.x + sh.x, a.act_s) : 0.f;
+                o.y = live[i] ? apply_act(acc[t][1] * sc.y + sh.y, a.act_s) : 0.f;
+                o.z = live[i] ? apply_act(acc[t][2] * sc.z + sh.z, a.act_s) : 0.f;
+                o.w = live[i] ? apply_act(acc[t][3] * sc.w + sh.w, a.act_s) : 0.f;
+                if (rg * 16 + l15 < NPIX) st4(sS + (rg * 16 + l15) * P + n4, o);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: depthwise 3x3 from LDS.  Unit = (4 channels, column, group of 4 rows): 256 units, one per thread
+    {
+        constexpr int RG = 4, WIN = RG + 2;
+        const int cg = tid & 7, lx = (tid >> 3) & 15, g = tid >> 7;
+        const int c4 = cg * 4;
+        float4 w[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] = ld4(sDw + k * 32 + c4);
+        const float4 sc = ld4(sAff + 64 + c4), sh = ld4(sAff + 96 + c4);
+        const float* col = sS + ((g * RG) * IW + lx) * P + c4;
+        float4 acc[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < WIN; ++u) {
+            float4 x3[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) x3[j] = ld4(col + (u * IW + j) * P);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (u - i >= 0 && u - i < RG) {                           // input row u is tap row i of output row u - i
+                    float4& o = acc[u - i];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float4 ww = w[i * 3 + j];
+                        o.x = fmaf(x3[j].x, ww.x, o.x); o.y = fmaf(x3[j].y, ww.y, o.y);
+                        o.z = fmaf(x3[j].z, ww.z, o.z); o.w = fmaf(x3[j].w, ww.w, o.w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            float4 o;
+            o.x = apply_act(acc[r].x * sc.x + sh.x, a.act_d); o.y = apply_act(acc[r].y * sc.y + sh.y, a.act_d);
+            o.z = apply_act(acc[r].z * sc.z + sh.z, a.act_d); o.w = apply_act(acc[r].w * sc.w + sh.w, a.act_d);
+            st4(sD + ((g * RG + r) * TW + lx) * P + c4, o);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: project 32 -> 16.  Pixel group = one tile row (16 pixels); wave w takes rows 2w, 2w + 1
+    float* yb = a.y + (int64_t)b * a.Ho * a.Wo * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 2 * wave + i;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 x4 = ld4(sD + (row * TW + l15) * P + 16 * c + 4 * q);
+            const float* sB = sWp + (16 * c + 4 * q) * PW + l15;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[0], x4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[PW], x4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[2 * PW], x4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[3 * PW], x4.w, acc, 0, 0, 0);
+        }
+        const float4 sc = ld4(sAff + 128 + 4 * q), sh = ld4(sAff + 144 + 4 * q);
+        float4 o;
+        o.x = apply_act(acc[0] * sc.x + sh.x, a.act_p); o.y = apply_act(acc[1] * sc.y + sh.y, a.act_p);
+        o.z = apply_act(acc[2] * sc.z + sh.z, a.act_p); o.w = apply_act(acc[3] * sc.w + sh.w, a.act_p);
+        const int oy = oy0 + row, ox = ox0 + l15;
+        if (oy < a.Ho && ox < a.Wo) st4(yb + ((int64_t)oy * a.Wo + ox) * 16 + 4 * q, o);
+    }
+}
+
+int launch_first_block(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem,
+                       const float* sc_s, const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d,
+                       int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st) {
+    AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "first_block: frames must be uint8 or float32");
+    FirstBlockArgs a;
+    memset(&a, 0, sizeof(a));
+    a.frames = frames; a.B = B; a.H = H; a.W = W; a.ps = pixel_scale;
+    a.w_stem = w_stem; a.sc_s = sc_s; a.sh_s = sh_s; a.act_s = act_s;
+    a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d;
+    a.w_pj = w_pj; a.sc_p = sc_p; a.sh_p = sh_p; a.act_p = act_p; a.y = y;
+    same_pad(H + 1, 3, 2, 1, &a.Ho, &a.pt);
+    same_pad(W + 1, 3, 2, 1, &a.Wo, &a.pl);
+    a.tiles_x = cdiv(a.Wo, 16);
+    a.tiles_y = cdiv(a.Ho, 8);
+    const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * B;
+    AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "first_block: bad grid");
+    note_kernel(dtype == AMS_DT_U8 ? "first_block_kernel<unsigned char>" : "first_block_kernel<float>");
+    if (dtype == AMS_DT_U8) hipLaunchKernelGGL(first_block_kernel<uint8_t>, dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
+    else hipLaunchKernelGGL(first_block_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+}  // namespace ams

@@ -53,6 +53,11 @@ int launch_pointwise_wgrad_x6(const WgArgs& a, int splits, hipStream_t st);
 size_t pointwise_wgrad_scratch(int64_t M, int K, int N);
 int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st);
 
+// ---- k_first_block.hip : stem + depthwise + project of the first block in one kernel (frozen inference; 3 -> 32 -> 32 -> 16)
+int launch_first_block(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem,
+                       const float* sc_s, const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d,
+                       int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st);
+
 // ---- k_ingest.hip : frame / label resize on the device (run.py:179-183)
 int launch_resize_u8(const uint8_t* src, int Hs, int Ws, int C, int mode, int swap_rb, uint8_t* dst, int H, int W, hipStream_t st);
 

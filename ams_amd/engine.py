@@ -198,6 +198,10 @@ class StudentEngine:
                   "ams_pack_masked_fp16")
         return out[:int(cnt.item())]
 
+    def set_fuse_first_block(self, on: bool) -> None:
+        """Frozen inference: stem + depthwise + project of the first block as one kernel (default on)."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_FIRST_BLOCK, int(bool(on))), "ams_student_set_option")
+
     def set_fuse_dw_project(self, on: bool) -> None:
         """Frozen inference: depthwise + project of the stride-16 blocks as one kernel (default off: measured no faster than
         the two kernels; split-bf16 mode only)."""

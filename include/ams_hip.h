@@ -168,7 +168,9 @@ int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t fr
  *   AMS_MATMUL_SPLIT_BF16 (default) f32 data split into bf16 hi+lo, 3 bf16 MFMAs per product group, f32 accumulate:
  *                         <= 2^-16 relative per product (~1e-5 on a layer output), 5x the matrix throughput.
  * Training and the live graph always use exact f32. */
-enum { AMS_OPT_FUSE_DW_PROJECT = 3 /* frozen inference: 1 = depthwise + project of the stride-16 blocks in one kernel (needs
+enum { AMS_OPT_FUSE_FIRST_BLOCK = 4 /* frozen inference: 1 (default) stem + depthwise + project of the first block in one
+                                       kernel, 0 three kernels */,
+       AMS_OPT_FUSE_DW_PROJECT = 3 /* frozen inference: 1 = depthwise + project of the stride-16 blocks in one kernel (needs
                                       AMS_MATMUL_SPLIT_BF16), 0 (default) separate kernels: measured no faster */,
        AMS_OPT_MATMUL = 1, AMS_OPT_FUSE_EXPAND_DW = 2 /* 0 never, 1 (default) blocks where the fused kernel is faster, 2 every supported block */ };
 enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1 };

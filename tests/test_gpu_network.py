@@ -60,6 +60,7 @@ def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     eng.set_matmul_mode(matmul)
     eng.set_fuse_expand_dw(2 if matmul == hip.MATMUL_SPLIT_BF16 else 0)   # 2: every supported block fused; 0: layer-by-layer plan
     eng.set_fuse_dw_project(matmul == hip.MATMUL_SPLIT_BF16)              # the optional depthwise+project kernel too
+    eng.set_fuse_first_block(matmul == hip.MATMUL_SPLIT_BF16)             # first block: one kernel vs three
     eng.freeze()
     o = _oracle(W0)
     with torch.no_grad():

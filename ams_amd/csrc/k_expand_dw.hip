@@ -25,6 +25,7 @@ struct XdwArgs {
     float* y;                // [B, Ho, Wo, Cexp]
     int Ho, Wo, pt, pl;
     int tiles_x, tiles_y, chunks;
+    int chunk_splits;        // blocks per tile: each walks chunks / chunk_splits channel chunks
 };
 
 template <int S, int R, int NT, int TH, int TW, int KC>
@@ -44,12 +45,11 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(XdwArgs a, unsigned nblo
     float* sAct = sDw + 9 * CC;                       // [NRG*16][AP]
 
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
-    const int chunk = lb % a.chunks;
-    unsigned t1 = lb / a.chunks;
+    const int cs = lb % a.chunk_splits;                // this block's share of the channel chunks
+    unsigned t1 = lb / a.chunk_splits;
     const int tx = t1 % a.tiles_x; t1 /= a.tiles_x;
     const int ty = t1 % a.tiles_y;
     const int b = t1 / a.tiles_y;
-    const int n0 = chunk * CC;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - a.pt, ix0 = ox0 * S - a.pl;
@@ -75,7 +75,13 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(XdwArgs a, unsigned nblo
         }
     }
 
-    // ---- stage the weight panel, BN vectors and depthwise taps of this channel chunk
+    // ---- the block walks its share of the channel chunks of the tile (all of them when the launch has enough tiles to fill
+    // the chip): the input fragments above are gathered once — they do not depend on the chunk, only the weights change —
+    // instead of once per (tile, chunk) block.
+    const int chunks_per_block = a.chunks / a.chunk_splits;
+    for (int ci = 0; ci < chunks_per_block; ++ci) {
+    const int n0 = (cs * chunks_per_block + ci) * CC;
+    if (ci > 0) __syncthreads();                       // phase 2 of the previous chunk still reads sDw / sAff / sAct
     for (int e = tid; e < Kpad * (CC / 4); e += 256) {
         const int kk = e / (CC / 4), c4 = (e - kk * (CC / 4)) * 4;
         const int kc = kk < a.Cin ? kk : a.Cin - 1;
@@ -155,6 +161,7 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(XdwArgs a, unsigned nblo
         o.z = apply_act(acc.z * sc.z + sh.z, a.act_d); o.w = apply_act(acc.w * sc.w + sh.w, a.act_d);
         st4(yb + ((int64_t)oy * a.Wo + ox) * a.Cexp + c4, o);
     }
+    }   // chunk
 }
 
 template <int S, int R, int NT, int TH, int TW, int KC>
@@ -174,7 +181,11 @@ static int launch_xdw_k(XdwArgs a, hipStream_t st) {
                                           150 * 1024));
         attr_set = true;
     }
-    const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * a.B * a.chunks;
+    // all chunks in one block when there are enough tiles to fill the chip (measured: from ~2000 tiles on, ~1000 with 4+ chunks), else one block
+    // per (tile, chunk) for parallelism
+    const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.B;
+    a.chunk_splits = (tiles >= 2048 || (tiles >= 1024 && a.chunks >= 4)) ? 1 : a.chunks;
+    const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * a.B * a.chunk_splits;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw: bad grid");
     static const std::string nm = "expand_dw_kernel<" + std::to_string(S) + ", " + std::to_string(R) + ", " + std::to_string(NT) + ", " +
                                   std::to_string(TH) + ", " + std::to_string(TW) + ", " + std::to_string(KC) + ">";

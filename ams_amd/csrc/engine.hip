@@ -59,7 +59,7 @@ struct LayerRt {
     // training activations (max_batch images each)
     float *z = nullptr, *a = nullptr, *da = nullptr;
     // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
-    uint16_t *whi = nullptr, *wlo = nullptr;
+    uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
 };
 
@@ -107,7 +107,7 @@ struct ams_student {
     int64_t* conf_buf = nullptr;
     int64_t adam_t = 0;
     bool frozen_ready = false;
-    int matmul_mode = AMS_MATMUL_SPLIT_BF16;   // frozen inference, late layers
+    int matmul_mode = AMS_MATMUL_SPLIT_BF16_X6;   // late layers: three-part bf16 split (f32-level products) in inference and training
     int fuse_dw_project = 0;                   // frozen inference: depthwise + project in one kernel on the stride-16 blocks.
                                                // Off by default: measured equal to the two kernels at B = 8 (LDS-read bound:
                                                // 60 b128 reads per wave and 32 channels) and slower at B = 1 (45 blocks)
@@ -163,8 +163,12 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
         l.split_k0 = 0;
         if (role == AMS_ROLE_CONCAT_PROJ) { l.split_k0 = s->L[s->iPool].d.cout; K = l.d.cin - l.split_k0; }
         l.Kp = (K + 31) / 32 * 32;
-        l.whi = cv.take<uint16_t>((size_t)l.d.cout * l.Kp);
-        l.wlo = cv.take<uint16_t>((size_t)l.d.cout * l.Kp);
+        {
+            const size_t plane = (size_t)l.d.cout * l.Kp;
+            l.whi = cv.take<uint16_t>(3 * plane);          // one allocation: the planes must be equally spaced
+            l.wlo = l.whi ? l.whi + plane : nullptr;
+            l.wlo3 = l.whi ? l.whi + 2 * plane : nullptr;
+        }
     }
     // BN sync region: loss (2 doubles) then per layer fwd sums [2][C], bwd sums [2][C]
     s->bn_sync_doubles = 2 + 4 * sum_c;
@@ -348,7 +352,7 @@ static bool split_pays(const PwArgs& a) {
 // live (training) 1x1 layer or its input gradient: same split-bf16 rule as the frozen path, the weights are split right
 // before the launch because they change every step (one small kernel; the panels live in one shared scratch buffer)
 static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
-    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && s->panel_scratch && split_pays(a) && a.Kw == a.K && a.ldx % 4 == 0;
+    const bool split = s->matmul_mode != AMS_MATMUL_F32 && s->panel_scratch && split_pays(a) && a.Kw == a.K && a.ldx % 4 == 0;
     if (!split) return launch_pointwise(a, st);
     // three-part split (6 MFMAs, f32-level products): gradients amplify product error ~1e5 x on this graph, the two-part
     // split of the frozen path would put the step outside the f32 error class
@@ -364,8 +368,9 @@ static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
 // frozen 1x1 layer: late layers (few rows, wide K/N: matrix-pipe bound) go through the split-bf16 kernel
 static int frozen_pointwise(ams_student* s, int layer, const PwArgs& a, hipStream_t st) {
     const LayerRt& l = s->L[layer];
-    const bool split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && l.whi && split_pays(a);
-    if (split) RUNK(layer, pw_bytes(a), launch_pointwise_split(a, l.whi, l.wlo, l.Kp, st));
+    const bool split = s->matmul_mode != AMS_MATMUL_F32 && l.whi && split_pays(a);
+    if (split && s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6) RUNK(layer, pw_bytes(a), launch_pointwise_split3(a, l.whi, l.wlo, l.wlo3, l.Kp, st));
+    else if (split) RUNK(layer, pw_bytes(a), launch_pointwise_split(a, l.whi, l.wlo, l.Kp, st));
     else RUNK(layer, pw_bytes(a), launch_pointwise(a, st));
     return AMS_OK;
 }
@@ -430,7 +435,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             LayerRt& l = s->L[i];
             AMS_REQUIRE(l.d.role == AMS_ROLE_DEPTHWISE, "engine: expected depthwise at layer %d", i);
             LayerRt& lpj = s->L[i + 1];
-            if (s->fuse_dw_project && s->matmul_mode == AMS_MATMUL_SPLIT_BF16 && i + 1 <= s->n_backbone &&
+            if (s->fuse_dw_project && s->matmul_mode == AMS_MATMUL_SPLIT_BF16 &&   /* two-part split only */ i + 1 <= s->n_backbone &&
                 lpj.d.role == AMS_ROLE_PROJECT && lpj.whi && (int64_t)B * l.px_out < 32768 && (int64_t)B * l.px_out >= 256 &&
                 lpj.Kp == l.d.cin && dw_project_supported(l.d.cin, lpj.d.cout, l.d.stride, l.d.rate)) {
                 // depthwise + project in one kernel (split-bf16 GEMM that computes its own operand): d never reaches HBM
@@ -595,7 +600,7 @@ static int pw_wgrad(ams_student* s, const float* x, int ldx, int K, const float*
     WgArgs a;
     a.x = x; a.ldx = ldx; a.K = K; a.dy = dy; a.ldy = ldy; a.N = N; a.M = M; a.dw = dw;
     a.scratch = s->scratch; a.scratch_floats = s->scratch_floats;
-    a.allow_split = s->matmul_mode == AMS_MATMUL_SPLIT_BF16;
+    a.allow_split = s->matmul_mode != AMS_MATMUL_F32;
     RUNK(0, 4.0 * ((double)M * (K + N) + (double)K * N), launch_pointwise_wgrad(a, st));
     return AMS_OK;
 }
@@ -791,7 +796,8 @@ int ams_student_freeze(ams_student* s, void* stream) {
         LayerRt& l = s->L[i];
         if (!l.whi) continue;
         const int K = l.d.cin - l.split_k0;
-        RUN(launch_split_weights(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whi, l.wlo, st));
+        RUN(launch_split_weights3(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whi, l.wlo,
+                                  l.wlo3, st));
     }
     s->frozen_ready = true;
     return AMS_OK;
@@ -881,7 +887,8 @@ int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frame
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     AMS_REQUIRE(s, "set_option: null student");
     if (option == AMS_OPT_MATMUL) {
-        AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16, "set_option: unknown matmul mode %d", value);
+        AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16 || value == AMS_MATMUL_SPLIT_BF16_X6,
+                    "set_option: unknown matmul mode %d", value);
         s->matmul_mode = value;
         return AMS_OK;
     }

@@ -244,6 +244,7 @@ static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp,
     pw_pick_tile(a.M, a.N, &rm, &nt);
     if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &rm, &nt);       // tuning knob
 #define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, w, Kp, st);
+    PW_X(4, 4) PW_X(4, 3) PW_X(4, 5)
     PW_X(2, 6) PW_X(2, 5) PW_X(2, 4) PW_X(2, 3) PW_X(2, 2) PW_X(2, 1)
     PW_X(1, 6) PW_X(1, 5) PW_X(1, 4) PW_X(1, 3) PW_X(1, 2) PW_X(1, 1)
 #undef PW_X

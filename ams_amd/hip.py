@@ -25,7 +25,7 @@ RESIZE_NEAREST, RESIZE_LINEAR = 0, 1
 OPT_FUSE_EXPAND_DW = 2
 OPT_FUSE_DW_PROJECT = 3
 OPT_FUSE_FIRST_BLOCK = 4
-MATMUL_F32, MATMUL_SPLIT_BF16 = 0, 1
+MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6 = 0, 1, 2
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)
 

@@ -163,17 +163,20 @@ int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t fr
                               void* stream);
 
 /* ---- options -----------------------------------------------------------------------------------------------
- * AMS_OPT_MATMUL selects how FROZEN inference forms the 1x1-conv products of the late layers (rows < 32768):
- *   AMS_MATMUL_F32        exact f32 MFMA (v_mfma_f32_16x16x4_f32), bit-for-bit an f32 fma chain
- *   AMS_MATMUL_SPLIT_BF16 (default) f32 data split into bf16 hi+lo, 3 bf16 MFMAs per product group, f32 accumulate:
- *                         <= 2^-16 relative per product (~1e-5 on a layer output), 5x the matrix throughput.
- * Training and the live graph always use exact f32. */
+ * AMS_OPT_MATMUL selects how the products of the 1x1-conv layers that would be matrix-pipe bound in exact f32 are formed
+ * (few rows, a large weight panel, or >= 20 FLOP per byte: the output-stride-16 layers and the head):
+ *   AMS_MATMUL_F32           exact f32 MFMA (v_mfma_f32_16x16x4_f32) everywhere
+ *   AMS_MATMUL_SPLIT_BF16_X6 (default) operands split into three bf16 parts (all 24 significand bits), 6 bf16 MFMAs per 32 k,
+ *                            f32 accumulate: products at f32 rounding level; 512x1024 logits 4e-5 from the f64 oracle, the
+ *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
+ *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
+ *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
 enum { AMS_OPT_FUSE_FIRST_BLOCK = 4 /* frozen inference: 1 (default) stem + depthwise + project of the first block in one
                                        kernel, 0 three kernels */,
        AMS_OPT_FUSE_DW_PROJECT = 3 /* frozen inference: 1 = depthwise + project of the stride-16 blocks in one kernel (needs
                                       AMS_MATMUL_SPLIT_BF16), 0 (default) separate kernels: measured no faster */,
        AMS_OPT_MATMUL = 1, AMS_OPT_FUSE_EXPAND_DW = 2 /* 0 never, 1 (default) blocks where the fused kernel is faster, 2 every supported block */ };
-enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1 };
+enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1, AMS_MATMUL_SPLIT_BF16_X6 = 2 };
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value);
 
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------------------------------

@@ -52,15 +52,16 @@ def _check_labels(got, oracle_logits_sel, tol):
 
 
 @pytest.mark.parametrize("H,B,matmul", [(64, 2, hip.MATMUL_F32), (48, 3, hip.MATMUL_F32), (64, 2, hip.MATMUL_SPLIT_BF16),
-                                        (128, 2, hip.MATMUL_SPLIT_BF16)])
+                                        (128, 2, hip.MATMUL_SPLIT_BF16), (64, 2, hip.MATMUL_SPLIT_BF16_X6),
+                                        (128, 3, hip.MATMUL_SPLIT_BF16_X6)])
 def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     frames, labels = synth.SyntheticVideo(H, B, CI, seed=3).clip()
     eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
     eng.load_variables(W0)
     eng.set_matmul_mode(matmul)
-    eng.set_fuse_expand_dw(2 if matmul == hip.MATMUL_SPLIT_BF16 else 0)   # 2: every supported block fused; 0: layer-by-layer plan
+    eng.set_fuse_expand_dw(2 if matmul != hip.MATMUL_F32 else 0)          # 2: every supported block fused; 0: layer-by-layer plan
     eng.set_fuse_dw_project(matmul == hip.MATMUL_SPLIT_BF16)              # the optional depthwise+project kernel too
-    eng.set_fuse_first_block(matmul == hip.MATMUL_SPLIT_BF16)             # first block: one kernel vs three
+    eng.set_fuse_first_block(matmul != hip.MATMUL_F32)                    # first block: one kernel vs three
     eng.freeze()
     o = _oracle(W0)
     with torch.no_grad():

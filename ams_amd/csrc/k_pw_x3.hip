@@ -1,15 +1,20 @@
-// 1x1 convolutions, split-bf16 ("bf16x3") variant for frozen late layers: see k_pointwise.hip for the overview.
+// 1x1 convolutions, split-bf16 variant for the layers where exact f32 would be matrix-pipe bound (the output-stride-16
+// section and the head): see k_pointwise.hip for the overview.
 #include "pw_common.hpp"
 
 namespace ams {
 
 // =========================================================================================================
-// Split-bf16 ("bf16x3") late-layer GEMM.  f32 activations stay f32 in HBM; inside the kernel every operand is split
-// into bf16 hi + bf16 lo (16 significand bits together) and the product is formed as hi*hi + lo*hi + hi*lo on the
-// bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, f32 accumulate): 3 instructions per 32 k instead of 8 f32-MFMA
-// instructions of twice the latency (the f32-input MFMA runs at 1/16 of the bf16 rate on gfx950).  Dropped terms are
-// <= 2^-16 relative per product, i.e. ~1e-5 on a layer output — two orders inside the 1e-3 logit tolerance.  The
-// weights are split once per ams_student_freeze into [N][Kp] hi / lo panels (k contiguous, Kp = K rounded up to 32).
+// Split-bf16 GEMM.  f32 activations stay f32 in HBM; inside the kernel every operand is split into bf16 parts and the
+// products run on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, f32 accumulate) — the f32-input MFMA runs at 1/16 of
+// that rate on gfx950 and needs 8 instructions of twice the latency per 32 k:
+//   NP = 3 (default, "x6"): hi + mid + lo hold all 24 significand bits; hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi,
+//           6 MFMAs; the dropped terms are <= 2^-24 relative, i.e. f32 rounding level (512x1024 logits 4e-5 from the f64
+//           oracle, the same as exact f32).  Inference and fine-tune step.
+//   NP = 2 ("x3", opt-in for frozen inference): hi*hi + lo*hi + hi*lo, 3 MFMAs; operands cut to 16 bits, ~1e-5 per layer,
+//           2e-4..5e-4 on the logits — inside the 1e-3 tolerance, not at f32 level.
+// The weights are split into [N][Kp] panels (k contiguous, Kp = K rounded up to 32; parts equally spaced): once per
+// ams_student_freeze for inference, per launch in the fine-tune step.
 // =========================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // native vector: stays in registers where HIP's uint4 struct may not
@@ -75,14 +80,12 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
     }
 }
 
-// D = stages of the activation operand in flight per lane (registers).  One stage is 32 k = 128 B per row; with a
-// single stage ahead the kernel is HBM-latency-bound (per CU only blocks x RM x 8 KB outstanding: ~2 TB/s by Little's
-// law), so long-K layers run D = 4.  The stage loop is unrolled by D so the ring is statically indexed; the stage count
-// is rounded up to a multiple of D and the surplus stages multiply zeros (all loads are branch-free: clamped address +
-// select, so the compiler never needs vmcnt(0) for a guarded load).
-// NP = 2: products hi*hi + lo*hi + hi*lo (3 MFMAs per 32 k, ~1e-5 relative: frozen inference).
-// NP = 3: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi (6 MFMAs; the dropped terms are <= 2^-24 relative, i.e. f32
-// rounding level: training, where the gradient is ~1e5 x more sensitive to product error than the logits are).
+// D = stages of the operands in flight per lane (registers); the stage loop is unrolled by D so the ring is statically
+// indexed, the stage count is rounded up to a multiple of D and the surplus stages only move data.  All loads are
+// unconditional (clamped addresses): hipcc turns a select around a load back into an exec-masked branch, and a masked load
+// costs a vmcnt(0).  D = 2 is what runs: deeper rings (4; 3 with the next stage's split interleaved into the MFMAs by
+// sched_group_barrier) measured slower — per 32 k the MFMAs, the LDS fragment reads and the split VALU work add up to
+// ~the measured time, and the extra registers cost a resident wave per SIMD.
 template <int RM, int NT, int EPI, int D, int NP>
 __global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
                                                         int Kp, int n_tiles_n, unsigned nblocks) {

@@ -298,9 +298,11 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     const int tx = lb % g.tiles_x;
     const int ty = (lb / g.tiles_x) % g.tiles_y;
     const int b = lb / (g.tiles_x * g.tiles_y);
-    const int cg = threadIdx.x % g.CG, slot = threadIdx.x / g.CG;
-    const int ox = tx * g.slots + slot;
-    if (slot >= g.slots || ox >= g.Wo) return;
+    // flat (column, channel group) index across the row: every wave is full whatever C/4 is (a block of CG x slots threads
+    // left the third wave of the 576-channel layers three quarters empty)
+    const int flat = tx * 256 + threadIdx.x;
+    const int ox = flat / g.CG, cg = flat - ox * g.CG;
+    if (ox >= g.Wo) return;
     const int c0 = cg * 4;
     const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
     float* yb = y + (int64_t)b * g.Ho * g.Wo * g.C + c0;
@@ -365,8 +367,9 @@ int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w,
     AMS_REQUIRE((scale == nullptr) == (shift == nullptr), "depthwise: scale and shift come together");
     constexpr int TH1 = 4, TH2 = 3, THR = 4;
     g.tiles_y = cdiv(g.Ho, stride == 2 ? TH2 : rate == 2 ? THR : TH1);
+    g.tiles_x = cdiv(g.Wo * g.CG, 256);
     const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
-    const int threads = g.CG * g.slots;
+    const int threads = 256;
     note_kernel(stride == 2 ? "dw3x3_fwd_kernel<2, 1, 3>" : rate == 2 ? "dw3x3_fwd_kernel<1, 2, 4>" : "dw3x3_fwd_kernel<1, 1, 4>");
     if (stride == 1 && rate == 1)
         hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 1, TH1>), dim3(nblocks), dim3(threads), 0, st, x, w, scale, shift, act, y, g, nblocks);
@@ -386,9 +389,9 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restric
     const int tx = lb % g.tiles_x;
     const int ty = (lb / g.tiles_x) % g.tiles_y;
     const int b = lb / (g.tiles_x * g.tiles_y);
-    const int cg = threadIdx.x % g.CG, slot = threadIdx.x / g.CG;
-    const int ix = tx * g.slots + slot;
-    if (slot >= g.slots || ix >= g.W) return;
+    const int flat = tx * 256 + threadIdx.x;               // flat (column, channel group) index: full waves for any C/4
+    const int ix = flat / g.CG, cg = flat - ix * g.CG;
+    if (ix >= g.W) return;
     const int c0 = cg * 4;
     float4 wv[9];
 #pragma unroll
@@ -427,8 +430,9 @@ int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const fl
     DwGeom g;
     int rc = dw_geom(B, H, W, C, stride, rate, true, &g);
     if (rc) return rc;
+    g.tiles_x = cdiv(g.W * g.CG, 256);
     const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
-    const int threads = g.CG * g.slots;
+    const int threads = 256;
     note_kernel(stride == 2 ? "dw3x3_dgrad_kernel<2, 1>" : rate == 2 ? "dw3x3_dgrad_kernel<1, 2>" : "dw3x3_dgrad_kernel<1, 1>");
     if (stride == 1 && rate == 1)
         hipLaunchKernelGGL((dw3x3_dgrad_kernel<1, 1>), dim3(nblocks), dim3(threads), 0, st, dy, w, dx, g, nblocks);

@@ -293,7 +293,12 @@ template <int S, int R, int TH>
 __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         int act, float* __restrict__ y, DwGeom g, unsigned nblocks) {
-    constexpr int NR = (TH - 1) * S + 2 * R + 1;           // input rows touched by TH output rows
+    // Rate 2 at stride 1 is two interleaved ordinary convolutions on the even and the odd rows: a thread takes TH output
+    // rows of ONE parity (row step RS = 2), which touch TH + 2 input rows of that parity instead of TH + 4 consecutive rows
+    // (18 loads per 4 outputs instead of 24).  tiles_y then counts (row block, parity) pairs.
+    constexpr int RS = (S == 1 && R == 2) ? 2 : 1;          // step between a thread's output rows
+    constexpr int US = RS == 2 ? R : 1;                     // step between the input rows it loads
+    constexpr int NR = RS == 2 ? TH + 2 : (TH - 1) * S + 2 * R + 1;        // input rows touched by the TH output rows
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     const int tx = lb % g.tiles_x;
     const int ty = (lb / g.tiles_x) % g.tiles_y;
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     const int c0 = cg * 4;
     const float* xb = x + (int64_t)b * g.H * g.W * g.C + c0;
     float* yb = y + (int64_t)b * g.Ho * g.Wo * g.C + c0;
-    const int oy0 = ty * TH;
+    const int oy0 = (ty / RS) * (TH * RS) + (ty % RS);
     const int iy0 = oy0 * S - g.pt;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int ixc[3];
@@ -320,8 +325,7 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     float4 in[NR][3];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-        // rows that no output row of this thread uses (rate 2: every other one is still used by the odd outputs) are all needed
-        const int iy = iy0 + rr;
+        const int iy = iy0 + rr * US;
         const bool oky = iy >= 0 && iy < g.H;
         const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
         const float* rp = xb + (int64_t)iyc * g.W * g.C;
@@ -340,14 +344,14 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     if (scale) { sc = ld4(scale + c0); sh = ld4(shift + c0); }
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
-        const int oy = oy0 + r;
+        const int oy = oy0 + r * RS;
         if (oy >= g.Ho) break;
         float4 acc = zero4;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const float4 v = in[r * S + i * R][j];
+                const float4 v = in[RS == 2 ? r + i : r * S + i * R][j];
                 const float4 w4 = wv[i * 3 + j];
                 acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
                 acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
@@ -366,7 +370,7 @@ int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w,
     if (rc) return rc;
     AMS_REQUIRE((scale == nullptr) == (shift == nullptr), "depthwise: scale and shift come together");
     constexpr int TH1 = 4, TH2 = 3, THR = 4;
-    g.tiles_y = cdiv(g.Ho, stride == 2 ? TH2 : rate == 2 ? THR : TH1);
+    g.tiles_y = stride == 2 ? cdiv(g.Ho, TH2) : rate == 2 ? 2 * cdiv(g.Ho, 2 * THR) : cdiv(g.Ho, TH1);     // rate 2: (row block, parity)
     g.tiles_x = cdiv(g.Wo * g.CG, 256);
     const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
     const int threads = 256;

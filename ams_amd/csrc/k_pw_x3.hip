@@ -87,15 +87,19 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
 // sched_group_barrier) measured slower — per 32 k the MFMAs, the LDS fragment reads and the split VALU work add up to
 // ~the measured time, and the extra registers cost a resident wave per SIMD.
 template <int RM, int NT, int EPI, int D, int NP>
-__global__ __launch_bounds__(256) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
+__global__ __launch_bounds__(256, (RM * NT <= 8 ? 4 : 3)) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
                                                         int Kp, int n_tiles_n, unsigned nblocks) {
     constexpr int PITCH = 40;                        // bf16 elements per LDS row: 80 B, conflict-free for ds_read_b128
     constexpr int ROWS = 16 * NT;
     constexpr int NPIECE = NP * ROWS * 4;            // 16-byte pieces per stage (NP panels, 32 k = 4 pieces per row)
     constexpr int NREG = (NPIECE + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned short sW[2][NP][ROWS * PITCH];    // [buffer][part]
+    // the weight stages and the epilogue slabs share one region (the stage loop ends with a barrier): more blocks per CU
+    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = (EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4)) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES > OUT_BYTES ? W_BYTES : OUT_BYTES];
+    typedef unsigned short (*WStage)[NP][ROWS * PITCH];
+    WStage sW = reinterpret_cast<WStage>(smem);                                        // [buffer][part][...]
+    float* sOutAll = reinterpret_cast<float*>(smem);
     __shared__ __attribute__((aligned(16))) float sSc[16 * NT], sSh[16 * NT];
-    __shared__ __attribute__((aligned(16))) float sOutAll[EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4)];
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     const int tile_n = lb % n_tiles_n;
     const int64_t tile_m = lb / n_tiles_n;

@@ -87,7 +87,7 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
 // sched_group_barrier) measured slower — per 32 k the MFMAs, the LDS fragment reads and the split VALU work add up to
 // ~the measured time, and the extra registers cost a resident wave per SIMD.
 template <int RM, int NT, int EPI, int D, int NP>
-__global__ __launch_bounds__(256, (RM * NT <= 8 ? 4 : 3)) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
+__global__ __launch_bounds__(256, ((RM * NT <= 8 && NT * NP <= 15) ? 4 : 3)) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
                                                         int Kp, int n_tiles_n, unsigned nblocks) {
     constexpr int PITCH = 40;                        // bf16 elements per LDS row: 80 B, conflict-free for ds_read_b128
     constexpr int ROWS = 16 * NT;

@@ -112,27 +112,31 @@ __global__ __launch_bounds__(256, ((RM * NT <= 8 && NT * NP <= 15) ? 4 : 3)) voi
     // vmcnt retires in order: a wait for the weight pieces of the next stage would also drain every older activation
     // load, so the weight pieces ride the same D-deep ring and are waited for at the same age.
     u32x4 wring[D][NREG];
+    // this thread's weight pieces: global source (stage 0) and LDS destination, computed once — the index arithmetic is
+    // loop-invariant and was a fifth of the VALU instructions of a stage
+    const unsigned short* wsrc[NREG];
+    int wdst[NREG];
+#pragma unroll
+    for (int u = 0; u < NREG; ++u) {
+        const int e = tid + u * 256 < NPIECE ? tid + u * 256 : NPIECE - 1;         // surplus lanes repeat the last piece
+        const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
+        int nn = n0 + n;
+        if (nn > a.N - 1) nn = a.N - 1;
+        // columns >= N repeat column N-1: they are never stored.  No select on the loaded value: hipcc would turn it back
+        // into an exec-masked branch around the load, and a masked load costs a vmcnt(0).  Part p of the panels starts at
+        // w0 + p * plane (one base pointer: a select between pointers becomes a stack table).
+        wsrc[u] = w0 + which * plane + (int64_t)nn * Kp + part * 8;
+        wdst[u] = which * (ROWS * PITCH) + n * PITCH + part * 8;
+    }
     auto load_stage = [&](int s, u32x4 (&wreg)[NREG]) {
         if (s > n_stages - 1) s = n_stages - 1;
 #pragma unroll
-        for (int u = 0; u < NREG; ++u) {
-            const int e = tid + u * 256 < NPIECE ? tid + u * 256 : NPIECE - 1;     // surplus lanes repeat the last piece
-            const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
-            int nn = n0 + n;
-            if (nn > a.N - 1) nn = a.N - 1;
-            // columns >= N repeat column N-1: they are never stored.  No select here: hipcc would turn it back into an
-            // exec-masked branch around the load, and a masked load costs a vmcnt(0)
-            // part p of the panels starts at w0 + p * plane (one base pointer: a select between pointers becomes a stack table)
-            wreg[u] = *reinterpret_cast<const u32x4*>(w0 + which * plane + (int64_t)nn * Kp + s * 32 + part * 8);
-        }
+        for (int u = 0; u < NREG; ++u) wreg[u] = *reinterpret_cast<const u32x4*>(wsrc[u] + s * 32);
     };
     auto store_stage = [&](int buf, const u32x4 (&wreg)[NREG]) {
+        unsigned short* base = &sW[buf][0][0];
 #pragma unroll
-        for (int u = 0; u < NREG; ++u) {
-            const int e = tid + u * 256 < NPIECE ? tid + u * 256 : NPIECE - 1;
-            const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
-            *reinterpret_cast<u32x4*>(&sW[buf][which][n * PITCH + part * 8]) = wreg[u];
-        }
+        for (int u = 0; u < NREG; ++u) *reinterpret_cast<u32x4*>(base + wdst[u]) = wreg[u];
     };
 
     const float* arow[RM];

@@ -79,22 +79,51 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(XdwArgs a, unsigned nblo
     // the chip): the input fragments above are gathered once — they do not depend on the chunk, only the weights change —
     // instead of once per (tile, chunk) block.
     const int chunks_per_block = a.chunks / a.chunk_splits;
+    // chunk parameters (expand weights, BN vectors, depthwise taps) go global -> registers -> LDS; the registers of chunk
+    // ci + 1 are requested before the depthwise phase of chunk ci, so their L2 latency is off the critical path
+    constexpr int NWV = (Kpad * (CC / 4) + 255) / 256, NDW = (9 * CC + 255) / 256;
+    float4 wpre[NWV];
+    float dpre[NDW];
+    float apre[4];
+    auto fetch_params = [&](int n0) {
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            int e = tid + 256 * u;
+            if (e > Kpad * (CC / 4) - 1) e = Kpad * (CC / 4) - 1;
+            const int kk = e / (CC / 4), c4 = (e - kk * (CC / 4)) * 4;
+            const int kc = kk < a.Cin ? kk : a.Cin - 1;
+            const float4 v = ld4(a.w_exp + (int64_t)kc * a.Cexp + n0 + c4);
+            wpre[u] = kk < a.Cin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NDW; ++u) {
+            int e = tid + 256 * u;
+            if (e > 9 * CC - 1) e = 9 * CC - 1;
+            dpre[u] = a.w_dw[(e / CC) * a.Cexp + n0 + (e % CC)];
+        }
+        const int ec = tid < CC ? tid : CC - 1;
+        apre[0] = a.sc_e[n0 + ec]; apre[1] = a.sh_e[n0 + ec]; apre[2] = a.sc_d[n0 + ec]; apre[3] = a.sh_d[n0 + ec];
+    };
+    auto store_params = [&]() {
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            const int e = tid + 256 * u;
+            if (e < Kpad * (CC / 4)) { const int kk = e / (CC / 4), c4 = (e - kk * (CC / 4)) * 4; st4(sW + kk * WP + c4, wpre[u]); }
+        }
+#pragma unroll
+        for (int u = 0; u < NDW; ++u) {
+            const int e = tid + 256 * u;
+            if (e < 9 * CC) sDw[e] = dpre[u];
+        }
+        if (tid < CC) { sAff[tid] = apre[0]; sAff[CC + tid] = apre[1]; sAff[2 * CC + tid] = apre[2]; sAff[3 * CC + tid] = apre[3]; }
+    };
+    fetch_params(cs * chunks_per_block * CC);
     for (int ci = 0; ci < chunks_per_block; ++ci) {
     const int n0 = (cs * chunks_per_block + ci) * CC;
     if (ci > 0) __syncthreads();                       // phase 2 of the previous chunk still reads sDw / sAff / sAct
-    for (int e = tid; e < Kpad * (CC / 4); e += 256) {
-        const int kk = e / (CC / 4), c4 = (e - kk * (CC / 4)) * 4;
-        const int kc = kk < a.Cin ? kk : a.Cin - 1;
-        float4 v = ld4(a.w_exp + (int64_t)kc * a.Cexp + n0 + c4);
-        if (kk >= a.Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        st4(sW + kk * WP + c4, v);
-    }
-    for (int e = tid; e < CC; e += 256) {
-        sAff[e] = a.sc_e[n0 + e]; sAff[CC + e] = a.sh_e[n0 + e];
-        sAff[2 * CC + e] = a.sc_d[n0 + e]; sAff[3 * CC + e] = a.sh_d[n0 + e];
-    }
-    for (int e = tid; e < 9 * CC; e += 256) sDw[e] = a.w_dw[(e / CC) * a.Cexp + n0 + (e % CC)];
+    store_params();
     __syncthreads();
+    if (ci + 1 < chunks_per_block) fetch_params(n0 + CC);      // block-uniform
 
     // ---- phase 1: expand GEMM over the input tile (halo included), BN + ReLU6, into LDS
 #pragma unroll

@@ -102,6 +102,10 @@ def test_full_size_properties(W0, clip):
     cm = np.zeros((len(CI), len(CI)), np.int64)
     np.add.at(cm, (t[valid], lab.cpu().numpy()[valid]), 1)
     assert np.array_equal(conf.cpu().numpy(), cm)
+    # the fused first block does the arithmetic of the three kernels it replaces in the same order: identical bits
+    eng.set_fuse_first_block(False)
+    eng.predict(frames)
+    assert np.array_equal(_lowres(eng, B), low)
     # exact-f32 plan vs the default split plan: logits agree at the f32 level
     eng.set_matmul_mode(hip.MATMUL_F32)
     eng.set_fuse_first_block(False)

@@ -112,6 +112,8 @@ struct ams_student {
                                                // Off by default: measured equal to the two kernels at B = 8 (LDS-read bound:
                                                // 60 b128 reads per wave and 32 channels) and slower at B = 1 (45 blocks)
     int fuse_first_block = 1;                  // frozen inference: stem + depthwise + project of the first block in one kernel
+    int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
+                                               // in one streaming kernel (k_xdw_stream.hip)
     int fuse_expand_dw = 1;                    // frozen inference, expand + depthwise in one kernel: 0 never, 1 where it
                                                // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
@@ -421,6 +423,21 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin + ld.px_out * ld.d.cout) + (double)le.d.cin * le.d.cout + 9.0 * ld.d.cin);
             RUNK(i + 1, bytes, launch_expand_dw(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                 P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act, s->act[o], st));
+            x = s->act[o]; x_i = o; i += 2;
+        } else if (s->fuse_expand_dw_stream && s->matmul_mode != AMS_MATMUL_F32 && s->L[i].d.role == AMS_ROLE_EXPAND &&
+                   i + 1 <= s->n_backbone && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[i].whi && s->L[i].Kp == s->L[i].d.cin &&
+                   (int64_t)B * s->L[i].px_in >= 16384 &&          /* a few frames: below that the launch cannot fill the chip */
+                   expand_dw_stream_supported(s->L[i].d.cin, s->L[i].d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate)) {
+            // stride-16 blocks: expand + depthwise streamed through an LDS ring, split-bf16 products (bit-identical to the two
+            // kernels it replaces); the 6x-expanded tensor is never written
+            LayerRt& le = s->L[i];
+            LayerRt& ld = s->L[i + 1];
+            const int o = other(cur_i, -1);
+            const int np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : 2;
+            const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin + ld.px_out * ld.d.cout) + (double)le.d.cin * le.d.cout + 9.0 * ld.d.cin);
+            RUNK(i + 1, bytes, launch_expand_dw_stream(x, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale, le.fshift,
+                                                       le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
+                                                       s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
         } else {
         if (s->L[i].d.role == AMS_ROLE_EXPAND) {
@@ -748,6 +765,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
+    if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e) != 0;      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     *out = s;
     return AMS_OK;
 }
@@ -900,6 +918,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         s->fuse_dw_project = value != 0;
         return AMS_OK;
     }
+    if (option == AMS_OPT_FUSE_EXPAND_DW_STREAM) {
+        s->fuse_expand_dw_stream = value != 0;
+        return AMS_OK;
+    }
     if (option == AMS_OPT_FUSE_EXPAND_DW) {
         s->fuse_expand_dw = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
@@ -985,6 +1007,19 @@ int ams_k_pointwise_split(const float* x, int64_t M, int32_t K, const float* w, 
     return launch_pointwise_split(a, hi, lo, Kp, st);
 }
 
+int ams_k_pointwise_split3(const float* x, int64_t M, int32_t K, const float* w, int32_t N, const float* scale, const float* shift,
+                           int32_t act, const float* res, float* y, uint16_t* panels, size_t panel_elems, void* stream) {
+    const int Kp = (K + 31) / 32 * 32;
+    const size_t plane = (size_t)N * Kp;
+    AMS_REQUIRE(panels && panel_elems >= 3 * plane, "pointwise_split3: panel scratch too small (need %zu)", 3 * plane);
+    hipStream_t st = (hipStream_t)stream;
+    RUN(launch_split_weights3(w, N, 1, K, N, Kp, panels, panels + plane, panels + 2 * plane, st));
+    PwArgs a = pw_args(x, M, K, K, w, N, y, N);
+    a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
+    if (scale && !shift) { set_error("pointwise_split3: scale without shift"); return AMS_E_INVALID; }
+    return launch_pointwise_split3(a, panels, panels + plane, panels + 2 * plane, Kp, st);
+}
+
 int ams_ingest_resize_u8(const uint8_t* src, int32_t Hs, int32_t Ws, int32_t Cn, int32_t mode, int32_t swap_rb, uint8_t* dst, int32_t H,
                          int32_t W, void* stream) {
     return launch_resize_u8(src, Hs, Ws, Cn, mode, swap_rb, dst, H, W, (hipStream_t)stream);
@@ -1011,6 +1046,21 @@ int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin
     if (!expand_dw_supported(Cin, Cexp, stride, rate)) { set_error("expand_dw: unsupported shape"); return AMS_E_INVALID; }
     return launch_expand_dw(x, B, H, W, Cin, w_exp, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, stride, rate, scale_d, shift_d,
                             AMS_ACT_RELU6, y, (hipStream_t)stream);
+}
+
+int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
+                           const float* shift_e, int32_t Cexp, const float* w_dw, int32_t rate, const float* scale_d, const float* shift_d,
+                           float* y, uint16_t* panels, size_t panel_elems, int32_t parts, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!expand_dw_stream_supported(Cin, Cexp, 1, rate) || (parts != 2 && parts != 3)) {
+        set_error("expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d parts=%d", Cin, Cexp, rate, parts);
+        return AMS_E_INVALID;
+    }
+    const size_t plane = (size_t)Cexp * Cin;
+    AMS_REQUIRE(panels && panel_elems >= 3 * plane, "expand_dw_stream: panel scratch too small (need %zu)", 3 * plane);
+    RUN(launch_split_weights3(w_exp, Cexp, 1, Cin, Cexp, Cin, panels, panels + plane, panels + 2 * plane, st));
+    return launch_expand_dw_stream(x, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, rate, scale_d,
+                                   shift_d, AMS_ACT_RELU6, y, st);
 }
 
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

@@ -1,6 +1,7 @@
 // 1x1 convolutions, split-bf16 variant for the layers where exact f32 would be matrix-pipe bound (the output-stride-16
 // section and the head): see k_pointwise.hip for the overview.
 #include "pw_common.hpp"
+#include "split_bf16.hpp"
 
 namespace ams {
 
@@ -16,9 +17,6 @@ namespace ams {
 // The weights are split into [N][Kp] panels (k contiguous, Kp = K rounded up to 32; parts equally spaced): once per
 // ams_student_freeze for inference, per launch in the fine-tune step.
 // =========================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // native vector: stays in registers where HIP's uint4 struct may not
-
 __device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
     unsigned u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -54,30 +52,6 @@ int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, 
     hipLaunchKernelGGL(split_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, sk, sn, K, N, Kp, hi, mid, lo);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
-}
-
-// 8 consecutive f32 -> bf16x8 parts (hi, mid, lo): successive bf16 roundings of the remainder.  Plain named vectors (an
-// array of vectors filled element-wise lands in scratch memory).
-__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& p0, bf16x8& p1) {
-    const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)f[j];
-        p0[j] = h;
-        p1[j] = (__bf16)(f[j] - (float)h);
-    }
-}
-__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-    const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)f[j];
-        const float r1 = f[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        p0[j] = h;
-        p1[j] = m;
-        p2[j] = (__bf16)(r1 - (float)m);
-    }
 }
 
 // D = stages of the operands in flight per lane (registers); the stage loop is unrolled by D so the ring is statically
@@ -186,25 +160,34 @@ __global__ __launch_bounds__(256, ((RM * NT <= 8 && NT * NP <= 15) ? 4 : 3)) voi
                     else split8(abuf[d][r][0], abuf[d][r][1], x0[r], x1[r]);
                 }
                 const unsigned short* bw = &sW[d & 1][0][l15 * PITCH + 8 * q];
+                // Per accumulator the six products arrive in a fixed order (smallest terms first), but consecutive MFMAs go to
+                // DIFFERENT accumulators: a dependent MFMA waits for its predecessor's 8 passes (~2.5 issue slots), and hipcc
+                // keeps the source order.  Column tiles are taken TG at a time (TG * RM chains in flight, TG * NP fragments live).
+                constexpr int TG = (NT >= 2 && RM <= 2) ? 2 : 1;        // an odd NT ends with a group of one
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bf16x8 q0 = *reinterpret_cast<const bf16x8*>(bw + t * 16 * PITCH);
-                    const bf16x8 q1 = *reinterpret_cast<const bf16x8*>(bw + (ROWS * PITCH) + t * 16 * PITCH);
+                for (int t0 = 0; t0 < NT; t0 += TG) {
+                    bf16x8 q0[TG], q1[TG], q2[TG];
+#pragma unroll
+                    for (int g = 0; g < TG; ++g) {
+                        if (t0 + g >= NT) continue;
+                        q0[g] = *reinterpret_cast<const bf16x8*>(bw + (t0 + g) * 16 * PITCH);
+                        q1[g] = *reinterpret_cast<const bf16x8*>(bw + (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
+                        if (NP == 3) q2[g] = *reinterpret_cast<const bf16x8*>(bw + 2 * (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
+                    }
+#define AMS_X3_TERM(QA, XB)                                                                                          \
+    _Pragma("unroll") for (int g = 0; g < TG; ++g)                                                                   \
+        _Pragma("unroll") for (int r = 0; r < RM; ++r)                                                               \
+            if (t0 + g < NT)                                                                                         \
+                acc[r][t0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QA[g], XB[r], acc[r][t0 + g], 0, 0, 0);
                     if (NP == 3) {           // smallest terms first
-                        const bf16x8 q2 = *reinterpret_cast<const bf16x8*>(bw + 2 * (ROWS * PITCH) + t * 16 * PITCH);
-#pragma unroll
-                        for (int r = 0; r < RM; ++r) {
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2, x0[r], acc[r][t], 0, 0, 0);
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, x2[r], acc[r][t], 0, 0, 0);
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, x1[r], acc[r][t], 0, 0, 0);
-                        }
+                        AMS_X3_TERM(q2, x0)
+                        AMS_X3_TERM(q0, x2)
+                        AMS_X3_TERM(q1, x1)
                     }
-#pragma unroll
-                    for (int r = 0; r < RM; ++r) {
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, x0[r], acc[r][t], 0, 0, 0);
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, x1[r], acc[r][t], 0, 0, 0);
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, x0[r], acc[r][t], 0, 0, 0);
-                    }
+                    AMS_X3_TERM(q1, x0)
+                    AMS_X3_TERM(q0, x1)
+                    AMS_X3_TERM(q0, x0)
+#undef AMS_X3_TERM
                 }
             }
             store_stage((d + 1) & 1, wring[(d + 1) % D]);

@@ -1,0 +1,385 @@
+// Fused expand (1x1, BN, ReLU6) -> depthwise 3x3 (BN, ReLU6) for the output-stride-16 blocks (Cin 64 / 96 / 160, stride 1,
+// rate 1 | 2), frozen inference, split-bf16 products: the STREAMING form.
+//
+// The tiled kernel of k_expand_dw.hip recomputes a 3x3 halo around every tile (x1.6 GEMM work at 8x8, x2.25 at rate 2)
+// and runs the expand on the f32 matrix pipe; on these blocks it loses to the two separate kernels.  Here a block takes
+// (frame, chunk of 16*NT expanded channels, sub-image, segment) and walks the segment's pixels in RASTER order, 64 per
+// step.  The expanded values live in an LDS ring that spans two image rows + 64 pixels; the depthwise conv trails the
+// GEMM by one row.  Nothing is recomputed along a row, only the 2 halo rows (and columns) of a segment.
+//   * rate 2 = four independent rate-1 convolutions on the (row parity, column parity) sub-images: a pixel is a
+//     contiguous Cin vector, so the strided gather is free, and the ring shrinks to two half-rows.
+//   * the chunk's expand weights (NP bf16 parts, [part][k/8][n][8] so that ds_read_b128 is conflict-free without padding)
+//     stay in LDS for the life of the block; depthwise taps and BN vectors of the thread's 4 channels stay in registers.
+//   * E-step (per step): wave w owns pixels 16w .. 16w+15 of the step; operands of the NEXT step are requested before the
+//     MFMAs of this one; products in the order of pw_gemm_bf16x3_l, so the result is bit-identical to the unfused pair.
+//   * pixels outside the image (SAME zero padding of the depthwise conv, halo outside the sub-image) are written as 0: the
+//     segment is laid out with one pad column on each side, so a tap never wraps into a neighbouring row and the
+//     D-step needs no masks.
+// The 6x-expanded tensor is never written; what reaches HBM is the depthwise output (the project GEMM's operand).
+#include "pw_common.hpp"
+#include "split_bf16.hpp"
+
+namespace ams {
+
+struct XdsArgs {
+    const float* x;                  // [B, H, W, Cin]
+    int B, H, W, Cin;
+    const unsigned short* wp;        // expand weights, bf16 parts [part][Cexp][Kp], part p at wp + p * plane
+    int64_t plane;
+    const float* sc_e; const float* sh_e;
+    int act_e;
+    int Cexp;
+    const float* w_dw;               // [9][Cexp]
+    const float* sc_d; const float* sh_d;
+    int act_d;
+    float* y;                        // [B, H, W, Cexp]
+    int rate;
+    int SH, SW;                      // output rows / columns of a work item (sub-image coordinates)
+    int Wp;                          // SW + 2: segment row pitch incl. one pad column on each side
+    int T;                           // steps: ceil((SH + 2) * Wp / STEP)
+    int ring;                        // ring size in pixels: a multiple of STEP, >= 2 * Wp + 2 + 2 * STEP
+    int nsy, nsx;                    // segments per sub-image
+    int chunks;                      // Cexp / (16 * NT)
+    int items;                       // B * rate^2 * nsy * nsx work items per chunk
+    int groups;                      // blocks per chunk; block g walks items g, g + groups, ...
+};
+
+// Roles: waves [0, NWE) run the E-steps (operand loads, split, MFMAs, BN + ReLU6 into the ring), waves [NWE, NWE + NWD) the
+// D-steps (depthwise from the ring, BN + ReLU6, stores).  D-step t - 1 runs beside E-step t, one barrier per step: the matrix
+// pipe of a SIMD works for an E-wave while its vector pipe works for a D-wave, and neither role carries the other's registers.
+template <int KS, int NT, int NP, int NWE, int NWD>
+__global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a, unsigned nblocks) {
+    constexpr int NC = 16 * NT;                      // expanded channels per block
+    constexpr int CG = NC / 4;                       // channel groups (float4) of the D-step
+    constexpr int STEP = 16 * NWE;                   // pixels per step
+    constexpr int PX = STEP * CG / (64 * NWD);       // consecutive centres per D-thread
+    static_assert(PX * 64 * NWD == STEP * CG && PX >= 1, "D-step mapping");
+    constexpr int PITCH = NC + 4;                    // ring row pitch in floats (odd number of 16-byte units)
+    constexpr int MIRROR = 4;                        // ring slots repeated after the end (a run of taps is <= 4 slots)
+    constexpr int Kp = KS * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* sW = reinterpret_cast<u32x4*>(smem);                      // [NP][KS][4][NC] 16-byte units (8 k each)
+    float* sAff = reinterpret_cast<float*>(smem + NP * Kp * NC * 2); // sc_e, sh_e : 2 x NC
+    float* ring = sAff + 2 * NC;                                     // [ring][PITCH]
+
+    const unsigned lb = xcd_remap(blockIdx.x, nblocks);
+    const int chunk = lb % a.chunks;
+    const int group = lb / a.chunks;
+    const int n0 = chunk * NC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the role branch is wave-uniform for the compiler too
+    const int Wp = a.Wp, rate = a.rate, R = a.ring;
+
+    // ---- chunk parameters -> LDS (once per block) -----------------------------------------------------------
+    {
+        constexpr int UPR = Kp / 8;                                  // 16-byte units per weight row
+        constexpr int NPIECE = NP * NC * UPR;
+        for (int e = tid; e < NPIECE; e += 64 * (NWE + NWD)) {
+            const int part = e / (NC * UPR), r = e - part * (NC * UPR), n = r / UPR, u = r - n * UPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(a.wp + part * a.plane + (int64_t)(n0 + n) * Kp + u * 8);
+            sW[((part * KS + (u >> 2)) * 4 + (u & 3)) * NC + n] = v;
+        }
+        if (tid < NC) { sAff[tid] = a.sc_e[n0 + tid]; sAff[NC + tid] = a.sh_e[n0 + tid]; }
+    }
+    __syncthreads();
+    const int qS = STEP / Wp, rS = STEP - qS * Wp;                   // both walkers advance by STEP pixels a step
+
+    if (wave < NWE) {
+        // =================================== E-waves ===================================
+        const int l15 = lane & 15, q = lane >> 4;
+        const int ring_lane = (16 * wave + l15) * PITCH + 4 * q;     // this lane's slot within a STEP-aligned ring chunk
+        int sbase = 0;                                               // (STEP * step counter) mod R, carried across items
+        for (int item = group; item < a.items; item += a.groups) {
+            int u1 = item;
+            const int segx = u1 % a.nsx; u1 /= a.nsx;
+            const int segy = u1 % a.nsy; u1 /= a.nsy;
+            const int sub = u1 % (rate * rate);
+            const int b = u1 / (rate * rate);
+            const int sy = sub / rate, sx = sub - sy * rate;
+            const int Hs = (a.H - sy + rate - 1) / rate, Ws = (a.W - sx + rate - 1) / rate;      // this sub-image
+            const int i0 = segy * a.SH, j0 = segx * a.SW;
+            const bool live = i0 < Hs && j0 < Ws;                    // a segment past the end of a smaller sub-image: barriers only
+            const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin + 8 * q;
+            int e_row, e_col;
+            { const int e0 = 16 * wave + l15; e_row = e0 / Wp; e_col = e0 - e_row * Wp; }
+            float4 raw[KS][2];
+            bool in_next = false;
+            auto next_pixel = [&]() -> const float* {                // clamped address; `in_next` decides what is kept
+                const int i = i0 - 1 + e_row, j = j0 - 1 + e_col;
+                in_next = (i >= 0) & (i < Hs) & (j >= 0) & (j < Ws) & (e_row < a.SH + 2) & live;
+                const int ic = i < 0 ? 0 : (i > Hs - 1 ? Hs - 1 : i), jc = j < 0 ? 0 : (j > Ws - 1 ? Ws - 1 : j);
+                return xb + ((int64_t)(sy + rate * ic) * a.W + (sx + rate * jc)) * a.Cin;
+            };
+            {
+                const float* p = next_pixel();
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { raw[s][0] = ld4(p + 32 * s); raw[s][1] = ld4(p + 32 * s + 4); }
+            }
+            for (int t = 0; t < a.T; ++t) {
+                const bool inside = in_next;
+                f32x4 acc[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                e_row += qS; e_col += rS;
+                if (e_col >= Wp) { e_col -= Wp; ++e_row; }
+                const float* pn = next_pixel();                       // pixel of step t + 1
+                // Operands are split stage by stage (12 registers live instead of 12 * KS) and a stage's registers are refilled
+                // with the next step's operands as soon as they are split: those loads have the rest of the step to land.
+                // Products in the order of pw_gemm_bf16x3_l per accumulator; consecutive MFMAs go to different accumulators
+                // (a dependent MFMA waits ~2.5 issue slots for its predecessor).
+                bf16x8 x0, x1, x2;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if (NP == 3) split8(raw[s][0], raw[s][1], x0, x1, x2);
+                    else split8(raw[s][0], raw[s][1], x0, x1);
+                    raw[s][0] = ld4(pn + 32 * s);
+                    raw[s][1] = ld4(pn + 32 * s + 4);
+                    const u32x4* bw = sW + (s * 4 + q) * NC + l15;
+                    bf16x8 q0[NT], q1[NT], q2[NT];
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        q0[tt] = *reinterpret_cast<const bf16x8*>(bw + 16 * tt);
+                        q1[tt] = *reinterpret_cast<const bf16x8*>(bw + KS * 4 * NC + 16 * tt);
+                        if (NP == 3) q2[tt] = *reinterpret_cast<const bf16x8*>(bw + 2 * KS * 4 * NC + 16 * tt);
+                    }
+                    if (NP == 3) {                                    // smallest terms first
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[tt], x0, acc[tt], 0, 0, 0);
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x2, acc[tt], 0, 0, 0);
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x1, acc[tt], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x0, acc[tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x1, acc[tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x0, acc[tt], 0, 0, 0);
+                }
+                {
+                    float* dst = ring + sbase * PITCH + ring_lane;
+                    const bool mirror = sbase == 0 && 16 * wave + l15 < MIRROR;
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const float4 sc = ld4(sAff + 16 * tt + 4 * q), sh = ld4(sAff + NC + 16 * tt + 4 * q);
+                        float4 v;
+                        v.x = apply_act(acc[tt][0] * sc.x + sh.x, a.act_e); v.y = apply_act(acc[tt][1] * sc.y + sh.y, a.act_e);
+                        v.z = apply_act(acc[tt][2] * sc.z + sh.z, a.act_e); v.w = apply_act(acc[tt][3] * sc.w + sh.w, a.act_e);
+                        // positions outside the image hold 0: SAME padding of the depthwise conv, halo outside the sub-image
+                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        st4(dst + 16 * tt, v);
+                        // the first MIRROR slots of the ring are repeated after its end: a D-thread's run of taps never wraps
+                        if (mirror) st4(dst + R * PITCH + 16 * tt, v);
+                    }
+                }
+                sbase += STEP;
+                if (sbase == R) sbase = 0;
+                __syncthreads();
+            }
+            __syncthreads();                                          // the D-waves finish the item (their step T - 1)
+        }
+    } else {
+        // =================================== D-waves ===================================
+        const int dt = tid - 64 * NWE;
+        const int cg = dt % CG, pt = dt / CG;
+        float4 wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + n0 + 4 * cg);
+        const float4 dsc = ld4(a.sc_d + n0 + 4 * cg), dsh = ld4(a.sh_d + n0 + 4 * cg);
+        const unsigned ych = (unsigned)(n0 + 4 * cg) * 4u;
+        // ring position of this thread's first tap, (first centre - Wp - 1) mod R, carried across items like sbase
+        int cb = (2 * R - 2 * Wp - 2 + pt * PX) % R;
+        for (int item = group; item < a.items; item += a.groups) {
+            int u1 = item;
+            const int segx = u1 % a.nsx; u1 /= a.nsx;
+            const int segy = u1 % a.nsy; u1 /= a.nsy;
+            const int sub = u1 % (rate * rate);
+            const int b = u1 / (rate * rate);
+            const int sy = sub / rate, sx = sub - sy * rate;
+            const int Hs = (a.H - sy + rate - 1) / rate, Ws = (a.W - sx + rate - 1) / rate;
+            const int i0 = segy * a.SH, j0 = segx * a.SW;
+            const bool live = i0 < Hs && j0 < Ws;
+            // Results leave through buffer stores on a descriptor of this frame: a lane with nothing to store gets an offset
+            // past the end, which the hardware drops.  No branch around the store, so hipcc counts it exactly.
+            const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)b * a.H * a.W * a.Cexp, 0,
+                                                                                   (int)((int64_t)a.H * a.W * a.Cexp * 4), 0x00020000);
+            int d_row, d_col;                                        // first centre of this thread at step 0: -Wp - 1 + pt * PX
+            { const int c0 = Wp - 1 + pt * PX; d_row = c0 / Wp; d_col = c0 - d_row * Wp; d_row -= 2; }
+            __syncthreads();                                          // E-step 0
+            for (int t = 0; t < a.T; ++t) {
+                // D-step t: the STEP centres whose neighbourhood is complete after E-step t
+#pragma unroll
+                for (int h = 0; h < PX; h += 2) {                     // two centres at a time: 12 taps live
+                    constexpr int PH = PX >= 2 ? 2 : 1;
+                    float4 v[3][PH + 2];
+#pragma unroll
+                    for (int di = 0; di < 3; ++di) {
+                        unsigned slot = (unsigned)(cb + di * Wp + h);         // first tap of the run; the run itself may pass the
+                        slot = slot < (unsigned)R ? slot : slot - (unsigned)R; // end of the ring into the mirrored slots
+                        const float* rp = ring + __umul24(slot, PITCH) + 4 * cg;
+#pragma unroll
+                        for (int jj = 0; jj < PH + 2; ++jj) v[di][jj] = ld4(rp + jj * PITCH);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PH; ++u) {
+                        // scalar FMAs: v_pk_fma_f32 halves the instruction count but measured SLOWER here (+20 % on the kernel) —
+                        // packed f32 shares a datapath with the MFMAs the E-waves keep in flight on the same SIMD
+                        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                const float4 vv = v[i][u + j];
+                                const float4 w4 = wv[i * 3 + j];
+                                acc4.x = fmaf(vv.x, w4.x, acc4.x); acc4.y = fmaf(vv.y, w4.y, acc4.y);
+                                acc4.z = fmaf(vv.z, w4.z, acc4.z); acc4.w = fmaf(vv.w, w4.w, acc4.w);
+                            }
+                        float4 o;
+                        o.x = apply_act(acc4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(acc4.y * dsc.y + dsh.y, a.act_d);
+                        o.z = apply_act(acc4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(acc4.w * dsc.w + dsh.w, a.act_d);
+                        int row = d_row, col = d_col + h + u;
+#pragma unroll
+                        for (int w = 0; w < (PX + 1) / 2; ++w)            // PX may span several rows of a tiny segment (Wp >= 3)
+                            if (col >= Wp) { col -= Wp; ++row; }
+                        const int i = i0 + row - 1, j = j0 + col - 1;
+                        const bool ok = (row >= 1) & (row <= a.SH) & (col >= 1) & (col <= a.SW) & (i < Hs) & (j < Ws) & live;
+                        const unsigned off = ok ? (unsigned)((sy + rate * i) * a.W + (sx + rate * j)) * (unsigned)(a.Cexp * 4) + ych : 0xfffffff0u;
+                        const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                    }
+                }
+                d_row += qS; d_col += rS;
+                if (d_col >= Wp) { d_col -= Wp; ++d_row; }
+                cb += STEP;
+                if (cb >= R) cb -= R;
+                __syncthreads();                                      // E-step t + 1 (after the last step: the next item may start)
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------
+struct XdsPlan { int nt, nwe, nwd, SH, SW, nsy, nsx, ring, groups; size_t lds; };
+
+static size_t xds_lds(int Kp, int nt, int np, int ring) {
+    const int NC = 16 * nt;
+    return (size_t)np * Kp * NC * 2 + 2 * NC * 4 + (size_t)(ring + 4) * (NC + 4) * 4;      // + the mirrored slots
+}
+static int xds_ring(int SW, int step) { return (2 * (SW + 2) + 2 + 2 * step + step - 1) / step * step; }
+
+// segment geometry: whole sub-image rows when the ring fits, column strips otherwise; row segments until there are enough
+// work items to fill the chip (each costs two halo rows of GEMM work)
+static bool xds_plan_try(int B, int H, int W, int Cin, int Cexp, int rate, int np, int nt, int nwe, int nwd, int nsy_force, int nsx_force,
+                         int groups_force, XdsPlan* p) {
+    const int Kp = Cin;
+    const int Hs = (H + rate - 1) / rate, Ws = (W + rate - 1) / rate;
+    if (Cexp % (16 * nt) != 0) return false;
+    const int step = 16 * nwe;
+    const size_t budget = 160 * 1024 - 512;
+    int nsx = nsx_force > 0 ? nsx_force : 1;
+    int SW, ring;
+    for (;; ++nsx) {
+        SW = (Ws + nsx - 1) / nsx;
+        ring = xds_ring(SW, step);
+        // two blocks per CU when a narrower strip allows it
+        if (xds_lds(Kp, nt, np, ring) <= budget / 2 || SW <= 24 || nsx_force > 0) break;
+    }
+    for (; xds_lds(Kp, nt, np, ring) > budget && SW > 1; ++nsx) {
+        SW = (Ws + nsx) / (nsx + 1);
+        ring = xds_ring(SW, step);
+    }
+    if (xds_lds(Kp, nt, np, ring) > budget || SW < 1) return false;
+    nsx = (Ws + SW - 1) / SW;
+    const int chunks = Cexp / (16 * nt);
+    int nsy = 1;
+    if (nsy_force > 0) nsy = nsy_force;
+    else
+        while ((int64_t)B * rate * rate * chunks * nsx * nsy < 1024 && (Hs + nsy - 1) / nsy > 8) ++nsy;
+    p->nt = nt; p->nwe = nwe; p->nwd = nwd; p->nsx = nsx; p->SW = SW; p->nsy = nsy; p->SH = (Hs + nsy - 1) / nsy; p->ring = ring;
+    p->lds = xds_lds(Kp, nt, np, ring);
+    // blocks per chunk: enough to fill the chip a few times over, so that a block amortises its weight fill over several items
+    const int64_t items = (int64_t)B * rate * rate * nsx * nsy;
+    int64_t groups = groups_force > 0 ? groups_force : (2048 + chunks - 1) / chunks;
+    if (groups > items) groups = items;
+    if (groups < 1) groups = 1;
+    p->groups = (int)groups;
+    return true;
+}
+
+// segment geometry: whole sub-image rows when the ring fits, column strips otherwise; row segments until there are enough
+// work items to fill the chip (each costs two halo rows of GEMM work).  AMS_XDS_FORCE = "tiles,row segments,column strips,
+// E-waves,D-waves,blocks per chunk" overrides the choices (0 = automatic); a forced shape that does not fit LDS falls back.
+static bool xds_plan(int B, int H, int W, int Cin, int Cexp, int rate, int np, XdsPlan* p) {
+    int nt = 2, nsy_force = 0, nsx_force = 0, nwe = 4, nwd = 4, groups_force = 0;
+    if (const char* e = getenv("AMS_XDS_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d", &nt, &nsy_force, &nsx_force, &nwe, &nwd, &groups_force);
+    if (nt != 2 && nt != 4) nt = 2;
+    if (!((nwe == 4 && (nwd == 2 || nwd == 4)) || (nwe == 8 && nwd == 4))) { nwe = 4; nwd = 4; }
+    if (xds_plan_try(B, H, W, Cin, Cexp, rate, np, nt, nwe, nwd, nsy_force, nsx_force, groups_force, p)) return true;
+    if (xds_plan_try(B, H, W, Cin, Cexp, rate, np, 2, nwe, nwd, nsy_force, nsx_force, groups_force, p)) return true;
+    return xds_plan_try(B, H, W, Cin, Cexp, rate, np, 2, 4, 4, nsy_force, 0, groups_force, p);
+}
+
+bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate) {
+    if (stride != 1 || (rate != 1 && rate != 2)) return false;
+    if (Cin != 64 && Cin != 96 && Cin != 160) return false;
+    return Cexp % 32 == 0;
+}
+
+template <int KS, int NT, int NP, int NWE, int NWD>
+static int launch_xds_k(XdsArgs a, const XdsPlan& p, hipStream_t st) {
+    static size_t attr_lds = 0;
+    if (p.lds > 64 * 1024 && p.lds > attr_lds) {
+        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)p.lds));
+        attr_lds = p.lds;
+    }
+    const int64_t nblocks = (int64_t)a.groups * a.chunks;
+    AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_stream: bad grid");
+    static const std::string nm = "xdw_stream_kernel<" + std::to_string(KS) + ", " + std::to_string(NT) + ", " + std::to_string(NP) + ", " +
+                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ">";
+    note_kernel(nm.c_str());
+    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+template <int KS, int NT, int NP>
+static int launch_xds_w(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
+    if (p.nwe == 8) return launch_xds_k<KS, NT, NP, 8, 4>(a, p, st);
+    if (p.nwd == 4) return launch_xds_k<KS, NT, NP, 4, 4>(a, p, st);
+    return launch_xds_k<KS, NT, NP, 4, 2>(a, p, st);
+}
+
+template <int KS>
+static int launch_xds_ks(const XdsArgs& a, const XdsPlan& p, int np, hipStream_t st) {
+    if (p.nt == 4) return np == 3 ? launch_xds_w<KS, 4, 3>(a, p, st) : launch_xds_w<KS, 4, 2>(a, p, st);
+    return np == 3 ? launch_xds_w<KS, 2, 3>(a, p, st) : launch_xds_w<KS, 2, 2>(a, p, st);
+}
+
+// w_parts: the expand layer's bf16 panels [part][Cexp][Cin] (np = 2: hi, lo; np = 3: hi, mid, lo), part p at w_parts + p * plane
+int launch_expand_dw_stream(const float* x, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane, int np,
+                            const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
+                            const float* sh_d, int act_d, float* y, hipStream_t st) {
+    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && (np == 2 || np == 3), "expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d",
+                Cin, Cexp, rate);
+    AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_stream: empty input");
+    AMS_REQUIRE((int64_t)H * W * Cexp * 4 < 0x7fffffffLL, "expand_dw_stream: a frame of the output exceeds 2 GiB");
+    XdsPlan p;
+    AMS_REQUIRE(xds_plan(B, H, W, Cin, Cexp, rate, np, &p), "expand_dw_stream: no segment geometry fits LDS (W=%d rate=%d)", W, rate);
+    XdsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.wp = w_parts; a.plane = plane; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e;
+    a.Cexp = Cexp; a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.y = y; a.rate = rate;
+    const int step = 16 * p.nwe;
+    a.SH = p.SH; a.SW = p.SW; a.Wp = p.SW + 2; a.T = ((p.SH + 2) * a.Wp + step - 1) / step; a.ring = p.ring;
+    a.nsy = p.nsy; a.nsx = p.nsx; a.chunks = Cexp / (16 * p.nt);
+    a.items = B * rate * rate * p.nsy * p.nsx; a.groups = p.groups;
+    switch (Cin / 32) {
+        case 2: return launch_xds_ks<2>(a, p, np, st);
+        case 3: return launch_xds_ks<3>(a, p, np, st);
+        default: return launch_xds_ks<5>(a, p, np, st);
+    }
+}
+
+}  // namespace ams

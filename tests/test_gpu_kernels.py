@@ -251,6 +251,49 @@ def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):
     assert rel_err(y.cpu().numpy(), ref.permute(0, 2, 3, 1).numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,Cin,Cexp,rate,parts", [(33, 65, 64, 384, 1, 3), (33, 65, 96, 576, 1, 2), (33, 65, 160, 960, 2, 3),
+                                                     (17, 33, 160, 960, 2, 2), (9, 200, 64, 384, 1, 3), (5, 3, 96, 576, 2, 3),
+                                                     (40, 7, 64, 96, 1, 2), (2, 2, 160, 320, 2, 3), (1, 70, 96, 192, 1, 3)])
+def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkeypatch):
+    """Streaming expand+depthwise (stride-16 blocks) vs f64, and bit-for-bit against the two kernels it replaces.  Ragged sizes: column strips (W = 200), images
+    smaller than one step, single rows, sub-images of unequal size (odd H, W at rate 2); every tile / segment geometry."""
+    rng = np.random.default_rng(H * 7 + W + Cin + rate)
+    B = 3
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    we = (rng.standard_normal((Cin, Cexp)) / np.sqrt(Cin)).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, Cexp, 1)) * 0.4).astype(np.float32)
+    se, sd = rng.uniform(0.5, 1.5, Cexp).astype(np.float32), rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
+    he, hd = rng.standard_normal(Cexp).astype(np.float32), rng.standard_normal(Cexp).astype(np.float32)
+    panels = torch.zeros(3 * Cexp * Cin, dtype=torch.int16, device=DEV)
+    e = np.clip((x.astype(np.float64) @ we.astype(np.float64)) * se + he, 0, 6)
+    et = torch.as_tensor(e).permute(0, 3, 1, 2)
+    raw = F.conv2d(F.pad(et, (rate, rate, rate, rate)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), dilation=rate, groups=Cexp)
+    ref = torch.clamp(raw * torch.as_tensor(sd).view(1, -1, 1, 1) + torch.as_tensor(hd).view(1, -1, 1, 1), 0, 6).permute(0, 2, 3, 1).numpy()
+    unfused = None
+    if True:
+        M = B * H * W
+        ebuf = torch.empty((M, Cexp), device=DEV)
+        hip.check((lib.ams_k_pointwise_split if parts == 2 else lib.ams_k_pointwise_split3)(PD(x), M, Cin, PD(we), Cexp, PD(se), PD(he), hip.ACT_RELU6, None, P(ebuf), P(panels),
+                                            panels.numel(), stream()))
+        unfused = torch.empty((B, H, W, Cexp), device=DEV)
+        hip.check(lib.ams_k_depthwise3x3(P(ebuf), B, H, W, Cexp, PD(wd), 1, rate, PD(sd), PD(hd), hip.ACT_RELU6, P(unfused), stream()))
+        unfused = unfused.cpu().numpy()
+    # (16-channel tiles per block, row segments, column strips, E-waves, D-waves, blocks per channel chunk)
+    for force in (None, "4,1,1", "2,3,2", "4,2,3", "2,1,1,4,4,5", "2,2,1,8,4,3", "4,1,2,8,4,1"):
+        if force is None:
+            monkeypatch.delenv("AMS_XDS_FORCE", raising=False)
+        else:
+            monkeypatch.setenv("AMS_XDS_FORCE", force)
+        y = torch.full((B, H, W, Cexp), np.nan, device=DEV)
+        hip.check(lib.ams_k_expand_dw_stream(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), rate, PD(sd), PD(hd), P(y),
+                                             P(panels), panels.numel(), parts, stream()))
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), force
+        assert rel_err(got, ref) < (5e-5 if parts == 2 else 2e-5), force
+        if unfused is not None:
+            assert np.array_equal(got, unfused), force
+
+
 @pytest.mark.parametrize("H,W,C_,N,rate,res", [(33, 65, 384, 64, 1, True), (33, 65, 576, 160, 1, False), (9, 17, 960, 160, 2, True),
                                                 (5, 9, 960, 320, 2, False), (17, 33, 384, 96, 1, False), (4, 16, 64, 16, 1, True)])
 def test_fused_depthwise_project(lib, H, W, C_, N, rate, res):

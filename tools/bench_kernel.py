@@ -11,6 +11,7 @@ from ams_amd import hip  # noqa: E402
 
 M, K, N = (int(v) for v in sys.argv[1:4])
 split = len(sys.argv) > 4
+split3 = split and sys.argv[4] == "split3"
 lib = hip.lib()
 dev = "cuda:0"
 x = torch.randn(M, K, device=dev)
@@ -21,11 +22,13 @@ y = torch.empty(M, N, device=dev)
 P = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 Kp = (K + 31) // 32 * 32
-panels = torch.zeros(2 * N * Kp, dtype=torch.int16, device=dev)
+panels = torch.zeros(3 * N * Kp, dtype=torch.int16, device=dev)
 
 
 def run():
-    if split:
+    if split3:
+        hip.check(lib.ams_k_pointwise_split3(P(x), M, K, P(w), N, P(sc), P(sh), hip.ACT_RELU6, None, P(y), P(panels), panels.numel(), st))
+    elif split:
         hip.check(lib.ams_k_pointwise_split(P(x), M, K, P(w), N, P(sc), P(sh), hip.ACT_RELU6, None, P(y), P(panels), panels.numel(), st))
     else:
         hip.check(lib.ams_k_pointwise(P(x), M, K, P(w), N, 0, None, 1, P(sc), P(sh), hip.ACT_RELU6, None, P(y), st))
@@ -43,4 +46,4 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / n
 nbytes = 4.0 * (M * (K + N) + K * N)
-print("M=%d K=%d N=%d %s: %.1f us  %.0f GB/s  %.1f TFLOP/s" % (M, K, N, "split" if split else "f32", us, nbytes / us / 1e3, 2.0 * M * K * N / us / 1e6))
+print("M=%d K=%d N=%d %s: %.1f us  %.0f GB/s  %.1f TFLOP/s" % (M, K, N, ("split3" if split3 else "split") if split else "f32", us, nbytes / us / 1e3, 2.0 * M * K * N / us / 1e6))

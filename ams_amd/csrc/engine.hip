@@ -93,6 +93,7 @@ struct ams_student {
     float *fparams = nullptr, *fstats = nullptr;      // frozen snapshot
     double* bn_sync = nullptr; size_t bn_sync_doubles = 0;
     float* logits = nullptr;         // [B,h,w,32]
+    uint16_t* xsplit = nullptr; size_t xsplit_plane = 0;         // bf16 parts of a stride-16 block's input (written by the project GEMM before it)
     uint16_t* panel_scratch = nullptr; size_t panel_elems = 0;   // live (training) weights split per launch: hi | lo
     float* dlogits = nullptr;
     float* act[4] = {nullptr, nullptr, nullptr, nullptr};   // inference ping-pong pool
@@ -113,7 +114,8 @@ struct ams_student {
                                                // 60 b128 reads per wave and 32 channels) and slower at B = 1 (45 blocks)
     int fuse_first_block = 1;                  // frozen inference: stem + depthwise + project of the first block in one kernel
     int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
-                                               // in one streaming kernel (k_xdw_stream.hip)
+                                               // in one streaming kernel (k_xdw_stream.hip): 0 never, 1 where measured
+                                               // faster (Cin 64 / 96, >= 16384 rows), 2 also the 160-channel blocks
     int fuse_expand_dw = 1;                    // frozen inference, expand + depthwise in one kernel: 0 never, 1 where it
                                                // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
@@ -192,6 +194,17 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
     s->img_bias = cv.take<float>((size_t)B * aspp_c);
     s->tmp_c = cv.take<float>(4096);
     s->act_elems = (size_t)B * max_elems;
+    {
+        size_t pl = 0;
+        for (int i = 2; i + 1 <= s->n_backbone; ++i) {
+            const LayerRt& l = s->L[i];
+            if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
+                expand_dw_stream_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate) && (size_t)B * l.px_in * l.d.cin > pl)
+                pl = (size_t)B * l.px_in * l.d.cin;
+        }
+        s->xsplit_plane = pl;
+        s->xsplit = pl ? cv.take<uint16_t>(3 * pl) : nullptr;
+    }
     for (int k = 0; k < 4; ++k) s->act[k] = cv.take<float>(s->act_elems);
     // scratch: column-reduction partials, wgrad splits, depthwise wgrad partials
     size_t sc = colstats_scratch(0, (int)max_c) + 1024;
@@ -368,9 +381,13 @@ static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
 }
 
 // frozen 1x1 layer: late layers (few rows, wide K/N: matrix-pipe bound) go through the split-bf16 kernel
-static int frozen_pointwise(ams_student* s, int layer, const PwArgs& a, hipStream_t st) {
+static int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st, bool* wrote_parts = nullptr) {
     const LayerRt& l = s->L[layer];
     const bool split = s->matmul_mode != AMS_MATMUL_F32 && l.whi && split_pays(a);
+    // the bf16 parts of the result (a.ysplit) exist only when the split kernel runs with a vector epilogue
+    const bool parts = split && a.ysplit && pointwise_split_writes_parts(a);
+    if (!parts) a.ysplit = nullptr;
+    if (wrote_parts) *wrote_parts = parts;
     if (split && s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6) RUNK(layer, pw_bytes(a), launch_pointwise_split3(a, l.whi, l.wlo, l.wlo3, l.Kp, st));
     else if (split) RUNK(layer, pw_bytes(a), launch_pointwise_split(a, l.whi, l.wlo, l.Kp, st));
     else RUNK(layer, pw_bytes(a), launch_pointwise(a, st));
@@ -407,6 +424,16 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
         }
     }
     auto other = [&](int avoid0, int avoid1) { for (int k = 0; k < 4; ++k) if (k != avoid0 && k != avoid1) return k; return -1; };
+    // layer k starts a block whose expand + depthwise run as the streaming kernel (stride-16 blocks, split-bf16 modes, a few
+    // frames: below that the launch cannot fill the chip)
+    auto stream_ok = [&](int k) {
+        return s->fuse_expand_dw_stream && s->matmul_mode != AMS_MATMUL_F32 && k + 1 <= s->n_backbone && s->L[k].d.role == AMS_ROLE_EXPAND &&
+               s->L[k + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[k].whi && s->L[k].Kp == s->L[k].d.cin &&
+               (int64_t)B * s->L[k].px_in >= 16384 &&
+               (s->fuse_expand_dw_stream >= 2 || s->L[k].d.cin <= 96) &&      /* 160 -> 960: measured slower than the two kernels in the step */
+               expand_dw_stream_supported(s->L[k].d.cin, s->L[k].d.cout, s->L[k + 1].d.stride, s->L[k + 1].d.rate);
+    };
+    const uint16_t* cur_parts = nullptr;       // `cur` as bf16 parts (s->xsplit), when the GEMM that produced it wrote them
     while (i <= s->n_backbone) {
         // one inverted-residual block: [expand] -> depthwise -> project (+ block input)
         const float* block_in = cur;
@@ -424,10 +451,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             RUNK(i + 1, bytes, launch_expand_dw(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                 P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act, s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
-        } else if (s->fuse_expand_dw_stream && s->matmul_mode != AMS_MATMUL_F32 && s->L[i].d.role == AMS_ROLE_EXPAND &&
-                   i + 1 <= s->n_backbone && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[i].whi && s->L[i].Kp == s->L[i].d.cin &&
-                   (int64_t)B * s->L[i].px_in >= 16384 &&          /* a few frames: below that the launch cannot fill the chip */
-                   expand_dw_stream_supported(s->L[i].d.cin, s->L[i].d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate)) {
+        } else if (stream_ok(i)) {
             // stride-16 blocks: expand + depthwise streamed through an LDS ring, split-bf16 products (bit-identical to the two
             // kernels it replaces); the 6x-expanded tensor is never written
             LayerRt& le = s->L[i];
@@ -435,7 +459,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             const int o = other(cur_i, -1);
             const int np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : 2;
             const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin + ld.px_out * ld.d.cout) + (double)le.d.cin * le.d.cout + 9.0 * ld.d.cin);
-            RUNK(i + 1, bytes, launch_expand_dw_stream(x, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale, le.fshift,
+            const int64_t xplane = (int64_t)B * le.px_in * le.d.cin;
+            RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale, le.fshift,
                                                        le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
                                                        s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
@@ -465,6 +490,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
                 RUNK(i + 1, bytes, launch_dw_project(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, l.fscale, l.fshift, l.d.act, a,
                                                      lpj.whi, lpj.wlo, lpj.Kp, st));
                 cur = s->act[o]; cur_i = o; i += 2;
+                cur_parts = nullptr;
                 continue;
             }
             const int o = other(cur_i, x_i);
@@ -480,7 +506,15 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
             if (l.d.residual_from) { a.res = block_in; a.ldr = l.d.cout; }
-            RUN(frozen_pointwise(s, i, a, st));
+            bool wrote = false;
+            if (stream_ok(i + 1) && s->xsplit && (size_t)a.M * a.N <= s->xsplit_plane && a.N <= 96) {
+                // (not for 160 channels: there the stream kernel is bound by operand traffic, and the parts are 1.5x the f32 bytes)
+                // the next block streams: its expand GEMM takes this result as bf16 parts, written here once instead of being
+                // split by every channel-chunk block there
+                a.ysplit = s->xsplit; a.ysplit_plane = a.M * a.N; a.ysplit_np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : 2;
+            }
+            RUN(frozen_pointwise(s, i, a, st, &wrote));
+            cur_parts = wrote ? s->xsplit : nullptr;
             cur = s->act[o]; cur_i = o; ++i;
         }
     }
@@ -765,7 +799,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
-    if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e) != 0;      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
+    if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     *out = s;
     return AMS_OK;
 }
@@ -919,7 +953,7 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_EXPAND_DW_STREAM) {
-        s->fuse_expand_dw_stream = value != 0;
+        s->fuse_expand_dw_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_EXPAND_DW) {
@@ -1050,7 +1084,7 @@ int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin
 
 int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
                            const float* shift_e, int32_t Cexp, const float* w_dw, int32_t rate, const float* scale_d, const float* shift_d,
-                           float* y, uint16_t* panels, size_t panel_elems, int32_t parts, void* stream) {
+                           float* y, uint16_t* panels, size_t panel_elems, int32_t parts, int32_t presplit, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (!expand_dw_stream_supported(Cin, Cexp, 1, rate) || (parts != 2 && parts != 3)) {
         set_error("expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d parts=%d", Cin, Cexp, rate, parts);
@@ -1059,8 +1093,17 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
     const size_t plane = (size_t)Cexp * Cin;
     AMS_REQUIRE(panels && panel_elems >= 3 * plane, "expand_dw_stream: panel scratch too small (need %zu)", 3 * plane);
     RUN(launch_split_weights3(w_exp, Cexp, 1, Cin, Cexp, Cin, panels, panels + plane, panels + 2 * plane, st));
-    return launch_expand_dw_stream(x, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, rate, scale_d,
-                                   shift_d, AMS_ACT_RELU6, y, st);
+    const uint16_t* xp = nullptr;
+    const size_t xplane = (size_t)B * H * W * Cin;
+    if (presplit) {          // the operand as bf16 parts, as a producing GEMM would leave it (PwArgs::ysplit)
+        AMS_REQUIRE(panel_elems >= 3 * plane + 3 * xplane, "expand_dw_stream: panel scratch too small for the pre-split operand (need %zu)",
+                    3 * plane + 3 * xplane);
+        uint16_t* xq = panels + 3 * plane;
+        RUN(launch_split_weights3(x, 1, Cin, Cin, (int)((int64_t)B * H * W), Cin, xq, xq + xplane, xq + 2 * xplane, st));
+        xp = xq;
+    }
+    return launch_expand_dw_stream(x, xp, (int64_t)xplane, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp,
+                                   w_dw, rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
 }
 
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

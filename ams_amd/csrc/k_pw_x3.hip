@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, ((RM * NT <= 8 && NT * NP <= 15) ? 4 : 3)) voi
         }
     }
     if (EPI == EPI_GENERIC) pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q, sSc, sSh);
-    else pw_epilogue_t<RM, NT, EPI>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)));
+    else pw_epilogue_t<RM, NT, EPI, true>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)));
 }
 
 struct SplitPanels { const uint16_t* base; int64_t plane; int np; };     // part p at base + p * plane
@@ -245,6 +245,8 @@ static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp,
     set_error("pointwise_split: no tile configuration");
     return AMS_E_INVALID;
 }
+
+bool pointwise_split_writes_parts(const PwArgs& a) { return pw_pick_epi(a) != EPI_GENERIC && a.N % 4 == 0; }
 
 // y = epilogue(x @ w) with w given as pre-split bf16 hi/lo panels [N][Kp]; requires K % 8 == 0
 int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {

@@ -23,6 +23,8 @@ namespace ams {
 
 struct XdsArgs {
     const float* x;                  // [B, H, W, Cin]
+    const unsigned short* xs;        // PRE: the same tensor as bf16 parts [part][B*H*W][Cin] (written by the producing GEMM), part p at xs + p * xs_plane
+    int64_t xs_plane;
     int B, H, W, Cin;
     const unsigned short* wp;        // expand weights, bf16 parts [part][Cexp][Kp], part p at wp + p * plane
     int64_t plane;
@@ -47,7 +49,7 @@ struct XdsArgs {
 // Roles: waves [0, NWE) run the E-steps (operand loads, split, MFMAs, BN + ReLU6 into the ring), waves [NWE, NWE + NWD) the
 // D-steps (depthwise from the ring, BN + ReLU6, stores).  D-step t - 1 runs beside E-step t, one barrier per step: the matrix
 // pipe of a SIMD works for an E-wave while its vector pipe works for a D-wave, and neither role carries the other's registers.
-template <int KS, int NT, int NP, int NWE, int NWD>
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a, unsigned nblocks) {
     constexpr int NC = 16 * NT;                      // expanded channels per block
     constexpr int CG = NC / 4;                       // channel groups (float4) of the D-step
@@ -99,21 +101,32 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
             const int Hs = (a.H - sy + rate - 1) / rate, Ws = (a.W - sx + rate - 1) / rate;      // this sub-image
             const int i0 = segy * a.SH, j0 = segx * a.SW;
             const bool live = i0 < Hs && j0 < Ws;                    // a segment past the end of a smaller sub-image: barriers only
-            const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin + 8 * q;
+            // operand source of a pixel: f32 activations (split here) or, PRE, the bf16 parts the producing GEMM wrote beside them
+            const int64_t frame0 = (int64_t)b * a.H * a.W * a.Cin + 8 * q;
             int e_row, e_col;
             { const int e0 = 16 * wave + l15; e_row = e0 / Wp; e_col = e0 - e_row * Wp; }
-            float4 raw[KS][2];
+            float4 raw[PRE ? 1 : KS][2];
+            u32x4 rawp[PRE ? KS : 1][NP];
             bool in_next = false;
-            auto next_pixel = [&]() -> const float* {                // clamped address; `in_next` decides what is kept
+            auto next_pixel = [&]() -> int64_t {                     // clamped element offset; `in_next` decides what is kept
                 const int i = i0 - 1 + e_row, j = j0 - 1 + e_col;
                 in_next = (i >= 0) & (i < Hs) & (j >= 0) & (j < Ws) & (e_row < a.SH + 2) & live;
                 const int ic = i < 0 ? 0 : (i > Hs - 1 ? Hs - 1 : i), jc = j < 0 ? 0 : (j > Ws - 1 ? Ws - 1 : j);
-                return xb + ((int64_t)(sy + rate * ic) * a.W + (sx + rate * jc)) * a.Cin;
+                return frame0 + ((int64_t)(sy + rate * ic) * a.W + (sx + rate * jc)) * a.Cin;
+            };
+            auto load_stage = [&](int64_t off, int s) {
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) rawp[s][pp] = *reinterpret_cast<const u32x4*>(a.xs + pp * a.xs_plane + off + 32 * s);
+                } else {
+                    raw[s][0] = ld4(a.x + off + 32 * s);
+                    raw[s][1] = ld4(a.x + off + 32 * s + 4);
+                }
             };
             {
-                const float* p = next_pixel();
+                const int64_t p = next_pixel();
 #pragma unroll
-                for (int s = 0; s < KS; ++s) { raw[s][0] = ld4(p + 32 * s); raw[s][1] = ld4(p + 32 * s + 4); }
+                for (int s = 0; s < KS; ++s) load_stage(p, s);
             }
             for (int t = 0; t < a.T; ++t) {
                 const bool inside = in_next;
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                 for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 e_row += qS; e_col += rS;
                 if (e_col >= Wp) { e_col -= Wp; ++e_row; }
-                const float* pn = next_pixel();                       // pixel of step t + 1
+                const int64_t pn = next_pixel();                      // pixel of step t + 1
                 // Operands are split stage by stage (12 registers live instead of 12 * KS) and a stage's registers are refilled
                 // with the next step's operands as soon as they are split: those loads have the rest of the step to land.
                 // Products in the order of pw_gemm_bf16x3_l per accumulator; consecutive MFMAs go to different accumulators
@@ -130,10 +143,15 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                 bf16x8 x0, x1, x2;
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    if (NP == 3) split8(raw[s][0], raw[s][1], x0, x1, x2);
-                    else split8(raw[s][0], raw[s][1], x0, x1);
-                    raw[s][0] = ld4(pn + 32 * s);
-                    raw[s][1] = ld4(pn + 32 * s + 4);
+                    if constexpr (PRE) {
+                        x0 = __builtin_bit_cast(bf16x8, rawp[s][0]);
+                        x1 = __builtin_bit_cast(bf16x8, rawp[s][1]);
+                        if (NP == 3) x2 = __builtin_bit_cast(bf16x8, rawp[s][NP - 1]);
+                    } else {
+                        if (NP == 3) split8(raw[s][0], raw[s][1], x0, x1, x2);
+                        else split8(raw[s][0], raw[s][1], x0, x1);
+                    }
+                    load_stage(pn, s);
                     const u32x4* bw = sW + (s * 4 + q) * NC + l15;
                     bf16x8 q0[NT], q1[NT], q2[NT];
 #pragma unroll
@@ -204,6 +222,10 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
             // past the end, which the hardware drops.  No branch around the store, so hipcc counts it exactly.
             const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)b * a.H * a.W * a.Cexp, 0,
                                                                                    (int)((int64_t)a.H * a.W * a.Cexp * 4), 0x00020000);
+            // valid output rows / columns of the item, and the byte offset of centre (row, col) = off0 + row * rowpitch + col * colpitch
+            const int rmax = live ? (a.SH < Hs - i0 ? a.SH : Hs - i0) : 0, cmax = a.SW < Ws - j0 ? a.SW : Ws - j0;
+            const int colpitch = rate * a.Cexp * 4, rowpitch = rate * a.W * a.Cexp * 4;
+            const int off0 = ((sy + rate * (i0 - 1)) * a.W + sx + rate * (j0 - 1)) * a.Cexp * 4 + (int)ych;
             int d_row, d_col;                                        // first centre of this thread at step 0: -Wp - 1 + pt * PX
             { const int c0 = Wp - 1 + pt * PX; d_row = c0 / Wp; d_col = c0 - d_row * Wp; d_row -= 2; }
             __syncthreads();                                          // E-step 0
@@ -238,13 +260,14 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                         float4 o;
                         o.x = apply_act(acc4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(acc4.y * dsc.y + dsh.y, a.act_d);
                         o.z = apply_act(acc4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(acc4.w * dsc.w + dsh.w, a.act_d);
+                        // centre (row, col) of the segment -> frame offset; (row - 1, col - 1) must lie inside the item's valid
+                        // rows x columns (unsigned compare covers the pad row / column 0)
                         int row = d_row, col = d_col + h + u;
 #pragma unroll
                         for (int w = 0; w < (PX + 1) / 2; ++w)            // PX may span several rows of a tiny segment (Wp >= 3)
                             if (col >= Wp) { col -= Wp; ++row; }
-                        const int i = i0 + row - 1, j = j0 + col - 1;
-                        const bool ok = (row >= 1) & (row <= a.SH) & (col >= 1) & (col <= a.SW) & (i < Hs) & (j < Ws) & live;
-                        const unsigned off = ok ? (unsigned)((sy + rate * i) * a.W + (sx + rate * j)) * (unsigned)(a.Cexp * 4) + ych : 0xfffffff0u;
+                        const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
+                        const unsigned off = ok ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
                         const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
                         __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
                     }
@@ -311,9 +334,11 @@ static bool xds_plan_try(int B, int H, int W, int Cin, int Cexp, int rate, int n
 // work items to fill the chip (each costs two halo rows of GEMM work).  AMS_XDS_FORCE = "tiles,row segments,column strips,
 // E-waves,D-waves,blocks per chunk" overrides the choices (0 = automatic); a forced shape that does not fit LDS falls back.
 static bool xds_plan(int B, int H, int W, int Cin, int Cexp, int rate, int np, XdsPlan* p) {
-    int nt = 2, nsy_force = 0, nsx_force = 0, nwe = 4, nwd = 4, groups_force = 0;
+    // measured on MI355X at 32 frames (tools/bench_xds.py): 32-channel chunks and two blocks per CU for Cin 64 / 96; Cin 160 is
+    // bound by the operand re-reads of its 30 chunk blocks (L1 / TA rate), 64-channel chunks halve them
+    int nt = Cin >= 128 ? 4 : 2, nsy_force = 0, nsx_force = 0, nwe = 4, nwd = 4, groups_force = 0;
     if (const char* e = getenv("AMS_XDS_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d", &nt, &nsy_force, &nsx_force, &nwe, &nwd, &groups_force);
-    if (nt != 2 && nt != 4) nt = 2;
+    if (nt != 2 && nt != 4) nt = Cin >= 128 ? 4 : 2;
     if (!((nwe == 4 && (nwd == 2 || nwd == 4)) || (nwe == 8 && nwd == 4))) { nwe = 4; nwd = 4; }
     if (xds_plan_try(B, H, W, Cin, Cexp, rate, np, nt, nwe, nwd, nsy_force, nsx_force, groups_force, p)) return true;
     if (xds_plan_try(B, H, W, Cin, Cexp, rate, np, 2, nwe, nwd, nsy_force, nsx_force, groups_force, p)) return true;
@@ -326,22 +351,27 @@ bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate) {
     return Cexp % 32 == 0;
 }
 
-template <int KS, int NT, int NP, int NWE, int NWD>
-static int launch_xds_k(XdsArgs a, const XdsPlan& p, hipStream_t st) {
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE>
+static int launch_xds_p(XdsArgs a, const XdsPlan& p, hipStream_t st) {
     static size_t attr_lds = 0;
     if (p.lds > 64 * 1024 && p.lds > attr_lds) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)p.lds));
         attr_lds = p.lds;
     }
     const int64_t nblocks = (int64_t)a.groups * a.chunks;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_stream: bad grid");
     static const std::string nm = "xdw_stream_kernel<" + std::to_string(KS) + ", " + std::to_string(NT) + ", " + std::to_string(NP) + ", " +
-                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ">";
+                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
+}
+
+template <int KS, int NT, int NP, int NWE, int NWD>
+static int launch_xds_k(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
+    return a.xs ? launch_xds_p<KS, NT, NP, NWE, NWD, true>(a, p, st) : launch_xds_p<KS, NT, NP, NWE, NWD, false>(a, p, st);
 }
 
 template <int KS, int NT, int NP>
@@ -357,8 +387,11 @@ static int launch_xds_ks(const XdsArgs& a, const XdsPlan& p, int np, hipStream_t
     return np == 3 ? launch_xds_w<KS, 2, 3>(a, p, st) : launch_xds_w<KS, 2, 2>(a, p, st);
 }
 
+// x_parts (optional): x as bf16 parts [part][B*H*W][Cin], x_plane apart, exactly what split8 makes of x (the producing GEMM writes
+// them, PwArgs::ysplit): the E-waves then load their operands ready-made instead of splitting them once per channel chunk.
 // w_parts: the expand layer's bf16 panels [part][Cexp][Cin] (np = 2: hi, lo; np = 3: hi, mid, lo), part p at w_parts + p * plane
-int launch_expand_dw_stream(const float* x, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane, int np,
+int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts,
+                            int64_t plane, int np,
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st) {
     AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && (np == 2 || np == 3), "expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d",
@@ -369,7 +402,7 @@ int launch_expand_dw_stream(const float* x, int B, int H, int W, int Cin, const 
     AMS_REQUIRE(xds_plan(B, H, W, Cin, Cexp, rate, np, &p), "expand_dw_stream: no segment geometry fits LDS (W=%d rate=%d)", W, rate);
     XdsArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.wp = w_parts; a.plane = plane; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e;
+    a.x = x; a.xs = x_parts; a.xs_plane = x_plane; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.wp = w_parts; a.plane = plane; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e;
     a.Cexp = Cexp; a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.y = y; a.rate = rate;
     const int step = 16 * p.nwe;
     a.SH = p.SH; a.SW = p.SW; a.Wp = p.SW + 2; a.T = ((p.SH + 2) * a.Wp + step - 1) / step; a.ring = p.ring;

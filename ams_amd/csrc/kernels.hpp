@@ -23,6 +23,11 @@ struct PwArgs {
     int ldr;
     float* y;              // [M, ldy]
     int ldy;
+    // optional second form of the result (split-bf16 kernel, vector epilogues only): bf16 parts [part][M][N], part p at
+    // ysplit + p * ysplit_plane, ysplit_np = 2 | 3 parts — the operand format of the next block's expand GEMM
+    uint16_t* ysplit;
+    int64_t ysplit_plane;
+    int ysplit_np;
 };
 int launch_pointwise(const PwArgs& a, hipStream_t st);
 bool pointwise_stream_applies(const PwArgs& a);     // the persistent streaming variant (small K x N) can take this problem
@@ -33,6 +38,7 @@ int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t*
 int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* mid, uint16_t* lo,
                           hipStream_t st);
 int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t* wmid, const uint16_t* wlo, int Kp, hipStream_t st);
+bool pointwise_split_writes_parts(const PwArgs& a);      // the split kernels will honour a.ysplit (vector epilogue)
 
 // dw[K,N] = x[M,K]^T @ dy[M,N];  scratch holds the per-split partial products.
 struct WgArgs {
@@ -83,7 +89,8 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
 // ---- k_xdw_stream.hip : the same fusion for the stride-16 blocks (Cin 64 / 96 / 160, stride 1, rate 1 | 2): raster-order
 // streaming through an LDS ring, split-bf16 products from the expand layer's bf16 panels (np = 2 | 3 parts, `plane` apart)
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate);
-int launch_expand_dw_stream(const float* x, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane, int np,
+int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts,
+                            int64_t plane, int np,
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st);
 

@@ -89,7 +89,9 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x4 (&acc)[RM][NT
 // sOut: this wave's buffer, 16 x (16*NT + 4) floats.
 enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_BIAS = 2, EPI_GENERIC = 3 };
 
-template <int RM, int NT, int EPI>
+// SPLIT_OUT (split-bf16 kernel): when a.ysplit is set the finished rows are also written as bf16 parts (hi, mid[, lo] — the
+// successive roundings of split8), so that the next block's expand GEMM loads its operand ready-made.
+template <int RM, int NT, int EPI, bool SPLIT_OUT = false>
 __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][NT], int64_t m_base, int n0, int lane,
                                               const float* sSc, const float* sSh, float* sOut) {
     constexpr int OP = 16 * NT + 4;
@@ -145,6 +147,22 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
             float4 v = ld4(sOut + row * OP + c4);
             if (EPI == EPI_RES) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
             if (m < a.M && n0 + c4 < a.N) st4(a.y + m * a.ldy + n0 + c4, v);
+            if (SPLIT_OUT && a.ysplit && m < a.M && n0 + c4 < a.N) {
+                const float f[4] = {v.x, v.y, v.z, v.w};
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 p0, p1, p2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const __bf16 h = (__bf16)f[j];
+                    const float r1 = f[j] - (float)h;
+                    const __bf16 md = (__bf16)r1;
+                    p0[j] = h; p1[j] = md; p2[j] = (__bf16)(r1 - (float)md);
+                }
+                uint16_t* sp = a.ysplit + m * (int64_t)a.N + n0 + c4;
+                *reinterpret_cast<bf16x4*>(sp) = p0;
+                *reinterpret_cast<bf16x4*>(sp + a.ysplit_plane) = p1;
+                if (a.ysplit_np == 3) *reinterpret_cast<bf16x4*>(sp + 2 * a.ysplit_plane) = p2;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -214,10 +214,10 @@ class StudentEngine:
         measured faster, 2 every supported block."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_EXPAND_DW, int(on)), "ams_student_set_option")
 
-    def set_fuse_expand_dw_stream(self, on: bool) -> None:
-        """Frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks as one streaming kernel (default on;
-        bit-identical to the two kernels it replaces)."""
-        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_EXPAND_DW_STREAM, int(bool(on))), "ams_student_set_option")
+    def set_fuse_expand_dw_stream(self, on: int) -> None:
+        """Frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks as one streaming kernel, bit-identical
+        to the two kernels it replaces: 0 never, 1 (default) where measured faster, 2 every supported block."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_EXPAND_DW_STREAM, int(on)), "ams_student_set_option")
 
     def freeze(self) -> None:
         """Device-side server->edge hand-off (replaces save_to_frozen_graph + reload)."""

@@ -175,9 +175,10 @@ enum { AMS_OPT_FUSE_FIRST_BLOCK = 4 /* frozen inference: 1 (default) stem + dept
                                        kernel, 0 three kernels */,
        AMS_OPT_FUSE_DW_PROJECT = 3 /* frozen inference: 1 = depthwise + project of the stride-16 blocks in one kernel (needs
                                       AMS_MATMUL_SPLIT_BF16), 0 (default) separate kernels: measured no faster */,
-       AMS_OPT_FUSE_EXPAND_DW_STREAM = 5 /* frozen inference, split-bf16 modes: 1 (default) expand + depthwise of the stride-16
-                                            blocks (Cin 64 / 96 / 160) in one streaming kernel, bit-identical to the two
-                                            kernels it replaces; 0 separate kernels */,
+       AMS_OPT_FUSE_EXPAND_DW_STREAM = 5 /* frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks in one
+                                            streaming kernel, bit-identical to the two kernels it replaces: 0 never, 1
+                                            (default) where measured faster (Cin 64 / 96, batches of >= 16384 pixels at
+                                            that stride), 2 every supported block (Cin 160 too) */,
        AMS_OPT_MATMUL = 1, AMS_OPT_FUSE_EXPAND_DW = 2 /* 0 never, 1 (default) blocks where the fused kernel is faster, 2 every supported block */ };
 enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1, AMS_MATMUL_SPLIT_BF16_X6 = 2 };
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value);
@@ -242,10 +243,13 @@ int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin
 
 /* K4+K3 fused, streaming form for the stride-16 blocks (Cin in {64, 96, 160}, stride 1, rate 1|2, Cexp % 32 == 0): the same
  * result as ams_k_pointwise_split (parts = 2) / the three-part split (parts = 3) followed by ams_k_depthwise3x3, bit for bit,
- * without writing the expanded tensor.  panels: scratch of >= 3*Cexp*Cin uint16 (w_exp [Cin,Cexp] is split into it). */
+ * without writing the expanded tensor.  panels: scratch of >= 3*Cexp*Cin uint16 (w_exp [Cin,Cexp] is split into it).
+ * presplit != 0: x is first written as bf16 parts (what the project GEMM of the previous block leaves behind in the engine) and
+ * the kernel loads its operand from them; panels then needs 3*B*H*W*Cin more elements.  Same result, bit for bit. */
 int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
                            const float* shift_e, int32_t Cexp, const float* w_dw, int32_t rate, const float* scale_d,
-                           const float* shift_d, float* y, uint16_t* panels, size_t panel_elems, int32_t parts, void* stream);
+                           const float* shift_d, float* y, uint16_t* panels, size_t panel_elems, int32_t parts, int32_t presplit,
+                           void* stream);
 
 /* K3+K4 fused (frozen inference): y = bn_p(relu6(bn_d(dw3x3(e))) @ w_proj) (+ res) — the depthwise output never reaches
  * HBM; the product uses the two-part bf16 split of ams_k_pointwise_split.  e [B,H,W,C] (C % 32 == 0), w_dw [3,3,C,1],

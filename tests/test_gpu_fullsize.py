@@ -108,15 +108,17 @@ def test_full_size_properties(W0, clip):
     assert np.array_equal(_lowres(eng, B), low)
     # so does the streaming expand+depthwise kernel of the stride-16 blocks (engaged at this batch: 8 x 2145 rows), in the
     # three-part and the two-part split
-    eng.set_fuse_expand_dw_stream(False)
-    eng.predict(frames)
-    assert np.array_equal(_lowres(eng, B), low)
+    for mode in (0, 2):          # never / every supported block (the 160-channel blocks too)
+        eng.set_fuse_expand_dw_stream(mode)
+        eng.predict(frames)
+        assert np.array_equal(_lowres(eng, B), low)
     eng.set_matmul_mode(hip.MATMUL_SPLIT_BF16)
     eng.predict(frames)
     low2 = _lowres(eng, B).copy()
-    eng.set_fuse_expand_dw_stream(True)
+    eng.set_fuse_expand_dw_stream(0)
     eng.predict(frames)
     assert np.array_equal(_lowres(eng, B), low2)
+    eng.set_fuse_expand_dw_stream(1)
     assert not np.array_equal(low2, low)
     eng.set_matmul_mode(hip.MATMUL_SPLIT_BF16_X6)
     # exact-f32 plan vs the default split plan: logits agree at the f32 level

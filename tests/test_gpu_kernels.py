@@ -264,7 +264,7 @@ def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkey
     wd = (rng.standard_normal((3, 3, Cexp, 1)) * 0.4).astype(np.float32)
     se, sd = rng.uniform(0.5, 1.5, Cexp).astype(np.float32), rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
     he, hd = rng.standard_normal(Cexp).astype(np.float32), rng.standard_normal(Cexp).astype(np.float32)
-    panels = torch.zeros(3 * Cexp * Cin, dtype=torch.int16, device=DEV)
+    panels = torch.zeros(3 * Cexp * Cin + 3 * B * H * W * Cin, dtype=torch.int16, device=DEV)
     e = np.clip((x.astype(np.float64) @ we.astype(np.float64)) * se + he, 0, 6)
     et = torch.as_tensor(e).permute(0, 3, 1, 2)
     raw = F.conv2d(F.pad(et, (rate, rate, rate, rate)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), dilation=rate, groups=Cexp)
@@ -284,14 +284,14 @@ def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkey
             monkeypatch.delenv("AMS_XDS_FORCE", raising=False)
         else:
             monkeypatch.setenv("AMS_XDS_FORCE", force)
-        y = torch.full((B, H, W, Cexp), np.nan, device=DEV)
-        hip.check(lib.ams_k_expand_dw_stream(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), rate, PD(sd), PD(hd), P(y),
-                                             P(panels), panels.numel(), parts, stream()))
-        got = y.cpu().numpy()
-        assert np.isfinite(got).all(), force
-        assert rel_err(got, ref) < (5e-5 if parts == 2 else 2e-5), force
-        if unfused is not None:
-            assert np.array_equal(got, unfused), force
+        for pre in (0, 1):       # operand split inside the kernel / loaded as bf16 parts (what the previous block's GEMM writes)
+            y = torch.full((B, H, W, Cexp), np.nan, device=DEV)
+            hip.check(lib.ams_k_expand_dw_stream(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), rate, PD(sd), PD(hd), P(y),
+                                                 P(panels), panels.numel(), parts, pre, stream()))
+            got = y.cpu().numpy()
+            assert np.isfinite(got).all(), (force, pre)
+            assert rel_err(got, ref) < (5e-5 if parts == 2 else 2e-5), (force, pre)
+            assert np.array_equal(got, unfused), (force, pre)
 
 
 @pytest.mark.parametrize("H,W,C_,N,rate,res", [(33, 65, 384, 64, 1, True), (33, 65, 576, 160, 1, False), (9, 17, 960, 160, 2, True),

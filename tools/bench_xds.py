@@ -16,6 +16,7 @@ P = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 H, W = 33, 65
 batches = [int(v) for v in sys.argv[1:]] or [32, 8, 1]
+PRE = int(os.environ.get("XDS_PRE", "1"))
 forces = os.environ.get("XDS_FORCES", "auto;2,1,1;2,2,1;2,4,1;4,1,1;4,2,1;4,4,1").split(";")
 
 
@@ -43,7 +44,7 @@ for B in batches:
         e = torch.empty(M, Cexp, device=dev)
         y0 = torch.empty(B, H, W, Cexp, device=dev)
         y1 = torch.empty(B, H, W, Cexp, device=dev)
-        panels = torch.zeros(3 * Cexp * Cin, dtype=torch.int16, device=dev)
+        panels = torch.zeros(3 * Cexp * Cin + 3 * M * Cin, dtype=torch.int16, device=dev)
         for parts in (3, 2):
             gemm = lib.ams_k_pointwise_split3 if parts == 3 else lib.ams_k_pointwise_split
 
@@ -53,7 +54,7 @@ for B in batches:
 
             def fused():
                 hip.check(lib.ams_k_expand_dw_stream(P(x), B, H, W, Cin, P(we), P(se), P(he), Cexp, P(wd), rate, P(sd), P(hd), P(y1),
-                                                     P(panels), panels.numel(), parts, st))
+                                                     P(panels), panels.numel(), parts, PRE, st))
 
             t0 = timeit(unfused)
             out_mb = M * Cexp * 4 / 1e6

@@ -11,6 +11,7 @@ from ams_amd import hip  # noqa: E402
 
 B, Cin, Cexp, rate, parts = (int(v) for v in sys.argv[1:6])
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+PRE = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 lib = hip.lib()
 dev = "cuda:0"
 P = lambda t: C.c_void_p(t.data_ptr())
@@ -22,9 +23,9 @@ wd = torch.randn(3, 3, Cexp, 1, device=dev) * 0.4
 se, sd = torch.rand(Cexp, device=dev) + 0.5, torch.rand(Cexp, device=dev) + 0.5
 he, hd = torch.randn(Cexp, device=dev), torch.randn(Cexp, device=dev)
 y = torch.empty(B, H, W, Cexp, device=dev)
-panels = torch.zeros(3 * Cexp * Cin, dtype=torch.int16, device=dev)
+panels = torch.zeros(3 * Cexp * Cin + 3 * B * H * W * Cin, dtype=torch.int16, device=dev)
 for _ in range(iters):
     hip.check(lib.ams_k_expand_dw_stream(P(x), B, H, W, Cin, P(we), P(se), P(he), Cexp, P(wd), rate, P(sd), P(hd), P(y), P(panels),
-                                         panels.numel(), parts, st))
+                                         panels.numel(), parts, PRE, st))
 torch.cuda.synchronize()
 print("done")

@@ -61,7 +61,7 @@ int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, 
 // sched_group_barrier) measured slower — per 32 k the MFMAs, the LDS fragment reads and the split VALU work add up to
 // ~the measured time, and the extra registers cost a resident wave per SIMD.
 template <int RM, int NT, int EPI, int D, int NP>
-__global__ __launch_bounds__(256, ((RM * NT <= 8 && NT * NP <= 15) ? 4 : 3)) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
+__global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <= 15) ? 4 : 3)) void pw_gemm_bf16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane,
                                                         int Kp, int n_tiles_n, unsigned nblocks) {
     constexpr int PITCH = 40;                        // bf16 elements per LDS row: 80 B, conflict-free for ds_read_b128
     constexpr int ROWS = 16 * NT;
@@ -236,9 +236,17 @@ static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp,
     AMS_REQUIRE(a.K % 8 == 0 && a.ldx % 4 == 0, "pointwise_split: K (%d) must be a multiple of 8", a.K);
     int rm, nt;
     pw_pick_tile(a.M, a.N, &rm, &nt);
+    // second sweep for this kernel (tools/sweep_pwx.sh, three-part split, 68640 rows): a 96-wide tile covers the 96-column layers
+    // in one pass over the operand (+10 %), 160-wide tiles the 320-column layer in two (+8 %), 960 columns run best as ten
+    // 96-wide tiles (+8 %).  Only with two row groups per wave (many rows): the one-row-group variants keep the narrow tiles.
+    if (rm == 2) {
+        if (a.N == 96 || a.N == 960) nt = 6;
+        else if (a.N == 320) nt = 10;
+    }
     if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &rm, &nt);       // tuning knob
 #define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, w, Kp, st);
     PW_X(4, 4) PW_X(4, 3) PW_X(4, 5)
+    PW_X(2, 10) PW_X(2, 8)
     PW_X(2, 6) PW_X(2, 5) PW_X(2, 4) PW_X(2, 3) PW_X(2, 2) PW_X(2, 1)
     PW_X(1, 6) PW_X(1, 5) PW_X(1, 4) PW_X(1, 3) PW_X(1, 2) PW_X(1, 1)
 #undef PW_X

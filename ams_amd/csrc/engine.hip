@@ -430,7 +430,6 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
         return s->fuse_expand_dw_stream && s->matmul_mode != AMS_MATMUL_F32 && k + 1 <= s->n_backbone && s->L[k].d.role == AMS_ROLE_EXPAND &&
                s->L[k + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[k].whi && s->L[k].Kp == s->L[k].d.cin &&
                (int64_t)B * s->L[k].px_in >= 16384 &&
-               (s->fuse_expand_dw_stream >= 2 || s->L[k].d.cin <= 96) &&      /* 160 -> 960: measured slower than the two kernels in the step */
                expand_dw_stream_supported(s->L[k].d.cin, s->L[k].d.cout, s->L[k + 1].d.stride, s->L[k + 1].d.rate);
     };
     const uint16_t* cur_parts = nullptr;       // `cur` as bf16 parts (s->xsplit), when the GEMM that produced it wrote them
@@ -451,7 +450,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             RUNK(i + 1, bytes, launch_expand_dw(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                 P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act, s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
-        } else if (stream_ok(i)) {
+        } else if (stream_ok(i) && (s->L[i].d.cin <= 96 || cur_parts || s->fuse_expand_dw_stream >= 2)) {
             // stride-16 blocks: expand + depthwise streamed through an LDS ring, split-bf16 products (bit-identical to the two
             // kernels it replaces); the 6x-expanded tensor is never written
             LayerRt& le = s->L[i];
@@ -460,9 +459,16 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             const int np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : 2;
             const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin + ld.px_out * ld.d.cout) + (double)le.d.cin * le.d.cout + 9.0 * ld.d.cin);
             const int64_t xplane = (int64_t)B * le.px_in * le.d.cin;
-            RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale, le.fshift,
-                                                       le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
-                                                       s->act[o], st));
+            if (le.d.cin > 96 && cur_parts)
+                // 160 -> 960: expand weights in registers, the operand staged once per block in LDS (k_xdw_wreg.hip); with 30 channel
+                // chunks the LDS-weight form is bound by its passes over the operand
+                RUNK(i + 1, bytes, launch_expand_dw_wreg(cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale,
+                                                         le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
+                                                         s->act[o], st));
+            else
+                RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale,
+                                                           le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
+                                                           s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
         } else {
         if (s->L[i].d.role == AMS_ROLE_EXPAND) {
@@ -507,8 +513,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
             if (l.d.residual_from) { a.res = block_in; a.ldr = l.d.cout; }
             bool wrote = false;
-            if (stream_ok(i + 1) && s->xsplit && (size_t)a.M * a.N <= s->xsplit_plane && a.N <= 96) {
-                // (not for 160 channels: there the stream kernel is bound by operand traffic, and the parts are 1.5x the f32 bytes)
+            if (stream_ok(i + 1) && s->xsplit && (size_t)a.M * a.N <= s->xsplit_plane) {
                 // the next block streams: its expand GEMM takes this result as bf16 parts, written here once instead of being
                 // split by every channel-chunk block there
                 a.ysplit = s->xsplit; a.ysplit_plane = a.M * a.N; a.ysplit_np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : 2;
@@ -1102,6 +1107,9 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
         RUN(launch_split_weights3(x, 1, Cin, Cin, (int)((int64_t)B * H * W), Cin, xq, xq + xplane, xq + 2 * xplane, st));
         xp = xq;
     }
+    if (presplit == 2)       // the weight-register form (k_xdw_wreg.hip)
+        return launch_expand_dw_wreg(xp, (int64_t)xplane, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw,
+                                     rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
     return launch_expand_dw_stream(x, xp, (int64_t)xplane, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp,
                                    w_dw, rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
 }

@@ -94,6 +94,11 @@ int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_p
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st);
 
+// ---- k_xdw_wreg.hip : the streaming fusion with the expand weights in registers and the operand staged in LDS (160 -> 960)
+int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane,
+                          int np, const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
+                          const float* sh_d, int act_d, float* y, hipStream_t st);
+
 // ---- k_elementwise.hip : BN pieces, pooling, reductions, Adam ------------------------------------------
 // per-image column reductions; scratch >= image_colsum_scratch(B, C) floats
 size_t image_colsum_scratch(int B, int C);

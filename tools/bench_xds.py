@@ -72,4 +72,14 @@ for B in batches:
                 same = bool(torch.equal(y0, y1))
                 line += " %s: %6.1f us (%.2f TB/s out)%s |" % (f, t1, out_mb / t1, "" if same else " MISMATCH")
             os.environ.pop("AMS_XDS_FORCE", None)
+            for wf in os.environ.get("XWR_FORCES", "4,1,1,0;8,1,1,0;4,1,1,32;8,1,1,64;4,2,1,0").split(";"):      # the weight-register form
+                os.environ["AMS_XWR_FORCE"] = wf
+                keep, PRE = PRE, 2
+                try:
+                    t1 = timeit(fused)
+                    line += " wreg %s: %6.1f us%s |" % (wf, t1, "" if bool(torch.equal(y0, y1)) else " MISMATCH")
+                except hip.AmsHipError as e:
+                    line += " wreg %s: n/a |" % wf
+                PRE = keep
+            os.environ.pop("AMS_XWR_FORCE", None)
             print(line, flush=True)

@@ -9,7 +9,7 @@
 //   * the operand of a 16-pixel step (bf16 parts written by the previous block's project GEMM, PwArgs::ysplit) is staged ONCE
 //     per block in LDS by the E-waves (two 16-byte pieces per thread, double-buffered) and read by all of them: the input is
 //     read 960 / (32 * NWE) times instead of 30;
-//   * raster-order steps of 16 pixels, LDS ring of the expanded values, D-waves one step behind, one barrier per step — as in
+//   * raster-order steps of 16 or 32 pixels (one or two MFMA row groups per E-wave: two give four accumulator chains), LDS ring of the expanded values, D-waves one step behind, one barrier per step — as in
 //     k_xdw_stream.hip (same products in the same order, same depthwise order: bit-identical to it and to the unfused pair).
 #include "pw_common.hpp"
 #include "split_bf16.hpp"
@@ -36,21 +36,22 @@ struct XwrArgs {
     int items, groups;               // work items per channel group; blocks per channel group
 };
 
-template <int KS, int NP, int NWE, int NWD>
+template <int KS, int NP, int NWE, int NWD, int NRG>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, unsigned nblocks) {
-    constexpr int STEP = 16;
+    constexpr int STEP = 16 * NRG;                   // pixels per step: NRG MFMA row groups per E-wave (2 * NRG accumulator chains)
     constexpr int NCB = 32 * NWE;                    // channels per block
     constexpr int CG = NCB / 4;                      // channel groups (float4) of the D-step
     constexpr int NDT = 64 * NWD;                    // D-threads
-    static_assert(NDT % CG == 0 && (STEP * CG) % NDT == 0, "D-step mapping");
-    constexpr int NPT = NDT / CG;                    // D-threads per channel group = centres handled at once
-    constexpr int NIT = STEP / NPT;                  // centres per D-thread per step (pt, pt + NPT, ...)
+    constexpr int PX = STEP * CG / NDT;              // consecutive centres per D-thread, taken two at a time
+    static_assert(PX * NDT == STEP * CG && NDT % CG == 0 && (PX == 1 || PX % 2 == 0), "D-step mapping");
+    constexpr int PH = PX >= 2 ? 2 : 1;
     constexpr int PITCH = NCB + 4;
-    constexpr int MIRROR = 2;                        // a run of 3 taps may pass the end of the ring by 2 slots
+    constexpr int MIRROR = 4;                        // a run of PH + 2 taps may pass the end of the ring by PH + 1 slots
     constexpr int Kp = KS * 32;
-    constexpr int AUNITS = NP * KS * 4 * 16;         // 16-byte units of one operand tile: [part][s][q][pixel]
-    constexpr int PPP = NP * KS * 4;                 // pieces per pixel
-    constexpr int LPT = (PPP + 4 * NWE - 1) / (4 * NWE);     // pieces per loader thread (4 * NWE threads share a pixel)
+    constexpr int PPP = NP * KS * 4;                 // 16-byte pieces of a pixel's operand: [part][s][q]
+    constexpr int AUNITS = NRG * PPP * 16;           // 16-byte units of one operand tile: [rg][part][s][q][pixel]
+    constexpr int TPP = 4 * NWE / NRG;               // loader threads per pixel
+    constexpr int LPT = (PPP + TPP - 1) / TPP;       // pieces per loader thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* sA = reinterpret_cast<u32x4*>(smem);                      // [2][AUNITS]
     float* ring = reinterpret_cast<float*>(smem + 2 * AUNITS * 16);  // [ring + MIRROR][PITCH]
@@ -82,8 +83,20 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) { esc[tt] = ld4(a.sc_e + n0c + 16 * tt + 4 * q); esh[tt] = ld4(a.sh_e + n0c + 16 * tt + 4 * q); }
         const int ring_lane = l15 * PITCH + 32 * wave + 4 * q;
-        // loader duty: pixel l15 of a step is shared by the 4 * NWE threads (wave, q); piece j = part * KS * 4 + s * 4 + qq
-        const int lj = wave * 4 + q;
+        // loader duty: pixel (lrg, l15) of a step is shared by TPP threads; thread lj of them takes pieces lj, lj + TPP, ...
+        // (piece j = part * KS * 4 + s * 4 + qq).  Source offsets (elements, relative to the pixel) and LDS slots are fixed.
+        const int lrg = NRG == 2 ? (q & 1) : 0;
+        const int lj = NRG == 2 ? wave * 2 + (q >> 1) : wave * 4 + q;
+        int64_t psrc[LPT];
+        int pdst[LPT];
+#pragma unroll
+        for (int k = 0; k < LPT; ++k) {
+            int j = lj + k * TPP;
+            if (j > PPP - 1) j = PPP - 1;                            // surplus threads repeat the last piece
+            const int part = j / (KS * 4), u = j - part * (KS * 4);
+            psrc[k] = part * a.xs_plane + 8 * u;
+            pdst[k] = (lrg * PPP + j) * 16 + l15;
+        }
         int sbase = 0;
         int par = 0;                                                 // operand buffer of the current step
         for (int item = group; item < a.items; item += a.groups) {
@@ -96,79 +109,86 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
             const int Hs = (a.H - sy + rate - 1) / rate, Ws = (a.W - sx + rate - 1) / rate;
             const int i0 = segy * a.SH, j0 = segx * a.SW;
             const bool live = i0 < Hs && j0 < Ws;
-            const int64_t frame0 = (int64_t)b * a.H * a.W * a.Cin;
-            int e_row = l15 / Wp, e_col = l15 - e_row * Wp;          // pixel l15 of step 0
-            bool in_next = false;
-            auto next_pixel = [&]() -> int64_t {                     // clamped element offset of the walker's pixel
-                const int i = i0 - 1 + e_row, j = j0 - 1 + e_col;
-                in_next = (i >= 0) & (i < Hs) & (j >= 0) & (j < Ws) & (e_row < a.SH + 2) & live;
+            const unsigned short* xf = a.xs + (int64_t)b * a.H * a.W * a.Cin;
+            // walkers: pixel l15 + 16 * rg of the step; both advance by STEP a step
+            int e_row[NRG], e_col[NRG];
+#pragma unroll
+            for (int rg = 0; rg < NRG; ++rg) { const int e0 = l15 + 16 * rg; e_row[rg] = e0 / Wp; e_col[rg] = e0 - e_row[rg] * Wp; }
+            bool in_cur[NRG];
+            auto inside_of = [&](int rg) {
+                const int i = i0 - 1 + e_row[rg], j = j0 - 1 + e_col[rg];
+                return (bool)((i >= 0) & (i < Hs) & (j >= 0) & (j < Ws) & (e_row[rg] < a.SH + 2) & live);
+            };
+            auto loader_pixel = [&]() -> const unsigned short* {     // clamped address of this thread's loader pixel
+                const int er = NRG == 2 ? (lrg ? e_row[NRG - 1] : e_row[0]) : e_row[0], ec = NRG == 2 ? (lrg ? e_col[NRG - 1] : e_col[0]) : e_col[0];
+                const int i = i0 - 1 + er, j = j0 - 1 + ec;
                 const int ic = i < 0 ? 0 : (i > Hs - 1 ? Hs - 1 : i), jc = j < 0 ? 0 : (j > Ws - 1 ? Ws - 1 : j);
-                return frame0 + ((int64_t)(sy + rate * ic) * a.W + (sx + rate * jc)) * a.Cin;
+                return xf + ((int64_t)(sy + rate * ic) * a.W + (sx + rate * jc)) * a.Cin;
             };
             u32x4 piece[LPT];
-            auto load_pieces = [&](int64_t off) {
+            auto load_pieces = [&](const unsigned short* px) {
 #pragma unroll
-                for (int k = 0; k < LPT; ++k) {
-                    int j = lj + k * 4 * NWE;
-                    if (j > PPP - 1) j = PPP - 1;                    // surplus threads repeat the last piece
-                    const int part = j / (KS * 4), u = j - part * (KS * 4);
-                    piece[k] = *reinterpret_cast<const u32x4*>(a.xs + part * a.xs_plane + off + 8 * u);
-                }
+                for (int k = 0; k < LPT; ++k) piece[k] = *reinterpret_cast<const u32x4*>(px + psrc[k]);
             };
             auto store_pieces = [&](int buf) {
 #pragma unroll
-                for (int k = 0; k < LPT; ++k) {
-                    int j = lj + k * 4 * NWE;
-                    if (j > PPP - 1) j = PPP - 1;
-                    sA[buf * AUNITS + j * 16 + l15] = piece[k];
-                }
+                for (int k = 0; k < LPT; ++k) sA[buf * AUNITS + pdst[k]] = piece[k];
             };
             // prologue of the item: operand tile of step 0
-            load_pieces(next_pixel());
+            load_pieces(loader_pixel());
             store_pieces(par);
             __syncthreads();                                          // (A) tile 0 visible; pairs with the D-waves' first barrier
             for (int t = 0; t < a.T; ++t) {
-                const bool inside = in_next;
-                e_row += qS; e_col += rS;
-                if (e_col >= Wp) { e_col -= Wp; ++e_row; }
-                load_pieces(next_pixel());                            // tile of step t + 1: lands during the MFMAs
-                f32x4 acc[2];
-                acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rg = 0; rg < NRG; ++rg) {
+                    in_cur[rg] = inside_of(rg);
+                    e_row[rg] += qS; e_col[rg] += rS;
+                    if (e_col[rg] >= Wp) { e_col[rg] -= Wp; ++e_row[rg]; }
+                }
+                load_pieces(loader_pixel());                          // tile of step t + 1: lands during the MFMAs
+                f32x4 acc[NRG][2];
+#pragma unroll
+                for (int rg = 0; rg < NRG; ++rg) { acc[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
                 if (active) {
                     const u32x4* ap = sA + par * AUNITS + q * 16 + l15;
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
-                        const bf16x8 x0 = __builtin_bit_cast(bf16x8, ap[(0 * KS + s) * 64]);
-                        const bf16x8 x1 = __builtin_bit_cast(bf16x8, ap[(1 * KS + s) * 64]);
-                        if (NP == 3) {                                // smallest terms first, chains alternate
-                            const bf16x8 x2 = __builtin_bit_cast(bf16x8, ap[((NP - 1) * KS + s) * 64]);
+                        bf16x8 x0[NRG], x1[NRG], x2[NRG];
 #pragma unroll
-                            for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[NP - 1][s][tt], x0, acc[tt], 0, 0, 0);
-#pragma unroll
-                            for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][s][tt], x2, acc[tt], 0, 0, 0);
-#pragma unroll
-                            for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[1][s][tt], x1, acc[tt], 0, 0, 0);
+                        for (int rg = 0; rg < NRG; ++rg) {
+                            x0[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + 0) * KS + s) * 64]);
+                            x1[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + 1) * KS + s) * 64]);
+                            if (NP == 3) x2[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + NP - 1) * KS + s) * 64]);
                         }
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[1][s][tt], x0, acc[tt], 0, 0, 0);
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][s][tt], x1, acc[tt], 0, 0, 0);
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0][s][tt], x0, acc[tt], 0, 0, 0);
+                        // per accumulator the products of pw_gemm_bf16x3_l in its order (smallest terms first); consecutive MFMAs
+                        // go to different accumulators
+#define AMS_XWR_TERM(WP, XB)                                                                                         \
+    _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg)                                                               \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                             \
+            acc[rg][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[WP][s][tt], XB[rg], acc[rg][tt], 0, 0, 0);
+                        if (NP == 3) {
+                            AMS_XWR_TERM(NP - 1, x0)
+                            AMS_XWR_TERM(0, x2)
+                            AMS_XWR_TERM(1, x1)
+                        }
+                        AMS_XWR_TERM(1, x0)
+                        AMS_XWR_TERM(0, x1)
+                        AMS_XWR_TERM(0, x0)
+#undef AMS_XWR_TERM
                     }
                 }
-                {
-                    const unsigned keep = inside ? 0xffffffffu : 0u;
-                    float* dst = ring + sbase * PITCH + ring_lane;
-                    const bool mirror = sbase == 0 && l15 < MIRROR;
+#pragma unroll
+                for (int rg = 0; rg < NRG; ++rg) {
+                    const unsigned keep = in_cur[rg] ? 0xffffffffu : 0u;
+                    float* dst = ring + (sbase + 16 * rg) * PITCH + ring_lane;
+                    const bool mirror = sbase == 0 && rg == 0 && l15 < MIRROR;
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         float4 v;
-                        v.x = __uint_as_float(__float_as_uint(apply_act(acc[tt][0] * esc[tt].x + esh[tt].x, a.act_e)) & keep);
-                        v.y = __uint_as_float(__float_as_uint(apply_act(acc[tt][1] * esc[tt].y + esh[tt].y, a.act_e)) & keep);
-                        v.z = __uint_as_float(__float_as_uint(apply_act(acc[tt][2] * esc[tt].z + esh[tt].z, a.act_e)) & keep);
-                        v.w = __uint_as_float(__float_as_uint(apply_act(acc[tt][3] * esc[tt].w + esh[tt].w, a.act_e)) & keep);
+                        v.x = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][0] * esc[tt].x + esh[tt].x, a.act_e)) & keep);
+                        v.y = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][1] * esc[tt].y + esh[tt].y, a.act_e)) & keep);
+                        v.z = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][2] * esc[tt].z + esh[tt].z, a.act_e)) & keep);
+                        v.w = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][3] * esc[tt].w + esh[tt].w, a.act_e)) & keep);
                         st4(dst + 16 * tt, v);
                         if (mirror) st4(dst + R * PITCH + 16 * tt, v);
                     }
@@ -194,9 +214,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
         for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + nchc);
         const float4 dsc = ld4(a.sc_d + nchc), dsh = ld4(a.sh_d + nchc);
         const unsigned ych = (unsigned)nchc * 4u;
-        int cb[NIT];                                                 // ring slot of the first tap of each centre, carried across items
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) cb[k] = (2 * R - 2 * Wp - 2 + pt + k * NPT) % R;
+        int cb = (2 * R - 2 * Wp - 2 + pt * PX) % R;                 // ring slot of the thread's first tap, carried across items
         for (int item = group; item < a.items; item += a.groups) {
             int u1 = item;
             const int segx = u1 % a.nsx; u1 /= a.nsx;
@@ -212,49 +230,51 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
             const int rmax = live ? (a.SH < Hs - i0 ? a.SH : Hs - i0) : 0, cmax = a.SW < Ws - j0 ? a.SW : Ws - j0;
             const int colpitch = rate * a.Cexp * 4, rowpitch = rate * a.W * a.Cexp * 4;
             const int off0 = ((sy + rate * (i0 - 1)) * a.W + sx + rate * (j0 - 1)) * a.Cexp * 4 + (int)ych;
-            int d_row[NIT], d_col[NIT];                              // centre k at step 0: -Wp - 1 + pt + k * NPT
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int c0 = Wp - 1 + pt + k * NPT;
-                d_row[k] = c0 / Wp; d_col[k] = c0 - d_row[k] * Wp; d_row[k] -= 2;
-            }
+            int d_row, d_col;                                        // first centre of this thread at step 0: -Wp - 1 + pt * PX
+            { const int c0 = Wp - 1 + pt * PX; d_row = c0 / Wp; d_col = c0 - d_row * Wp; d_row -= 2; }
             __syncthreads();                                          // (A)
             __syncthreads();                                          // E-step 0
             for (int t = 0; t < a.T; ++t) {
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    float4 v[3][3];
+                for (int h = 0; h < PX; h += 2) {                     // two centres at a time: 12 taps live
+                    float4 v[3][PH + 2];
 #pragma unroll
                     for (int di = 0; di < 3; ++di) {
-                        unsigned slot = (unsigned)(cb[k] + di * Wp);
+                        unsigned slot = (unsigned)(cb + di * Wp + h);
                         slot = slot < (unsigned)R ? slot : slot - (unsigned)R;
                         const float* rp = ring + __umul24(slot, PITCH) + 4 * cg;
 #pragma unroll
-                        for (int jj = 0; jj < 3; ++jj) v[di][jj] = ld4(rp + jj * PITCH);
+                        for (int jj = 0; jj < PH + 2; ++jj) v[di][jj] = ld4(rp + jj * PITCH);
                     }
-                    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                    for (int u = 0; u < PH; ++u) {
+                        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const float4 vv = v[i][j];
-                            const float4 w4 = wv[i * 3 + j];
-                            acc4.x = fmaf(vv.x, w4.x, acc4.x); acc4.y = fmaf(vv.y, w4.y, acc4.y);
-                            acc4.z = fmaf(vv.z, w4.z, acc4.z); acc4.w = fmaf(vv.w, w4.w, acc4.w);
-                        }
-                    float4 o;
-                    o.x = apply_act(acc4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(acc4.y * dsc.y + dsh.y, a.act_d);
-                    o.z = apply_act(acc4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(acc4.w * dsc.w + dsh.w, a.act_d);
-                    const int row = d_row[k], col = d_col[k];
-                    const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
-                    const unsigned off = ok ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
-                    const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
-                    d_row[k] += qS; d_col[k] += rS;
-                    if (d_col[k] >= Wp) { d_col[k] -= Wp; ++d_row[k]; }
-                    cb[k] += STEP;
-                    if (cb[k] >= R) cb[k] -= R;
+                        for (int i = 0; i < 3; ++i)
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                const float4 vv = v[i][u + j];
+                                const float4 w4 = wv[i * 3 + j];
+                                acc4.x = fmaf(vv.x, w4.x, acc4.x); acc4.y = fmaf(vv.y, w4.y, acc4.y);
+                                acc4.z = fmaf(vv.z, w4.z, acc4.z); acc4.w = fmaf(vv.w, w4.w, acc4.w);
+                            }
+                        float4 o;
+                        o.x = apply_act(acc4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(acc4.y * dsc.y + dsh.y, a.act_d);
+                        o.z = apply_act(acc4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(acc4.w * dsc.w + dsh.w, a.act_d);
+                        int row = d_row, col = d_col + h + u;
+#pragma unroll
+                        for (int w = 0; w < (PX + 1) / 2; ++w)            // PX may span several rows of a tiny segment (Wp >= 3)
+                            if (col >= Wp) { col -= Wp; ++row; }
+                        const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
+                        const unsigned off = ok ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
+                        const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                    }
                 }
+                d_row += qS; d_col += rS;
+                if (d_col >= Wp) { d_col -= Wp; ++d_row; }
+                cb += STEP;
+                if (cb >= R) cb -= R;
                 __syncthreads();
             }
         }
@@ -262,35 +282,36 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
-static size_t xwr_lds(int Kp, int np, int nwe, int ring) {
-    return (size_t)2 * np * (Kp / 8) * 16 * 16 + (size_t)(ring + 2) * (32 * nwe + 4) * 4;
+static size_t xwr_lds(int Kp, int np, int nwe, int nrg, int ring) {
+    return (size_t)2 * nrg * np * (Kp / 8) * 16 * 16 + (size_t)(ring + 4) * (32 * nwe + 4) * 4;
 }
 
-template <int KS, int NP, int NWE, int NWD>
+template <int KS, int NP, int NWE, int NWD, int NRG>
 static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
     static size_t attr_lds = 0;
     if (lds > 64 * 1024 && lds > attr_lds) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");
     static const std::string nm = "xdw_wreg_kernel<" + std::to_string(KS) + ", " + std::to_string(NP) + ", " + std::to_string(NWE) + ", " +
-                                  std::to_string(NWD) + ">";
+                                  std::to_string(NWD) + ", " + std::to_string(NRG) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
 
 template <int KS, int NP>
-static int launch_xwr_w(const XwrArgs& a, int nwe, size_t lds, hipStream_t st) {
-    if (nwe == 8) return launch_xwr_k<KS, NP, 8, 4>(a, lds, st);
-    return launch_xwr_k<KS, NP, 4, 4>(a, lds, st);
+static int launch_xwr_w(const XwrArgs& a, int nwe, int nrg, size_t lds, hipStream_t st) {
+    if (nwe == 8) return launch_xwr_k<KS, NP, 8, 4, 1>(a, lds, st);
+    if (nrg == 2) return launch_xwr_k<KS, NP, 4, 4, 2>(a, lds, st);
+    return launch_xwr_k<KS, NP, 4, 4, 1>(a, lds, st);
 }
 
 // the weight-register form; x_parts is required (bf16 parts of the input, np of them).  AMS_XWR_FORCE = "E-waves (4|8),row
-// segments,column strips,blocks per channel group" (0 = automatic).
+// segments,column strips,blocks per channel group,row groups per E-wave and step (1|2; 2 only with 4 E-waves)" (0 = automatic).
 int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane,
                           int np, const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                           const float* sh_d, int act_d, float* y, hipStream_t st) {
@@ -298,18 +319,21 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
                 Cin, Cexp, rate);
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_wreg: empty input");
     AMS_REQUIRE((int64_t)H * W * Cexp * 4 < 0x7fffffffLL, "expand_dw_wreg: a frame of the output exceeds 2 GiB");
-    int nwe = 4, nsy_force = 0, nsx_force = 0, groups_force = 0;
-    if (const char* e = getenv("AMS_XWR_FORCE")) sscanf(e, "%d,%d,%d,%d", &nwe, &nsy_force, &nsx_force, &groups_force);
+    int nwe = 4, nsy_force = 0, nsx_force = 0, groups_force = 0, nrg = 2;
+    if (const char* e = getenv("AMS_XWR_FORCE")) sscanf(e, "%d,%d,%d,%d,%d", &nwe, &nsy_force, &nsx_force, &groups_force, &nrg);
     if (nwe != 4 && nwe != 8) nwe = 4;
+    if (nrg != 1 && nrg != 2) nrg = 2;
+    if (nwe == 8) nrg = 1;
+    const int step = 16 * nrg;
     const int Hs = (H + rate - 1) / rate, Ws = (W + rate - 1) / rate;
     const size_t budget = 160 * 1024 - 512;
     int nsx = nsx_force > 0 ? nsx_force : 1, SW, ring;
     for (;; ++nsx) {
         SW = (Ws + nsx - 1) / nsx;
-        ring = (2 * (SW + 2) + 2 + 2 * 16 + 15) / 16 * 16;
-        if (xwr_lds(Cin, np, nwe, ring) <= budget || SW <= 1) break;
+        ring = (2 * (SW + 2) + 2 + 2 * step + step - 1) / step * step;
+        if (xwr_lds(Cin, np, nwe, nrg, ring) <= budget || SW <= 1) break;
     }
-    AMS_REQUIRE(xwr_lds(Cin, np, nwe, ring) <= budget, "expand_dw_wreg: no segment geometry fits LDS (W=%d rate=%d)", W, rate);
+    AMS_REQUIRE(xwr_lds(Cin, np, nwe, nrg, ring) <= budget, "expand_dw_wreg: no segment geometry fits LDS (W=%d rate=%d)", W, rate);
     nsx = (Ws + SW - 1) / SW;
     const int cgroups = (Cexp + 32 * nwe - 1) / (32 * nwe);
     int nsy = 1;
@@ -320,17 +344,17 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     memset(&a, 0, sizeof(a));
     a.xs = x_parts; a.xs_plane = x_plane; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.wp = w_parts; a.plane = plane; a.sc_e = sc_e; a.sh_e = sh_e;
     a.act_e = act_e; a.Cexp = Cexp; a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.y = y; a.rate = rate;
-    a.SH = (Hs + nsy - 1) / nsy; a.SW = SW; a.Wp = SW + 2; a.T = ((a.SH + 2) * a.Wp + 15) / 16; a.ring = ring;
+    a.SH = (Hs + nsy - 1) / nsy; a.SW = SW; a.Wp = SW + 2; a.T = ((a.SH + 2) * a.Wp + step - 1) / step; a.ring = ring;
     a.nsy = nsy; a.nsx = nsx; a.cgroups = cgroups;
     a.items = B * rate * rate * nsy * nsx;
     int64_t groups = groups_force > 0 ? groups_force : (512 + cgroups - 1) / cgroups;      // one block per CU (LDS), twice over
     if (groups > a.items) groups = a.items;
     a.groups = (int)groups;
-    const size_t lds = xwr_lds(Cin, np, nwe, ring);
+    const size_t lds = xwr_lds(Cin, np, nwe, nrg, ring);
     switch (Cin / 32) {
-        case 2: return np == 3 ? launch_xwr_w<2, 3>(a, nwe, lds, st) : launch_xwr_w<2, 2>(a, nwe, lds, st);
-        case 3: return np == 3 ? launch_xwr_w<3, 3>(a, nwe, lds, st) : launch_xwr_w<3, 2>(a, nwe, lds, st);
-        default: return np == 3 ? launch_xwr_w<5, 3>(a, nwe, lds, st) : launch_xwr_w<5, 2>(a, nwe, lds, st);
+        case 2: return np == 3 ? launch_xwr_w<2, 3>(a, nwe, nrg, lds, st) : launch_xwr_w<2, 2>(a, nwe, nrg, lds, st);
+        case 3: return np == 3 ? launch_xwr_w<3, 3>(a, nwe, nrg, lds, st) : launch_xwr_w<3, 2>(a, nwe, nrg, lds, st);
+        default: return np == 3 ? launch_xwr_w<5, 3>(a, nwe, nrg, lds, st) : launch_xwr_w<5, 2>(a, nwe, nrg, lds, st);
     }
 }
 

@@ -285,8 +285,9 @@ def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkey
         else:
             monkeypatch.setenv("AMS_XDS_FORCE", force)
         # operand split inside the kernel / loaded as bf16 parts (what the previous block's GEMM writes) / the weight-register
-        # form of the kernel (k_xdw_wreg.hip: AMS_XWR_FORCE = E-waves, row segments, column strips, blocks per channel group)
-        monkeypatch.setenv("AMS_XWR_FORCE", {None: "4,0,0,0", "4,1,1": "8,1,1,0", "2,3,2": "4,3,2,0", "4,2,3": "8,2,3,2"}.get(force, "4,2,1,3"))
+        # form of the kernel (k_xdw_wreg.hip: AMS_XWR_FORCE = E-waves, row segments, column strips, blocks per channel group,
+        # row groups per E-wave and step)
+        monkeypatch.setenv("AMS_XWR_FORCE", {None: "4,0,0,0,2", "4,1,1": "8,1,1,0,1", "2,3,2": "4,3,2,0,1", "4,2,3": "8,2,3,2,1"}.get(force, "4,2,1,3,2"))
         for pre in (0, 1, 2):
             y = torch.full((B, H, W, Cexp), np.nan, device=DEV)
             hip.check(lib.ams_k_expand_dw_stream(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), rate, PD(sd), PD(hd), P(y),

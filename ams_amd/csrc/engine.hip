@@ -381,9 +381,9 @@ static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
 }
 
 // frozen 1x1 layer: late layers (few rows, wide K/N: matrix-pipe bound) go through the split-bf16 kernel
-static int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st, bool* wrote_parts = nullptr) {
+static int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st, bool* wrote_parts = nullptr, bool force_split = false) {
     const LayerRt& l = s->L[layer];
-    const bool split = s->matmul_mode != AMS_MATMUL_F32 && l.whi && split_pays(a);
+    const bool split = s->matmul_mode != AMS_MATMUL_F32 && l.whi && (split_pays(a) || (force_split && a.K % 8 == 0 && a.K >= 32));
     // the bf16 parts of the result (a.ysplit) exist only when the split kernel runs with a vector epilogue
     const bool parts = split && a.ysplit && pointwise_split_writes_parts(a);
     if (!parts) a.ysplit = nullptr;
@@ -476,7 +476,11 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             const int o = other(cur_i, -1);
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
-            RUN(frozen_pointwise(s, i, a, st));
+            // an expand layer the streaming kernel can take forms its products the same way when it runs alone (split bf16), so
+            // that the result does not depend on batch size or on AMS_OPT_FUSE_EXPAND_DW_STREAM
+            const bool streamable = i + 1 <= s->n_backbone && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && l.Kp == l.d.cin &&
+                                    expand_dw_stream_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate);
+            RUN(frozen_pointwise(s, i, a, st, nullptr, streamable));
             x = s->act[o]; x_i = o; ++i;
         }
         {

@@ -1,5 +1,5 @@
-// Fused expand (1x1, BN, ReLU6) -> depthwise 3x3 (BN, ReLU6) for the output-stride-16 blocks (Cin 64 / 96 / 160, stride 1,
-// rate 1 | 2), frozen inference, split-bf16 products: the STREAMING form.
+// Fused expand (1x1, BN, ReLU6) -> depthwise 3x3 (BN, ReLU6) for the stride-1 blocks with 32 / 64 / 96 / 160 input channels
+// (the two stride-8 blocks and the output-stride-16 section; rate 1 | 2), frozen inference, split-bf16 products: the STREAMING form.
 //
 // The tiled kernel of k_expand_dw.hip recomputes a 3x3 halo around every tile (x1.6 GEMM work at 8x8, x2.25 at rate 2)
 // and runs the expand on the f32 matrix pipe; on these blocks it loses to the two separate kernels.  Here a block takes
@@ -347,7 +347,7 @@ static bool xds_plan(int B, int H, int W, int Cin, int Cexp, int rate, int np, X
 
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate) {
     if (stride != 1 || (rate != 1 && rate != 2)) return false;
-    if (Cin != 64 && Cin != 96 && Cin != 160) return false;
+    if (Cin != 32 && Cin != 64 && Cin != 96 && Cin != 160) return false;
     return Cexp % 32 == 0;
 }
 
@@ -409,6 +409,7 @@ int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_p
     a.nsy = p.nsy; a.nsx = p.nsx; a.chunks = Cexp / (16 * p.nt);
     a.items = B * rate * rate * p.nsy * p.nsx; a.groups = p.groups;
     switch (Cin / 32) {
+        case 1: return launch_xds_ks<1>(a, p, np, st);
         case 2: return launch_xds_ks<2>(a, p, np, st);
         case 3: return launch_xds_ks<3>(a, p, np, st);
         default: return launch_xds_ks<5>(a, p, np, st);

@@ -315,7 +315,7 @@ static int launch_xwr_w(const XwrArgs& a, int nwe, int nrg, size_t lds, hipStrea
 int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane,
                           int np, const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                           const float* sh_d, int act_d, float* y, hipStream_t st) {
-    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && (np == 2 || np == 3) && x_parts, "expand_dw_wreg: unsupported shape Cin=%d Cexp=%d rate=%d",
+    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && Cin >= 64 && (np == 2 || np == 3) && x_parts, "expand_dw_wreg: unsupported shape Cin=%d Cexp=%d rate=%d",
                 Cin, Cexp, rate);
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_wreg: empty input");
     AMS_REQUIRE((int64_t)H * W * Cexp * 4 < 0x7fffffffLL, "expand_dw_wreg: a frame of the output exceeds 2 GiB");

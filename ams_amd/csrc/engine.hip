@@ -427,10 +427,12 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
     // layer k starts a block whose expand + depthwise run as the streaming kernel (stride-16 blocks, split-bf16 modes, a few
     // frames: below that the launch cannot fill the chip)
     auto stream_ok = [&](int k) {
-        return s->fuse_expand_dw_stream && s->matmul_mode != AMS_MATMUL_F32 && k + 1 <= s->n_backbone && s->L[k].d.role == AMS_ROLE_EXPAND &&
-               s->L[k + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[k].whi && s->L[k].Kp == s->L[k].d.cin &&
-               (int64_t)B * s->L[k].px_in >= 16384 &&
-               expand_dw_stream_supported(s->L[k].d.cin, s->L[k].d.cout, s->L[k + 1].d.stride, s->L[k + 1].d.rate);
+        if (!(s->fuse_expand_dw_stream && k + 1 <= s->n_backbone && s->L[k].d.role == AMS_ROLE_EXPAND && s->L[k + 1].d.role == AMS_ROLE_DEPTHWISE &&
+              (int64_t)B * s->L[k].px_in >= 16384 &&
+              expand_dw_stream_supported(s->L[k].d.cin, s->L[k].d.cout, s->L[k + 1].d.stride, s->L[k + 1].d.rate)))
+            return false;
+        if (s->L[k].d.cin <= 32) return true;                        // exact-f32 form: any matmul mode
+        return s->matmul_mode != AMS_MATMUL_F32 && s->L[k].whi && s->L[k].Kp == s->L[k].d.cin;
     };
     const uint16_t* cur_parts = nullptr;       // `cur` as bf16 parts (s->xsplit), when the GEMM that produced it wrote them
     while (i <= s->n_backbone) {
@@ -438,7 +440,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
         const float* block_in = cur;
         const float* x = cur;
         int x_i = cur_i;
-        if (s->fuse_expand_dw && s->L[i].d.role == AMS_ROLE_EXPAND && i + 1 <= s->n_backbone &&
+        const bool stream_here = stream_ok(i) && (s->L[i].d.cin <= 96 || cur_parts || s->fuse_expand_dw_stream >= 2);
+        if (!stream_here && s->fuse_expand_dw && s->L[i].d.role == AMS_ROLE_EXPAND && i + 1 <= s->n_backbone &&
             s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
             expand_dw_supported(s->L[i].d.cin, s->L[i].d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate) &&
             (s->fuse_expand_dw >= 2 || s->L[i].d.cin <= 24 || s->L[i + 1].d.stride == 2)) {
@@ -450,7 +453,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             RUNK(i + 1, bytes, launch_expand_dw(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                 P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act, s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
-        } else if (stream_ok(i) && (s->L[i].d.cin <= 96 || cur_parts || s->fuse_expand_dw_stream >= 2)) {
+        } else if (stream_here) {
             // stride-16 blocks: expand + depthwise streamed through an LDS ring, split-bf16 products (bit-identical to the two
             // kernels it replaces); the 6x-expanded tensor is never written
             LayerRt& le = s->L[i];
@@ -466,7 +469,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
                                                          le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
                                                          s->act[o], st));
             else
-                RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale,
+                RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale,
                                                            le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
                                                            s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
@@ -478,7 +481,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
             // an expand layer the streaming kernel can take forms its products the same way when it runs alone (split bf16), so
             // that the result does not depend on batch size or on AMS_OPT_FUSE_EXPAND_DW_STREAM
-            const bool streamable = i + 1 <= s->n_backbone && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && l.Kp == l.d.cin &&
+            const bool streamable = i + 1 <= s->n_backbone && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && l.Kp == l.d.cin && l.d.cin >= 64 &&
                                     expand_dw_stream_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate);
             RUN(frozen_pointwise(s, i, a, st, nullptr, streamable));
             x = s->act[o]; x_i = o; ++i;
@@ -1099,6 +1102,9 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
         set_error("expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d parts=%d", Cin, Cexp, rate, parts);
         return AMS_E_INVALID;
     }
+    if (Cin <= 32)           // exact-f32 form: no panels
+        return launch_expand_dw_stream(x, nullptr, 0, B, H, W, Cin, w_exp, nullptr, 0, 0, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, rate, scale_d,
+                                       shift_d, AMS_ACT_RELU6, y, st);
     const size_t plane = (size_t)Cexp * Cin;
     AMS_REQUIRE(panels && panel_elems >= 3 * plane, "expand_dw_stream: panel scratch too small (need %zu)", 3 * plane);
     RUN(launch_split_weights3(w_exp, Cexp, 1, Cin, Cexp, Cin, panels, panels + plane, panels + 2 * plane, st));
@@ -1114,8 +1120,8 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
     if (presplit == 2)       // the weight-register form (k_xdw_wreg.hip)
         return launch_expand_dw_wreg(xp, (int64_t)xplane, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw,
                                      rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
-    return launch_expand_dw_stream(x, xp, (int64_t)xplane, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp,
-                                   w_dw, rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
+    return launch_expand_dw_stream(x, xp, (int64_t)xplane, B, H, W, Cin, nullptr, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6,
+                                   Cexp, w_dw, rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
 }
 
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

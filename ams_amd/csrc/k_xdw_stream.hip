@@ -28,6 +28,7 @@ struct XdsArgs {
     int B, H, W, Cin;
     const unsigned short* wp;        // expand weights, bf16 parts [part][Cexp][Kp], part p at wp + p * plane
     int64_t plane;
+    const float* wf;                 // F32: expand weights f32 [Cin][Cexp] (exact-f32 products for Cin <= 32)
     const float* sc_e; const float* sh_e;
     int act_e;
     int Cexp;
@@ -49,39 +50,56 @@ struct XdsArgs {
 // Roles: waves [0, NWE) run the E-steps (operand loads, split, MFMAs, BN + ReLU6 into the ring), waves [NWE, NWE + NWD) the
 // D-steps (depthwise from the ring, BN + ReLU6, stores).  D-step t - 1 runs beside E-step t, one barrier per step: the matrix
 // pipe of a SIMD works for an E-wave while its vector pipe works for a D-wave, and neither role carries the other's registers.
-template <int KS, int NT, int NP, int NWE, int NWD, bool PRE>
+// F32 (Cin <= 32: the early blocks): exact-f32 products on v_mfma_f32_16x16x4_f32, KS = number of 16-k chunks, k order of
+// pw_gemm_f32_s / expand_dw_kernel (bit-identical to them); the contraction is so short that the f32 matrix pipe costs no more
+// than six bf16 MFMAs plus the split.  Otherwise KS = 32-k stages of the split-bf16 product.
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a, unsigned nblocks) {
     constexpr int NC = 16 * NT;                      // expanded channels per block
     constexpr int CG = NC / 4;                       // channel groups (float4) of the D-step
     constexpr int STEP = 16 * NWE;                   // pixels per step
     constexpr int PX = STEP * CG / (64 * NWD);       // consecutive centres per D-thread
     static_assert(PX * 64 * NWD == STEP * CG && PX >= 1, "D-step mapping");
+    static_assert(!(F32 && PRE), "the exact-f32 form splits nothing");
     constexpr int PITCH = NC + 4;                    // ring row pitch in floats (odd number of 16-byte units)
     constexpr int MIRROR = 4;                        // ring slots repeated after the end (a run of taps is <= 4 slots)
-    constexpr int Kp = KS * 32;
+    constexpr int Kp = F32 ? KS * 16 : KS * 32;
+    constexpr int WPF = NC + 4;                      // F32: pitch of the weight rows [k][n]
+    constexpr int W_BYTES = F32 ? Kp * WPF * 4 : NP * Kp * NC * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* sW = reinterpret_cast<u32x4*>(smem);                      // [NP][KS][4][NC] 16-byte units (8 k each)
-    float* sAff = reinterpret_cast<float*>(smem + NP * Kp * NC * 2); // sc_e, sh_e : 2 x NC
+    float* sWf = reinterpret_cast<float*>(smem);                     // F32: [Kp][WPF]
+    float* sAff = reinterpret_cast<float*>(smem + W_BYTES);          // sc_e, sh_e : 2 x NC
     float* ring = sAff + 2 * NC;                                     // [ring][PITCH]
 
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     const int chunk = lb % a.chunks;
     const int group = lb / a.chunks;
-    const int n0 = chunk * NC;
+    const int n0 = chunk * NC;                                       // the last chunk may be short (Cexp = 144: 16 of 32 channels)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the role branch is wave-uniform for the compiler too
     const int Wp = a.Wp, rate = a.rate, R = a.ring;
 
-    // ---- chunk parameters -> LDS (once per block) -----------------------------------------------------------
-    {
+    // ---- chunk parameters -> LDS (once per block); channels past Cexp repeat the last one and are never stored -------------
+    if constexpr (F32) {
+        for (int e = tid; e < Kp * NC; e += 64 * (NWE + NWD)) {
+            const int k = e / NC, n = e - k * NC;
+            const int nn = n0 + n < a.Cexp ? n0 + n : a.Cexp - 1;
+            sWf[k * WPF + n] = k < a.Cin ? a.wf[(int64_t)k * a.Cexp + nn] : 0.f;
+        }
+    } else {
         constexpr int UPR = Kp / 8;                                  // 16-byte units per weight row
         constexpr int NPIECE = NP * NC * UPR;
         for (int e = tid; e < NPIECE; e += 64 * (NWE + NWD)) {
             const int part = e / (NC * UPR), r = e - part * (NC * UPR), n = r / UPR, u = r - n * UPR;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(a.wp + part * a.plane + (int64_t)(n0 + n) * Kp + u * 8);
+            const int nn = n0 + n < a.Cexp ? n0 + n : a.Cexp - 1;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(a.wp + part * a.plane + (int64_t)nn * Kp + u * 8);
             sW[((part * KS + (u >> 2)) * 4 + (u & 3)) * NC + n] = v;
         }
-        if (tid < NC) { sAff[tid] = a.sc_e[n0 + tid]; sAff[NC + tid] = a.sh_e[n0 + tid]; }
+    }
+    if (tid < NC) {
+        const int nn = n0 + tid < a.Cexp ? n0 + tid : a.Cexp - 1;
+        sAff[tid] = a.sc_e[nn]; sAff[NC + tid] = a.sh_e[nn];
     }
     __syncthreads();
     const int qS = STEP / Wp, rS = STEP - qS * Wp;                   // both walkers advance by STEP pixels a step
@@ -102,11 +120,12 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
             const int i0 = segy * a.SH, j0 = segx * a.SW;
             const bool live = i0 < Hs && j0 < Ws;                    // a segment past the end of a smaller sub-image: barriers only
             // operand source of a pixel: f32 activations (split here) or, PRE, the bf16 parts the producing GEMM wrote beside them
-            const int64_t frame0 = (int64_t)b * a.H * a.W * a.Cin + 8 * q;
+            const int64_t frame0 = (int64_t)b * a.H * a.W * a.Cin + (F32 ? 0 : 8 * q);
             int e_row, e_col;
             { const int e0 = 16 * wave + l15; e_row = e0 / Wp; e_col = e0 - e_row * Wp; }
-            float4 raw[PRE ? 1 : KS][2];
+            float4 raw[(PRE || F32) ? 1 : KS][2];
             u32x4 rawp[PRE ? KS : 1][NP];
+            float4 rawf[F32 ? KS : 1];                                // F32: k = 16c + 4q .. + 3 of the lane's pixel
             bool in_next = false;
             auto next_pixel = [&]() -> int64_t {                     // clamped element offset; `in_next` decides what is kept
                 const int i = i0 - 1 + e_row, j = j0 - 1 + e_col;
@@ -115,7 +134,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                 return frame0 + ((int64_t)(sy + rate * ic) * a.W + (sx + rate * jc)) * a.Cin;
             };
             auto load_stage = [&](int64_t off, int s) {
-                if constexpr (PRE) {
+                if constexpr (F32) {
+                    int ko = 16 * s + 4 * q;                          // k past Cin meets zero weight rows: any finite value will do
+                    if (ko > a.Cin - 4) ko = a.Cin - 4;
+                    rawf[s] = ld4(a.x + off + ko);
+                } else if constexpr (PRE) {
 #pragma unroll
                     for (int pp = 0; pp < NP; ++pp) rawp[s][pp] = *reinterpret_cast<const u32x4*>(a.xs + pp * a.xs_plane + off + 32 * s);
                 } else {
@@ -140,40 +163,50 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                 // with the next step's operands as soon as they are split: those loads have the rest of the step to land.
                 // Products in the order of pw_gemm_bf16x3_l per accumulator; consecutive MFMAs go to different accumulators
                 // (a dependent MFMA waits ~2.5 issue slots for its predecessor).
+                if constexpr (F32) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const float4 av[1] = {rawf[s]};
+                        load_stage(pn, s);
+                        f32x4(&acc2)[1][NT] = *reinterpret_cast<f32x4(*)[1][NT]>(&acc);
+                        pw_chunk<1, NT, WPF>(acc2, av, sWf + (16 * s + 4 * q) * WPF + l15);
+                    }
+                } else {
                 bf16x8 x0, x1, x2;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    if constexpr (PRE) {
-                        x0 = __builtin_bit_cast(bf16x8, rawp[s][0]);
-                        x1 = __builtin_bit_cast(bf16x8, rawp[s][1]);
-                        if (NP == 3) x2 = __builtin_bit_cast(bf16x8, rawp[s][NP - 1]);
-                    } else {
-                        if (NP == 3) split8(raw[s][0], raw[s][1], x0, x1, x2);
-                        else split8(raw[s][0], raw[s][1], x0, x1);
+    #pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        if constexpr (PRE) {
+                            x0 = __builtin_bit_cast(bf16x8, rawp[s][0]);
+                            x1 = __builtin_bit_cast(bf16x8, rawp[s][1]);
+                            if (NP == 3) x2 = __builtin_bit_cast(bf16x8, rawp[s][NP - 1]);
+                        } else {
+                            if (NP == 3) split8(raw[s][0], raw[s][1], x0, x1, x2);
+                            else split8(raw[s][0], raw[s][1], x0, x1);
+                        }
+                        load_stage(pn, s);
+                        const u32x4* bw = sW + (s * 4 + q) * NC + l15;
+                        bf16x8 q0[NT], q1[NT], q2[NT];
+    #pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) {
+                            q0[tt] = *reinterpret_cast<const bf16x8*>(bw + 16 * tt);
+                            q1[tt] = *reinterpret_cast<const bf16x8*>(bw + KS * 4 * NC + 16 * tt);
+                            if (NP == 3) q2[tt] = *reinterpret_cast<const bf16x8*>(bw + 2 * KS * 4 * NC + 16 * tt);
+                        }
+                        if (NP == 3) {                                    // smallest terms first
+    #pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[tt], x0, acc[tt], 0, 0, 0);
+    #pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x2, acc[tt], 0, 0, 0);
+    #pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x1, acc[tt], 0, 0, 0);
+                        }
+    #pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x0, acc[tt], 0, 0, 0);
+    #pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x1, acc[tt], 0, 0, 0);
+    #pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x0, acc[tt], 0, 0, 0);
                     }
-                    load_stage(pn, s);
-                    const u32x4* bw = sW + (s * 4 + q) * NC + l15;
-                    bf16x8 q0[NT], q1[NT], q2[NT];
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) {
-                        q0[tt] = *reinterpret_cast<const bf16x8*>(bw + 16 * tt);
-                        q1[tt] = *reinterpret_cast<const bf16x8*>(bw + KS * 4 * NC + 16 * tt);
-                        if (NP == 3) q2[tt] = *reinterpret_cast<const bf16x8*>(bw + 2 * KS * 4 * NC + 16 * tt);
-                    }
-                    if (NP == 3) {                                    // smallest terms first
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[tt], x0, acc[tt], 0, 0, 0);
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x2, acc[tt], 0, 0, 0);
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x1, acc[tt], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x0, acc[tt], 0, 0, 0);
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x1, acc[tt], 0, 0, 0);
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x0, acc[tt], 0, 0, 0);
                 }
                 {
                     float* dst = ring + sbase * PITCH + ring_lane;
@@ -201,11 +234,13 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
         // =================================== D-waves ===================================
         const int dt = tid - 64 * NWE;
         const int cg = dt % CG, pt = dt / CG;
+        const bool chan_ok = n0 + 4 * cg < a.Cexp;                   // short last chunk
+        const int nch = chan_ok ? n0 + 4 * cg : 0;
         float4 wv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + n0 + 4 * cg);
-        const float4 dsc = ld4(a.sc_d + n0 + 4 * cg), dsh = ld4(a.sh_d + n0 + 4 * cg);
-        const unsigned ych = (unsigned)(n0 + 4 * cg) * 4u;
+        for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + nch);
+        const float4 dsc = ld4(a.sc_d + nch), dsh = ld4(a.sh_d + nch);
+        const unsigned ych = (unsigned)nch * 4u;
         // ring position of this thread's first tap, (first centre - Wp - 1) mod R, carried across items like sbase
         int cb = (2 * R - 2 * Wp - 2 + pt * PX) % R;
         for (int item = group; item < a.items; item += a.groups) {
@@ -217,7 +252,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
             const int sy = sub / rate, sx = sub - sy * rate;
             const int Hs = (a.H - sy + rate - 1) / rate, Ws = (a.W - sx + rate - 1) / rate;
             const int i0 = segy * a.SH, j0 = segx * a.SW;
-            const bool live = i0 < Hs && j0 < Ws;
+            const bool live = i0 < Hs && j0 < Ws && chan_ok;
             // Results leave through buffer stores on a descriptor of this frame: a lane with nothing to store gets an offset
             // past the end, which the hardware drops.  No branch around the store, so hipcc counts it exactly.
             const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)b * a.H * a.W * a.Cexp, 0,
@@ -285,9 +320,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
 // ---- host side -----------------------------------------------------------------------------------------------------
 struct XdsPlan { int nt, nwe, nwd, SH, SW, nsy, nsx, ring, groups; size_t lds; };
 
+// Kp = contraction length as staged (Cin rounded up to 32 for the split form, to 16 for the exact-f32 form: np = 0)
 static size_t xds_lds(int Kp, int nt, int np, int ring) {
     const int NC = 16 * nt;
-    return (size_t)np * Kp * NC * 2 + 2 * NC * 4 + (size_t)(ring + 4) * (NC + 4) * 4;      // + the mirrored slots
+    const size_t w = np == 0 ? (size_t)Kp * (NC + 4) * 4 : (size_t)np * Kp * NC * 2;
+    return w + 2 * NC * 4 + (size_t)(ring + 4) * (NC + 4) * 4;      // + the mirrored slots
 }
 static int xds_ring(int SW, int step) { return (2 * (SW + 2) + 2 + 2 * step + step - 1) / step * step; }
 
@@ -295,9 +332,8 @@ static int xds_ring(int SW, int step) { return (2 * (SW + 2) + 2 + 2 * step + st
 // work items to fill the chip (each costs two halo rows of GEMM work)
 static bool xds_plan_try(int B, int H, int W, int Cin, int Cexp, int rate, int np, int nt, int nwe, int nwd, int nsy_force, int nsx_force,
                          int groups_force, XdsPlan* p) {
-    const int Kp = Cin;
+    const int Kp = np == 0 ? (Cin + 15) / 16 * 16 : Cin;
     const int Hs = (H + rate - 1) / rate, Ws = (W + rate - 1) / rate;
-    if (Cexp % (16 * nt) != 0) return false;
     const int step = 16 * nwe;
     const size_t budget = 160 * 1024 - 512;
     int nsx = nsx_force > 0 ? nsx_force : 1;
@@ -314,7 +350,7 @@ static bool xds_plan_try(int B, int H, int W, int Cin, int Cexp, int rate, int n
     }
     if (xds_lds(Kp, nt, np, ring) > budget || SW < 1) return false;
     nsx = (Ws + SW - 1) / SW;
-    const int chunks = Cexp / (16 * nt);
+    const int chunks = (Cexp + 16 * nt - 1) / (16 * nt);
     int nsy = 1;
     if (nsy_force > 0) nsy = nsy_force;
     else
@@ -339,32 +375,34 @@ static bool xds_plan(int B, int H, int W, int Cin, int Cexp, int rate, int np, X
     int nt = Cin >= 128 ? 4 : 2, nsy_force = 0, nsx_force = 0, nwe = 4, nwd = 4, groups_force = 0;
     if (const char* e = getenv("AMS_XDS_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d", &nt, &nsy_force, &nsx_force, &nwe, &nwd, &groups_force);
     if (nt != 2 && nt != 4) nt = Cin >= 128 ? 4 : 2;
+    if (np == 0) { nwe = 4; nwd = 4; }               // the exact-f32 form is built for 4 + 4 waves
     if (!((nwe == 4 && (nwd == 2 || nwd == 4)) || (nwe == 8 && nwd == 4))) { nwe = 4; nwd = 4; }
     if (xds_plan_try(B, H, W, Cin, Cexp, rate, np, nt, nwe, nwd, nsy_force, nsx_force, groups_force, p)) return true;
     if (xds_plan_try(B, H, W, Cin, Cexp, rate, np, 2, nwe, nwd, nsy_force, nsx_force, groups_force, p)) return true;
     return xds_plan_try(B, H, W, Cin, Cexp, rate, np, 2, 4, 4, nsy_force, 0, groups_force, p);
 }
 
+// Cin 16 / 24 / 32: exact-f32 products (the early blocks); 64 / 96 / 160: split-bf16 products (the stride-16 section)
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate) {
     if (stride != 1 || (rate != 1 && rate != 2)) return false;
-    if (Cin != 32 && Cin != 64 && Cin != 96 && Cin != 160) return false;
-    return Cexp % 32 == 0;
+    if (Cin != 16 && Cin != 24 && Cin != 32 && Cin != 64 && Cin != 96 && Cin != 160) return false;
+    return Cexp % 16 == 0 && Cexp >= 32;
 }
 
-template <int KS, int NT, int NP, int NWE, int NWD, bool PRE>
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32 = false>
 static int launch_xds_p(XdsArgs a, const XdsPlan& p, hipStream_t st) {
     static size_t attr_lds = 0;
     if (p.lds > 64 * 1024 && p.lds > attr_lds) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)p.lds));
         attr_lds = p.lds;
     }
     const int64_t nblocks = (int64_t)a.groups * a.chunks;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_stream: bad grid");
     static const std::string nm = "xdw_stream_kernel<" + std::to_string(KS) + ", " + std::to_string(NT) + ", " + std::to_string(NP) + ", " +
-                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ">";
+                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ", " + std::to_string((int)F32) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -381,35 +419,45 @@ static int launch_xds_w(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
     return launch_xds_k<KS, NT, NP, 4, 2>(a, p, st);
 }
 
+// exact-f32 form: KC 16-k chunks, 4 E-waves + 4 D-waves
+template <int KC>
+static int launch_xds_f32(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
+    if (p.nt == 4) return launch_xds_p<KC, 4, 3, 4, 4, false, true>(a, p, st);
+    return launch_xds_p<KC, 2, 3, 4, 4, false, true>(a, p, st);
+}
+
 template <int KS>
 static int launch_xds_ks(const XdsArgs& a, const XdsPlan& p, int np, hipStream_t st) {
     if (p.nt == 4) return np == 3 ? launch_xds_w<KS, 4, 3>(a, p, st) : launch_xds_w<KS, 4, 2>(a, p, st);
     return np == 3 ? launch_xds_w<KS, 2, 3>(a, p, st) : launch_xds_w<KS, 2, 2>(a, p, st);
 }
 
+// w_f32: the expand weights [Cin][Cexp] for the exact-f32 form (Cin <= 32; w_parts / np / x_parts are then unused).
 // x_parts (optional): x as bf16 parts [part][B*H*W][Cin], x_plane apart, exactly what split8 makes of x (the producing GEMM writes
 // them, PwArgs::ysplit): the E-waves then load their operands ready-made instead of splitting them once per channel chunk.
 // w_parts: the expand layer's bf16 panels [part][Cexp][Cin] (np = 2: hi, lo; np = 3: hi, mid, lo), part p at w_parts + p * plane
-int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts,
-                            int64_t plane, int np,
+int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const float* w_f32,
+                            const uint16_t* w_parts, int64_t plane, int np,
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st) {
-    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && (np == 2 || np == 3), "expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d",
-                Cin, Cexp, rate);
+    const bool f32 = Cin <= 32;
+    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && (f32 ? w_f32 != nullptr : (w_parts && (np == 2 || np == 3))),
+                "expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d", Cin, Cexp, rate);
+    if (f32) { np = 0; x_parts = nullptr; }
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_stream: empty input");
     AMS_REQUIRE((int64_t)H * W * Cexp * 4 < 0x7fffffffLL, "expand_dw_stream: a frame of the output exceeds 2 GiB");
     XdsPlan p;
     AMS_REQUIRE(xds_plan(B, H, W, Cin, Cexp, rate, np, &p), "expand_dw_stream: no segment geometry fits LDS (W=%d rate=%d)", W, rate);
     XdsArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.xs = x_parts; a.xs_plane = x_plane; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.wp = w_parts; a.plane = plane; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e;
+    a.x = x; a.xs = x_parts; a.xs_plane = x_plane; a.wf = w_f32; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.wp = w_parts; a.plane = plane; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e;
     a.Cexp = Cexp; a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.y = y; a.rate = rate;
     const int step = 16 * p.nwe;
     a.SH = p.SH; a.SW = p.SW; a.Wp = p.SW + 2; a.T = ((p.SH + 2) * a.Wp + step - 1) / step; a.ring = p.ring;
-    a.nsy = p.nsy; a.nsx = p.nsx; a.chunks = Cexp / (16 * p.nt);
+    a.nsy = p.nsy; a.nsx = p.nsx; a.chunks = (Cexp + 16 * p.nt - 1) / (16 * p.nt);
     a.items = B * rate * rate * p.nsy * p.nsx; a.groups = p.groups;
+    if (f32) return Cin <= 16 ? launch_xds_f32<1>(a, p, st) : launch_xds_f32<2>(a, p, st);
     switch (Cin / 32) {
-        case 1: return launch_xds_ks<1>(a, p, np, st);
         case 2: return launch_xds_ks<2>(a, p, np, st);
         case 3: return launch_xds_ks<3>(a, p, np, st);
         default: return launch_xds_ks<5>(a, p, np, st);

@@ -89,8 +89,8 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
 // ---- k_xdw_stream.hip : the same fusion for the stride-16 blocks (Cin 64 / 96 / 160, stride 1, rate 1 | 2): raster-order
 // streaming through an LDS ring, split-bf16 products from the expand layer's bf16 panels (np = 2 | 3 parts, `plane` apart)
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate);
-int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts,
-                            int64_t plane, int np,
+int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const float* w_f32,
+                            const uint16_t* w_parts, int64_t plane, int np,
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st);
 

@@ -431,6 +431,9 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
               (int64_t)B * s->L[k].px_in >= 16384 &&
               expand_dw_stream_supported(s->L[k].d.cin, s->L[k].d.cout, s->L[k + 1].d.stride, s->L[k + 1].d.rate)))
             return false;
+        // stride 2 on the streaming kernel is correct and tested but measured no faster than the tiled kernel (the expand runs at
+        // full resolution either way: 412 vs 376 us on the first such block) — only with option value 2
+        if (s->L[k + 1].d.stride != 1 && s->fuse_expand_dw_stream < 2) return false;
         if (s->L[k].d.cin <= 32) return true;                        // exact-f32 form: any matmul mode
         return s->matmul_mode != AMS_MATMUL_F32 && s->L[k].whi && s->L[k].Kp == s->L[k].d.cin;
     };
@@ -470,7 +473,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
                                                          s->act[o], st));
             else
                 RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale,
-                                                           le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
+                                                           le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
                                                            s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
         } else {
@@ -1098,13 +1101,15 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
                            const float* shift_e, int32_t Cexp, const float* w_dw, int32_t rate, const float* scale_d, const float* shift_d,
                            float* y, uint16_t* panels, size_t panel_elems, int32_t parts, int32_t presplit, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (!expand_dw_stream_supported(Cin, Cexp, 1, rate) || (parts != 2 && parts != 3)) {
+    int stride = 1;
+    if (rate < 0) { stride = -rate; rate = 1; }          // rate = -2 selects stride 2 (Cin <= 32 only)
+    if (!expand_dw_stream_supported(Cin, Cexp, stride, rate) || (parts != 2 && parts != 3)) {
         set_error("expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d parts=%d", Cin, Cexp, rate, parts);
         return AMS_E_INVALID;
     }
     if (Cin <= 32)           // exact-f32 form: no panels
-        return launch_expand_dw_stream(x, nullptr, 0, B, H, W, Cin, w_exp, nullptr, 0, 0, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, rate, scale_d,
-                                       shift_d, AMS_ACT_RELU6, y, st);
+        return launch_expand_dw_stream(x, nullptr, 0, B, H, W, Cin, w_exp, nullptr, 0, 0, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, stride, rate,
+                                       scale_d, shift_d, AMS_ACT_RELU6, y, st);
     const size_t plane = (size_t)Cexp * Cin;
     AMS_REQUIRE(panels && panel_elems >= 3 * plane, "expand_dw_stream: panel scratch too small (need %zu)", 3 * plane);
     RUN(launch_split_weights3(w_exp, Cexp, 1, Cin, Cexp, Cin, panels, panels + plane, panels + 2 * plane, st));
@@ -1121,7 +1126,7 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
         return launch_expand_dw_wreg(xp, (int64_t)xplane, B, H, W, Cin, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw,
                                      rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
     return launch_expand_dw_stream(x, xp, (int64_t)xplane, B, H, W, Cin, nullptr, panels, (int64_t)plane, parts, scale_e, shift_e, AMS_ACT_RELU6,
-                                   Cexp, w_dw, rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
+                                   Cexp, w_dw, 1, rate, scale_d, shift_d, AMS_ACT_RELU6, y, st);
 }
 
 int ams_k_global_mean(const float* x, int32_t B, int64_t HW, int32_t C, float* y, float* scratch, size_t scratch_floats,

@@ -37,7 +37,9 @@ struct XdsArgs {
     int act_d;
     float* y;                        // [B, H, W, Cexp]
     int rate;
-    int SH, SW;                      // output rows / columns of a work item (sub-image coordinates)
+    int stride;                      // 1 | 2 (2: exact-f32 form only, rate 1); output [B, Ho, Wo, Cexp]
+    int Ho, Wo, cy0, cx0;            // stride 2: output size; image row / column parity of the window centres (1 - pad before)
+    int SH, SW;                      // rows / columns of a work item (sub-image coordinates; input pixels at stride 2)
     int Wp;                          // SW + 2: segment row pitch incl. one pad column on each side
     int T;                           // steps: ceil((SH + 2) * Wp / STEP)
     int ring;                        // ring size in pixels: a multiple of STEP, >= 2 * Wp + 2 + 2 * STEP
@@ -53,7 +55,7 @@ struct XdsArgs {
 // F32 (Cin <= 32: the early blocks): exact-f32 products on v_mfma_f32_16x16x4_f32, KS = number of 16-k chunks, k order of
 // pw_gemm_f32_s / expand_dw_kernel (bit-identical to them); the contraction is so short that the f32 matrix pipe costs no more
 // than six bf16 MFMAs plus the split.  Otherwise KS = 32-k stages of the split-bf16 product.
-template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32>
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32, int S = 1>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a, unsigned nblocks) {
     constexpr int NC = 16 * NT;                      // expanded channels per block
     constexpr int CG = NC / 4;                       // channel groups (float4) of the D-step
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
             const bool live = i0 < Hs && j0 < Ws && chan_ok;
             // Results leave through buffer stores on a descriptor of this frame: a lane with nothing to store gets an offset
             // past the end, which the hardware drops.  No branch around the store, so hipcc counts it exactly.
-            const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + (int64_t)b * a.H * a.W * a.Cexp, 0,
-                                                                                   (int)((int64_t)a.H * a.W * a.Cexp * 4), 0x00020000);
+            const int64_t oframe = S == 2 ? (int64_t)a.Ho * a.Wo * a.Cexp : (int64_t)a.H * a.W * a.Cexp;      // output elements per frame
+            const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(a.y + b * oframe, 0, (int)(oframe * 4), 0x00020000);
             // valid output rows / columns of the item, and the byte offset of centre (row, col) = off0 + row * rowpitch + col * colpitch
             const int rmax = live ? (a.SH < Hs - i0 ? a.SH : Hs - i0) : 0, cmax = a.SW < Ws - j0 ? a.SW : Ws - j0;
             const int colpitch = rate * a.Cexp * 4, rowpitch = rate * a.W * a.Cexp * 4;
@@ -266,6 +268,51 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
             __syncthreads();                                          // E-step 0
             for (int t = 0; t < a.T; ++t) {
                 // D-step t: the STEP centres whose neighbourhood is complete after E-step t
+                if constexpr (S == 2) {
+                    // stride 2: the window centres sit on every other row and column of the input, so of a thread's pair of adjacent
+                    // positions at most one is a centre, and whole steps fall on rows without any (wave-uniform skip)
+#pragma unroll
+                    for (int h = 0; h < PX; h += 2) {
+                        int row = d_row, col = d_col + h;
+#pragma unroll
+                        for (int w = 0; w < (PX + 1) / 2; ++w)
+                            if (col >= Wp) { col -= Wp; ++row; }
+                        const int u = (j0 + col - 1 - a.cx0) & 1;     // 0: the first position of the pair is on a centre column
+                        col += u;
+                        if (col >= Wp) { col -= Wp; ++row; }
+                        const int i = i0 + row - 1, j = j0 + col - 1;
+                        const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax) &
+                                        ((((i - a.cy0) | (j - a.cx0)) & 1) == 0);
+                        if (__builtin_amdgcn_ballot_w64(ok) != 0) {
+                            float4 v[3][3];
+#pragma unroll
+                            for (int di = 0; di < 3; ++di) {
+                                unsigned slot = (unsigned)(cb + di * Wp + h + u);
+                                slot = slot < (unsigned)R ? slot : slot - (unsigned)R;
+                                const float* rp = ring + __umul24(slot, PITCH) + 4 * cg;
+#pragma unroll
+                                for (int jj = 0; jj < 3; ++jj) v[di][jj] = ld4(rp + jj * PITCH);
+                            }
+                            float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                            for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                                for (int jj = 0; jj < 3; ++jj) {
+                                    const float4 vv = v[ii][jj];
+                                    const float4 w4 = wv[ii * 3 + jj];
+                                    acc4.x = fmaf(vv.x, w4.x, acc4.x); acc4.y = fmaf(vv.y, w4.y, acc4.y);
+                                    acc4.z = fmaf(vv.z, w4.z, acc4.z); acc4.w = fmaf(vv.w, w4.w, acc4.w);
+                                }
+                            float4 o;
+                            o.x = apply_act(acc4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(acc4.y * dsc.y + dsh.y, a.act_d);
+                            o.z = apply_act(acc4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(acc4.w * dsc.w + dsh.w, a.act_d);
+                            const int oy = (i - a.cy0) >> 1, ox = (j - a.cx0) >> 1;
+                            const unsigned off = ok ? (unsigned)((oy * a.Wo + ox) * a.Cexp * 4) + ych : 0xfffffff0u;
+                            const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                            __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int h = 0; h < PX; h += 2) {                     // two centres at a time: 12 taps live
                     constexpr int PH = PX >= 2 ? 2 : 1;
@@ -384,25 +431,27 @@ static bool xds_plan(int B, int H, int W, int Cin, int Cexp, int rate, int np, X
 
 // Cin 16 / 24 / 32: exact-f32 products (the early blocks); 64 / 96 / 160: split-bf16 products (the stride-16 section)
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate) {
-    if (stride != 1 || (rate != 1 && rate != 2)) return false;
+    if (rate != 1 && rate != 2) return false;
+    if (stride == 2) { if (rate != 1 || Cin > 32) return false; }          // stride 2: the exact-f32 form only
+    else if (stride != 1) return false;
     if (Cin != 16 && Cin != 24 && Cin != 32 && Cin != 64 && Cin != 96 && Cin != 160) return false;
     return Cexp % 16 == 0 && Cexp >= 32;
 }
 
-template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32 = false>
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32 = false, int S = 1>
 static int launch_xds_p(XdsArgs a, const XdsPlan& p, hipStream_t st) {
     static size_t attr_lds = 0;
     if (p.lds > 64 * 1024 && p.lds > attr_lds) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)p.lds));
         attr_lds = p.lds;
     }
     const int64_t nblocks = (int64_t)a.groups * a.chunks;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_stream: bad grid");
     static const std::string nm = "xdw_stream_kernel<" + std::to_string(KS) + ", " + std::to_string(NT) + ", " + std::to_string(NP) + ", " +
-                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ", " + std::to_string((int)F32) + ">";
+                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ", " + std::to_string((int)F32) + ", " + std::to_string(S) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -422,6 +471,7 @@ static int launch_xds_w(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
 // exact-f32 form: KC 16-k chunks, 4 E-waves + 4 D-waves
 template <int KC>
 static int launch_xds_f32(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
+    if (a.stride == 2) return p.nt == 4 ? launch_xds_p<KC, 4, 3, 4, 4, false, true, 2>(a, p, st) : launch_xds_p<KC, 2, 3, 4, 4, false, true, 2>(a, p, st);
     if (p.nt == 4) return launch_xds_p<KC, 4, 3, 4, 4, false, true>(a, p, st);
     return launch_xds_p<KC, 2, 3, 4, 4, false, true>(a, p, st);
 }
@@ -438,10 +488,10 @@ static int launch_xds_ks(const XdsArgs& a, const XdsPlan& p, int np, hipStream_t
 // w_parts: the expand layer's bf16 panels [part][Cexp][Cin] (np = 2: hi, lo; np = 3: hi, mid, lo), part p at w_parts + p * plane
 int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const float* w_f32,
                             const uint16_t* w_parts, int64_t plane, int np,
-                            const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
+                            const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int stride, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st) {
     const bool f32 = Cin <= 32;
-    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && (f32 ? w_f32 != nullptr : (w_parts && (np == 2 || np == 3))),
+    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, stride, rate) && (f32 ? w_f32 != nullptr : (w_parts && (np == 2 || np == 3))),
                 "expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d", Cin, Cexp, rate);
     if (f32) { np = 0; x_parts = nullptr; }
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_stream: empty input");
@@ -452,6 +502,13 @@ int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_p
     memset(&a, 0, sizeof(a));
     a.x = x; a.xs = x_parts; a.xs_plane = x_plane; a.wf = w_f32; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.wp = w_parts; a.plane = plane; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e;
     a.Cexp = Cexp; a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.y = y; a.rate = rate;
+    a.stride = stride;
+    if (stride == 2) {
+        int pt, pl;
+        same_pad(H, 3, 2, 1, &a.Ho, &pt);
+        same_pad(W, 3, 2, 1, &a.Wo, &pl);
+        a.cy0 = 1 - pt; a.cx0 = 1 - pl;
+    }
     const int step = 16 * p.nwe;
     a.SH = p.SH; a.SW = p.SW; a.Wp = p.SW + 2; a.T = ((p.SH + 2) * a.Wp + step - 1) / step; a.ring = p.ring;
     a.nsy = p.nsy; a.nsx = p.nsx; a.chunks = (Cexp + 16 * p.nt - 1) / (16 * p.nt);

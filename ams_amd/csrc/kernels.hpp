@@ -91,7 +91,7 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate);
 int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const float* w_f32,
                             const uint16_t* w_parts, int64_t plane, int np,
-                            const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
+                            const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int stride, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st);
 
 // ---- k_xdw_wreg.hip : the streaming fusion with the expand weights in registers and the operand staged in LDS (160 -> 960)

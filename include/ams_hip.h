@@ -244,6 +244,8 @@ int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin
 /* K4+K3 fused, streaming form for the stride-16 blocks (Cin in {64, 96, 160}, stride 1, rate 1|2, Cexp % 32 == 0): the same
  * result as ams_k_pointwise_split (parts = 2) / the three-part split (parts = 3) followed by ams_k_depthwise3x3, bit for bit,
  * without writing the expanded tensor.  panels: scratch of >= 3*Cexp*Cin uint16 (w_exp [Cin,Cexp] is split into it).
+ * Cin in {16, 24, 32}: exact-f32 products instead (bit-identical to ams_k_pointwise + ams_k_depthwise3x3; parts / presplit /
+ * panels unused), and rate = -2 selects the stride-2 depthwise conv (y [B,Ho,Wo,Cexp], SAME).
  * presplit != 0: x is first written as bf16 parts (what the project GEMM of the previous block leaves behind in the engine) and
  * the kernel loads its operand from them; panels then needs 3*B*H*W*Cin more elements.  Same result, bit for bit. */
 int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,

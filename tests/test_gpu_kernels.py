@@ -304,6 +304,43 @@ def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkey
             assert np.array_equal(got, unfused), (force, pre)
 
 
+@pytest.mark.parametrize("H,W,Cin,Cexp", [(65, 129, 16, 96), (64, 130, 24, 144), (33, 40, 32, 192), (7, 9, 16, 32), (2, 3, 24, 48)])
+def test_fused_expand_depthwise_stream_stride2(lib, H, W, Cin, Cexp, monkeypatch):
+    """Stride-2 blocks on the streaming kernel (exact-f32 products): vs f64 and bit-for-bit against f32 GEMM + stride-2 depthwise.
+    Odd and even sizes (SAME padding puts the window centres on even or odd input positions)."""
+    rng = np.random.default_rng(H * 5 + W + Cin)
+    B = 3
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    we = (rng.standard_normal((Cin, Cexp)) / np.sqrt(Cin)).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, Cexp, 1)) * 0.4).astype(np.float32)
+    se, sd = rng.uniform(0.5, 1.5, Cexp).astype(np.float32), rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
+    he, hd = rng.standard_normal(Cexp).astype(np.float32), rng.standard_normal(Cexp).astype(np.float32)
+    Ho, pt, pb = S.same_pad(H, 3, 2, 1)
+    Wo, pl, pr = S.same_pad(W, 3, 2, 1)
+    e = np.clip((x.astype(np.float64) @ we.astype(np.float64)) * se + he, 0, 6)
+    et = torch.as_tensor(e).permute(0, 3, 1, 2)
+    raw = F.conv2d(F.pad(et, (pl, pr, pt, pb)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), stride=2, groups=Cexp)
+    ref = torch.clamp(raw * torch.as_tensor(sd).view(1, -1, 1, 1) + torch.as_tensor(hd).view(1, -1, 1, 1), 0, 6).permute(0, 2, 3, 1).numpy()
+    M = B * H * W
+    ebuf = torch.empty((M, Cexp), device=DEV)
+    hip.check(lib.ams_k_pointwise(PD(x), M, Cin, PD(we), Cexp, 0, None, 1, PD(se), PD(he), hip.ACT_RELU6, None, P(ebuf), stream()))
+    unfused = torch.empty((B, Ho, Wo, Cexp), device=DEV)
+    hip.check(lib.ams_k_depthwise3x3(P(ebuf), B, H, W, Cexp, PD(wd), 2, 1, PD(sd), PD(hd), hip.ACT_RELU6, P(unfused), stream()))
+    unfused = unfused.cpu().numpy()
+    for force in (None, "4,1,1", "2,3,2", "4,2,3", "2,5,1"):
+        if force is None:
+            monkeypatch.delenv("AMS_XDS_FORCE", raising=False)
+        else:
+            monkeypatch.setenv("AMS_XDS_FORCE", force)
+        y = torch.full((B, Ho, Wo, Cexp), np.nan, device=DEV)
+        hip.check(lib.ams_k_expand_dw_stream(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), -2, PD(sd), PD(hd), P(y), None, 0, 3, 0,
+                                             stream()))
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), force
+        assert rel_err(got, ref) < 2e-5, force
+        assert np.array_equal(got, unfused), force
+
+
 @pytest.mark.parametrize("H,W,C_,N,rate,res", [(33, 65, 384, 64, 1, True), (33, 65, 576, 160, 1, False), (9, 17, 960, 160, 2, True),
                                                 (5, 9, 960, 320, 2, False), (17, 33, 384, 96, 1, False), (4, 16, 64, 16, 1, True)])
 def test_fused_depthwise_project(lib, H, W, C_, N, rate, res):

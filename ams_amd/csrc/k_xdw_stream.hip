@@ -401,7 +401,7 @@ static bool xds_plan_try(int B, int H, int W, int Cin, int Cexp, int rate, int n
     int nsy = 1;
     if (nsy_force > 0) nsy = nsy_force;
     else
-        while ((int64_t)B * rate * rate * chunks * nsx * nsy < 1024 && (Hs + nsy - 1) / nsy > 8) ++nsy;
+        while ((int64_t)B * rate * rate * chunks * nsx * nsy < 768 && (Hs + nsy - 1) / nsy > 8) ++nsy;     // three blocks per CU (sweeps: bench_xds.py)
     p->nt = nt; p->nwe = nwe; p->nwd = nwd; p->nsx = nsx; p->SW = SW; p->nsy = nsy; p->SH = (Hs + nsy - 1) / nsy; p->ring = ring;
     p->lds = xds_lds(Kp, nt, np, ring);
     // blocks per chunk: enough to fill the chip a few times over, so that a block amortises its weight fill over several items

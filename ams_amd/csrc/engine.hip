@@ -198,7 +198,7 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
         size_t pl = 0;
         for (int i = 2; i + 1 <= s->n_backbone; ++i) {
             const LayerRt& l = s->L[i];
-            if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
+            if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && l.d.cin >= 64 &&      /* split-bf16 forms only */
                 expand_dw_stream_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate) && (size_t)B * l.px_in * l.d.cin > pl)
                 pl = (size_t)B * l.px_in * l.d.cin;
         }
@@ -428,7 +428,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
     // frames: below that the launch cannot fill the chip)
     auto stream_ok = [&](int k) {
         if (!(s->fuse_expand_dw_stream && k + 1 <= s->n_backbone && s->L[k].d.role == AMS_ROLE_EXPAND && s->L[k + 1].d.role == AMS_ROLE_DEPTHWISE &&
-              (int64_t)B * s->L[k].px_in >= 16384 &&
+              (int64_t)B * s->L[k].px_in >= 16384 && (int64_t)s->L[k + 1].px_out * s->L[k + 1].d.cout * 4 < 0x7fffffffLL &&
               expand_dw_stream_supported(s->L[k].d.cin, s->L[k].d.cout, s->L[k + 1].d.stride, s->L[k + 1].d.rate)))
             return false;
         // stride 2 on the streaming kernel is correct and tested but measured no faster than the tiled kernel (the expand runs at

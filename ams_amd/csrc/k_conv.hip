@@ -268,13 +268,14 @@ int launch_stem_im2col(const void* frames, int dtype, int B, int H, int W, float
 // ---------------------------------------------------------------------------------------------------------
 struct DwGeom {
     int B, H, W, C, Ho, Wo, pt, pl, CG, slots, TH, tiles_x, tiles_y;
+    int flip;      // forward kernel: taps taken in reverse order (the input gradient of a stride-1 conv is the conv with the flipped kernel)
 };
 
 static int dw_geom(int B, int H, int W, int C, int stride, int rate, bool over_input, DwGeom* g) {
     AMS_REQUIRE(C % 4 == 0 && C / 4 <= 256, "depthwise: C=%d must be a multiple of 4 and <= 1024", C);
     AMS_REQUIRE((stride == 1 || stride == 2) && (rate == 1 || rate == 2) && !(stride == 2 && rate == 2),
                 "depthwise: unsupported stride %d / rate %d", stride, rate);
-    g->B = B; g->H = H; g->W = W; g->C = C;
+    g->B = B; g->H = H; g->W = W; g->C = C; g->flip = 0;
     same_pad(H, 3, stride, rate, &g->Ho, &g->pt);
     same_pad(W, 3, stride, rate, &g->Wo, &g->pl);
     g->CG = C / 4;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void dw3x3_fwd_kernel(const float* __restrict_
     }
     float4 wv[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + k * g.C + c0);
+    for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + (g.flip ? 8 - k : k) * g.C + c0);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero4;
     if (scale) { sc = ld4(scale + c0); sh = ld4(shift + c0); }
 #pragma unroll
@@ -429,11 +430,96 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_kernel(const float* __restric
     }
 }
 
+// Stride 2: an input pixel receives 1, 2 or 4 of the 9 taps, depending on the parity of its row and column.  A thread takes the
+// 2x2 block of input pixels whose top-left pixel has (row + pad) and (column + pad) even: the block needs exactly 2x2 gradient
+// values and 9 products in all (the generic kernel loads 36 values for the same four pixels, 27 of them masked); per pixel the
+// products come in the generic kernel's order (i, then j), so the result is bit-identical.
+__global__ __launch_bounds__(256) void dw3x3_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ wgt,
+                                                             float* __restrict__ dx, DwGeom g, int blocks_x, int blocks_y, int th) {
+    const int tiles_x = (blocks_x * g.CG + 255) / 256;
+    const int tx = blockIdx.x % tiles_x;
+    const int ty = (blockIdx.x / tiles_x) % ((blocks_y + th - 1) / th);
+    const int b = blockIdx.x / (tiles_x * ((blocks_y + th - 1) / th));
+    const int flat = tx * 256 + threadIdx.x;
+    const int bx = flat / g.CG, cg = flat - bx * g.CG;
+    if (bx >= blocks_x) return;
+    const int c0 = cg * 4;
+    float4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + k * g.C + c0);
+    const float* dyb = dy + (int64_t)b * g.Ho * g.Wo * g.C + c0;
+    float* dxb = dx + (int64_t)b * g.H * g.W * g.C + c0;
+    const int ix0 = 2 * bx - g.pl;                          // ix0 + pl even
+    const int oxH = (ix0 + g.pl) / 2, oxL = oxH - 1;
+    const bool okxH = oxH < g.Wo, okxL = oxL >= 0;
+    const int oxHc = okxH ? oxH : g.Wo - 1, oxLc = okxL ? oxL : 0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int r = 0; r < th; ++r) {
+        const int by = ty * th + r;
+        if (by >= blocks_y) break;
+        const int iy0 = 2 * by - g.pt;
+        const int oyH = (iy0 + g.pt) / 2, oyL = oyH - 1;
+        const bool okyH = oyH < g.Ho, okyL = oyL >= 0;
+        const int oyHc = okyH ? oyH : g.Ho - 1, oyLc = okyL ? oyL : 0;
+        float4 dHH = ld4(dyb + ((int64_t)oyHc * g.Wo + oxHc) * g.C), dHL = ld4(dyb + ((int64_t)oyHc * g.Wo + oxLc) * g.C);
+        float4 dLH = ld4(dyb + ((int64_t)oyLc * g.Wo + oxHc) * g.C), dLL = ld4(dyb + ((int64_t)oyLc * g.Wo + oxLc) * g.C);
+        if (!(okyH && okxH)) dHH = z4;
+        if (!(okyH && okxL)) dHL = z4;
+        if (!(okyL && okxH)) dLH = z4;
+        if (!(okyL && okxL)) dLL = z4;
+        auto fma4 = [](float4 a, const float4& v, const float4& w4) {
+            a.x = fmaf(v.x, w4.x, a.x); a.y = fmaf(v.y, w4.y, a.y); a.z = fmaf(v.z, w4.z, a.z); a.w = fmaf(v.w, w4.w, a.w);
+            return a;
+        };
+        // pixel (A, A): taps (0,0) (0,2) (2,0) (2,2); (A, B): (0,1) (2,1); (B, A): (1,0) (1,2); (B, B): (1,1)
+        float4 aAA = fma4(fma4(fma4(fma4(z4, dHH, wv[0]), dHL, wv[2]), dLH, wv[6]), dLL, wv[8]);
+        float4 aAB = fma4(fma4(z4, dHH, wv[1]), dLH, wv[7]);
+        float4 aBA = fma4(fma4(z4, dHH, wv[3]), dHL, wv[5]);
+        float4 aBB = fma4(z4, dHH, wv[4]);
+        const bool rA = iy0 >= 0 && iy0 < g.H, rB = iy0 + 1 < g.H, cA = ix0 >= 0 && ix0 < g.W, cB = ix0 + 1 < g.W;
+        if (rA && cA) st4(dxb + ((int64_t)iy0 * g.W + ix0) * g.C, aAA);
+        if (rA && cB) st4(dxb + ((int64_t)iy0 * g.W + ix0 + 1) * g.C, aAB);
+        if (rB && cA) st4(dxb + ((int64_t)(iy0 + 1) * g.W + ix0) * g.C, aBA);
+        if (rB && cB) st4(dxb + ((int64_t)(iy0 + 1) * g.W + ix0 + 1) * g.C, aBB);
+    }
+}
+
 int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const float* w, int stride, int rate,
                            float* dx, hipStream_t st) {
     DwGeom g;
     int rc = dw_geom(B, H, W, C, stride, rate, true, &g);
     if (rc) return rc;
+    if (stride == 1) {
+        // dx[iy] = sum_i dy[iy + R - i R] w[i] = sum_i' dy[iy - R + i' R] w[2 - i'] (SAME padding is symmetric at stride 1): the
+        // forward kernel with the taps reversed — its row reuse (4.5 loads per output instead of 9) and its HBM rate
+        DwGeom f;
+        rc = dw_geom(B, H, W, C, 1, rate, false, &f);
+        if (rc) return rc;
+        f.flip = 1;
+        constexpr int TH1 = 4, THR = 4;
+        f.tiles_y = rate == 2 ? 2 * cdiv(f.Ho, 2 * THR) : cdiv(f.Ho, TH1);
+        f.tiles_x = cdiv(f.Wo * f.CG, 256);
+        const unsigned nb = (unsigned)f.tiles_x * f.tiles_y * B;
+        note_kernel(rate == 2 ? "dw3x3_fwd_kernel<1, 2, 4>" : "dw3x3_fwd_kernel<1, 1, 4>");
+        if (rate == 1)
+            hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 1, TH1>), dim3(nb), dim3(256), 0, st, dy, w, (const float*)nullptr, (const float*)nullptr,
+                               (int)AMS_ACT_NONE, dx, f, nb);
+        else
+            hipLaunchKernelGGL((dw3x3_fwd_kernel<1, 2, THR>), dim3(nb), dim3(256), 0, st, dy, w, (const float*)nullptr, (const float*)nullptr,
+                               (int)AMS_ACT_NONE, dx, f, nb);
+        AMS_CHECK_LAUNCH();
+        return AMS_OK;
+    }
+    if (stride == 2) {
+        // 2x2 input blocks aligned to the padding: block (by, bx) starts at (2 by - pt, 2 bx - pl)
+        const int blocks_y = (H + g.pt + 1) / 2, blocks_x = (W + g.pl + 1) / 2, th = 4;
+        const unsigned nb = (unsigned)cdiv((int64_t)blocks_x * g.CG, 256) * cdiv(blocks_y, th) * B;
+        note_kernel("dw3x3_dgrad_s2_kernel");
+        hipLaunchKernelGGL(dw3x3_dgrad_s2_kernel, dim3(nb), dim3(256), 0, st, dy, w, dx, g, blocks_x, blocks_y, th);
+        AMS_CHECK_LAUNCH();
+        return AMS_OK;
+    }
     g.tiles_x = cdiv(g.W * g.CG, 256);
     const unsigned nblocks = (unsigned)g.tiles_x * g.tiles_y * B;
     const int threads = 256;

@@ -130,6 +130,27 @@ def test_full_size_properties(W0, clip):
     eng.close()
 
 
+def test_bench_batch_fused_equals_unfused(W0):
+    """At the benchmark's batch (32 frames: other segment / chunk plans than at 8) the streaming and weight-register kernels
+    give the bits of the kernels they replace, and a frame's logits do not depend on the batch it travels in beyond the
+    kernel-choice tolerance."""
+    frames, _ = synth.SyntheticVideo(H, 32, CI, seed=3).clip()
+    B = 32
+    eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
+    eng.load_variables(W0)
+    eng.freeze()
+    lab = eng.predict(frames)
+    low = _lowres(eng, B).copy()
+    eng.set_fuse_expand_dw_stream(0)
+    lab0 = eng.predict(frames)
+    assert torch.equal(lab0, lab)
+    assert np.array_equal(_lowres(eng, B), low)
+    eng.set_fuse_expand_dw_stream(1)
+    eng.predict(frames[5:6])
+    assert rel(_lowres(eng, 1)[0], low[5]) < 1e-4
+    eng.close()
+
+
 def test_fine_tune_step_full_size_against_f64_oracle(W0, clip):
     """One 2-frame step at 512 x 1024: the late layers run the 3-part bf16 GEMMs and weight gradients here (4290 rows);
     loss within 1e-3 and the whole gradient within the f32 error class of the f64 oracle (cosine)."""

@@ -208,6 +208,17 @@ def main():
                     "note": "HIP events on the launch stream around every kernel of a profiled replay of the timed step; "
                             "algorithmic bytes = f32 operands read once + results written once (DESIGN.md)"}
         roofline.update(pmc_traffic(dom[0], B, H))
+        if dom[0].startswith("xdw_wreg_kernel"):
+            # The fused expand+depthwise of the 160 -> 960 blocks moves 12 % of the bytes of the two kernels it replaces; what
+            # bounds it is the matrix pipe (every f32 product is 6, or 3, bf16 MFMAs) next to the depthwise VALU work.  Reported
+            # beside the HBM figure, not instead of it.
+            hl, wl = eng.lowres
+            parts = 2 if os.environ.get("AMS_MATMUL") == "1" else 3
+            flops = 2.0 * B * hl * wl * 160 * 960 * (6 if parts == 3 else 3)
+            tf_s = flops / (1e3 * ms / cnt * 1e-6) / 1e12
+            roofline["matrix_pipe"] = {"bound": "mfma", "achieved": round(tf_s, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf_s / 2500.0, 4),
+                                       "note": "bf16 MFMA FLOPs issued for the split-bf16 products of the expand GEMM (halo rows excluded); "
+                                               "f32-equivalent rate = achieved / %d" % (6 if parts == 3 else 3)}
     eng.close()
     del eng
     torch.cuda.empty_cache()

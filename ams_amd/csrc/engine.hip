@@ -102,6 +102,19 @@ struct ams_student {
     float *d_img_bias = nullptr, *d_pool_a = nullptr, *d_pool_z = nullptr, *d_pooled = nullptr;
     float* im2col = nullptr;         // [B*px1, 32]
     float* dz = nullptr;             // scratch: gradient wrt a raw conv output, max layer size
+    // Backward overlap: the weight gradient of a layer runs on a side stream beside the input gradient / BN backward chain of the
+    // main stream (it only feeds the optimizer).  dz alternates between two buffers so that the chain can move on, and the side
+    // stream has its own reduction scratch.
+    float* dz2 = nullptr;
+    float* scratch2 = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_wg[2] = {nullptr, nullptr};
+    int overlap_wgrad = 1;
+    ~ams_student() {
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (auto& e : ev_wg) if (e) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
+    }
     float* scratch = nullptr; size_t scratch_floats = 0;
     float* tmp_c = nullptr;          // [1024] small per-channel temp
     double* loss_buf = nullptr;      // [2] sum, count (inside BN_SYNC region so DP can all-reduce it)
@@ -243,6 +256,8 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
         s->d_pooled = cv.take<float>((size_t)B * head_cin);
         s->im2col = cv.take<float>((size_t)B * s->L[1].px_out * 32);
         s->dz = cv.take<float>((size_t)B * max_elems);
+        s->dz2 = cv.take<float>((size_t)B * max_elems);
+        s->scratch2 = cv.take<float>(sc);
         for (int i = 1; i <= c.n_layers; ++i) {
             LayerRt& l = s->L[i];
             if (l.d.role == AMS_ROLE_LOGITS) continue;     // logits live in s->logits / s->dlogits
@@ -641,7 +656,8 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
 // =======================================================================================================
 // BN backward of layer l given da (gradient wrt the layer's activated output): writes dz into s->dz, dgamma/dbeta into grads
 static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_local, double n_global, const SyncCtx* sc,
-                       hipStream_t st) {
+                       hipStream_t st, float* dz = nullptr) {
+    if (!dz) dz = s->dz;
     if (!sc || !sc->cb) {
         RUNK(0, 8.0 * M_local * l.d.cout,
              launch_bn_bwd_reduce_coef(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch,
@@ -657,15 +673,15 @@ static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_lo
                                nullptr, nullptr, st));
     }
     RUNK(0, 12.0 * M_local * l.d.cout,
-         launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, s->dz, st));
+         launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, dz, st));
     return AMS_OK;
 }
 
 static int pw_wgrad(ams_student* s, const float* x, int ldx, int K, const float* dy, int ldy, int N, int64_t M, float* dw,
-                    hipStream_t st) {
+                    hipStream_t st, float* scratch = nullptr) {
     WgArgs a;
     a.x = x; a.ldx = ldx; a.K = K; a.dy = dy; a.ldy = ldy; a.N = N; a.M = M; a.dw = dw;
-    a.scratch = s->scratch; a.scratch_floats = s->scratch_floats;
+    a.scratch = scratch ? scratch : s->scratch; a.scratch_floats = s->scratch_floats;
     a.allow_split = s->matmul_mode != AMS_MATMUL_F32;
     RUNK(0, 4.0 * ((double)M * (K + N) + (double)K * N), launch_pointwise_wgrad(a, st));
     return AMS_OK;
@@ -739,24 +755,49 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         a.img_bias = s->d_pooled; a.rows_per_img = HW;
         RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
-    // backbone, last layer to first
+    // backbone, last layer to first.  A layer's weight gradient only feeds the optimizer: it runs on the side stream while the main
+    // stream goes on with the input gradient and the next layer's BN backward (many of these kernels are latency-bound at 8 frames
+    // and share the chip well).  dz alternates between two buffers; the main stream waits for the weight gradient that read a
+    // buffer two layers ago before it overwrites it.
+    const bool overlap = s->overlap_wgrad && !s->prof.on && s->dz2 && s->scratch2;
+    if (overlap && !s->side) {
+        AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        for (auto& e : s->ev_wg) AMS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    bool wg_pending[2] = {false, false};
     for (int i = s->n_backbone; i >= 1; --i) {
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
-        RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st));
+        const int zb = i & 1;
+        float* dz = overlap && zb ? s->dz2 : s->dz;
+        if (overlap && wg_pending[zb]) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_wg[zb], 0)); wg_pending[zb] = false; }
+        RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz));
         if (l.d.role == AMS_ROLE_STEM) {
             RUN(launch_stem_im2col(frames, dtype, B, c.height, c.width, c.pixel_scale, s->im2col, st));
-            RUN(pw_wgrad(s, s->im2col, 32, 27, s->dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, st));
+            RUN(pw_wgrad(s, s->im2col, 32, 27, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, st));
             break;
         }
         LayerRt& prev = s->L[i - 1];
+        hipStream_t wst = st;
+        float* wscratch = s->scratch;
+        if (overlap) {
+            AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+            AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+            wst = s->side; wscratch = s->scratch2;
+        }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
-            RUNK(i, dw_bytes(l, B), launch_depthwise_wgrad(prev.a, s->dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off,
-                                                           s->scratch, s->scratch_floats, st));
-            RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(s->dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
+            if (overlap) RUN(launch_depthwise_wgrad(prev.a, dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off, wscratch, s->scratch_floats, wst));
+            else RUNK(i, dw_bytes(l, B), launch_depthwise_wgrad(prev.a, dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off,
+                                                                wscratch, s->scratch_floats, wst));
         } else {
-            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, s->dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, st));
-            PwArgs a = dgrad_args(s->dz, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, prev.da);
+            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch));
+        }
+        if (overlap) { AMS_CHECK_HIP(hipEventRecord(s->ev_wg[zb], s->side)); wg_pending[zb] = true; }
+        if (l.d.role == AMS_ROLE_DEPTHWISE) {
+            RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
+        } else {
+            PwArgs a = dgrad_args(dz, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, prev.da);
             // the block input also feeds the residual add at the end of this block: add that gradient here
             if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) {
                 a.res = s->L[i + 2].da; a.ldr = l.d.cin;
@@ -764,6 +805,9 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         }
     }
+    // the optimizer (and the gradient all-reduce) wait for every weight gradient
+    for (int k = 0; k < 2; ++k)
+        if (overlap && wg_pending[k]) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_wg[k], 0));
     return AMS_OK;
 }
 

@@ -187,6 +187,43 @@ def test_train_step_matches_oracle(W0, clip64):
     eng.close()
 
 
+def test_free_running_schedule_tracks_oracle(W0):
+    """a short free-running distillation schedule (no re-synchronisation with the oracle between steps).  Two
+    evaluations of this graph drift apart from the second step on (noise-driven sign flips of Adam's normalised steps on
+    zero-gradient entries, see _compare_train_state), so the bar is the f32 error class again: the HIP path's loss curve may
+    leave the f64 oracle's by no more than 3x what the f32 CPU oracle's does (+1 %), the first step agrees to 1e-3, the loss
+    falls, and the student's mIoU against the teacher labels on held-out frames ends as close to the f64 oracle's as the f32 CPU
+    oracle's does (3x + 0.5 point: on 3 x 8192 pixels a few hundred flipped labels move the mIoU by points in any f32 run)."""
+    from ams_amd.utils import calculate_miou
+    frames, labels = synth.SyntheticVideo(64, 7, CI, seed=5).clip()
+    B, steps, lr = 4, 6, 1e-3
+    eng = StudentEngine(CI, 64, 128, max_batch=B, trainable=True)
+    eng.load_variables(W0)
+    o64, o32 = _oracle(W0, torch.float64), _oracle(W0, torch.float32)
+    fr, lb = frames[:B], labels[:B]
+    held_f, held_l = frames[4:7], labels[4:7]
+    curve_g, curve_64, curve_32 = [], [], []
+    for _ in range(steps):
+        ls = eng.train_step(fr, lb, lr).cpu().numpy()
+        curve_g.append(ls[0] / ls[1])
+        curve_64.append(float(o64.train_step(fr.astype(np.float32), lb, lr)))
+        curve_32.append(float(o32.train_step(fr.astype(np.float32), lb, lr)))
+    curve_g, curve_64, curve_32 = np.array(curve_g), np.array(curve_64), np.array(curve_32)
+    assert abs(curve_g[0] - curve_64[0]) <= 1e-3 * curve_64[0]
+    dev_g, dev_32 = np.abs(curve_g - curve_64) / curve_64, np.abs(curve_32 - curve_64) / curve_64
+    assert np.all(dev_g <= 3 * np.maximum.accumulate(dev_32) + 1e-2), (dev_g, dev_32)
+    assert curve_g[-1] < 0.5 * curve_g[0] and curve_64[-1] < 0.5 * curve_64[0]
+    # held-out frame, live graph (BN batch statistics, as the server evaluates it)
+    _, conf, _ = eng.predict_with_metric(held_f, held_l, hip.MODE_LIVE)
+    _, cm_64, _ = o64.predict_with_metric(held_f.astype(np.float32), held_l, "live")
+    _, cm_32, _ = o32.predict_with_metric(held_f.astype(np.float32), held_l, "live")
+    miou_g = np.nanmean(calculate_miou(conf.cpu().numpy().astype(np.float64), nan=True))
+    miou_64 = np.nanmean(calculate_miou(np.asarray(cm_64, dtype=np.float64), nan=True))
+    miou_32 = np.nanmean(calculate_miou(np.asarray(cm_32, dtype=np.float64), nan=True))
+    assert abs(miou_g - miou_64) <= 3 * abs(miou_32 - miou_64) + 0.005, (miou_g, miou_32, miou_64)
+    eng.close()
+
+
 def test_masked_step_reverts_weights_but_advances_moments(W0, clip64):
     frames, labels = clip64
     B = 2

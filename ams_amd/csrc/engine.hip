@@ -1058,10 +1058,14 @@ int ams_student_set_adam_step(ams_student* s, int64_t t) {
     return AMS_OK;
 }
 
+size_t ams_pack_masked_fp16_scratch(int64_t n) { return n > 0 ? pack_fp16_scratch(n) : 0; }
+
 int ams_pack_masked_fp16(const float* params_dev, const uint8_t* mask_dev, int64_t n, uint16_t* out_half_dev, int64_t* n_out_dev,
-                         void* stream) {
+                         int64_t* scratch_dev, size_t scratch_elems, void* stream) {
     AMS_REQUIRE(params_dev && out_half_dev && n_out_dev && n > 0, "pack_masked_fp16: bad argument");
-    return launch_pack_fp16(params_dev, mask_dev, n, out_half_dev, n_out_dev, (hipStream_t)stream);
+    AMS_REQUIRE(scratch_dev && scratch_elems >= pack_fp16_scratch(n), "pack_masked_fp16: scratch too small (need %zu int64)",
+                pack_fp16_scratch(n));
+    return launch_pack_fp16(params_dev, mask_dev, n, out_half_dev, n_out_dev, scratch_dev, (hipStream_t)stream);
 }
 
 // ---- kernel-level entry points -----------------------------------------------------------------------------

@@ -566,16 +566,13 @@ __global__ void pack_write_kernel(const float* p, const uint8_t* mask, int64_t n
         if (!mask || mask[i]) out[o++] = __float2half_rn(p[i]);
 }
 
-int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* out, int64_t* n_out, hipStream_t st) {
+size_t pack_fp16_scratch(int64_t n) { return (size_t)cdiv64(n, 256); }
+
+// counts: caller-owned device scratch of pack_fp16_scratch(n) int64 (no allocation here: the call is capture-safe and two
+// students on different devices or streams never share state)
+int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* out, int64_t* n_out, int64_t* counts, hipStream_t st) {
     const int64_t seg = 256;
     const int nseg = (int)cdiv64(n, seg);
-    static int64_t* counts = nullptr;
-    static int cap = 0;
-    if (nseg > cap) {
-        if (counts) (void)hipFree(counts);
-        AMS_CHECK_HIP(hipMalloc(&counts, (size_t)nseg * sizeof(int64_t)));
-        cap = nseg;
-    }
     hipLaunchKernelGGL(pack_count_kernel, dim3(nseg), dim3(256), 0, st, mask, n, seg, counts);
     AMS_CHECK_LAUNCH();
     hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1), 0, st, counts, nseg, n_out);

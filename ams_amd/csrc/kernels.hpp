@@ -145,7 +145,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mas
 int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st);
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
 int launch_copy(float* dst, const float* src, int64_t n, hipStream_t st);
-int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* out, int64_t* n_out, hipStream_t st);
+size_t pack_fp16_scratch(int64_t n);
+int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* out, int64_t* n_out, int64_t* counts, hipStream_t st);
 
 // ---- k_head.hip : fused upsample + argmax + metrics, CE gradient, phi-score confusion --------------------
 int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,

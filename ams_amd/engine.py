@@ -195,8 +195,10 @@ class StudentEngine:
             assert mask.dtype == torch.uint8 and mask.numel() == n and mask.device == self.arena.device
         out = torch.empty(n, dtype=torch.int16, device=self.device)
         cnt = torch.zeros(1, dtype=torch.int64, device=self.device)
+        scratch = torch.empty(int(self.lib.ams_pack_masked_fp16_scratch(n)), dtype=torch.int64, device=self.device)
         hip.check(self.lib.ams_pack_masked_fp16(C.c_void_p(self.params.data_ptr()), C.c_void_p(mask.data_ptr()) if mask is not None else None,
-                                                n, C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()), self._stream()),
+                                                n, C.c_void_p(out.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                C.c_void_p(scratch.data_ptr()), scratch.numel(), self._stream()),
                   "ams_pack_masked_fp16")
         return out[:int(cnt.item())]
 

@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libams_hip.so"
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums of include/ams_hip.h
 ROLE_STEM, ROLE_EXPAND, ROLE_DEPTHWISE, ROLE_PROJECT, ROLE_POOL_CONV, ROLE_ASPP, ROLE_CONCAT_PROJ, ROLE_LOGITS = range(8)
@@ -71,7 +71,8 @@ SIGNATURES = {
     "ams_student_profile_read": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "ams_student_get_adam_step": (C.c_int, [_vp, C.POINTER(_i64)]),
     "ams_student_set_adam_step": (C.c_int, [_vp, _i64]),
-    "ams_pack_masked_fp16": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "ams_pack_masked_fp16": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "ams_pack_masked_fp16_scratch": (_sz, [_i64]),
     "ams_k_stem_conv": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _f32, _vp, _vp]),
     "ams_k_depthwise3x3": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "ams_k_pointwise": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),

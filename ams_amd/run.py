@@ -9,7 +9,14 @@ committed; the defects listed in SURVEY.md Appendix D are resolved towards their
   * sampling and training fire ONCE per matching second (reference: once per frame of that second);
   * ``label_memory.append`` (reference ``extend`` pushes rows);
   * first training at ceil(100 / train_period) * train_period seconds, then every ``train_period`` (int range);
-  * ``send_rate`` is the fraction of bucket frames to upload (1.0 by default, clipped to [0.1, 1] under ASR).
+  * ``send_rate`` is the uplink sampling rate in frames per SECOND: ``fps / sampling_period`` at the start (1.0 with the
+    defaults 30 / 30, the value the reference's ``sampling_period / fps`` also gives there), clipped to [0.1, 1] under ASR
+    as in the reference; ``choose_frames`` receives ``send_rate / fps`` as the fraction of the bucket, so the replay memory
+    of ``memory_len / sampling_period * fps`` entries spans ``memory_len`` seconds (the reference passes ``send_rate``
+    itself as the fraction, which uploads every frame and shrinks the memory's span to a few seconds);
+  * samples are uploaded every ``train_period`` seconds (the reference's last ``train_model`` argument, run.py:600-601);
+  * a training event that finds the replay memory empty still publishes the current model for that time, so that the edge
+    has a model to load (the reference would fail inside ``mini_batch``).
 Out of scope (networking emulation / reporting): H.264 uplink through ffmpeg (``--compress_uplink``
 is rejected), PNG-exact uplink byte counts (zlib-deflated frame size is logged instead), the matplotlib plots.
 Video comes from a ``FrameSource``: there is no OpenCV here, so ``--input_video`` is either
@@ -187,7 +194,7 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
     train_end_frame = min(train_end * fps, len(ctx.source))
     i = train_start * fps
     update_count = 0
-    send_rate = 1.0
+    send_rate = min(float(fps), fps / float(sampling_period))      # frames per second uploaded (module docstring)
     sample_per_period, up_bw_per_period, down_bw_per_period = [], [], []
     frame_label_bucket = []
     num_unseen_frames = 0
@@ -221,7 +228,7 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
             print_process("%d seconds elapsed" % second, second)
 
         if second % sample_send_period == 0:
-            frames_chosen, labels_chosen = choose_frames(frame_label_bucket, send_rate)
+            frames_chosen, labels_chosen = choose_frames(frame_label_bucket, min(1.0, send_rate / fps))
             size_images = 0.0
             for fr, label in zip(frames_chosen, labels_chosen):
                 fr, label_resized = _to_size(fr, label, ctx.size, ctx.ingest)
@@ -236,7 +243,14 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
             num_unseen_frames += len(frames_chosen)
             up_bw_per_period.append(size_images * 8)
 
-        if second in save_range and len(frame_memory) > 0:
+        if second in save_range and len(frame_memory) == 0:
+            # nothing has been uploaded yet (e.g. a horizon window shorter than the upload period): the model of this event
+            # time is the current one, published unchanged
+            print_process("No samples in memory at %d s: publishing the current model unchanged" % second, second)
+            save_dir = ctx.save_dir(run_label + "_%d" % second)
+            semantic_network.save_to_frozen_graph(save_dir + "_final")
+            model_save_times.append(float(second))
+        elif second in save_range:
             if FLAGS.enable_ASR and len(label_memory) > 1:
                 # phi-score over the frames that arrived since the last update -> sampling rate (run.py:279-290)
                 i_start = max(0, len(label_memory) - num_unseen_frames - 1)
@@ -358,18 +372,18 @@ def main(argv: Optional[List[str]] = None):
         events = event_times(flags, length)
         if not flags.only_results:
             events = train_model(ctx, 0, length, flags.send_period, flags.gpu, run_label, flags.gt_video, vid_num, events,
-                                 flags.send_period)           # the times at which a model was actually published
+                                 flags.train_period)          # the times at which a model was actually published
             summary = infer_output(ctx, 0, length, flags.gpu, run_label, flags.gt_video, vid_num, events)
     elif flags.mode == 'early':
         run_label = "early%d_f%d" % (flags.early_cutoff_time, flags.send_period)
         events = [0, flags.early_cutoff_time]
         if not flags.only_results:
             events = train_model(ctx, 0, flags.early_cutoff_time, flags.send_period, flags.gpu, run_label, flags.gt_video,
-                                 vid_num, events, flags.send_period)
+                                 vid_num, events, flags.train_period)
             summary = infer_output(ctx, 0, length, flags.gpu, run_label, flags.gt_video, vid_num, events)
     elif flags.mode == 'pretrained':
         run_label = "pretrained"
-        train_model(ctx, 0, 1, flags.send_period, flags.gpu, run_label, flags.gt_video, vid_num, [0], flags.send_period)
+        train_model(ctx, 0, 1, flags.send_period, flags.gpu, run_label, flags.gt_video, vid_num, [0], flags.train_period)
         summary = infer_output(ctx, 0, length, flags.gpu, run_label, flags.gt_video, vid_num, [0])
     else:  # horizon: retrain on [t-k1, t), evaluate on [t, t+k2)
         k1s, k2 = [16, 32, 64, 128, 256, 512], 256
@@ -380,7 +394,7 @@ def main(argv: Optional[List[str]] = None):
             t = k1s[-1] + p * step
             for k1 in k1s:
                 run_label = "%d__%d__%d_f%d" % (t - k1, t, t + k2, flags.send_period)
-                train_model(ctx, t - k1, t, flags.send_period, flags.gpu, run_label, flags.gt_video, vid_num, [t], flags.send_period)
+                train_model(ctx, t - k1, t, flags.send_period, flags.gpu, run_label, flags.gt_video, vid_num, [t], flags.train_period)
                 summary = infer_output(ctx, t, t + k2, flags.gpu, run_label, flags.gt_video, vid_num, [t])
     print("Process [Main]:", "Done!!!", summary if summary else "")
     return summary

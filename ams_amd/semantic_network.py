@@ -268,7 +268,13 @@ class SemanticNetwork(object):
                     time.sleep(self.THREAD_SLEEP_INTERVAL)
             t1 = time.time()
             frames_dev, labels_dev, ready = staged
-            torch.cuda.current_stream(self.engine.device).wait_event(ready)
+            compute = torch.cuda.current_stream(self.engine.device)
+            compute.wait_event(ready)
+            # the buffers were allocated on the stager's copy stream: tell the caching allocator that the compute stream uses
+            # them too, or dropping the references one iteration later hands the block back to the copy stream's pool while
+            # this step's kernels (the stem weight gradient re-reads the frames in backward) are still queued
+            frames_dev.record_stream(compute)
+            labels_dev.record_stream(compute)
             loss_dev = self.engine.train_step(frames_dev, labels_dev, self.lr, mask_dev)
             losses.append(loss_dev)
             if self.verbose:
@@ -423,42 +429,53 @@ class SemanticNetwork(object):
         self.engine.close()
 
     # ------------------------------------------------------------------ visualisation helpers (NumPy only)
+    # Same signatures and return conventions as the reference (SemanticNetwork.py:719-755); bodies are this build's own:
+    # palettes are looked up through one helper, the 50/50 overlay is integer arithmetic (cv2.addWeighted rounds half
+    # to even on the float sum; so does _overlay), and the disagreement picture is built from boolean planes.
+    def _check_hw(self, arr, channels=None, what="array"):
+        want = (self.height, 2 * self.height) + (() if channels is None else (channels,))
+        assert arr.shape == want, "%s must be %s, got %s" % (what, want, arr.shape)
+
     @staticmethod
-    def _blend(a, b):
-        return np.clip(np.rint(0.5 * a.astype(np.float32) + 0.5 * b.astype(np.float32)), 0, 255).astype(np.uint8)
+    def _overlay(frame, colours):
+        total = frame.astype(np.uint16) + colours.astype(np.uint16)           # 0..510
+        half = total >> 1
+        half += (total & 1) & (half & 1)                                      # x.5 -> nearest even, like rint
+        return half.astype(np.uint8)
+
+    def _paint(self, palette, label, frame):
+        colours = np.asarray(palette)[np.asarray(label)]
+        return colours if frame is None else (colours, self._overlay(frame, colours))
 
     def colorize(self, frame=None, label=None):
         assert frame is not None or label is not None, "At least a label or frame must be given"
-        assert frame is None or frame.shape == (self.height, self.height * 2, 3)
-        if label is None:
-            label = self.predict_input(np.expand_dims(frame, axis=0))[0]
-        assert label.shape == (self.height, self.height * 2)
-        label_colored = self.color_map_reduced_[label]
         if frame is not None:
-            return label_colored, self._blend(frame, label_colored)
-        return label_colored
+            self._check_hw(frame, 3, "frame")
+        if label is None:
+            label = self.predict_input(frame[None])[0]
+        self._check_hw(label, None, "label")
+        return self._paint(self.color_map_reduced_, label, frame)
 
     def colorize_teacher(self, label, frame=None):
-        assert frame is None or frame.shape == (self.height, self.height * 2, 3)
-        assert label.shape == (self.height, self.height * 2)
-        label_colored = colormap()[label]
         if frame is not None:
-            return label_colored, self._blend(frame, label_colored)
-        return label_colored
+            self._check_hw(frame, 3, "frame")
+        self._check_hw(label, None, "label")
+        return self._paint(colormap(), label, frame)
 
     def cross_ignore(self, label_teacher, label_student=None, frame_student=None):
+        """(cross_mask, ignore_mask): where teacher and student disagree (teacher colour, black elsewhere) and which
+        pixels the metric skips (white).  As in the reference, subset index 0 doubles as 'ignored'."""
         assert label_student is not None or frame_student is not None, \
             "At least a label or frame from student must be given"
-        assert label_teacher.shape == (self.height, self.height * 2)
-        label_teacher_reduced = self.take_array[label_teacher]
+        self._check_hw(label_teacher, None, "label_teacher")
         if label_student is None:
-            label_student = self.predict_input(np.expand_dims(frame_student, axis=0))[0]
-        assert label_student.shape == (self.height, self.height * 2)
-        ignore_mask = np.where(np.expand_dims(label_teacher_reduced, axis=-1) == 0, self.WHITE, self.BLACK)
-        colorized_label_teacher = self.colorize(label=label_teacher_reduced)
-        cross_cond = np.logical_and(np.logical_not(ignore_mask[:, :, :1]),
-                                    np.expand_dims(np.not_equal(label_teacher_reduced, label_student), axis=-1))
-        cross_mask = np.where(cross_cond, colorized_label_teacher, self.BLACK)
-        assert ignore_mask.shape == cross_mask.shape
-        assert ignore_mask.shape == (self.height, self.height * 2, 3)
+            label_student = self.predict_input(frame_student[None])[0]
+        self._check_hw(label_student, None, "label_student")
+        teacher_k = self.take_array[label_teacher]
+        skipped = teacher_k == 0
+        ignore_mask = np.zeros(teacher_k.shape + (3,), dtype=np.uint8)
+        ignore_mask[skipped] = self.WHITE
+        differs = ~skipped & (teacher_k != label_student)
+        cross_mask = np.zeros_like(ignore_mask)
+        cross_mask[differs] = self.color_map_reduced_[teacher_k[differs]]
         return cross_mask, ignore_mask

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AMS_ABI_VERSION 1
+#define AMS_ABI_VERSION 2
 
 enum {
     AMS_OK = 0,
@@ -198,7 +198,9 @@ int ams_student_set_adam_step(ams_student* s, int64_t t);
  * Casts the masked parameters to fp16 in trainable order: out_half_dev receives sum(mask) halves, and
  * n_out_dev (int64) the count.  mask_dev NULL = all parameters. */
 int ams_pack_masked_fp16(const float* params_dev, const uint8_t* mask_dev, int64_t n, uint16_t* out_half_dev,
-                         int64_t* n_out_dev, void* stream);
+                         int64_t* n_out_dev, int64_t* scratch_dev, size_t scratch_elems, void* stream);
+/* int64 elements of caller-owned device scratch the call above needs (segment counts; nothing is allocated inside) */
+size_t ams_pack_masked_fp16_scratch(int64_t n);
 
 /* =====================================================================================================
  * Kernel-level entry points.  Same kernels the engine launches, exposed one by one so that tests/ can

@@ -55,6 +55,20 @@ def batch_norm(x, gamma, beta, mean, var, eps):
     return (x - mean) * (1.0 / np.sqrt(var + eps)) * gamma + beta
 
 
+def preprocess(frames):
+    """[B,H,W,3] 0..255 -> padded by one row / column of 127.5, times f32(1/127.5), minus 1 (nodes concat, concat_1, mul_4, sub_2)."""
+    x = np.pad(frames, ((0, 0), (0, 1), (0, 1), (0, 0)), constant_values=S.PAD_VALUE)
+    return x * frames.dtype.type(np.float32(S.PIXEL_SCALE)) - frames.dtype.type(1.0)
+
+
+def batch_norm_train(x, gamma, beta, eps):
+    """FusedBatchNormV3(is_training=True), NHWC: (y, batch mean, unbiased batch variance)."""
+    n = x.shape[0] * x.shape[1] * x.shape[2]
+    mu = x.mean(axis=(0, 1, 2))
+    var = ((x - mu) ** 2).mean(axis=(0, 1, 2))
+    return batch_norm(x, gamma, beta, mu, var, eps), mu, var * (n / max(n - 1, 1))
+
+
 def resize_bilinear_align_corners(x, out_h, out_w):
     b, in_h, in_w, c = x.shape
 
@@ -79,9 +93,7 @@ def forward_lowres(variables: Dict[str, np.ndarray], frames: np.ndarray, mode: s
                    num_classes: int = 19, dtype=np.float32, batch_stats: Optional[dict] = None) -> np.ndarray:
     spec = S.build_spec(num_classes)
     p = {k: np.asarray(v, dtype=dtype) for k, v in variables.items()}
-    x = np.asarray(frames, dtype=dtype)
-    x = np.pad(x, ((0, 0), (0, 1), (0, 1), (0, 0)), constant_values=S.PAD_VALUE)
-    x = x * dtype(np.float32(S.PIXEL_SCALE)) - dtype(1.0)
+    x = preprocess(np.asarray(frames, dtype=dtype))
 
     def bn_act(y, l):
         g, bta = p[l.scope + "/BatchNorm/gamma:0"], p[l.scope + "/BatchNorm/beta:0"]
@@ -89,12 +101,9 @@ def forward_lowres(variables: Dict[str, np.ndarray], frames: np.ndarray, mode: s
             y = batch_norm(y, g, bta, p[l.scope + "/BatchNorm/moving_mean:0"],
                            p[l.scope + "/BatchNorm/moving_variance:0"], dtype(S.BN_EPS_FROZEN))
         else:
-            mu = y.mean(axis=(0, 1, 2))
-            var = ((y - mu) ** 2).mean(axis=(0, 1, 2))
+            y, mu, var_unbiased = batch_norm_train(y, g, bta, dtype(l.bn_eps))
             if batch_stats is not None:
-                n = y.shape[0] * y.shape[1] * y.shape[2]
-                batch_stats[l.scope] = (mu, var * (n / max(n - 1, 1)))
-            y = batch_norm(y, g, bta, mu, var, dtype(l.bn_eps))
+                batch_stats[l.scope] = (mu, var_unbiased)
         if l.act == "relu6":
             y = np.clip(y, 0, 6)
         elif l.act == "relu":
@@ -133,20 +142,39 @@ def predict_with_metric(variables, frames, labels_teacher, class_indices: Sequen
     low = forward_lowres(variables, frames, mode, num_classes, dtype)
     full = resize_bilinear_align_corners(low, frames.shape[1], frames.shape[2])
     z = full[..., ci]
-    pred = np.argmax(z, axis=-1).astype(np.int32)
-    lab = np.asarray(labels_teacher).astype(np.float32).astype(np.int32)
-    onehot = (lab[..., None] == np.arange(num_classes)).astype(dtype)     # out-of-range -> all-zero row
-    sel = onehot[..., ci]
-    target = np.argmax(sel, axis=-1)
-    weight = sel.sum(axis=-1)
-    cm = np.zeros((k, k), dtype=np.float64)
-    np.add.at(cm, (target.reshape(-1), pred.reshape(-1)), weight.reshape(-1).astype(np.float64))
-    zmax = z.max(axis=-1, keepdims=True)
-    lse = np.log(np.exp(z - zmax).sum(axis=-1)) + zmax[..., 0]
-    pixel = lse - (z * sel).sum(axis=-1)
+    pred = gather_argmax(full, ci)
+    target, weight, sel = label_targets(labels_teacher, ci, num_classes, dtype)
+    cm = confusion(target, pred, weight, k)
+    pixel = softmax_ce(z, sel)
     valid = weight > 0
     loss = float(pixel[valid].mean()) if valid.any() else float("nan")
     return pred, cm, loss
+
+
+def gather_argmax(logits, class_indices):
+    """tf.gather(axis=-1) then tf.argmax: index of the FIRST maximum among the selected classes, int32."""
+    return np.argmax(logits[..., np.asarray(class_indices)], axis=-1).astype(np.int32)
+
+
+def label_targets(labels_teacher, class_indices, num_classes=19, dtype=np.float32):
+    """cast -> one_hot(num_classes) (ids outside 0..num_classes-1: all-zero row) -> gather -> (argmax, row sum, gathered rows)."""
+    lab = np.asarray(labels_teacher).astype(np.float32).astype(np.int32)
+    onehot = (lab[..., None] == np.arange(num_classes)).astype(dtype)
+    sel = onehot[..., np.asarray(class_indices)]
+    return np.argmax(sel, axis=-1), sel.sum(axis=-1), sel
+
+
+def softmax_ce(z, onehot):
+    """softmax_cross_entropy_with_logits, max-subtracted: logsumexp(z) - sum(onehot * z)."""
+    zmax = z.max(axis=-1, keepdims=True)
+    return np.log(np.exp(z - zmax).sum(axis=-1)) + zmax[..., 0] - (z * onehot).sum(axis=-1)
+
+
+def confusion(target, pred, weight, k):
+    """tf.metrics.mean_iou's matrix: [label, prediction] += weight, float64."""
+    cm = np.zeros((k, k), dtype=np.float64)
+    np.add.at(cm, (np.asarray(target).reshape(-1), np.asarray(pred).reshape(-1)), np.asarray(weight).reshape(-1).astype(np.float64))
+    return cm
 
 
 def adam_step(w, g, m, v, lr, beta1_power, beta2_power, beta1=0.9, beta2=0.999, eps=1e-8):

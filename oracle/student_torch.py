@@ -61,6 +61,47 @@ def resize_bilinear_align_corners(x: torch.Tensor, out_h: int, out_w: int) -> to
     return top + (bot - top) * ty
 
 
+def preprocess(frames: torch.Tensor) -> torch.Tensor:
+    """nodes concat / concat_1 (one row, one column of 127.5), mul_4, sub_2: NHWC 0..255 -> NCHW network input."""
+    x = F.pad(frames.permute(0, 3, 1, 2), (0, 1, 0, 1), value=S.PAD_VALUE)
+    return x * torch.tensor(S.PIXEL_SCALE, dtype=torch.float32).to(frames.dtype) - 1.0
+
+
+def conv_same(x: torch.Tensor, w: torch.Tensor, kind: str, stride: int, rate: int) -> torch.Tensor:
+    """Conv2D (kind 'conv', w HWIO) or DepthwiseConv2dNative (kind 'dw', w HWC1) with SAME padding, NCHW activations."""
+    xp = _same_pad_2d(x, w.shape[0], stride, rate)
+    if kind == "dw":
+        return F.conv2d(xp, w.permute(2, 3, 0, 1), stride=stride, dilation=rate, groups=w.shape[2])
+    return F.conv2d(xp, w.permute(3, 2, 0, 1), stride=stride)
+
+
+def batch_norm_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    """FusedBatchNormV3(is_training=True) on NCHW: (y, batch mean, UNBIASED batch variance) — outputs 0, 1, 2 (Appendix C.3)."""
+    n = x.shape[0] * x.shape[2] * x.shape[3]
+    mu = x.mean(dim=(0, 2, 3), keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=(0, 2, 3), keepdim=True)                # biased: what normalises
+    y = (x - mu) * torch.rsqrt(var + eps) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    return y, mu.reshape(-1), (var * (n / max(n - 1, 1))).reshape(-1)
+
+
+def batch_norm_frozen(x, gamma, beta, moving_mean, moving_var, eps: float = S.BN_EPS_FROZEN):
+    v = lambda t: t.view(1, -1, 1, 1)  # noqa: E731
+    return (x - v(moving_mean)) * torch.rsqrt(v(moving_var) + eps) * v(gamma) + v(beta)
+
+
+def ema_update(moving: torch.Tensor, stat: torch.Tensor) -> torch.Tensor:
+    """AssignMovingAvg: moving -= (moving - stat) * (1 - decay), (1 - decay) formed in f32 as the graph's Sub node does."""
+    return moving - (moving - stat) * float(np.float32(1.0) - np.float32(S.BN_DECAY))
+
+
+def adam_update(w, g, m, v, lr: float, beta1_power: float, beta2_power: float, b1=0.9, b2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer dense apply (Appendix C.10): eps is added OUTSIDE the square root.  -> (w, m, v)."""
+    lr_t = lr * np.sqrt(1.0 - beta2_power) / (1.0 - beta1_power)
+    m = m * b1 + (1.0 - b1) * g
+    v = v * b2 + (1.0 - b2) * g * g
+    return w - lr_t * m / (torch.sqrt(v) + eps), m, v
+
+
 class StudentOracle:
     """Stateful restatement of the live (trainable) student plus its frozen twin."""
 
@@ -92,18 +133,13 @@ class StudentOracle:
 
     # ------------------------------------------------------------------ forward
     def _bn(self, x: torch.Tensor, layer: S.Layer, mode: str, p: Dict[str, torch.Tensor]) -> torch.Tensor:
-        g = p[layer.scope + "/BatchNorm/gamma:0"].view(1, -1, 1, 1)
-        b = p[layer.scope + "/BatchNorm/beta:0"].view(1, -1, 1, 1)
+        g = p[layer.scope + "/BatchNorm/gamma:0"]
+        b = p[layer.scope + "/BatchNorm/beta:0"]
         if mode == "frozen":
-            mu = p[layer.scope + "/BatchNorm/moving_mean:0"].view(1, -1, 1, 1)
-            var = p[layer.scope + "/BatchNorm/moving_variance:0"].view(1, -1, 1, 1)
-            return (x - mu) * torch.rsqrt(var + S.BN_EPS_FROZEN) * g + b
-        n = x.shape[0] * x.shape[2] * x.shape[3]
-        mu = x.mean(dim=(0, 2, 3), keepdim=True)
-        var = ((x - mu) ** 2).mean(dim=(0, 2, 3), keepdim=True)            # biased, used to normalise
-        self.last_batch_stats[layer.scope] = (mu.detach().reshape(-1),
-                                              (var.detach() * (n / max(n - 1, 1))).reshape(-1))   # unbiased -> EMA
-        return (x - mu) * torch.rsqrt(var + layer.bn_eps) * g + b
+            return batch_norm_frozen(x, g, b, p[layer.scope + "/BatchNorm/moving_mean:0"], p[layer.scope + "/BatchNorm/moving_variance:0"])
+        y, mu, var_unbiased = batch_norm_train(x, g, b, layer.bn_eps)
+        self.last_batch_stats[layer.scope] = (mu.detach(), var_unbiased.detach())      # what feeds the moving averages
+        return y
 
     @staticmethod
     def _act(x: torch.Tensor, act: str) -> torch.Tensor:
@@ -123,20 +159,14 @@ class StudentOracle:
         """
         p = params if params is not None else self.vars
         x = torch.as_tensor(np.asarray(frames), dtype=self.dtype) if not torch.is_tensor(frames) else frames.to(self.dtype)
-        # nodes concat / concat_1 (pad 1 row + 1 col of 127.5), mul_4, sub_2
-        x = F.pad(x.permute(0, 3, 1, 2), (0, 1, 0, 1), value=S.PAD_VALUE)
-        x = x * torch.tensor(S.PIXEL_SCALE, dtype=torch.float32).to(self.dtype) - 1.0
+        x = preprocess(x)
         outs: Dict[int, torch.Tensor] = {0: x}
         layers = self.spec.layers
         backbone = [l for l in layers if l.scope.startswith("MobilenetV2")]
         for l in backbone:
             w = p[l.weight_name]
             xin = outs[l.idx - 1]
-            xp = _same_pad_2d(xin, l.k, l.stride, l.rate)
-            if l.kind == "dw":
-                y = F.conv2d(xp, w.permute(2, 3, 0, 1), stride=l.stride, dilation=l.rate, groups=l.cin)
-            else:
-                y = F.conv2d(xp, w.permute(3, 2, 0, 1), stride=l.stride)
+            y = conv_same(xin, w, l.kind, l.stride, l.rate)
             y = self._act(self._bn(y, l, mode, p), l.act)
             if l.residual_from is not None:
                 y = y + outs[l.residual_from]
@@ -228,22 +258,17 @@ class StudentOracle:
         loss, grads = self.gradients(frames, labels_teacher)
         if grads_override is not None:
             grads = grads_override
-        one_minus_decay = float(np.float32(1.0) - np.float32(S.BN_DECAY))
         for l in self.spec.layers:
             if l.bn_eps is None:
                 continue
             mu, var_unbiased = self.last_batch_stats[l.scope]
-            mm = self.vars[l.scope + "/BatchNorm/moving_mean:0"]
-            mv = self.vars[l.scope + "/BatchNorm/moving_variance:0"]
-            self.vars[l.scope + "/BatchNorm/moving_mean:0"] = mm - (mm - mu) * one_minus_decay
-            self.vars[l.scope + "/BatchNorm/moving_variance:0"] = mv - (mv - var_unbiased) * one_minus_decay
-        b1, b2, eps = 0.9, 0.999, 1e-8
-        lr_t = lr * np.sqrt(1.0 - self.beta2_power) / (1.0 - self.beta1_power)
+            for name, stat in ((l.scope + "/BatchNorm/moving_mean:0", mu), (l.scope + "/BatchNorm/moving_variance:0", var_unbiased)):
+                self.vars[name] = ema_update(self.vars[name], stat)
+        b1, b2 = 0.9, 0.999
         for v in self.spec.trainable:
             g = grads[v.name].to(self.dtype)
-            m = self.adam_m[v.name] = self.adam_m[v.name] * b1 + (1.0 - b1) * g
-            vv = self.adam_v[v.name] = self.adam_v[v.name] * b2 + (1.0 - b2) * g * g
-            new = self.vars[v.name] - lr_t * m / (torch.sqrt(vv) + eps)
+            new, self.adam_m[v.name], self.adam_v[v.name] = adam_update(self.vars[v.name], g, self.adam_m[v.name], self.adam_v[v.name],
+                                                                        lr, self.beta1_power, self.beta2_power, b1, b2)
             if mask is not None:
                 keep = torch.as_tensor(np.asarray(mask[v.name]).astype(bool))
                 new = torch.where(keep, new, self.vars[v.name])

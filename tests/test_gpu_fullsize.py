@@ -173,3 +173,50 @@ def test_fine_tune_step_full_size_against_f64_oracle(W0, clip):
         e = np.linalg.norm(g[v.offset:v.offset + v.size] - want) / np.linalg.norm(want)
         assert e < 3e-2, (name, e)
     eng.close()
+
+
+def test_fine_tune_step_config2_batch_against_f64_oracle(W0, clip):
+    """BASELINE.json configs[2] at its own batch: ONE 8-frame step at 512 x 1024 (17160 rows at output stride 16: other GEMM tiles /
+    weight-gradient plans than the 2-frame case above) against the f64 oracle — loss to 1e-3, the whole gradient by cosine, three
+    late-layer tensors, one early one, the Adam update of the significant entries and the BN moving averages."""
+    from oracle.student_torch import StudentOracle
+    frames, labels = clip
+    B, lr = 8, 1e-3
+    eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+    eng.load_variables(W0)
+    o = StudentOracle(W0, CI, dtype=torch.float64)
+    loss_o, grads_o = o.gradients(frames[:B].astype(np.float32), labels[:B])
+    stats_o = {k: (m.numpy().copy(), v.numpy().copy()) for k, (m, v) in o.last_batch_stats.items()}
+    before = eng.params.cpu().numpy().astype(np.float64)
+    ls = eng.train_step(frames[:B], labels[:B], lr).cpu().numpy()
+    assert ls[0] / ls[1] == pytest.approx(loss_o, rel=1e-3)
+    assert ls[1] == float(np.isin(labels[:B], CI).sum())
+    g = eng.grads.cpu().numpy().astype(np.float64)
+    flat = np.concatenate([grads_o[v.name].numpy().reshape(-1) for v in eng.spec.trainable])
+    cos = float(g @ flat / (np.linalg.norm(g) * np.linalg.norm(flat)))
+    assert cos > 0.9995, cos
+    for name in ("aspp0/weights:0", "MobilenetV2/expanded_conv_16/project/weights:0", "MobilenetV2/expanded_conv_13/expand/weights:0",
+                 "MobilenetV2/expanded_conv_2/depthwise/depthwise_weights:0"):
+        v = eng.spec.by_name[name]
+        want = grads_o[name].numpy().reshape(-1)
+        e = np.linalg.norm(g[v.offset:v.offset + v.size] - want) / np.linalg.norm(want)
+        assert e < 3e-2, (name, e)
+    # first Adam step: -lr * sign(g) wherever |g| is far above eps; entries whose f64 gradient is significant must move the
+    # way the oracle's do
+    after = eng.params.cpu().numpy().astype(np.float64)
+    sig = np.abs(flat) > 1e-2 * np.abs(flat).max()
+    step = after - before
+    assert sig.sum() > 1000
+    agree = np.sign(step[sig]) == -np.sign(flat[sig])
+    assert agree.mean() > 0.999, agree.mean()
+    np.testing.assert_allclose(np.abs(step[sig]), lr, rtol=2e-3)
+    # BN moving averages of a first, a middle and a head layer: mean and UNBIASED variance of the 8-frame batch
+    omd = float(np.float32(1.0) - np.float32(S.BN_DECAY))
+    got = eng.get_variables()
+    for scope in ("MobilenetV2/Conv", "MobilenetV2/expanded_conv_7/depthwise", "aspp0"):
+        mu, var_u = stats_o[scope]
+        mm0 = W0[scope + "/BatchNorm/moving_mean:0"].astype(np.float64)
+        mv0 = W0[scope + "/BatchNorm/moving_variance:0"].astype(np.float64)
+        assert rel(got[scope + "/BatchNorm/moving_mean:0"], mm0 - (mm0 - mu) * omd) < 1e-4, scope
+        assert rel(got[scope + "/BatchNorm/moving_variance:0"], mv0 - (mv0 - var_u) * omd) < 1e-4, scope
+    eng.close()

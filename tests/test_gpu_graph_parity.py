@@ -1,0 +1,42 @@
+"""The HIP engine against an executor of the reference's own graph (oracle/graph_interp.py over
+tests/golden/student_program_*.json, decoded from checkpoints/*/model.meta).  No table written in this repository sits
+between the two: a wiring error in ams_amd/spec.py would show here even if both hand-written oracles shared it."""
+import numpy as np
+import pytest
+
+from ams_amd import hip, spec as S, synth, weights as Wt
+from ams_amd.engine import StudentEngine
+from oracle import graph_interp as GI
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("tag,nc,ci", [("cityscapes", 19, [0, 1, 2, 10, 11, 13]), ("pascalvoc2012", 21, [0, 7, 15, 20])])
+def test_engine_follows_the_reference_graph(tag, nc, ci):
+    H, B = 64, 2
+    W0 = Wt.synthetic_weights(S.build_spec(nc), seed=2)
+    frames, labels = synth.SyntheticVideo(H, B, ci, num_classes=nc, seed=3).clip()
+    ex = GI.GraphExecutor(GI.load_program(tag), W0, np.float64)
+    eng = StudentEngine(ci, H, 2 * H, max_batch=B, trainable=True, num_classes=nc)
+    eng.load_variables(W0)
+    eng.freeze()
+    h, w = eng.lowres
+    for mode, name, tol in ((hip.MODE_FROZEN, "frozen", 1e-3), (hip.MODE_LIVE, "train", 2e-3)):
+        want_full = ex.run(frames.astype(np.float64), name)
+        want_low = ex.run(frames.astype(np.float64), name, fetch="logits/semantic/BiasAdd")
+        lab = eng.predict(frames, mode).cpu().numpy()
+        got_low = eng.logits_lowres.view(-1, h, w, 32)[:B, :, :, :nc].cpu().numpy()
+        assert want_low.shape == got_low.shape == (B, h, w, nc)
+        assert rel(got_low, want_low) < tol, (mode, rel(got_low, want_low))
+        sel = want_full[..., ci]
+        want_lab = np.argmax(sel, axis=-1)
+        srt = np.sort(sel, axis=-1)
+        margin = srt[..., -1] - srt[..., -2]
+        bad = lab != want_lab
+        assert not np.any(bad & (margin > 2 * tol * np.abs(want_low).max())), "label mismatch away from a tie"
+        assert bad.mean() < 2e-3
+    eng.close()

@@ -224,6 +224,45 @@ def test_free_running_schedule_tracks_oracle(W0):
     eng.close()
 
 
+def test_parameter_delta_after_ten_free_running_steps(W0):
+    """SURVEY 8 d6, "parameter delta after 1 and 10 steps", with a bar on the entries that carry signal instead of the
+    2*lr*steps worst case.  Adam moves EVERY entry by ~lr per step whatever its gradient's size, so an f32 and an f64 evaluation of
+    this graph drift apart quickly: measured here for the f32 CPU oracle against the f64 one, after 1 step 0.2 % of the consistently
+    moving entries differ by more than 10 % of their own displacement, after 2 steps 30 %, after 10 steps 70 % (mean relative
+    deviation 0.004 -> 0.12 -> 0.28).  SURVEY's literal "rel <= 1e-3" is therefore not reachable by any f32 run, the reference's
+    own GPU/CPU pair included; what CAN be held is the error class, step by step: on the entries the f64 oracle has moved by more
+    than half the maximum (0.5 * lr * k after k steps), the HIP run's mean relative deviation and its fraction of entries off by
+    more than 10 % stay within 1.5x the f32 CPU oracle's (+1 %), and after the first step they are below 1 % / 0.5 % outright."""
+    frames, labels = synth.SyntheticVideo(64, 4, CI, seed=8).clip()
+    B, steps, lr = 4, 10, 1e-3
+    eng = StudentEngine(CI, 64, 128, max_batch=B, trainable=True)
+    eng.load_variables(W0)
+    o64, o32 = _oracle(W0, torch.float64), _oracle(W0, torch.float32)
+    names = [v.name for v in eng.spec.trainable]
+    cat = lambda d: np.concatenate([np.asarray(d[k], np.float64).reshape(-1) for k in names])  # noqa: E731
+    w0 = cat(W0)
+    rows = []
+    for k in range(1, steps + 1):
+        eng.train_step(frames, labels, lr)
+        o64.train_step(frames.astype(np.float32), labels, lr)
+        o32.train_step(frames.astype(np.float32), labels, lr)
+        d_g = eng.params.cpu().numpy().astype(np.float64) - w0
+        d_64, d_32 = cat(o64.get_vars()) - w0, cat(o32.get_vars()) - w0
+        sig = np.abs(d_64) > 0.5 * lr * k
+        assert sig.sum() > 0.05 * sig.size, "step %d: too few consistently moving entries (%d)" % (k, sig.sum())
+        dev_g = np.abs(d_g[sig] - d_64[sig]) / np.abs(d_64[sig])
+        dev_32 = np.abs(d_32[sig] - d_64[sig]) / np.abs(d_64[sig])
+        rows.append((k, int(sig.sum()), dev_g.mean(), (dev_g > 0.1).mean(), dev_32.mean(), (dev_32 > 0.1).mean()))
+    for r in rows:
+        print("step %2d: %7d entries | HIP mean dev %.4f, >10%%: %.4f | f32 CPU oracle mean dev %.4f, >10%%: %.4f" % r)
+    k, _, mg, og, m32, o32f = rows[0]
+    assert mg < 1e-2 and og < 5e-3, rows[0]
+    for k, _, mg, og, m32, o32f in rows:
+        assert mg <= 1.5 * m32 + 0.01, "step %d: mean deviation %.4f vs f32 CPU oracle %.4f" % (k, mg, m32)
+        assert og <= 1.5 * o32f + 0.01, "step %d: fraction off by >10%% %.4f vs f32 CPU oracle %.4f" % (k, og, o32f)
+    eng.close()
+
+
 def test_masked_step_reverts_weights_but_advances_moments(W0, clip64):
     frames, labels = clip64
     B = 2
@@ -366,3 +405,41 @@ def test_delta_payload_matches_reference_host_loop(W0):
         got = net.delta_payload()
         assert got == bytes(want), strategy
         net.close_model()
+
+
+@pytest.mark.parametrize("H,ci", [(64, CI), (48, [2, 8, 9, 10, 11, 13]), (32, list(range(19)))])
+def test_cross_confusion_matches_oracle(H, ci):
+    """phi-score confusion matrix (SemanticNetwork.py:124-139, :184-194): two teacher label maps, pixels valid in BOTH, rows = the
+    earlier map.  Labels carry ids outside the subset, ids >= 19 and 255; the matrix must equal the oracle's exactly, and the
+    SemanticNetwork wrapper's mIoU must be the oracle matrix's mIoU."""
+    from oracle.student_torch import cross_miou_confusion
+    from ams_amd.utils import calculate_miou
+    rng = np.random.default_rng(H)
+    a = rng.integers(0, 19, (H, 2 * H)).astype(np.uint8)
+    b = a.copy()
+    flip = rng.random(a.shape) < 0.2
+    b[flip] = rng.integers(0, 19, int(flip.sum()))
+    for lab in (a, b):
+        lab[rng.random(a.shape) < 0.05] = 255
+        lab[rng.random(a.shape) < 0.02] = 19
+        lab[rng.random(a.shape) < 0.02] = 200
+    eng = StudentEngine(ci, H, 2 * H, max_batch=1, trainable=False)
+    got = eng.cross_confusion(np.stack([a, b])).cpu().numpy()
+    want = cross_miou_confusion(a, b, ci)
+    assert got.dtype == np.int64 and np.array_equal(got, want.astype(np.int64))
+    assert got.sum() == (np.isin(a, ci) & np.isin(b, ci)).sum() and not np.array_equal(got, got.T)
+    eng.close()
+    if ci == CI:
+        cw = np.zeros((19, 1))
+        cw[ci] = 1
+        net = SemanticNetwork("unused", class_weights_exp=cw, height=H, frozen=True, cross_miou_compat=True,
+                              frozen_graph=_frozen_graph_for(ci, H))
+        cm, iou, miou = net.calc_cross_miou(np.stack([a, b]))
+        assert cm.dtype == np.float64 and np.array_equal(cm, want)
+        assert miou == pytest.approx(np.nanmean(calculate_miou(want, nan=True)), rel=1e-12)
+        net.close_model()
+
+
+def _frozen_graph_for(ci, H):
+    from ams_amd.semantic_network import FrozenGraph
+    return FrozenGraph(Wt.synthetic_weights(S.build_spec(), seed=0), ci, H, 19)

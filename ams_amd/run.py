@@ -76,6 +76,9 @@ def build_parser() -> argparse.ArgumentParser:
     # additions (not in the reference): make short synthetic runs possible
     p.add_argument("--length", type=int, default=None, help="override exp_configs.test_length (seconds)")
     p.add_argument("--first_train_time", type=int, default=None, help="override ceil(100/train_period)*train_period")
+    p.add_argument("--horizon_k1s", default="16,32,64,128,256,512", help="horizon mode: training-window lengths in seconds (reference: hard-coded)")
+    p.add_argument("--horizon_k2", type=int, default=256, help="horizon mode: evaluation window in seconds (reference: 256)")
+    p.add_argument("--horizon_points", type=int, default=3, help="horizon mode: number of evaluation points (reference: 3)")
     return p
 
 
@@ -153,8 +156,11 @@ def _host(x) -> np.ndarray:
 
 
 class Context:
-    def __init__(self, flags):
+    def __init__(self, flags, network_cls=None):
         self.flags = flags
+        # the class behind the SemanticNetwork boundary; tests/golden/make_scheduler_fixture.py passes an oracle-backed stand-in
+        # with the same surface to pin this loop.  The product default is the HIP-backed class.
+        self.network_cls = network_cls or SemanticNetwork
         self.size = [flags.height, flags.height * 2]
         self.source, self.vid_num = open_source(flags)
         self.length = flags.length or (len(self.source) // self.source.fps)
@@ -206,7 +212,7 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
     mem = max(1, int(FLAGS.memory_len / sampling_period * fps))
     frame_memory, label_memory = deque(maxlen=mem), deque(maxlen=mem)
 
-    semantic_network = SemanticNetwork(meta_dir=FLAGS.student_checkpoint, class_weights_exp=class_weights(exp_num),
+    semantic_network = ctx.network_cls(meta_dir=FLAGS.student_checkpoint, class_weights_exp=class_weights(exp_num),
                                        height=FLAGS.height, gpu_id=gpu_id, scale=[1], mini_batch_size=FLAGS.batch_size,
                                        lr=FLAGS.lr, mem_frac=1, coord_frac=float(FLAGS.coord_fraction),
                                        train_biases_only=False, regularize=False,
@@ -216,6 +222,7 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
     semantic_network.save_to_frozen_graph(save_dir + "_final")
     print_process("Saved model to %s_final.pb" % save_dir, 0)
     train_ms = []
+    control_log = []          # per training event: (second, mean phi-score or nan, send_rate, train_period_current, hibernating)
 
     while i < train_end_frame:
         frame, gt = ctx.source.read(i)
@@ -251,12 +258,14 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
             semantic_network.save_to_frozen_graph(save_dir + "_final")
             model_save_times.append(float(second))
         elif second in save_range:
+            phi = float("nan")
             if FLAGS.enable_ASR and len(label_memory) > 1:
                 # phi-score over the frames that arrived since the last update -> sampling rate (run.py:279-290)
                 i_start = max(0, len(label_memory) - num_unseen_frames - 1)
                 cross = [semantic_network.calc_cross_miou(np.array([label_memory[k], label_memory[k + 1]]))[2]
                          for k in range(i_start, len(label_memory) - 1)]
                 if cross:
+                    phi = float(np.mean(cross))
                     send_rate = float(np.clip(send_rate - 0.2 * np.tanh((np.mean(cross) - 0.6) * 20), 0.1, 1))
                     send_rate_deq.append(send_rate)
                     print_process("Send rate updated to %.2f" % send_rate, second)
@@ -271,6 +280,7 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
                     train_period_current = min(train_period_current + 2, 6 * train_period_reset)
                 idx = save_range.index(second)
                 save_range = save_range[:idx] + list(range(second, train_end, train_period_current))
+            control_log.append((second, phi, send_rate, train_period_current, int(hibernate)))
 
             if not FLAGS.no_restore:
                 semantic_network.restore_initial()
@@ -301,6 +311,7 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
     np.save(final_save_dir + '_bw_downlink.npy', down_bw_per_period)
     np.save(final_save_dir + '_model_update_times.npy', model_save_times)
     np.save(final_save_dir + '_train_ms.npy', train_ms)
+    np.save(final_save_dir + '_control.npy', np.asarray(control_log, dtype=np.float64).reshape(-1, 5))
     with open(final_save_dir + '_update.txt', 'w') as f:
         f.write("%d\n%d\n%d\n%d\n%d" % (sum(down_bw_per_period), sum(up_bw_per_period), update_count,
                                         train_end - train_start, sum(sample_per_period)))
@@ -326,7 +337,7 @@ def infer_output(ctx: Context, inf_start, inf_end, gpu_id, run_label, gt_path, e
             save_dir = ctx.save_dir(run_label + "_%d" % (i // fps))
             if semantic_network is not None:
                 semantic_network.close_model()
-            semantic_network = SemanticNetwork(meta_dir=save_dir + "_final", class_weights_exp=class_weights(exp_num),
+            semantic_network = ctx.network_cls(meta_dir=save_dir + "_final", class_weights_exp=class_weights(exp_num),
                                                height=FLAGS.height, gpu_id=gpu_id, mem_frac=1, frozen=True)
         frame, gt_frame = _to_size(*ctx.source.read(i), ctx.size, ctx.ingest)
         t0 = time.time()
@@ -358,13 +369,13 @@ def event_times(flags, length: int) -> List[int]:
                   if t == 0 or t >= flags.memory_len or not flags.initial_fill]
 
 
-def main(argv: Optional[List[str]] = None):
+def main(argv: Optional[List[str]] = None, network_cls=None):
     flags = build_parser().parse_args(argv)
     assert not flags.enable_ATR or flags.enable_ASR, 'ASR must be enabled for ATR to work'
     assert not flags.enable_ASR or flags.mode == 'simple', 'ASR can only be used in simple mode'
     assert not flags.enable_ATR or flags.mode == 'simple', 'ATR can only be used in simple mode'
     os.makedirs(flags.output_dir, exist_ok=True)
-    ctx = Context(flags)
+    ctx = Context(flags, network_cls)
     vid_num, length = ctx.vid_num, ctx.length
     summary = None
     if flags.mode == 'simple':
@@ -386,10 +397,13 @@ def main(argv: Optional[List[str]] = None):
         train_model(ctx, 0, 1, flags.send_period, flags.gpu, run_label, flags.gt_video, vid_num, [0], flags.train_period)
         summary = infer_output(ctx, 0, length, flags.gpu, run_label, flags.gt_video, vid_num, [0])
     else:  # horizon: retrain on [t-k1, t), evaluate on [t, t+k2)
-        k1s, k2 = [16, 32, 64, 128, 256, 512], 256
-        number_of_points = 3
-        step = (length - k2 - k1s[-1]) // (number_of_points - 1)
+        k1s, k2 = [int(k) for k in flags.horizon_k1s.split(",")], flags.horizon_k2
+        number_of_points = flags.horizon_points
+        step = (length - k2 - k1s[-1]) // max(number_of_points - 1, 1)
         assert step > 0, "video too short for horizon mode"
+        # the un-adapted model over the whole video first, as the reference does (run.py:617-619)
+        train_model(ctx, 0, 1, flags.send_period, flags.gpu, "pretrained", flags.gt_video, vid_num, [0], flags.train_period)
+        infer_output(ctx, 0, length, flags.gpu, "pretrained", flags.gt_video, vid_num, [0])
         for p in range(number_of_points):
             t = k1s[-1] + p * step
             for k1 in k1s:

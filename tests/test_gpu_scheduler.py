@@ -74,3 +74,50 @@ def test_directory_source_with_gpu_ingest_equals_host_resize(tmp_path):
     la = np.load(glob.glob(outs["host"] + "*_loss.npy")[0])
     lb = np.load(glob.glob(outs["dev"] + "*_loss.npy")[0])
     np.testing.assert_allclose(la, lb, rtol=1e-5)
+
+
+from sched_cases import _results, case_asr_atr_control_loop, case_other_scheduler_modes, case_upload_period_is_the_train_period
+
+
+def test_scheduler_matches_the_oracle_backed_run(tmp_path, golden_dir):
+    """the same command line, once on the CPU oracle behind the SemanticNetwork boundary (committed fixture,
+    tests/golden/make_scheduler_fixture.py) and once on the HIP path.  Control flow must be identical (event times, samples per
+    upload, file set, frame count); per-frame outputs agree within the f32 error class of two 4-iteration fine-tune phases."""
+    import json
+    fx = json.loads((golden_dir / "scheduler_oracle_run.json").read_text())
+    out = str(tmp_path / "out") + "/"
+    np.random.seed(fx["seed"])
+    random.seed(fx["seed"])
+    summary = R.main(fx["args"] + ["--output_dir", out])
+    assert summary["frames"] == fx["frames"]
+    assert _results(out, "_model_update_times.npy").tolist() == fx["model_update_times"]
+    assert _results(out, "_fps_client.npy").tolist() == fx["fps_client"]
+    import glob
+    from pathlib import Path
+    files = sorted(f.split("_64_")[-1] if "_64_" in f else f for f in (Path(p).name for p in glob.glob(out + "*")))
+    assert files == fx["files"]
+    loss, want_loss = _results(out, "_loss.npy").astype(np.float64), np.asarray(fx["loss"])
+    mious, want_mious = _results(out, "_mious.npy").astype(np.float64), np.asarray(fx["mious"])
+    cats, want_cats = _results(out, "_mioucats.npy"), np.asarray(fx["mioucats"])
+    n0 = 8                                              # frames served by the un-adapted model: plain frozen inference, f32-exact class
+    np.testing.assert_allclose(loss[:n0], want_loss[:n0], rtol=1e-3)
+    assert np.abs(cats[:n0] - want_cats[:n0]).sum() <= 2e-3 * want_cats[:n0].sum()
+    dev = np.abs(loss - want_loss) / want_loss
+    print("scheduler vs oracle run: max loss deviation %.4f (first model %.2e), max mIoU deviation %.4f, confusion L1 %.4f"
+          % (dev.max(), dev[:n0].max(), np.abs(mious - want_mious).max(), np.abs(cats - want_cats).sum() / want_cats.sum()))
+    assert cats.shape == want_cats.shape and np.array_equal(cats.sum(axis=(1, 2)), want_cats.sum(axis=(1, 2)))    # same valid pixels per frame
+    assert dev.max() < 0.1 and np.abs(mious - want_mious).max() < 0.03
+    assert loss[-8:].mean() < 0.5 * loss[:8].mean()                     # the published models are picked up and help
+
+
+def test_asr_atr_control_loop(tmp_path):
+    case_asr_atr_control_loop(tmp_path)
+
+
+def test_upload_period_is_the_train_period_not_the_send_period(tmp_path):
+    case_upload_period_is_the_train_period(tmp_path)
+
+
+@pytest.mark.parametrize("mode", ["early", "pretrained", "horizon"])
+def test_other_scheduler_modes(tmp_path, mode):
+    case_other_scheduler_modes(tmp_path, mode)

@@ -1,0 +1,20 @@
+"""Host logic of the run.py-style scheduler without a GPU: the class behind the SemanticNetwork boundary is the oracle-backed stand-in
+(oracle/oracle_network.py), so only control flow is exercised here; tests/test_gpu_scheduler.py runs the same scenarios on the HIP
+path."""
+import pytest
+
+from oracle.oracle_network import OracleSemanticNetwork
+from sched_cases import case_asr_atr_control_loop, case_other_scheduler_modes, case_upload_period_is_the_train_period
+
+
+def test_asr_atr_control_loop(tmp_path):
+    case_asr_atr_control_loop(tmp_path, OracleSemanticNetwork)
+
+
+def test_upload_period_is_the_train_period_not_the_send_period(tmp_path):
+    case_upload_period_is_the_train_period(tmp_path, OracleSemanticNetwork)
+
+
+@pytest.mark.parametrize("mode", ["early", "pretrained", "horizon"])
+def test_other_scheduler_modes(tmp_path, mode):
+    case_other_scheduler_modes(tmp_path, mode, OracleSemanticNetwork)

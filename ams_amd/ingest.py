@@ -6,7 +6,7 @@
     label = ing.label(teacher_png_u8, H, 2 * H)                    # torch.uint8 [H, 2H]
 
 The arithmetic is that of ``ams_amd.utils.resize_linear`` / ``resize_nearest`` (bit-identical; those restate OpenCV's
-INTER_LINEAR / INTER_NEAREST, the former within 1 LSB of its fixed-point uint8 path).  No CPU fallback: without the HIP
+INTER_LINEAR / INTER_NEAREST, the former the former in its fixed-point uint8 arithmetic, bit for bit).  No CPU fallback: without the HIP
 library or a GPU this raises.
 """
 from __future__ import annotations

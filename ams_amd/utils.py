@@ -4,7 +4,8 @@ Behavioural mirrors of reference utils/utils.py (``mini_batch`` :129-185, ``calc
 ``choose_frames`` :237-254, ``colormap`` :52-77, ``string_class_iou`` :188-213); values are pinned against
 outputs captured from the reference (tests/golden/ref_helpers.json, tests/test_helpers_golden.py).
 OpenCV is not available here, so the two resamplers the reference takes from cv2 (``INTER_LINEAR`` for
-frames, ``INTER_NEAREST`` for labels; run.py:179-183, utils/utils.py:165-173) are restated in NumPy.
+frames, ``INTER_NEAREST`` for labels; run.py:179-183, utils/utils.py:165-173) are restated in NumPy, the uint8 linear one
+in OpenCV's own fixed-point arithmetic.
 """
 from __future__ import annotations
 
@@ -71,19 +72,62 @@ def choose_frames(frame_label_list, sample_fraction):
     return ([frame_label_list[i][0] for i in picks], [frame_label_list[i][1] for i in picks])
 
 
+def _cv_scale(n_in, n_out):
+    """OpenCV forms the source step as 1 / (dst / src) in double (cv::resize: inv_scale = dsize / ssize; scale = 1. / inv_scale)."""
+    return 1.0 / (float(n_out) / float(n_in))
+
+
 def resize_nearest(img, out_w, out_h):
-    """cv2.resize(..., interpolation=INTER_NEAREST): src = floor(dst * in/out)."""
+    """cv2.resize(..., interpolation=INTER_NEAREST): src = min(floor(dst * scale), size - 1)  (resizeNN)."""
     h, w = img.shape[:2]
-    ys = np.minimum((np.arange(out_h) * (h / out_h)).astype(np.int64), h - 1)
-    xs = np.minimum((np.arange(out_w) * (w / out_w)).astype(np.int64), w - 1)
+    ys = np.minimum(np.floor(np.arange(out_h) * _cv_scale(h, out_h)).astype(np.int64), h - 1)
+    xs = np.minimum(np.floor(np.arange(out_w) * _cv_scale(w, out_w)).astype(np.int64), w - 1)
     return img[ys][:, xs]
 
 
-def resize_linear(img, out_w, out_h):
-    """cv2.resize(..., interpolation=INTER_LINEAR) for uint8/float images (half-pixel centres, edge clamp).
+def _fixed_taps(n_in, n_out, border_zeroes_weight):
+    """Tap table of OpenCV's 8-bit INTER_LINEAR: (first tap, second tap, weight of the first, weight of the second) per output
+    index; weights are 11-bit integers rounded half-to-even from float32 products.  Columns zero the fractional weight where the
+    window leaves the image; rows keep it and clamp the taps instead."""
+    first = np.empty(n_out, np.int64)
+    second = np.empty(n_out, np.int64)
+    w0 = np.empty(n_out, np.int64)
+    w1 = np.empty(n_out, np.int64)
+    step = _cv_scale(n_in, n_out)
+    for d in range(n_out):
+        pos = np.float32((d + 0.5) * step - 0.5)
+        base = int(np.floor(pos))
+        frac = np.float32(pos - np.float32(base))
+        if border_zeroes_weight and (base < 0 or base >= n_in - 1):
+            base, frac = min(max(base, 0), n_in - 1), np.float32(0.0)
+        first[d] = min(max(base, 0), n_in - 1)
+        second[d] = min(max(base + 1, 0), n_in - 1)
+        w0[d] = int(np.rint((np.float32(1.0) - frac) * np.float32(2048.0)))
+        w1[d] = int(np.rint(frac * np.float32(2048.0)))
+    return first, second, w0, w1
 
-    OpenCV's uint8 path uses 11-bit fixed-point weights; this float restatement can differ by 1 LSB."""
+
+def resize_linear(img, out_w, out_h):
+    """cv2.resize(..., interpolation=INTER_LINEAR).
+
+    uint8 images follow OpenCV's fixed-point path bit for bit (11-bit weights, integer horizontal pass, ``>> 4`` / ``>> 16`` /
+    ``(+2) >> 2`` vertical pass; an exact 2x down-scale is the 2x2 box average ``(a+b+c+d+2) >> 2``; equal sizes copy) — pinned
+    against hand-derived vectors through oracle/cv_resize.py (tests/test_cv_resize.py).  Other dtypes interpolate in float64
+    with half-pixel centres and edge clamp."""
     h, w = img.shape[:2]
+    if img.dtype == np.uint8:
+        if (h, w) == (out_h, out_w):
+            return img.copy()
+        wide = img.astype(np.int64)
+        if h == 2 * out_h and w == 2 * out_w:
+            return ((wide[0::2, 0::2] + wide[0::2, 1::2] + wide[1::2, 0::2] + wide[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        x0, x1, ax0, ax1 = _fixed_taps(w, out_w, True)
+        y0, y1, by0, by1 = _fixed_taps(h, out_h, False)
+        tail = (1,) * (img.ndim - 2)
+        rows = np.take(wide, x0, axis=1) * ax0.reshape((1, -1) + tail) + np.take(wide, x1, axis=1) * ax1.reshape((1, -1) + tail)
+        upper = (by0.reshape((-1, 1) + tail) * (np.take(rows, y0, axis=0) >> 4)) >> 16
+        lower = (by1.reshape((-1, 1) + tail) * (np.take(rows, y1, axis=0) >> 4)) >> 16
+        return ((upper + lower + 2) >> 2).astype(np.uint8)
     src = img.astype(np.float64)
 
     def taps(n_in, n_out):

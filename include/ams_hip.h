@@ -265,7 +265,8 @@ int ams_k_dw_project(const float* e, int32_t B, int32_t H, int32_t W, int32_t C,
 
 /* Frame ingest (reference run.py:179-183, :415-421: cv2.resize of the decoded frame to [H, 2H] + BGR->RGB; INTER_NEAREST for
  * the teacher label map).  src [Hs,Ws,C] uint8 -> dst [H,W,C] uint8, both device memory.  mode AMS_RESIZE_NEAREST |
- * AMS_RESIZE_LINEAR (half-pixel centres, edge clamp, round half to even); swap_rb != 0 reverses the 3 channels. */
+ * AMS_RESIZE_LINEAR (OpenCV's 8-bit fixed-point INTER_LINEAR: 11-bit weights, integer passes, the 2x box-average shortcut; bit-identical
+ * to the restatement in oracle/cv_resize.py, which hand-derived vectors pin); swap_rb != 0 reverses the 3 channels. */
 enum { AMS_RESIZE_NEAREST = 0, AMS_RESIZE_LINEAR = 1 };
 int ams_ingest_resize_u8(const uint8_t* src, int32_t Hs, int32_t Ws, int32_t C, int32_t mode, int32_t swap_rb, uint8_t* dst,
                          int32_t H, int32_t W, void* stream);

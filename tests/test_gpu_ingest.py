@@ -1,9 +1,11 @@
-"""Frame ingest on the device against the host restatement of cv2.resize (ams_amd/utils.py): bit-exact."""
+"""Frame ingest on the device against the ORACLE's restatement of cv2.resize (oracle/cv_resize.py: OpenCV's fixed-point
+uint8 INTER_LINEAR and INTER_NEAREST, pinned by hand-derived vectors in tests/test_cv_resize.py): bit-exact.  The product's own host
+resampler (ams_amd/utils.py) is held to the same oracle on CPU, so the device and host paths of the scheduler agree as well."""
 import numpy as np
 import pytest
 import torch
 
-from ams_amd import utils as U
+from oracle import cv_resize as CV
 
 pytestmark = pytest.mark.gpu
 
@@ -14,12 +16,12 @@ def ing():
     return FrameIngest("cuda:0")
 
 
-@pytest.mark.parametrize("src,dst", [((1208, 1920), (512, 1024)), ((1080, 1920), (256, 512)), ((100, 200), (256, 512)),
-                                     ((513, 1025), (512, 1024)), ((37, 53), (37, 53)), ((7, 5), (64, 128))])
-def test_frame_resize_matches_host_restatement(ing, src, dst):
+@pytest.mark.parametrize("src,dst", [((1208, 1920), (512, 1024)), ((1080, 1920), (256, 512)), ((100, 200), (256, 512)), ((1024, 2048), (512, 1024)),
+                                     ((513, 1025), (512, 1024)), ((37, 53), (37, 53)), ((7, 5), (64, 128)), ((2, 2), (5, 9))])
+def test_frame_resize_matches_the_opencv_restatement(ing, src, dst):
     rng = np.random.default_rng(src[0] + dst[1])
     img = rng.integers(0, 256, (src[0], src[1], 3), dtype=np.uint8)
-    want = U.resize_linear(img, dst[1], dst[0])
+    want = CV.resize_linear_u8(img, dst[1], dst[0])
     got = ing.frame(img, dst[0], dst[1]).cpu().numpy()
     assert got.dtype == np.uint8 and got.shape == want.shape
     assert np.array_equal(got, want)
@@ -33,7 +35,7 @@ def test_label_resize_is_nearest(ing, src, dst):
     rng = np.random.default_rng(src[0])
     lab = rng.integers(0, 20, src, dtype=np.uint8)
     lab[rng.random(src) < 0.05] = 255
-    want = U.resize_nearest(lab, dst[1], dst[0])
+    want = CV.resize_nearest_u8(lab, dst[1], dst[0])
     got = ing.label(lab, dst[0], dst[1]).cpu().numpy()
     assert np.array_equal(got, want)
 
@@ -43,7 +45,7 @@ def test_device_tensor_input_and_extremes(ing):
     img[::2] = 255
     out = ing.frame(img, 32, 32)
     assert out.is_cuda and out.shape == (32, 32, 3)
-    want = U.resize_linear(img.cpu().numpy(), 32, 32)
+    want = CV.resize_linear_u8(img.cpu().numpy(), 32, 32)
     assert np.array_equal(out.cpu().numpy(), want)
     with pytest.raises(AssertionError):
         ing.frame(np.zeros((4, 4, 3), np.float32), 8, 8)

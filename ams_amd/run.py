@@ -158,8 +158,8 @@ def _host(x) -> np.ndarray:
 class Context:
     def __init__(self, flags, network_cls=None):
         self.flags = flags
-        # the class behind the SemanticNetwork boundary; tests/golden/make_scheduler_fixture.py passes an oracle-backed stand-in
-        # with the same surface to pin this loop.  The product default is the HIP-backed class.
+        # the class behind the SemanticNetwork boundary: the HIP-backed one unless a caller injects another with the same
+        # surface (tests/golden/make_scheduler_fixture.py pins this loop with a CPU stand-in)
         self.network_cls = network_cls or SemanticNetwork
         self.size = [flags.height, flags.height * 2]
         self.source, self.vid_num = open_source(flags)

@@ -1,0 +1,129 @@
+// RCCL communicator owned by the library: the data-parallel fine-tune step issues its all-reduces (SyncBN sums, loss normaliser,
+// the flat gradient arena) straight onto the launch stream, with no host round trip between them (the reference runs
+// one process per GPU, run.py:28).  librccl is resolved at run time with dlopen/dlsym: the library has no link-time dependency on
+// it (it loads and passes its CPU tests on a box without RCCL), and inside a PyTorch-ROCm process the copy PyTorch already loaded
+// (same soname) is the one that serves both.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "kernels.hpp"
+
+struct ams_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    int64_t calls = 0, bytes = 0;        // what the steps exchanged so far (tests)
+};
+
+namespace ams {
+
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    const char* error = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) {        // a copy that is already mapped (PyTorch's) wins over a second instance
+            r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (r.handle) break;
+        }
+        for (const char* n : names) {
+            if (r.handle) break;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!r.handle) { r.error = "librccl.so.1 not found (dlopen)"; return; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.error = "librccl lacks a required symbol";
+    });
+    return r;
+}
+
+int fail(const char* what, ncclResult_t rc) {
+    Rccl& r = rccl();
+    set_error("%s: %s", what, r.GetErrorString ? r.GetErrorString(rc) : "RCCL error");
+    return AMS_E_HIP;
+}
+}  // namespace
+
+int comm_allreduce(ams_comm* c, void* p, size_t n, int dtype, hipStream_t st) {
+    if (!c || c->world <= 1) return AMS_OK;
+    Rccl& r = rccl();
+    const ncclDataType_t dt = dtype == AMS_DT_F64 ? ncclFloat64 : ncclFloat32;
+    const ncclResult_t rc = r.AllReduce(p, p, n, dt, ncclSum, c->comm, st);
+    if (rc != ncclSuccess) return fail("ncclAllReduce", rc);
+    c->calls += 1;
+    c->bytes += (int64_t)n * (dtype == AMS_DT_F64 ? 8 : 4);
+    return AMS_OK;
+}
+
+}  // namespace ams
+
+using namespace ams;
+
+extern "C" {
+
+int ams_comm_unique_id(uint8_t* id_out, size_t cap) {
+    AMS_REQUIRE(id_out && cap >= NCCL_UNIQUE_ID_BYTES, "comm_unique_id: buffer must hold %d bytes", NCCL_UNIQUE_ID_BYTES);
+    Rccl& r = rccl();
+    if (r.error) { set_error("comm: %s", r.error); return AMS_E_STATE; }
+    ncclUniqueId id;
+    const ncclResult_t rc = r.GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail("ncclGetUniqueId", rc);
+    memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return AMS_OK;
+}
+
+int ams_comm_create(const uint8_t* id_bytes, size_t id_len, int32_t rank, int32_t world, ams_comm** out) {
+    AMS_REQUIRE(out && world >= 1 && rank >= 0 && rank < world, "comm_create: rank %d of %d", rank, world);
+    ams_comm* c = new ams_comm();
+    c->rank = rank; c->world = world;
+    if (world > 1) {
+        AMS_REQUIRE(id_bytes && id_len >= NCCL_UNIQUE_ID_BYTES, "comm_create: the unique id is %d bytes", NCCL_UNIQUE_ID_BYTES);
+        Rccl& r = rccl();
+        if (r.error) { set_error("comm: %s", r.error); delete c; return AMS_E_STATE; }
+        ncclUniqueId id;
+        memcpy(id.internal, id_bytes, NCCL_UNIQUE_ID_BYTES);
+        const ncclResult_t rc = r.CommInitRank(&c->comm, world, id, rank);      // binds to the calling thread's current device
+        if (rc != ncclSuccess) { delete c; return fail("ncclCommInitRank", rc); }
+    }
+    *out = c;
+    return AMS_OK;
+}
+
+void ams_comm_destroy(ams_comm* c) {
+    if (!c) return;
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+int ams_comm_stats(const ams_comm* c, int32_t* rank, int32_t* world, int64_t* calls, int64_t* bytes) {
+    AMS_REQUIRE(c, "comm_stats: null communicator");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (calls) *calls = c->calls;
+    if (bytes) *bytes = c->bytes;
+    return AMS_OK;
+}
+
+/* sum `count` elements (AMS_DT_F32 | AMS_DT_F64) in place across the communicator, on `stream` */
+int ams_comm_allreduce(ams_comm* c, void* buf_dev, size_t count, int32_t dtype, void* stream) {
+    AMS_REQUIRE(c && buf_dev && (dtype == AMS_DT_F32 || dtype == AMS_DT_F64), "comm_allreduce: bad argument");
+    return comm_allreduce(c, buf_dev, count, dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -362,14 +362,20 @@ static inline double pw_bytes(const PwArgs& a) {
 }
 static inline double dw_bytes(const LayerRt& l, int B) { return 4.0 * ((double)B * (l.px_in + l.px_out) * l.d.cin + 9.0 * l.d.cin); }
 
-struct SyncCtx { ams_allreduce_cb cb; void* user; ams_student* s; };
+// cross-rank sums of the data-parallel step: through the library's RCCL communicator on the launch stream (comm), or through a
+// host callback (cb: the gloo test hook / any other transport).  `cb` doubles as "a sync is configured" for the callers below.
+struct SyncCtx { ams_allreduce_cb cb; void* user; ams_student* s; ams_comm* comm; };
 
-static int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream_t) {
+static int comm_as_cb(void*, size_t, size_t, int32_t) { return 0; }      // never called: marks SyncCtx::cb when comm is used
+
+static int sync_any(const SyncCtx* sc, void* p, size_t n, int dtype, hipStream_t st) {
     if (!sc || !sc->cb) return AMS_OK;
-    const int rc = sc->cb(sc->user, (size_t)((char*)p - sc->s->arena), n, AMS_DT_F64);
+    if (sc->comm) return comm_allreduce(sc->comm, p, n, dtype, st);
+    const int rc = sc->cb(sc->user, (size_t)((char*)p - sc->s->arena), n, dtype);
     if (rc) { set_error("all-reduce callback failed (%d)", rc); return AMS_E_STATE; }
     return AMS_OK;
 }
+static int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream_t st) { return sync_any(sc, p, n, AMS_DT_F64, st); }
 
 // Split-bf16 pays where the exact-f32 kernels are matrix-pipe bound (f32-input MFMA = 157 TFLOP/s against ~5 TB/s of HBM:
 // ~31 FLOP per byte): few rows (the streaming kernel needs >= 32768), a weight panel too large for the streaming kernel,
@@ -963,24 +969,22 @@ int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t
                                   (hipStream_t)stream);
 }
 
-int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
-                              int32_t batch, int32_t global_batch, float lr, const uint8_t* mask_dev, double* loss_dev,
-                              ams_allreduce_cb cb, void* user, void* stream) {
+static int train_step_impl(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
+                           int32_t batch, int32_t global_batch, float lr, const uint8_t* mask_dev, double* loss_dev,
+                           ams_allreduce_cb cb, void* user, ams_comm* comm, void* stream) {
     RUN(check_call(s, frames_dev, frames_dtype, batch));
     AMS_REQUIRE(teacher_dev, "train_step: null teacher labels");
     if (!s->cfg.trainable) { set_error("train_step: this student was created frozen (trainable=0)"); return AMS_E_STATE; }
     AMS_REQUIRE(global_batch >= batch, "train_step: global batch %d < local batch %d", global_batch, batch);
     hipStream_t st = (hipStream_t)stream;
-    SyncCtx sc{cb, user, s};
+    if (comm) cb = comm_as_cb;
+    SyncCtx sc{cb, user, s, comm};
     const SyncCtx* psc = cb ? &sc : nullptr;
     RUN(forward_live(s, frames_dev, frames_dtype, batch, global_batch, /*update_ema=*/true, psc, st));
     RUN(loss_forward(s, teacher_dev, batch, nullptr, st));
     RUN(sync_doubles(psc, s->loss_buf, 2, st));         // loss sum and valid-pixel count over all ranks
     RUN(backward(s, frames_dev, frames_dtype, teacher_dev, batch, global_batch, psc, st));
-    if (cb) {
-        const int rc = cb(user, (size_t)((char*)s->grads - s->arena), (size_t)s->cfg.n_trainable, AMS_DT_F32);
-        if (rc) { set_error("gradient all-reduce callback failed (%d)", rc); return AMS_E_STATE; }
-    }
+    RUN(sync_any(psc, s->grads, (size_t)s->cfg.n_trainable, AMS_DT_F32, st));       // one flat 8.45 MB message
     if (loss_dev) AMS_CHECK_HIP(hipMemcpyAsync(loss_dev, s->loss_buf, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     // Adam, TF1 form; the step counter is never reset (SemanticNetwork.py:25, :154-156)
     s->adam_t += 1;
@@ -989,10 +993,22 @@ int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t fr
     return launch_adam(s->params, s->grads, s->adam_m, s->adam_v, mask_dev, s->cfg.n_trainable, (float)lr_t, 0.9f, 0.999f, 1e-8f, st);
 }
 
+int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
+                              int32_t batch, int32_t global_batch, float lr, const uint8_t* mask_dev, double* loss_dev,
+                              ams_allreduce_cb cb, void* user, void* stream) {
+    return train_step_impl(s, frames_dev, frames_dtype, teacher_dev, batch, global_batch, lr, mask_dev, loss_dev, cb, user, nullptr, stream);
+}
+
+int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
+                                int32_t batch, int32_t global_batch, float lr, const uint8_t* mask_dev, double* loss_dev,
+                                ams_comm* comm, void* stream) {
+    AMS_REQUIRE(comm, "train_step_rccl: null communicator");
+    return train_step_impl(s, frames_dev, frames_dtype, teacher_dev, batch, global_batch, lr, mask_dev, loss_dev, nullptr, nullptr, comm, stream);
+}
+
 int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev, int32_t batch,
                            float lr, const uint8_t* mask_dev, double* loss_dev, void* stream) {
-    return ams_student_train_step_dp(s, frames_dev, frames_dtype, teacher_dev, batch, batch, lr, mask_dev, loss_dev, nullptr, nullptr,
-                                     stream);
+    return train_step_impl(s, frames_dev, frames_dtype, teacher_dev, batch, batch, lr, mask_dev, loss_dev, nullptr, nullptr, nullptr, stream);
 }
 
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {

@@ -2,7 +2,12 @@
 #pragma once
 #include "common.hpp"
 
+struct ams_comm;
+
 namespace ams {
+
+// ---- comm.hip : RCCL communicator (resolved at run time) ------------------------------------------------
+int comm_allreduce(ams_comm* c, void* p, size_t n, int dtype, hipStream_t st);
 
 // ---- k_pointwise.hip : 1x1 convolutions as f32-MFMA GEMMs ---------------------------------------------
 struct PwArgs {

@@ -49,6 +49,59 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+class RcclComm:
+    """The library's own RCCL communicator (``ams_comm_*`` in include/ams_hip.h): the production transport of the data-parallel
+    step.  Every cross-rank sum of ``StudentEngine.train_step(..., comm=...)`` is one ``ncclAllReduce`` on the launch stream,
+    enqueued by the engine in launch order — no Python, no host synchronisation between the 110 collectives of a step.
+
+    Construct on every rank after ``torch.cuda.set_device(local_rank)``; the 128-byte unique id travels from rank 0 through the
+    default ``torch.distributed`` group (any backend).  ``world == 1`` gives a no-op communicator."""
+
+    def __init__(self, rank: int, world: int, device: Optional[torch.device] = None):
+        import ctypes as C
+        self.lib = hip.lib()
+        self.rank, self.world = int(rank), int(world)
+        ident = (C.c_uint8 * 128)()
+        if self.world > 1:
+            import torch.distributed as dist
+            box = [None]
+            if self.rank == 0:
+                hip.check(self.lib.ams_comm_unique_id(ident, 128), "ams_comm_unique_id")
+                box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(ident, box[0], 128)
+        handle = C.c_void_p()
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            hip.check(self.lib.ams_comm_create(ident, 128, self.rank, self.world, C.byref(handle)), "ams_comm_create")
+        self._h = handle
+
+    def stats(self) -> Tuple[int, int]:
+        """(collectives issued, bytes reduced) since construction."""
+        import ctypes as C
+        calls, nbytes = C.c_int64(), C.c_int64()
+        hip.check(self.lib.ams_comm_stats(self._h, None, None, C.byref(calls), C.byref(nbytes)), "ams_comm_stats")
+        return int(calls.value), int(nbytes.value)
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        """Sum ``t`` (float32 / float64, contiguous, on this rank's GPU) in place across ranks on torch's current stream."""
+        import ctypes as C
+        code = {torch.float32: hip.DT_F32, torch.float64: hip.DT_F64}[t.dtype]
+        assert t.is_cuda and t.is_contiguous()
+        hip.check(self.lib.ams_comm_allreduce(self._h, C.c_void_p(t.data_ptr()), t.numel(), code,
+                                              C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)), "ams_comm_allreduce")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.ams_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class ArenaAllReduce:
     """The engine's ``ams_allreduce_cb``: sum ``count`` elements at byte ``offset`` of the arena across ranks.
 

@@ -260,11 +260,12 @@ class StudentEngine:
         return conf.view(self.K, self.K)
 
     def train_step(self, frames, labels_teacher, lr: float, mask: Optional[torch.Tensor] = None,
-                   allreduce=None, global_batch: Optional[int] = None) -> torch.Tensor:
+                   allreduce=None, global_batch: Optional[int] = None, comm=None) -> torch.Tensor:
         """One Adam iteration; returns the device tensor f64[2] = (CE sum over valid pixels, valid pixel count).
 
-        ``allreduce``: an ``ams_amd.dist.ArenaAllReduce`` or a callable(tensor) summing in place across ranks
-        (data-parallel step); ``global_batch`` = frames over all ranks."""
+        Data-parallel step, ``global_batch`` = frames over all ranks: ``comm`` = an ``ams_amd.dist.RcclComm``
+        (production: the engine issues its all-reduces on the launch stream through RCCL), or ``allreduce`` = an
+        ``ams_amd.dist.ArenaAllReduce`` / a callable(tensor) summing in place across ranks (host callback: gloo tests)."""
         assert self.trainable, "Can't train frozen graph!!!"
         t, dt, b = self._frames_to_device(frames)
         lab = self._labels_to_device(labels_teacher, b)
@@ -272,6 +273,12 @@ class StudentEngine:
         mptr = C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0)
         if mask is not None:
             assert mask.dtype == torch.uint8 and mask.numel() == self.spec.n_trainable and mask.device == self.arena.device
+        if comm is not None:
+            assert allreduce is None, "pass either comm (RCCL inside the engine) or allreduce (host callback), not both"
+            hip.check(self.lib.ams_student_train_step_rccl(self._h, C.c_void_p(t.data_ptr()), dt, C.c_void_p(lab.data_ptr()), b,
+                                                           int(global_batch or b), float(lr), mptr, C.c_void_p(loss.data_ptr()),
+                                                           comm._h, self._stream()), "ams_student_train_step_rccl")
+            return loss
         if allreduce is None:
             hip.check(self.lib.ams_student_train_step(self._h, C.c_void_p(t.data_ptr()), dt, C.c_void_p(lab.data_ptr()), b,
                                                       float(lr), mptr, C.c_void_p(loss.data_ptr()), self._stream()),

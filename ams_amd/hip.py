@@ -66,6 +66,12 @@ SIGNATURES = {
     "ams_cross_confusion": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "ams_student_train_step": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _vp]),
     "ams_student_train_step_dp": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, ALLREDUCE_CB, _vp, _vp]),
+    "ams_comm_unique_id": (C.c_int, [_vp, _sz]),
+    "ams_comm_create": (C.c_int, [_vp, _sz, _i32, _i32, C.POINTER(_vp)]),
+    "ams_comm_destroy": (None, [_vp]),
+    "ams_comm_stats": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
+    "ams_comm_allreduce": (C.c_int, [_vp, _vp, _sz, _i32, _vp]),
+    "ams_student_train_step_rccl": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "ams_student_set_option": (C.c_int, [_vp, _i32, _i32]),
     "ams_student_profile": (C.c_int, [_vp, _i32]),
     "ams_student_profile_read": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),

@@ -3,18 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): student inference only, 512x1024 synthetic video, frames resident in HBM
-as uint8 when the timed region starts.  One step = one pass of the hot path (frozen student forward + fused
-upsample/argmax -> int32 label maps) over one batch of --batch frames per GPU.  value = frames/s over all GPUs.
-Extra legs on the same JSON line:
-  distill_steps_per_sec : config[2]'s fine-tune step (B=8 frames, BN batch statistics, backward, Adam), timed apart
-  roofline              : dominant kernel of the inference step, HIP events on the launch stream over a profiled replay
-  cpu_baseline          : the CPU oracle (PyTorch-CPU restatement, all host cores) on a bounded sample, rank 0 / N=1
+With N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts N fresh children (one rank per GPU, RCCL
+rendezvous on 127.0.0.1) before making any GPU call itself, waits for them and prints rank 0's JSON line.  Under torchrun
+(WORLD_SIZE set) it is a rank.
+
+Workload (BASELINE.json configs[1]): student inference only, 512x1024 synthetic video, frames resident in HBM as uint8 when the
+timed region starts.  One step = one pass of the hot path (frozen student forward + fused upsample/argmax -> int32 label maps) over
+one batch of --batch frames per GPU.  value = frames/s over all GPUs (replicas: no collective on this path).
+Extra legs on the same JSON line (none of them is `value`):
+  distill        configs[2]: the 8-frame fine-tune step (BN batch statistics, backward, Adam); N > 1: weak scaling (8 frames per GPU,
+                 SyncBN + one gradient all-reduce through RCCL inside the engine) and `distill_strong` = configs[4]'s shape: the
+                 global 8-frame batch split N ways
+  stream         configs[2] as a workload / configs[3] at N > 1: per second of video 30 single-frame inferences with metric on the
+                 edge model + one 8-frame fine-tune step + server->edge hand-off, sustained; every rank runs its own video
+  roofline       dominant kernel of the inference step + whole-step fractions, HIP events on the launch stream over a profiled replay
+  parity         HIP vs the CPU oracle on two 512x1024 frames: exact label-match fraction, logits error, mIoU against the teacher
+  cpu_baseline   the CPU oracle (PyTorch-CPU restatement) on bounded samples, rank 0 / N = 1
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from collections import defaultdict
@@ -33,6 +44,57 @@ CI = [0, 1, 2, 10, 11, 13]          # exp 25 (Cityscapes) class subset, referenc
 HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (throughput saturates at ~24)")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--train-batch", type=int, default=8)
+    ap.add_argument("--stream-seconds", type=int, default=8, help="seconds of video in the interleaved infer + fine-tune leg")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-stream", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--only-timed", action="store_true", help="warm-up + timed loop only (what the rocprofv3 --pmc passes wrap)")
+    ap.add_argument("--dump-layers", action="store_true", help="print the per-launch profile of one step to stderr")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args) -> int:
+    """Parent of `python bench.py --gpus N` (N > 1, not under torchrun).  Makes NO GPU call: torch.cuda.device_count() does not
+    initialise the runtime on this image, and a process that has touched the GPU must never re-exec.  Each child is a fresh
+    interpreter with torchrun's environment contract."""
+    n = args.gpus
+    visible = torch.cuda.device_count()
+    assert visible >= 1, "bench.py needs an MI355X"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    share = visible < n          # fewer GPUs than ranks: ranks share devices and talk over gloo — a plumbing check, not a measurement
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r % visible), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if share:
+            env["AMS_BENCH_SHARED_GPUS"] = str(visible)
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if any(rcs) or not lines:
+        sys.stderr.write("bench.py: rank exit codes %s\n%s\n" % (rcs, out.decode(errors="replace")[-2000:]))
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------- helpers
 def read_profile(eng):
     need = C.c_size_t(0)
     hip.check(eng.lib.ams_student_profile_read(eng._h, None, 0, C.byref(need)))
@@ -50,13 +112,12 @@ def pmc_traffic(kernel, batch, height):
     `bench.py --only-timed`, FETCH_SIZE and WRITE_SIZE in separate passes).  Counter units are KiB.  Correction per
     MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE tallies 128-byte requests at 64 B, so it is doubled; WRITE_SIZE is
     exact.  Both were re-checked on kernels of known size in this library's access patterns (profiles/*_pmc_calib*:
-    1 GiB copy 0.500 / 1.000, depthwise 0.500 / 1.000).  The passes are valid for the default workload only."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    tag = "_b%d_pmc_traffic.json" % batch              # the passes are valid for the batch they were collected at
-    files = sorted(f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith(tag))
+    1 GiB copy 0.500 / 1.000, depthwise 0.500 / 1.000).  The passes are valid for the workload they were collected at."""
+    tag = "_b%d_pmc_traffic.json" % batch
+    files = sorted(f for f in os.listdir(ROOT / "profiles") if f.endswith(tag))
     if not files or height != 512:
         return {"traffic": None}
-    table = json.load(open(os.path.join(here, "profiles", files[-1])))
+    table = json.load(open(ROOT / "profiles" / files[-1]))
     for name, v in table.items():
         if kernel + "(" in name and v.get("fetch_kb_raw_avg") is not None and v.get("write_kb_raw_avg") is not None:
             fetch, write = 2.0 * v["fetch_kb_raw_avg"] * 1024, v["write_kb_raw_avg"] * 1024
@@ -66,33 +127,57 @@ def pmc_traffic(kernel, batch, height):
     return {"traffic": None}
 
 
+def algorithmic_bytes(H):
+    """SURVEY.md §8 d4 per-frame byte counts at f32 storage: layer-wise convention (every conv reads its input and writes its
+    output once) and block-fused convention (only block inputs / outputs, the frame and the label map touch HBM)."""
+    spec = S.build_spec()
+    W = 2 * H
+    el = S.activation_elements(H, W)
+    frame, labels = H * W * 3, H * W * 4
+    layerwise = 4.0 * (el["total"] + spec.n_trainable) + frame + labels
+    sizes = S.feature_sizes(H, W, spec.layers)
+    fused_el = 0
+    block_in = None
+    for l, (h, w) in zip(spec.layers, sizes):
+        if l.idx == 1:
+            fused_el += h * w * l.cout                       # stem output = first block's input
+            block_in = h * w * l.cout
+        elif l.scope.endswith("/project"):
+            fused_el += block_in + h * w * l.cout + (h * w * l.cout if l.residual_from else 0)
+            block_in = h * w * l.cout
+    hl, wl = sizes[-1]
+    fused_el += 2 * block_in + hl * wl * 19                  # head: features read by the pool and by aspp0, low-res logits out
+    blockfused = 4.0 * (fused_el + spec.n_trainable) + frame + labels
+    return layerwise, blockfused
+
+
+def miou_of(conf):
+    from ams_amd.utils import calculate_miou
+    return float(np.nanmean(calculate_miou(np.asarray(conf, dtype=np.float64), nan=True)))
+
+
+# ------------------------------------------------------------------------------------------------------------- rank
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (throughput saturates at ~24; 8: 5.1 k, 32: 5.5 k frames/s)")
-    ap.add_argument("--height", type=int, default=512)
-    ap.add_argument("--train-batch", type=int, default=8)
-    ap.add_argument("--no-train", action="store_true")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--only-timed", action="store_true", help="warm-up + timed loop only (what the rocprofv3 --pmc passes wrap)")
-    ap.add_argument("--dump-layers", action="store_true", help="print the per-launch profile of one step to stderr")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    shared = os.environ.get("AMS_BENCH_SHARED_GPUS")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1 or os.environ.get("AMS_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = "gloo" if shared else "nccl"          # RCCL needs one GPU per rank
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     n_gpus = world
 
     H, B = args.height, args.batch
@@ -105,7 +190,7 @@ def main():
     eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False, device=dev)
     eng.load_variables(W0)
     eng.freeze()
-    if os.environ.get("AMS_MATMUL"):                   # tuning knob: 0 exact f32, 1 split x3 (default), 2 split x6
+    if os.environ.get("AMS_MATMUL"):                   # tuning knob: 0 exact f32, 1 two-part split, 2 three-part split (default)
         eng.set_matmul_mode(int(os.environ["AMS_MATMUL"]))
     if os.environ.get("AMS_FUSE_DW_PROJECT"):          # tuning knob: the optional depthwise+project kernel
         eng.set_fuse_dw_project(os.environ["AMS_FUSE_DW_PROJECT"] == "1")
@@ -115,6 +200,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def max_over_ranks(seconds):
+        if dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(args.warmup):
         eng.predict(frames)
     barrier()
@@ -122,11 +214,7 @@ def main():
     for _ in range(args.steps):
         out = eng.predict(frames)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     fps = n_gpus * B * args.steps / elapsed
     checksum = int(out.sum().item())
 
@@ -138,43 +226,43 @@ def main():
                               "labels_checksum": checksum, "note": "--only-timed: no other leg was run"}), flush=True)
         return
 
-    # ---- latency mode: one frame per call (what the edge loop of run.py:400-423 does) ---------------------------
-    one = frames[:1].contiguous()
-    for _ in range(3):
-        eng.predict(one)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    n1 = max(10, args.steps)
-    for _ in range(n1):
-        eng.predict(one)
-    torch.cuda.synchronize(dev)
-    fps_b1 = n1 / (time.perf_counter() - t1)
-
-    # ---- the same two loops replayed from a hipGraph (one launch per step instead of ~60) -------------------------
-    graph_fps = graph_fps_b1 = None
-    try:
-        gp = eng.graphed_predict(B)
-        gp1 = eng.graphed_predict(1)
-        for g_, fr_, n_, key in ((gp, frames, args.steps, "b"), (gp1, one, n1, "b1")):
-            for _ in range(3):
-                g_(fr_)
-            torch.cuda.synchronize(dev)
-            tg = time.perf_counter()
-            for _ in range(n_):
-                lab_g = g_(fr_)
-            torch.cuda.synchronize(dev)
-            rate = n_ * fr_.shape[0] / (time.perf_counter() - tg)
-            if key == "b":
-                graph_fps = rate
-                assert int(lab_g.sum().item()) == checksum, "graph replay changed the label maps"
-            else:
-                graph_fps_b1 = rate
-    except Exception as e:  # noqa: BLE001
-        print("hipGraph leg skipped:", e, file=sys.stderr)
+    # ---- latency mode + hipGraph replay (single GPU only: they say nothing about scaling) -------------------------
+    fps_b1 = graph_fps = graph_fps_b1 = None
+    if n_gpus == 1:
+        one = frames[:1].contiguous()
+        for _ in range(3):
+            eng.predict(one)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        n1 = max(10, args.steps)
+        for _ in range(n1):
+            eng.predict(one)
+        torch.cuda.synchronize(dev)
+        fps_b1 = n1 / (time.perf_counter() - t1)
+        try:
+            gp = eng.graphed_predict(B)
+            gp1 = eng.graphed_predict(1)
+            for g_, fr_, n_, key in ((gp, frames, args.steps, "b"), (gp1, one, n1, "b1")):
+                for _ in range(3):
+                    g_(fr_)
+                torch.cuda.synchronize(dev)
+                tg = time.perf_counter()
+                for _ in range(n_):
+                    lab_g = g_(fr_)
+                torch.cuda.synchronize(dev)
+                rate = n_ * fr_.shape[0] / (time.perf_counter() - tg)
+                if key == "b":
+                    graph_fps = rate
+                    assert int(lab_g.sum().item()) == checksum, "graph replay changed the label maps"
+                else:
+                    graph_fps_b1 = rate
+        except Exception as e:  # noqa: BLE001
+            print("hipGraph leg skipped:", e, file=sys.stderr)
 
     # ---- roofline leg: profiled replay of the same step ----------------------------------------------------------
     roofline = None
     kernels = {}
+    layerwise_b, blockfused_b = algorithmic_bytes(H)
     if not args.no_profile and rank == 0:
         hip.check(eng.lib.ams_student_profile(eng._h, 1))
         n_prof = min(args.steps, 5)
@@ -194,12 +282,14 @@ def main():
             a[1] += ms
             a[2] += nbytes
         total_ms = sum(a[1] for a in agg.values())
+        total_bytes = sum(a[2] for a in agg.values())
         for name, (cnt, ms, nbytes) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             kernels[name] = {"launches": cnt, "avg_us": round(1e3 * ms / cnt, 2), "share": round(ms / total_ms, 4),
                              "alg_GBps": round(nbytes / ms / 1e6, 1)}
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         cnt, ms, nbytes = dom[1]
         achieved = nbytes / ms / 1e6          # bytes / ms -> GB/s
+        step_ms = 1e3 * elapsed / args.steps
         roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_us": round(1e3 * ms / cnt, 2), "launches": cnt,
@@ -208,6 +298,19 @@ def main():
                     "note": "HIP events on the launch stream around every kernel of a profiled replay of the timed step; "
                             "algorithmic bytes = f32 operands read once + results written once (DESIGN.md)"}
         roofline.update(pmc_traffic(dom[0], B, H))
+        # the whole step against the three denominators of SURVEY 8 d4, over the TIMED step (not the profiled replay)
+        as_built = total_bytes / n_prof
+        roofline["whole_step"] = {
+            "ms_per_step": round(step_ms, 4), "frames": B,
+            "as_built": {"alg_bytes": round(as_built), "achieved_GBps": round(as_built / step_ms / 1e6, 1),
+                         "frac": round(as_built / step_ms / 1e6 / HBM_PEAK_GBS, 4),
+                         "note": "sum over the launches of this plan: fused kernels count only what they must move"},
+            "layerwise_f32": {"alg_bytes": round(B * layerwise_b), "achieved_GBps": round(B * layerwise_b / step_ms / 1e6, 1),
+                              "frac": round(B * layerwise_b / step_ms / 1e6 / HBM_PEAK_GBS, 4),
+                              "note": "SURVEY 8 d4: every conv reads its input and writes its output once, f32 (%.0f MB/frame)" % (layerwise_b / 1e6)},
+            "blockfused_f32": {"alg_bytes": round(B * blockfused_b), "achieved_GBps": round(B * blockfused_b / step_ms / 1e6, 1),
+                               "frac": round(B * blockfused_b / step_ms / 1e6 / HBM_PEAK_GBS, 4),
+                               "note": "SURVEY 8 d4 stretch: only block inputs / outputs, frame and labels touch HBM, f32 (%.0f MB/frame)" % (blockfused_b / 1e6)}}
         if dom[0].startswith("xdw_wreg_kernel"):
             # The fused expand+depthwise of the 160 -> 960 blocks moves 12 % of the bytes of the two kernels it replaces; what
             # bounds it is the matrix pipe (every f32 product is 6, or 3, bf16 MFMAs) next to the depthwise VALU work.  Reported
@@ -219,43 +322,161 @@ def main():
             roofline["matrix_pipe"] = {"bound": "mfma", "achieved": round(tf_s, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf_s / 2500.0, 4),
                                        "note": "bf16 MFMA FLOPs issued for the split-bf16 products of the expand GEMM (halo rows excluded); "
                                                "f32-equivalent rate = achieved / %d" % (6 if parts == 3 else 3)}
+
+    # ---- parity leg (rank 0, N = 1): HIP vs the CPU oracle at the benchmark's own size -----------------------------------
+    parity = None
+    if not args.no_parity and rank == 0 and n_gpus == 1:
+        from oracle.student_torch import StudentOracle
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        nf = 2
+        oracle = StudentOracle(W0, CI)
+        fr32 = frames_np[:nf].astype(np.float32)
+        with torch.no_grad():
+            low_o = oracle.forward_lowres(fr32, "frozen").numpy()
+        lab_o, cm_o, loss_o = oracle.predict_with_metric(fr32, labels_np[:nf], "frozen")
+        lab_g, cm_g, loss_g = eng.predict_with_metric(frames[:nf], torch.from_numpy(labels_np[:nf]).to(dev))
+        hl, wl = eng.lowres
+        low_g = eng.logits_lowres.view(-1, hl, wl, 32)[:nf, :, :, :19].cpu().numpy()
+        lab_g = lab_g.cpu().numpy()
+        lg = loss_g.cpu().numpy()
+        parity = {"frames": nf, "size": "%dx%d" % (H, 2 * H), "oracle": "oracle/student_torch.py, PyTorch-CPU f32 (parity unpinned: no TensorFlow here, DESIGN.md §2)",
+                  "label_exact_match_fraction": round(float((lab_g == lab_o).mean()), 7),
+                  "label_mismatch_pixels": int((lab_g != lab_o).sum()),
+                  "logits_max_rel_err": float("%.3e" % (np.abs(low_g - low_o).max() / np.abs(low_o).max())),
+                  "loss": {"hip": round(float(lg[0] / lg[1]), 6), "oracle": round(float(loss_o), 6)},
+                  "miou_vs_teacher": {"hip": round(miou_of(cm_g.cpu().numpy()), 6), "oracle": round(miou_of(cm_o), 6)},
+                  "note": "synthetic weights and a procedural teacher: the mIoU values are small and only their AGREEMENT is meaningful"}
     eng.close()
     del eng
     torch.cuda.empty_cache()
 
-    # ---- config[2] leg: one 8-frame fine-tune step --------------------------------------------------------------
-    distill = None
+    # ---- fine-tune legs -----------------------------------------------------------------------------------------------------
+    def make_sync(engine):
+        """-> kwargs for StudentEngine.train_step: RCCL inside the engine (one GPU per rank), gloo callback when ranks share GPUs."""
+        if dist is None:
+            return {}, None
+        if backend == "nccl":
+            from ams_amd.dist import RcclComm
+            comm = RcclComm(rank, world, dev)
+            return {"comm": comm}, comm
+        from ams_amd.dist import ArenaAllReduce
+
+        class _HostReduce(ArenaAllReduce):           # gloo reduces host tensors: stage through the CPU (plumbing check only)
+            def __call__(self, _user, offset, count, dtype_code):
+                try:
+                    t = self.view(int(offset), int(count), int(dtype_code))
+                    torch.cuda.synchronize(t.device)
+                    h = t.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    t.copy_(h)
+                    self.calls += 1
+                    self.bytes += t.numel() * t.element_size()
+                    return 0
+                except BaseException as e:  # noqa: BLE001
+                    self.error = e
+                    return 1
+        red = _HostReduce(engine.arena)
+        return {"allreduce": red}, red
+
+    def time_steps(engine, tf, tl, kw, global_batch, n_steps):
+        for _ in range(2):
+            engine.train_step(tf, tl, 1e-3, global_batch=global_batch, **kw)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(n_steps):
+            loss = engine.train_step(tf, tl, 1e-3, global_batch=global_batch, **kw)
+        barrier()
+        tt = max_over_ranks(time.perf_counter() - ts)
+        ls = loss.cpu().numpy()
+        return tt, float(ls[0] / max(ls[1], 1))
+
+    distill = distill_strong = None
+    TB = args.train_batch
+    n_train = max(3, min(args.steps, 10))
     if not args.no_train:
-        TB = args.train_batch
         teng = StudentEngine(CI, H, 2 * H, max_batch=TB, trainable=True, device=dev)
         teng.load_variables(W0)
         tf = torch.from_numpy(frames_np[:TB]).to(dev)
         tl = torch.from_numpy(labels_np[:TB]).to(dev)
-        allreduce = None
-        if dist is not None:
-            from ams_amd.dist import ArenaAllReduce
-            allreduce = ArenaAllReduce(teng.arena)
-        for _ in range(2):
-            teng.train_step(tf, tl, 1e-3, allreduce=allreduce, global_batch=TB * n_gpus)
-        barrier()
-        ts = time.perf_counter()
-        n_train = max(3, min(args.steps, 10))
-        for _ in range(n_train):
-            loss = teng.train_step(tf, tl, 1e-3, allreduce=allreduce, global_batch=TB * n_gpus)
-        barrier()
-        tt = time.perf_counter() - ts
-        if dist is not None:
-            t = torch.tensor([tt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tt = float(t.item())
-        ls = loss.cpu().numpy()
-        distill = {"steps_per_sec": round(n_train / tt, 3), "ms_per_step": round(1e3 * tt / n_train, 3), "batch_per_gpu": TB,
-                   "global_batch": TB * n_gpus, "mode": "dp-allreduce+syncbn" if dist is not None else "single",
-                   "loss": round(float(ls[0] / max(ls[1], 1)), 5)}
+        kw, sync = make_sync(teng)
+        tt, loss_v = time_steps(teng, tf, tl, kw, TB * n_gpus, n_train)
+        step_bytes = 3.0 * TB * layerwise_b + 7 * 4.0 * spec.n_trainable + 4.0 * 2 * spec.n_stats
+        ms = 1e3 * tt / n_train
+        distill = {"steps_per_sec": round(n_train / tt, 3), "ms_per_step": round(ms, 3), "batch_per_gpu": TB,
+                   "global_batch": TB * n_gpus, "scaling": "weak",
+                   "mode": ("syncbn + gradient all-reduce, %s" % ("RCCL issued by the engine on the launch stream" if backend == "nccl" else "gloo host callback (ranks share GPUs)"))
+                   if dist is not None else "single",
+                   "loss": round(loss_v, 5),
+                   "roofline": {"bound": "hbm", "alg_bytes_per_step": round(step_bytes), "achieved": round(step_bytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(step_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                "note": "SURVEY 8 d4: 3 x B x layer-wise f32 inference bytes + optimizer (7 x 4 B x params) + BN moving averages, per GPU"}}
+        if sync is not None and hasattr(sync, "stats"):
+            calls, nbytes = sync.stats()
+            distill["collectives_per_step"] = round(calls / (n_train + 2), 1)
+            distill["bytes_reduced_per_step"] = round(nbytes / (n_train + 2))
+        # configs[4]'s shape: ONE 8-frame batch split over the ranks (strong scaling; SyncBN keeps full-batch semantics)
+        if dist is not None and TB % n_gpus == 0:
+            per = TB // n_gpus
+            lo = rank * per
+            tfs, tls = tf[lo:lo + per].contiguous(), tl[lo:lo + per].contiguous()
+            tt2, loss2 = time_steps(teng, tfs, tls, kw, TB, n_train)
+            distill_strong = {"steps_per_sec": round(n_train / tt2, 3), "ms_per_step": round(1e3 * tt2 / n_train, 3), "batch_per_gpu": per,
+                              "global_batch": TB, "scaling": "strong", "loss": round(loss2, 5),
+                              "note": "BASELINE.json configs[4] shape: one stream's 8-frame fine-tune batch sharded over the GPUs; 110 latency-bound "
+                                      "collectives per step (SURVEY 8 e4: communication-latency-bound by construction)"}
+        if sync is not None and hasattr(sync, "close"):
+            sync.close()
         teng.close()
         del teng
+        torch.cuda.empty_cache()
 
-    # ---- CPU baseline leg: the oracle on the host cores (rank 0, N = 1 only) ----------------------------------------
+    # ---- stream leg: configs[2] as a workload (N = 1) / configs[3] (N > 1: one video and one student pair per GPU, no collective) ----
+    stream = None
+    if not args.no_stream and not args.no_train:
+        fps_video = 30
+        secs = args.stream_seconds
+        clip_f, clip_l = synth.SyntheticVideo(H, 40, CI, seed=100 + rank).clip()
+        vf = torch.from_numpy(clip_f).to(dev)                # 40 distinct frames resident in HBM, cycled
+        vl = torch.from_numpy(clip_l).to(dev)
+        server = StudentEngine(CI, H, 2 * H, max_batch=TB, trainable=True, device=dev)
+        server.load_variables(W0)
+        edge = StudentEngine(CI, H, 2 * H, max_batch=1, trainable=False, device=dev)
+        edge.load_variables(W0)
+        edge.freeze()
+
+        def one_second(sec):
+            conf_sum = torch.zeros(len(CI), len(CI), dtype=torch.int64, device=dev)
+            for k in range(fps_video):                        # edge: every frame of this second, one at a time, with metric
+                i = (sec * fps_video + k) % vf.shape[0]
+                _lab, conf, _loss = edge.predict_with_metric(vf[i:i + 1], vl[i:i + 1])
+                conf_sum += conf
+            idx = torch.arange(TB, device=dev) * 5 % vf.shape[0]
+            server.train_step(vf[idx], vl[idx], 1e-3)         # server: one 8-frame fine-tune step per second (configs[2])
+            edge.params.copy_(server.params)                  # hand-off: trained variables -> edge, BN folded again
+            edge.stats.copy_(server.stats)
+            edge.freeze()
+            return conf_sum
+        one_second(0)
+        barrier()
+        ts = time.perf_counter()
+        conf_total = torch.zeros(len(CI), len(CI), dtype=torch.int64, device=dev)
+        for sec in range(secs):
+            conf_total += one_second(sec + 1)
+        barrier()
+        tt = max_over_ranks(time.perf_counter() - ts)
+        stream = {"videos": n_gpus, "video_seconds_each": secs, "wall_s": round(tt, 4),
+                  "sustained_frames_per_sec": round(n_gpus * secs * fps_video / tt, 1),
+                  "realtime_factor_per_video": round(secs / tt, 2),
+                  "per_video_second": "30 x predict_with_metric(1 frame) on the edge model + 1 x %d-frame fine-tune step + server->edge hand-off (device copy + BN fold)" % TB,
+                  "miou_vs_teacher_rank0": round(miou_of(conf_total.cpu().numpy()), 5),
+                  "target": ">= 30 frames/s of inference + one 8-frame step per second on one GPU (BASELINE.json north star): realtime_factor >= 1",
+                  "note": "configs[2] interleaved on one GPU; with N > 1 configs[3]: every rank serves its own video with its own student pair, no collective"}
+        server.close()
+        edge.close()
+        del server, edge
+        torch.cuda.empty_cache()
+
+    # ---- CPU baseline legs: the oracle on the host cores (rank 0, N = 1 only) --------------------------------------------------
     cpu = None
     if not args.no_cpu and rank == 0 and n_gpus == 1:
         from oracle.student_torch import StudentOracle
@@ -264,18 +485,36 @@ def main():
         cores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(cores)
         oracle = StudentOracle(W0, CI)
-        sample = frames_np[:1].astype(np.float32)
-        oracle.predict(sample)                           # warm-up
-        tc = time.perf_counter()
-        n_cpu = 0
-        while time.perf_counter() - tc < 12.0 and n_cpu < 16:
-            oracle.predict(frames_np[n_cpu % len(frames_np)][None].astype(np.float32))
-            n_cpu += 1
-        tcpu = time.perf_counter() - tc
-        cpu = {"value": round(n_cpu / tcpu, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": "%d frames of the same %dx%d synthetic clip, one at a time, PyTorch-CPU f32 restatement "
-                         "(oracle/student_torch.py) with %d threads; stand-in for the reference's TF1 CPU path, which "
-                         "cannot run here (TF 1.15 absent)" % (n_cpu, H, 2 * H, torch.get_num_threads())}
+        oracle.predict(frames_np[:1].astype(np.float32))                           # warm-up
+        rates = []
+        for rep in range(3):                                                       # three bounded samples: the spread is part of the figure
+            tc = time.perf_counter()
+            n_cpu = 0
+            while time.perf_counter() - tc < 4.0 and n_cpu < 16:
+                oracle.predict(frames_np[n_cpu % len(frames_np)][None].astype(np.float32))
+                n_cpu += 1
+            rates.append(n_cpu / (time.perf_counter() - tc))
+        legs = {}
+        # configs[0]: 64 frames of 256x512 (bounded to 6 s)
+        small_f = synth.SyntheticVideo(256, 8, CI, seed=3).clip()[0].astype(np.float32)
+        oracle.predict(small_f[:1])
+        tc, n_small = time.perf_counter(), 0
+        while n_small < 64 and time.perf_counter() - tc < 6.0:
+            oracle.predict(small_f[n_small % 8][None])
+            n_small += 1
+        legs["cfg0_infer_256x512"] = {"value": round(n_small / (time.perf_counter() - tc), 3), "unit": "frames/s", "frames": n_small}
+        # configs[2]: one 8-frame fine-tune step at 512x1024 (forward with batch statistics, autograd backward, Adam), once
+        if not args.no_train:
+            tc = time.perf_counter()
+            oracle.train_step(frames_np[:TB].astype(np.float32), labels_np[:TB], 1e-3)
+            dt = time.perf_counter() - tc
+            legs["cfg2_train_step_%dx512x1024" % TB] = {"value": round(1.0 / dt, 4), "unit": "steps/s", "seconds": round(dt, 2), "steps": 1}
+        cpu = {"value": round(float(np.median(rates)), 3), "unit": "frames/s", "cores": cores, "kind": "port",
+               "spread": {"min": round(min(rates), 3), "max": round(max(rates), 3), "samples": 3},
+               "legs": legs,
+               "sample": "3 x <= 4 s of single 512x1024 frames of the same synthetic clip, PyTorch-CPU f32 restatement "
+                         "(oracle/student_torch.py) with %d threads, median reported; stand-in for the reference's TF1 CPU path, which "
+                         "cannot run here (TF 1.15 absent)" % torch.get_num_threads()}
 
     if rank == 0:
         result = {
@@ -283,6 +522,7 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "precision_note": "f32 storage and accumulation everywhere; products of the late 1x1 layers (output stride 16 + head) are "
                               "formed as 6 bf16 MFMAs on three-part splits of the f32 operands (all 24 significand bits: f32-level; "
                               "512x1024 logits 4e-5 from the f64 oracle, same as exact f32 MFMA and as the f32 CPU oracle: "
@@ -291,16 +531,22 @@ def main():
                                    "int32 label maps out (BASELINE.json configs[1])" % (H, 2 * H),
                        "frames_per_step_per_gpu": B, "class_subset": CI, "weights": "synthetic seed 0",
                        "parallelism": "replicas x%d (no collective on the inference path)" % n_gpus},
-            "frames_per_sec_batch1": round(fps_b1, 2),
+            "frames_per_sec_batch1": round(fps_b1, 2) if fps_b1 else None,
             "hipgraph": {"frames_per_sec": round(graph_fps, 2) if graph_fps else None,
                          "frames_per_sec_batch1": round(graph_fps_b1, 2) if graph_fps_b1 else None,
                          "note": "same step captured once with torch.cuda.graph and replayed; single GPU, not the headline"},
             "distill": distill,
+            "distill_strong": distill_strong,
+            "stream": stream,
             "roofline": roofline,
+            "parity": parity,
             "cpu_baseline": cpu,
             "kernels": kernels,
             "labels_checksum": checksum,
         }
+        if shared:
+            result["gpu_sharing"] = {"ranks": world, "gpus": int(shared), "backend": backend,
+                                     "note": "fewer GPUs than ranks: a plumbing check of the multi-rank path, NOT a scaling measurement"}
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -151,16 +151,33 @@ int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frame
                            int32_t batch, float lr, const uint8_t* mask_dev, double* loss_dev, void* stream);
 
 /* ---- data-parallel split of the same step (one process per GPU) -------------------------
- * A sync callback is invoked on the host between phases whenever cross-rank sums are needed; it must
- * all-reduce (sum) `count` float32 values at arena byte offset `offset_bytes` on `stream` order (the Python
- * host wraps the arena in a torch tensor and calls torch.distributed.all_reduce -> RCCL).  With cb == NULL the
- * step is the single-GPU step above.  Call sites: valid-pixel count (1 value), per-BN-layer (sum, sumsq)
- * forward and (sum dy, sum dy*xhat) backward, and the flat gradient arena before Adam. */
+ * Callback form (any transport; what the gloo CPU tests and a host without RCCL use): `cb` is invoked on the host
+ * whenever cross-rank sums are needed and must all-reduce (sum) `count` values of `dtype` at arena byte offset
+ * `offset_bytes`, ordered after the work already enqueued on `stream`.  With cb == NULL the step is the single-GPU
+ * step above.  Call sites: per-BN-layer (sum, sumsq) forward, (CE sum, valid-pixel count), per-BN-layer
+ * (sum dy, sum dy*xhat) backward, and the flat gradient arena before Adam.  ams_student_train_step_rccl below is
+ * the production form. */
 typedef int (*ams_allreduce_cb)(void* user, size_t offset_bytes, size_t count, int32_t dtype);
 int ams_student_train_step_dp(ams_student* s, const void* frames_dev, int32_t frames_dtype,
                               const uint8_t* teacher_dev, int32_t batch, int32_t global_batch, float lr,
                               const uint8_t* mask_dev, double* loss_dev, ams_allreduce_cb cb, void* user,
                               void* stream);
+
+/* The same step with the exchange done by the library itself: every cross-rank sum is one ncclAllReduce on `stream`, issued in launch
+ * order with no host round trip in between (110 per step: 54 BN forward, loss, 54 BN backward, the gradient arena).  librccl is
+ * resolved at run time (dlopen; inside a PyTorch-ROCm process the copy PyTorch loaded is reused), so the library loads without it.
+ *   rank 0: ams_comm_unique_id(id, 128) -> ship the 128 bytes to every rank (torch.distributed broadcast, a file, ...)
+ *   all   : hipSetDevice(local gpu); ams_comm_create(id, 128, rank, world, &comm)   (world == 1: a no-op communicator)
+ * One process per GPU, as the reference runs one process per --gpu (run.py:28). */
+typedef struct ams_comm ams_comm;
+int ams_comm_unique_id(uint8_t* id_out, size_t cap);
+int ams_comm_create(const uint8_t* id, size_t id_len, int32_t rank, int32_t world, ams_comm** out);
+void ams_comm_destroy(ams_comm* c);
+int ams_comm_stats(const ams_comm* c, int32_t* rank, int32_t* world, int64_t* calls, int64_t* bytes);
+int ams_comm_allreduce(ams_comm* c, void* buf_dev, size_t count, int32_t dtype, void* stream);
+int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
+                                int32_t batch, int32_t global_batch, float lr, const uint8_t* mask_dev, double* loss_dev,
+                                ams_comm* comm, void* stream);
 
 /* ---- options -----------------------------------------------------------------------------------------------
  * AMS_OPT_MATMUL selects how the products of the 1x1-conv layers that would be matrix-pipe bound in exact f32 are formed

@@ -129,6 +129,8 @@ struct ams_student {
     int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
                                                // in one streaming kernel (k_xdw_stream.hip): 0 never, 1 where measured
                                                // faster (Cin 64 / 96, >= 16384 rows), 2 also the 160-channel blocks
+    int fuse_block = 1;                        // frozen inference: a whole early block (Cin <= 32: expand + depthwise + project
+                                               // [+ input]) in one kernel, bit-identical to the layer-by-layer plan
     int fuse_expand_dw = 1;                    // frozen inference, expand + depthwise in one kernel: 0 never, 1 where it
                                                // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
@@ -464,6 +466,25 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
         const float* block_in = cur;
         const float* x = cur;
         int x_i = cur_i;
+        if (s->fuse_block && i + 2 <= s->n_backbone && s->L[i].d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
+            s->L[i + 2].d.role == AMS_ROLE_PROJECT && (!s->L[i + 2].d.residual_from || s->L[i + 2].d.residual_from == i - 1) &&
+            block_fused_supported(s->L[i].d.cin, s->L[i].d.cout, s->L[i + 2].d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate,
+                                  s->L[i + 2].d.residual_from != 0)) {
+            // early blocks: only the block input and output touch HBM (k_block.hip)
+            LayerRt& le = s->L[i];
+            LayerRt& ld = s->L[i + 1];
+            LayerRt& lj = s->L[i + 2];
+            const int o = other(cur_i, -1);
+            const bool res = lj.d.residual_from != 0;
+            const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin * (res ? 2 : 1) + lj.px_out * lj.d.cout) + (double)le.d.cin * le.d.cout +
+                                        9.0 * ld.d.cin + (double)lj.d.cin * lj.d.cout);
+            RUNK(i + 2, bytes, launch_block_fused(cur, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
+                                                  P + ld.d.w_off, ld.d.stride, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale, lj.fshift,
+                                                  lj.d.act, lj.d.cout, res, s->act[o], st));
+            cur = s->act[o]; cur_i = o; i += 3;
+            cur_parts = nullptr;
+            continue;
+        }
         const bool stream_here = stream_ok(i) && (s->L[i].d.cin <= 96 || cur_parts || s->fuse_expand_dw_stream >= 2);
         if (!stream_here && s->fuse_expand_dw && s->L[i].d.role == AMS_ROLE_EXPAND && i + 1 <= s->n_backbone &&
             s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
@@ -864,6 +885,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
+    if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     *out = s;
     return AMS_OK;
@@ -1031,6 +1053,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         s->fuse_expand_dw_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
     }
+    if (option == AMS_OPT_FUSE_BLOCK) {
+        s->fuse_block = value != 0;
+        return AMS_OK;
+    }
     if (option == AMS_OPT_FUSE_EXPAND_DW) {
         s->fuse_expand_dw = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
@@ -1151,6 +1177,14 @@ int ams_k_dw_project(const float* e, int32_t B, int32_t H, int32_t W, int32_t Cc
     a.scale = scale_p; a.shift = shift_p; a.act = AMS_ACT_NONE;
     if (res) { a.res = res; a.ldr = N; }
     return launch_dw_project(e, B, H, W, Cc, w_dw, rate, scale_d, shift_d, AMS_ACT_RELU6, a, hi, lo, Cc, st);
+}
+
+int ams_k_block_fused(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e, const float* shift_e,
+                      int32_t Cexp, const float* w_dw, int32_t stride, const float* scale_d, const float* shift_d, const float* w_proj, int32_t Cout,
+                      const float* scale_p, const float* shift_p, int32_t residual, float* y, void* stream) {
+    if (!block_fused_supported(Cin, Cexp, Cout, stride, 1, residual != 0)) { set_error("block_fused: unsupported shape"); return AMS_E_INVALID; }
+    return launch_block_fused(x, B, H, W, Cin, w_exp, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, stride, scale_d, shift_d, AMS_ACT_RELU6, w_proj,
+                              scale_p, shift_p, AMS_ACT_NONE, Cout, residual != 0, y, (hipStream_t)stream);
 }
 
 int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,

@@ -91,6 +91,12 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
                      int Cexp, const float* w_dw, int stride, int rate, const float* sc_d, const float* sh_d, int act_d, float* y,
                      hipStream_t st);
 
+// ---- k_block.hip : a whole early inverted-residual block (expand -> depthwise -> project [+ input]) in one kernel ----
+bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bool residual);
+int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
+                       const float* w_dw, int stride, const float* sc_d, const float* sh_d, int act_d, const float* w_pj, const float* sc_p,
+                       const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st);
+
 // ---- k_xdw_stream.hip : the same fusion for the stride-16 blocks (Cin 64 / 96 / 160, stride 1, rate 1 | 2): raster-order
 // streaming through an LDS ring, split-bf16 products from the expand layer's bf16 panels (np = 2 | 3 parts, `plane` apart)
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate);

@@ -211,6 +211,10 @@ class StudentEngine:
         the two kernels; split-bf16 mode only)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DW_PROJECT, int(bool(on))), "ams_student_set_option")
 
+    def set_fuse_block(self, on: bool) -> None:
+        """Frozen inference: every early block with Cin <= 32 as ONE kernel (expand + depthwise + project [+ input]; default on)."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_BLOCK, int(bool(on))), "ams_student_set_option")
+
     def set_fuse_expand_dw(self, on: int) -> None:
         """Frozen inference, expand + depthwise of a block as one kernel: 0 never, 1 (default) the blocks where it is
         measured faster, 2 every supported block."""

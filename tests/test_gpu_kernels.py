@@ -251,6 +251,46 @@ def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):
     assert rel_err(y.cpu().numpy(), ref.permute(0, 2, 3, 1).numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,Cin,Cexp,Cout,stride,res", [(33, 65, 16, 96, 24, 2, False), (40, 37, 24, 144, 24, 1, True), (33, 65, 24, 144, 32, 2, False),
+                                                          (29, 50, 32, 192, 32, 1, True), (34, 66, 32, 192, 64, 2, False), (65, 129, 16, 96, 24, 1, False),
+                                                          (7, 5, 24, 144, 24, 1, True), (16, 16, 32, 192, 32, 1, False)])
+def test_whole_block_kernel(lib, H, W, Cin, Cexp, Cout, stride, res):
+    """k_block.hip: expand + depthwise + project (+ block input) in one kernel.  Against f64 math, and bit for bit against the
+    kernels it replaces (fused expand+depthwise, then the f32 GEMM with its epilogue) — same products, same k order."""
+    rng = np.random.default_rng(H * 3 + Cin + Cout)
+    B = 2
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    we = (rng.standard_normal((Cin, Cexp)) / np.sqrt(Cin)).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, Cexp, 1)) * 0.4).astype(np.float32)
+    wp = (rng.standard_normal((Cexp, Cout)) / np.sqrt(Cexp)).astype(np.float32)
+    se, sd, sp = (rng.uniform(0.5, 1.5, n).astype(np.float32) for n in (Cexp, Cexp, Cout))
+    he, hd, hp = (rng.standard_normal(n).astype(np.float32) for n in (Cexp, Cexp, Cout))
+    Ho, pt, pb = S.same_pad(H, 3, stride, 1)
+    Wo, pl, pr = S.same_pad(W, 3, stride, 1)
+    xd, wed, wdd, wpd = dev(x), dev(we), dev(wd), dev(wp)
+    sed, hed, sdd, hdd, spd, hpd = dev(se), dev(he), dev(sd), dev(hd), dev(sp), dev(hp)
+    y = torch.full((B, Ho, Wo, Cout), np.nan, device=DEV)
+    hip.check(lib.ams_k_block_fused(P(xd), B, H, W, Cin, P(wed), P(sed), P(hed), Cexp, P(wdd), stride, P(sdd), P(hdd), P(wpd), Cout, P(spd), P(hpd),
+                                    int(res), P(y), stream()))
+    e = np.clip((x.astype(np.float64) @ we.astype(np.float64)) * se + he, 0, 6)
+    et = torch.as_tensor(e).permute(0, 3, 1, 2)
+    raw = F.conv2d(F.pad(et, (pl, pr, pt, pb)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), stride=stride, groups=Cexp)
+    d = torch.clamp(raw * torch.as_tensor(sd).view(1, -1, 1, 1) + torch.as_tensor(hd).view(1, -1, 1, 1), 0, 6).permute(0, 2, 3, 1).numpy()
+    ref = (d @ wp.astype(np.float64)) * sp + hp
+    if res:
+        ref = ref + x
+    got = y.cpu().numpy()
+    assert not np.isnan(got).any()
+    assert rel_err(got, ref) < 2e-5
+    # the two kernels it replaces
+    dmid = torch.empty((B, Ho, Wo, Cexp), device=DEV)
+    hip.check(lib.ams_k_expand_dw(P(xd), B, H, W, Cin, P(wed), P(sed), P(hed), Cexp, P(wdd), stride, 1, P(sdd), P(hdd), P(dmid), stream()))
+    y2 = torch.empty((B, Ho, Wo, Cout), device=DEV)
+    hip.check(lib.ams_k_pointwise(P(dmid), B * Ho * Wo, Cexp, P(wpd), Cout, 0, None, 1, P(spd), P(hpd), hip.ACT_NONE, P(xd) if res else None, P(y2),
+                                  stream()))
+    assert torch.equal(y, y2), "max abs diff %g" % (y - y2).abs().max().item()
+
+
 @pytest.mark.parametrize("H,W,Cin,Cexp,rate,parts", [(33, 65, 64, 384, 1, 3), (33, 65, 96, 576, 1, 2), (33, 65, 160, 960, 2, 3),
                                                      (17, 33, 160, 960, 2, 2), (9, 200, 64, 384, 1, 3), (5, 3, 96, 576, 2, 3),
                                                      (40, 7, 64, 96, 1, 2), (2, 2, 160, 320, 2, 3), (1, 70, 96, 192, 1, 3),

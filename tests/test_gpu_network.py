@@ -62,6 +62,7 @@ def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     eng.set_fuse_expand_dw(2 if matmul != hip.MATMUL_F32 else 0)          # 2: every supported block fused; 0: layer-by-layer plan
     eng.set_fuse_dw_project(matmul == hip.MATMUL_SPLIT_BF16)              # the optional depthwise+project kernel too
     eng.set_fuse_first_block(matmul != hip.MATMUL_F32)                    # first block: one kernel vs three
+    eng.set_fuse_block(matmul != hip.MATMUL_F32)                          # early blocks: one kernel each vs layer by layer
     eng.freeze()
     o = _oracle(W0)
     with torch.no_grad():

@@ -1010,7 +1010,8 @@ static int train_step_impl(ams_student* s, const void* frames_dev, int32_t frame
     if (loss_dev) AMS_CHECK_HIP(hipMemcpyAsync(loss_dev, s->loss_buf, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     // Adam, TF1 form; the step counter is never reset (SemanticNetwork.py:25, :154-156)
     s->adam_t += 1;
-    const double b1 = 0.9, b2 = 0.999;
+    // beta1 / beta2 are f32 tensors in the TF graph (0.9f, 0.999f), and so are their running powers
+    const double b1 = (double)0.9f, b2 = (double)0.999f;
     const double lr_t = (double)lr * sqrt(1.0 - pow(b2, (double)s->adam_t)) / (1.0 - pow(b1, (double)s->adam_t));
     return launch_adam(s->params, s->grads, s->adam_m, s->adam_v, mask_dev, s->cfg.n_trainable, (float)lr_t, 0.9f, 0.999f, 1e-8f, st);
 }

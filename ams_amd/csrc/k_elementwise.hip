@@ -470,12 +470,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, const uint8_t* __restrict__ mask, int64_t n,
                                                    float lr_t, float b1, float b2, float eps) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // the form of TensorFlow's ApplyAdam functor (core/kernels/training_ops.cc), in f32 like its T = float instantiation:
+        //   m += (g - m) * (1 - beta1);  v += (g*g - v) * (1 - beta2);  var -= (m * alpha) / (sqrt(v) + epsilon)
         const float gi = g[i];
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float m0 = m[i], v0 = v[i];
+        const float mi = m0 + (gi - m0) * (1.f - b1);
+        const float vi = v0 + (gi * gi - v0) * (1.f - b2);
         m[i] = mi;
         v[i] = vi;
-        if (!mask || mask[i]) p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+        if (!mask || mask[i]) p[i] = p[i] - (mi * lr_t) / (sqrtf(vi) + eps);
     }
 }
 

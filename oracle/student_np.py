@@ -177,12 +177,16 @@ def confusion(target, pred, weight, k):
     return cm
 
 
-def adam_step(w, g, m, v, lr, beta1_power, beta2_power, beta1=0.9, beta2=0.999, eps=1e-8):
-    """tf.train.AdamOptimizer dense apply (Appendix C.10). Returns (w, m, v)."""
-    lr_t = lr * np.sqrt(1.0 - beta2_power) / (1.0 - beta1_power)
-    m = beta1 * m + (1.0 - beta1) * g
-    v = beta2 * v + (1.0 - beta2) * g * g
-    return w - lr_t * m / (np.sqrt(v) + eps), m, v
+def adam_step(w, g, m, v, lr, beta1_power, beta2_power):
+    """TensorFlow's ApplyAdam functor (core/kernels/training_ops.cc, Appendix C.10) with the graph's f32 hyper-parameter values.
+    Returns (w, m, v)."""
+    one_minus_b1 = float(np.float32(1.0) - np.float32(0.9))
+    one_minus_b2 = float(np.float32(1.0) - np.float32(0.999))
+    eps = float(np.float32(1e-8))
+    alpha = lr * np.sqrt(1.0 - beta2_power) / (1.0 - beta1_power)
+    m = m + (g - m) * one_minus_b1
+    v = v + (g * g - v) * one_minus_b2
+    return w - (m * alpha) / (np.sqrt(v) + eps), m, v
 
 
 def ema_update(moving, stat, decay=np.float32(S.BN_DECAY)):

@@ -94,12 +94,20 @@ def ema_update(moving: torch.Tensor, stat: torch.Tensor) -> torch.Tensor:
     return moving - (moving - stat) * float(np.float32(1.0) - np.float32(S.BN_DECAY))
 
 
-def adam_update(w, g, m, v, lr: float, beta1_power: float, beta2_power: float, b1=0.9, b2=0.999, eps=1e-8):
-    """tf.train.AdamOptimizer dense apply (Appendix C.10): eps is added OUTSIDE the square root.  -> (w, m, v)."""
-    lr_t = lr * np.sqrt(1.0 - beta2_power) / (1.0 - beta1_power)
-    m = m * b1 + (1.0 - b1) * g
-    v = v * b2 + (1.0 - b2) * g * g
-    return w - lr_t * m / (torch.sqrt(v) + eps), m, v
+ADAM_B1 = float(np.float32(0.9))          # the hyper-parameters are f32 tensors in the TF graph: these are their VALUES
+ADAM_B2 = float(np.float32(0.999))
+ADAM_EPS = float(np.float32(1e-8))
+ADAM_1MB1 = float(np.float32(1.0) - np.float32(0.9))       # (T(1) - beta1()) formed in f32 by the ApplyAdam functor
+ADAM_1MB2 = float(np.float32(1.0) - np.float32(0.999))
+
+
+def adam_update(w, g, m, v, lr: float, beta1_power: float, beta2_power: float):
+    """TensorFlow's ApplyAdam functor (core/kernels/training_ops.cc; Appendix C.10), eps OUTSIDE the square root:
+    alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); var -= (m*alpha)/(sqrt(v)+eps).  -> (w, m, v)."""
+    alpha = lr * np.sqrt(1.0 - beta2_power) / (1.0 - beta1_power)
+    m = m + (g - m) * ADAM_1MB1
+    v = v + (g * g - v) * ADAM_1MB2
+    return w - (m * alpha) / (torch.sqrt(v) + ADAM_EPS), m, v
 
 
 class StudentOracle:
@@ -117,8 +125,8 @@ class StudentOracle:
         # Adam slots; never reset by restore (SemanticNetwork.py:25, :154-156)
         self.adam_m = {v.name: torch.zeros(v.shape, dtype=dtype) for v in self.spec.trainable}
         self.adam_v = {v.name: torch.zeros(v.shape, dtype=dtype) for v in self.spec.trainable}
-        self.beta1_power = 0.9
-        self.beta2_power = 0.999
+        self.beta1_power = ADAM_B1
+        self.beta2_power = ADAM_B2
         self.last_batch_stats: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     # ------------------------------------------------------------------ variables
@@ -264,17 +272,16 @@ class StudentOracle:
             mu, var_unbiased = self.last_batch_stats[l.scope]
             for name, stat in ((l.scope + "/BatchNorm/moving_mean:0", mu), (l.scope + "/BatchNorm/moving_variance:0", var_unbiased)):
                 self.vars[name] = ema_update(self.vars[name], stat)
-        b1, b2 = 0.9, 0.999
         for v in self.spec.trainable:
             g = grads[v.name].to(self.dtype)
             new, self.adam_m[v.name], self.adam_v[v.name] = adam_update(self.vars[v.name], g, self.adam_m[v.name], self.adam_v[v.name],
-                                                                        lr, self.beta1_power, self.beta2_power, b1, b2)
+                                                                        lr, self.beta1_power, self.beta2_power)
             if mask is not None:
                 keep = torch.as_tensor(np.asarray(mask[v.name]).astype(bool))
                 new = torch.where(keep, new, self.vars[v.name])
             self.vars[v.name] = new.detach()
-        self.beta1_power *= b1
-        self.beta2_power *= b2
+        self.beta1_power *= ADAM_B1
+        self.beta2_power *= ADAM_B2
         return loss
 
 

@@ -190,11 +190,17 @@ def main():
                                "nonzero": [[0, 0, 1], [0, 1, 1], [5, 5, 1], [5, 0, 1]]}}
 
     # ---- 10. Adam, TF1 form -------------------------------------------------------------------------------------------
-    def adam(w, g, m, vv, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    # hyper-parameters are f32 tensors in the graph; ApplyAdam (core/kernels/training_ops.cc) forms (1 - beta) in T = float:
+    #   alpha = lr*sqrt(1-b2^t)/(1-b1^t);  m += (g-m)*(1-b1);  v += (g*g-v)*(1-b2);  var -= (m*alpha)/(sqrt(v)+eps)
+    b1, b2, eps = f32(0.9), f32(0.999), f32(1e-8)
+    omb1, omb2 = f32(1.0 - b1), f32(1.0 - b2)
+    assert abs(omb2 - 0.00099998713) < 1e-11           # hand: f32(0.999) = 0.99900001287..., so 1 - beta2 is NOT 0.001
+
+    def adam(w, g, m, vv, t, lr):
         lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
-        m2 = b1 * m + (1 - b1) * g
-        v2 = b2 * vv + (1 - b2) * g * g
-        return w - lr_t * m2 / (math.sqrt(v2) + eps), m2, v2, lr_t
+        m2 = m + (g - m) * omb1
+        v2 = vv + (g * g - vv) * omb2
+        return w - (m2 * lr_t) / (math.sqrt(v2) + eps), m2, v2, lr_t
 
     cases = []
     for (w, g, m, vv, t, lr) in [(1.0, 0.5, 0.0, 0.0, 1, 1e-3), (1.0, 1e-8, 0.0, 0.0, 1, 1e-3), (-0.25, -0.125, 0.02, 3e-4, 2, 1e-3),
@@ -202,10 +208,10 @@ def main():
         w2, m2, v2, lr_t = adam(w, g, m, vv, t, lr)
         cases.append({"w": w, "g": g, "m": m, "v": vv, "t": t, "lr": lr, "lr_t": lr_t, "w_after": w2, "m_after": m2, "v_after": v2})
     # hand: first step with a sizeable gradient moves by ~lr (m/sqrt(v) = 0.05/0.0158114 = 3.1623, lr_t = lr*0.31623)
-    assert abs((1.0 - cases[0]["w_after"]) - 1e-3) < 1e-9
+    assert abs((1.0 - cases[0]["w_after"]) - 1e-3) < 1e-8
     # hand: with g = 1e-8 eps dominates the denominator: step = lr_t * 1e-9 / (3.1623e-10 + 1e-8) = lr_t * 0.096935
-    assert abs((1.0 - cases[1]["w_after"]) / cases[1]["lr_t"] - 0.0969346) < 1e-6
-    v["adam_tf1"] = {"rule": "C.10", "beta1": 0.9, "beta2": 0.999, "eps": 1e-8, "cases": cases,
+    assert abs((1.0 - cases[1]["w_after"]) / cases[1]["lr_t"] - 0.0969346) < 2e-6
+    v["adam_tf1"] = {"rule": "C.10", "beta1": b1, "beta2": b2, "eps": eps, "one_minus_beta1": omb1, "one_minus_beta2": omb2, "cases": cases,
                      "note": "case 2 separates eps OUTSIDE the square root (step 0.0969*lr_t) from eps inside it (1e-5*lr_t)"}
 
     # ---- 4b. activations ---------------------------------------------------------------------------------------------

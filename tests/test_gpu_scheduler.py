@@ -82,7 +82,7 @@ from sched_cases import _results, case_asr_atr_control_loop, case_other_schedule
 def test_scheduler_matches_the_oracle_backed_run(tmp_path, golden_dir):
     """the same command line, once on the CPU oracle behind the SemanticNetwork boundary (committed fixture,
     tests/golden/make_scheduler_fixture.py) and once on the HIP path.  Control flow must be identical (event times, samples per
-    upload, file set, frame count); per-frame outputs agree within the f32 error class of two 4-iteration fine-tune phases."""
+    upload, file set, frame count); per-frame outputs agree within the f32 error class of two 1-iteration fine-tune phases."""
     import json
     fx = json.loads((golden_dir / "scheduler_oracle_run.json").read_text())
     out = str(tmp_path / "out") + "/"
@@ -106,8 +106,10 @@ def test_scheduler_matches_the_oracle_backed_run(tmp_path, golden_dir):
     print("scheduler vs oracle run: max loss deviation %.4f (first model %.2e), max mIoU deviation %.4f, confusion L1 %.4f"
           % (dev.max(), dev[:n0].max(), np.abs(mious - want_mious).max(), np.abs(cats - want_cats).sum() / want_cats.sum()))
     assert cats.shape == want_cats.shape and np.array_equal(cats.sum(axis=(1, 2)), want_cats.sum(axis=(1, 2)))    # same valid pixels per frame
-    assert dev.max() < 0.1 and np.abs(mious - want_mious).max() < 0.03
-    assert loss[-8:].mean() < 0.5 * loss[:8].mean()                     # the published models are picked up and help
+    # one Adam iteration per training event: with more, two f32 evaluations of this graph drift apart chaotically (the f32 and f64
+    # CPU oracles differ by up to 60 % in per-frame loss after two 4-iteration phases, by 1.4 % after two 1-iteration phases)
+    assert dev.max() < 0.05 and np.abs(mious - want_mious).max() < 0.01
+    assert loss[-8:].mean() < 0.75 * loss[:8].mean()                    # the published models are picked up and help
 
 
 def test_asr_atr_control_loop(tmp_path):

@@ -7,10 +7,13 @@
 // A block owns a TH x TW tile of OUTPUT pixels and walks all channel chunks (16*NT expanded channels each) of it:
 //   phase 1  exact-f32 MFMA GEMM over the tile's input pixels incl. the 3x3 halo, BN + ReLU6, into LDS (k_expand_dw.hip's phase 1:
 //            operands gathered once per tile, zeros outside the image = the depthwise conv's SAME padding);
-//   phase 2  depthwise 3x3 from LDS, BN + ReLU6 — organised per WAVE and 16-pixel row group: the 16 x 16*NT slab of `d` goes
-//            to a per-wave LDS slab (wave-local hand-over, no block barrier);
-//   phase 3  the same wave multiplies its slab with the chunk's rows of the project weights (exact-f32 MFMA, roles swapped:
-//            a lane owns 4 consecutive output channels of one pixel) into accumulators that live across the chunks.
+//   phase 2  depthwise 3x3 from LDS, BN + ReLU6 — per WAVE and 16-pixel output row group, lane (pixel l15, k-group q) forming the
+//            four channels 16kc + 4q .. +3 of its pixel: exactly the lane's operand of
+//   phase 3  the project MFMAs (exact f32, roles swapped: a lane owns 4 consecutive output channels of one pixel), whose
+//            accumulators live across the chunks: `d` never leaves the registers.
+// The weights of a chunk are MFMA operand A and live in registers as well (KC*4*NT + NT*4*NTO floats per lane, requested one
+// chunk ahead straight from L2); LDS holds the expanded tile of one chunk and the per-channel vectors of all chunks, staged once:
+// two barriers per chunk, 40-60 KB per block.
 // After the last chunk: BN of the project layer, residual (= the block input at the output pixel), float4 stores.
 // Products, k order and tap order are those of the kernels it replaces (pw_gemm_f32_s walks k in 16-wide chunks, 4 MFMA steps
 // each, k = 16c + 4q + j; so does phase 3 across the channel chunks): the result is bit-identical to the layer-by-layer plan.
@@ -42,21 +45,14 @@ __global__ __launch_bounds__(256) void block_kernel(BlkArgs a, unsigned nblocks)
     constexpr int NPIX = IH * IW;
     constexpr int NRG = (NPIX + 15) / 16;             // 16-pixel row groups of the input tile
     constexpr int MRG = (NRG + 3) / 4;                // input row groups per wave
-    constexpr int WP = CC + 4, AP = CC + 4, DP = CC + 4;
-    constexpr int NO = 16 * NTO, PP = NO + 4;         // project column tile (>= Cout) and the pitch of its weight rows
+    constexpr int AP = CC + 4;
     constexpr int ORG = TH * TW / 16;                 // output row groups of the tile
     static_assert(TH * TW % 64 == 0, "every wave takes the same number of output row groups");
     constexpr int MRO = ORG / 4;
-    constexpr int Kpad = KC * 16;
-    constexpr int CG = CC / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sW = smem;                                 // [Kpad][WP]      expand weights of the chunk
-    float* sAff = sW + Kpad * WP;                     // sc_e, sh_e, sc_d, sh_d : 4 x CC
-    float* sDw = sAff + 4 * CC;                       // [9][CC]
-    float* sWp = sDw + 9 * CC;                        // [CC][PP]        project weights: rows of the chunk
-    float* sAffP = sWp + CC * PP;                     // sc_p, sh_p : 2 x NO (whole kernel)
-    float* sAct = sAffP + 2 * NO;                     // [NRG*16][AP]    expanded tile incl. halo
-    float* sSlab = sAct + NRG * 16 * AP;              // [4 waves][16][DP]
+    // per-channel vectors of ALL chunks, staged once: sc_e | sh_e | sc_d | sh_d | depthwise taps [9][Cexp]
+    float* sVec = smem;                               // [13][Cexp]
+    float* sAct = smem + 13 * a.Cexp;                 // [NRG*16][AP]    expanded tile incl. halo, one chunk at a time
 
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     unsigned t1 = lb;
@@ -86,78 +82,55 @@ __global__ __launch_bounds__(256) void block_kernel(BlkArgs a, unsigned nblocks)
             areg[i][c] = ld4(px + koff);
         }
     }
-    if (tid < NO) {
-        sAffP[tid] = tid < a.Cout ? a.sc_p[tid] : 1.f;
-        sAffP[NO + tid] = tid < a.Cout ? a.sh_p[tid] : 0.f;
+    // ---- the weights of a chunk live in REGISTERS: with the roles swapped (weights = MFMA operand A) a lane only ever needs
+    // w[k = 16c + 4q + j][n = 16t + l15], i.e. KC*4*NT expand and NT*4*NTO project values per chunk.  No LDS staging, no barrier
+    // for it; the next chunk's values are requested as soon as the current ones have been consumed.
+    float wa[KC][4][NT];
+    float wp[NT][4][NTO];
+    auto load_wa = [&](int n0) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * c + 4 * q + j;
+                const int kc = k < a.Cin ? k : a.Cin - 1;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float v = a.w_exp[(int64_t)kc * a.Cexp + n0 + 16 * t + l15];
+                    wa[c][j][t] = k < a.Cin ? v : 0.f;
+                }
+            }
+    };
+    auto load_wp = [&](int n0) {
+#pragma unroll
+        for (int kc = 0; kc < NT; ++kc)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NTO; ++t) {
+                    const int n = 16 * t + l15;
+                    const int nc = n < a.Cout ? n : a.Cout - 1;
+                    const float v = a.w_pj[(int64_t)(n0 + 16 * kc + 4 * q + j) * a.Cout + nc];
+                    wp[kc][j][t] = n < a.Cout ? v : 0.f;
+                }
+    };
+    load_wa(0);
+    load_wp(0);
+    for (int e = tid; e < 13 * a.Cexp; e += 256) {
+        const int which = e / a.Cexp, c = e - which * a.Cexp;
+        sVec[e] = which == 0 ? a.sc_e[c] : which == 1 ? a.sh_e[c] : which == 2 ? a.sc_d[c] : which == 3 ? a.sh_d[c] : a.w_dw[(which - 4) * a.Cexp + c];
     }
-
-    // ---- chunk parameters: global -> registers -> LDS, those of chunk ci + 1 requested before the phases of chunk ci
-    constexpr int NWV = (Kpad * (CC / 4) + 255) / 256, NDW = (9 * CC + 255) / 256, NWPJ = (CC * (NO / 4) + 255) / 256;
-    float4 wpre[NWV];
-    float dpre[NDW];
-    float apre[4];
-    float4 ppre[NWPJ];
-    auto fetch_params = [&](int n0) {
-#pragma unroll
-        for (int u = 0; u < NWV; ++u) {
-            int e = tid + 256 * u;
-            if (e > Kpad * (CC / 4) - 1) e = Kpad * (CC / 4) - 1;
-            const int kk = e / (CC / 4), c4 = (e - kk * (CC / 4)) * 4;
-            const int kc = kk < a.Cin ? kk : a.Cin - 1;
-            const float4 v = ld4(a.w_exp + (int64_t)kc * a.Cexp + n0 + c4);
-            wpre[u] = kk < a.Cin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < NDW; ++u) {
-            int e = tid + 256 * u;
-            if (e > 9 * CC - 1) e = 9 * CC - 1;
-            dpre[u] = a.w_dw[(e / CC) * a.Cexp + n0 + (e % CC)];
-        }
-        const int ec = tid < CC ? tid : CC - 1;
-        apre[0] = a.sc_e[n0 + ec]; apre[1] = a.sh_e[n0 + ec]; apre[2] = a.sc_d[n0 + ec]; apre[3] = a.sh_d[n0 + ec];
-#pragma unroll
-        for (int u = 0; u < NWPJ; ++u) {
-            int e = tid + 256 * u;
-            if (e > CC * (NO / 4) - 1) e = CC * (NO / 4) - 1;
-            const int kk = e / (NO / 4), c4 = (e - kk * (NO / 4)) * 4;
-            const int cc = c4 < a.Cout ? c4 : a.Cout - 4;
-            const float4 v = ld4(a.w_pj + (int64_t)(n0 + kk) * a.Cout + cc);
-            ppre[u] = c4 < a.Cout ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_params = [&]() {
-#pragma unroll
-        for (int u = 0; u < NWV; ++u) {
-            const int e = tid + 256 * u;
-            if (e < Kpad * (CC / 4)) { const int kk = e / (CC / 4), c4 = (e - kk * (CC / 4)) * 4; st4(sW + kk * WP + c4, wpre[u]); }
-        }
-#pragma unroll
-        for (int u = 0; u < NDW; ++u) {
-            const int e = tid + 256 * u;
-            if (e < 9 * CC) sDw[e] = dpre[u];
-        }
-        if (tid < CC) { sAff[tid] = apre[0]; sAff[CC + tid] = apre[1]; sAff[2 * CC + tid] = apre[2]; sAff[3 * CC + tid] = apre[3]; }
-#pragma unroll
-        for (int u = 0; u < NWPJ; ++u) {
-            const int e = tid + 256 * u;
-            if (e < CC * (NO / 4)) { const int kk = e / (NO / 4), c4 = (e - kk * (NO / 4)) * 4; st4(sWp + kk * PP + c4, ppre[u]); }
-        }
-    };
 
     f32x4 out[MRO][NTO];
 #pragma unroll
     for (int i = 0; i < MRO; ++i)
 #pragma unroll
         for (int t = 0; t < NTO; ++t) out[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float* slab = sSlab + wave * (16 * DP);
 
-    fetch_params(0);
     for (int ci = 0; ci < a.chunks; ++ci) {
         const int n0 = ci * CC;
-        if (ci > 0) __syncthreads();                   // the previous chunk's phases still read the parameters and sAct
-        store_params();
-        __syncthreads();
-        if (ci + 1 < a.chunks) fetch_params(n0 + CC);  // block-uniform
+        const int n_next = ci + 1 < a.chunks ? n0 + CC : n0;       // the last chunk re-requests itself: no branch around the loads
+        __syncthreads();                               // sVec staged (first pass) / the previous chunk's phase 2 is done with sAct
 
         // ---- phase 1: expand GEMM over the input tile (halo included), BN + ReLU6, into LDS
 #pragma unroll
@@ -170,13 +143,12 @@ __global__ __launch_bounds__(256) void block_kernel(BlkArgs a, unsigned nblocks)
 #pragma unroll
                 for (int c = 0; c < KC; ++c) {
                     const bool ok = c * 16 + 4 * q < a.Cin;
-                    const float* sB = sW + (c * 16 + 4 * q) * WP + l15;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float xv = j == 0 ? areg[i][c].x : j == 1 ? areg[i][c].y : j == 2 ? areg[i][c].z : areg[i][c].w;
                         xv = ok ? xv : 0.f;
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[j * WP + 16 * t], xv, acc[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j][t], xv, acc[t], 0, 0, 0);
                     }
                 }
                 const int m = rg * 16 + l15;
@@ -186,7 +158,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlkArgs a, unsigned nblocks)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int c4 = 16 * t + 4 * q;
-                    const float4 sc = ld4(sAff + c4), sh = ld4(sAff + CC + c4);
+                    const float4 sc = ld4(sVec + n0 + c4), sh = ld4(sVec + a.Cexp + n0 + c4);
                     float4 v;
                     v.x = inside ? apply_act(acc[t][0] * sc.x + sh.x, a.act_e) : 0.f;
                     v.y = inside ? apply_act(acc[t][1] * sc.y + sh.y, a.act_e) : 0.f;
@@ -196,56 +168,40 @@ __global__ __launch_bounds__(256) void block_kernel(BlkArgs a, unsigned nblocks)
                 }
             }
         }
+        load_wa(n_next);                               // in flight across the depthwise / project phases
         __syncthreads();
 
-        // ---- phases 2 + 3, per wave and output row group
+        // ---- phases 2 + 3 per wave and 16-pixel output row group: lane (l15, q) forms the depthwise result of pixel l15 for the
+        // channels 16kc + 4q .. +3 — exactly its operand of the project MFMAs (k = 16kc + 4q + j), so `d` stays in registers
 #pragma unroll
         for (int i = 0; i < MRO; ++i) {
-            const int rg_o = wave + 4 * i;
-            constexpr int ITEMS = 16 * CG;
-#pragma unroll
-            for (int u = 0; u < (ITEMS + 63) / 64; ++u) {
-                const int item = lane + 64 * u;
-                if (item < ITEMS) {
-                    const int cg = item % CG, p = item / CG;
-                    const int P = rg_o * 16 + p;
-                    const int ly = P / TW, lx = P - ly * TW;
-                    const int c4 = cg * 4;
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int ii = 0; ii < 3; ++ii)
-#pragma unroll
-                        for (int jj = 0; jj < 3; ++jj) {
-                            const float4 v = ld4(sAct + ((ly * S + ii) * IW + lx * S + jj) * AP + c4);
-                            const float4 w4 = ld4(sDw + (ii * 3 + jj) * CC + c4);
-                            acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
-                            acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
-                        }
-                    const float4 sc = ld4(sAff + 2 * CC + c4), sh = ld4(sAff + 3 * CC + c4);
-                    float4 o;
-                    o.x = apply_act(acc.x * sc.x + sh.x, a.act_d); o.y = apply_act(acc.y * sc.y + sh.y, a.act_d);
-                    o.z = apply_act(acc.z * sc.z + sh.z, a.act_d); o.w = apply_act(acc.w * sc.w + sh.w, a.act_d);
-                    st4(slab + p * DP + c4, o);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int P = (wave + 4 * i) * 16 + l15;
+            const int ly = P / TW, lx = P - ly * TW;
+            const float* tap0 = sAct + ((ly * S) * IW + lx * S) * AP + 4 * q;
 #pragma unroll
             for (int kc = 0; kc < NT; ++kc) {
-                const float4 dv = ld4(slab + l15 * DP + kc * 16 + 4 * q);
-                const float* sB = sWp + (kc * 16 + 4 * q) * PP + l15;
+                const float* wv = sVec + 4 * a.Cexp + n0 + 16 * kc + 4 * q;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xv = j == 0 ? dv.x : j == 1 ? dv.y : j == 2 ? dv.z : dv.w;
+                for (int ii = 0; ii < 3; ++ii)
 #pragma unroll
-                    for (int t = 0; t < NTO; ++t) out[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[j * PP + 16 * t], xv, out[i][t], 0, 0, 0);
-                }
+                    for (int jj = 0; jj < 3; ++jj) {
+                        const float4 v = ld4(tap0 + (ii * IW + jj) * AP + 16 * kc);
+                        const float4 w4 = ld4(wv + (ii * 3 + jj) * a.Cexp);
+                        acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
+                        acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
+                    }
+                const float4 sc = ld4(sVec + 2 * a.Cexp + n0 + 16 * kc + 4 * q), sh = ld4(sVec + 3 * a.Cexp + n0 + 16 * kc + 4 * q);
+                float dv[4];
+                dv[0] = apply_act(acc.x * sc.x + sh.x, a.act_d); dv[1] = apply_act(acc.y * sc.y + sh.y, a.act_d);
+                dv[2] = apply_act(acc.z * sc.z + sh.z, a.act_d); dv[3] = apply_act(acc.w * sc.w + sh.w, a.act_d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t) out[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[kc][j][t], dv[j], out[i][t], 0, 0, 0);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+        load_wp(n_next);                               // in flight across the next chunk's expand phase
     }
 
     // ---- project epilogue: BN, residual = block input at the output pixel (stride 1, Cin == Cout), 16-byte stores
@@ -260,7 +216,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlkArgs a, unsigned nblocks)
         for (int t = 0; t < NTO; ++t) {
             const int c4 = 16 * t + 4 * q;
             if (c4 >= a.Cout) continue;
-            const float4 sc = ld4(sAffP + c4), sh = ld4(sAffP + NO + c4);
+            const float4 sc = ld4(a.sc_p + c4), sh = ld4(a.sh_p + c4);
             float4 v;
             v.x = apply_act(out[i][t][0] * sc.x + sh.x, a.act_p); v.y = apply_act(out[i][t][1] * sc.y + sh.y, a.act_p);
             v.z = apply_act(out[i][t][2] * sc.z + sh.z, a.act_p); v.w = apply_act(out[i][t][3] * sc.w + sh.w, a.act_p);
@@ -278,12 +234,10 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
     constexpr int CC = 16 * NT;
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NRG = (IH * IW + 15) / 16;
-    constexpr int Kpad = KC * 16, NO = 16 * NTO;
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = cdiv(a.Ho, TH);
     a.chunks = a.Cexp / CC;
-    const size_t lds = ((size_t)Kpad * (CC + 4) + 4 * CC + 9 * CC + (size_t)CC * (NO + 4) + 2 * NO + (size_t)NRG * 16 * (CC + 4) +
-                        4 * 16 * (CC + 4)) * sizeof(float);
+    const size_t lds = ((size_t)13 * a.Cexp + (size_t)NRG * 16 * (CC + 4)) * sizeof(float);
     AMS_REQUIRE(lds <= 150 * 1024, "block kernel: tile needs %zu bytes of LDS", lds);
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
@@ -302,12 +256,7 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
 
 template <int S, int NT, int TH, int TW, int KC>
 static int launch_blk_o(const BlkArgs& a, hipStream_t st) {
-    switch ((a.Cout + 15) / 16) {
-        case 1: return launch_blk_k<S, NT, TH, TW, KC, 1>(a, st);
-        case 2: return launch_blk_k<S, NT, TH, TW, KC, 2>(a, st);
-        case 3: return launch_blk_k<S, NT, TH, TW, KC, 3>(a, st);
-        default: return launch_blk_k<S, NT, TH, TW, KC, 4>(a, st);
-    }
+    return a.Cout <= 32 ? launch_blk_k<S, NT, TH, TW, KC, 2>(a, st) : launch_blk_k<S, NT, TH, TW, KC, 4>(a, st);
 }
 
 template <int S, int NT, int TH, int TW>
@@ -335,8 +284,15 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
     same_pad(H, 3, stride, 1, &a.Ho, &a.pt);
     same_pad(W, 3, stride, 1, &a.Wo, &a.pl);
     const bool nt2 = Cexp % 32 == 0;
-    if (stride == 1) return nt2 ? launch_blk_t<1, 2, 16, 16>(a, st) : launch_blk_t<1, 3, 8, 16>(a, st);
-    return nt2 ? launch_blk_t<2, 2, 8, 8>(a, st) : launch_blk_t<2, 3, 8, 8>(a, st);
+    // tile of output pixels per block: small enough that three or four blocks (12-16 waves) share a CU's LDS
+    int th = 8, tw = 8;
+    if (const char* e = getenv("AMS_BLK_TILE")) sscanf(e, "%dx%d", &th, &tw);          // tuning knob (tools/bench_block.py)
+#define BLK(S_, NT_, TH_, TW_) if (stride == S_ && nt2 == (NT_ == 2) && th == TH_ && tw == TW_) return launch_blk_t<S_, NT_, TH_, TW_>(a, st);
+    BLK(1, 2, 8, 16) BLK(1, 2, 16, 16) BLK(1, 2, 8, 8) BLK(1, 3, 8, 16) BLK(1, 3, 16, 16) BLK(1, 3, 8, 8)
+    BLK(2, 2, 8, 8) BLK(2, 2, 8, 16) BLK(2, 3, 8, 8) BLK(2, 3, 8, 16)
+#undef BLK
+    set_error("block kernel: no %dx%d tile for stride %d", th, tw, stride);
+    return AMS_E_INVALID;
 }
 
 }  // namespace ams

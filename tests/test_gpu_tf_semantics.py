@@ -29,8 +29,22 @@ def P(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_KEEP = []
+
+
 def dev(a, dtype=torch.float32):
-    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(DEV).contiguous()
+    """device copy that stays alive: a temporary passed as P(dev(x)) would return its block to the caching allocator before the
+    next temporary of the same call is allocated, and the second copy could land on top of the first."""
+    t = torch.as_tensor(np.ascontiguousarray(a)).to(dtype).to(DEV).contiguous()
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
+
+
+def devu8(a):
+    return dev(a, torch.uint8)
 
 
 def stream():
@@ -57,7 +71,7 @@ def test_stem_pad_normalise_conv(lib, V):
     w = np.asarray(c["w_hwio"], np.float32)
     want = np.asarray(c["y"])
     for arr, code in ((frame, hip.DT_U8), (frame.astype(np.float32), hip.DT_F32)):
-        fd = torch.as_tensor(arr).to(DEV)
+        fd = dev(arr, torch.as_tensor(arr).dtype)
         y = torch.full((1,) + want.shape, np.nan, device=DEV)
         hip.check(lib.ams_k_stem_conv(P(fd), code, 1, 3, 3, P(dev(w)), 32, None, None, hip.ACT_NONE, float(np.float32(c["pixel_scale"])), P(y), stream()))
         np.testing.assert_allclose(y.cpu().numpy()[0], want, rtol=0, atol=2e-5)
@@ -75,7 +89,7 @@ def test_upsample_argmax_ce_confusion(lib, V):
     labels = torch.empty((1, 2, 2), dtype=torch.int32, device=DEV)
     conf = torch.empty(K * K, dtype=torch.int64, device=DEV)
     loss = torch.empty(2, dtype=torch.float64, device=DEV)
-    hip.check(lib.ams_k_upsample_argmax(P(dev(logits)), 1, 2, 2, nc, cidx, K, 2, 2, P(torch.as_tensor(teacher).to(DEV)), P(labels), P(conf), P(loss),
+    hip.check(lib.ams_k_upsample_argmax(P(dev(logits)), 1, 2, 2, nc, cidx, K, 2, 2, P(devu8(teacher)), P(labels), P(conf), P(loss),
                                         stream()))
     assert labels.cpu().numpy().reshape(-1).tolist() == h["argmax_in_subset"]      # ties -> first maximum; classes outside the subset never win
     cm = conf.cpu().numpy().reshape(K, K)
@@ -87,8 +101,8 @@ def test_upsample_argmax_ce_confusion(lib, V):
     ids = np.asarray(h["teacher_ids"], np.uint8).reshape(1, 1, -1)
     n = ids.size
     flat = np.zeros((1, 1, n, nc), np.float32)
-    hip.check(lib.ams_k_upsample_argmax(P(dev(flat)), 1, 1, n, nc, cidx, K, 1, n, P(torch.as_tensor(ids).to(DEV)),
-                                        P(torch.empty((1, 1, n), dtype=torch.int32, device=DEV)), P(conf), P(loss), stream()))
+    hip.check(lib.ams_k_upsample_argmax(P(dev(flat)), 1, 1, n, nc, cidx, K, 1, n, P(devu8(ids)),
+                                        P(dev(np.zeros((1, 1, n), np.int32), torch.int32)), P(conf), P(loss), stream()))
     cm = conf.cpu().numpy().reshape(K, K)
     assert loss.cpu().numpy()[1] == sum(h["weight"])
     want_rows = np.zeros(K, np.int64)
@@ -101,7 +115,7 @@ def test_upsample_argmax_ce_confusion(lib, V):
     z[0, 0, 0, ci[:3]] = h["ce_logits"]
     z[0, 0, 0, ci[3:]] = -1e4
     t = torch.tensor([[[ci[h["ce_target"]]]]], dtype=torch.uint8, device=DEV)
-    hip.check(lib.ams_k_upsample_argmax(P(dev(z)), 1, 1, 1, nc, cidx, K, 1, 1, P(t), P(torch.empty((1, 1, 1), dtype=torch.int32, device=DEV)), P(conf),
+    hip.check(lib.ams_k_upsample_argmax(P(dev(z)), 1, 1, 1, nc, cidx, K, 1, 1, P(t), P(dev(np.zeros((1, 1, 1), np.int32), torch.int32)), P(conf),
                                         P(loss), stream()))
     assert loss.cpu().numpy()[0] == pytest.approx(h["ce"], rel=1e-6)
     # (d) resize cases: class 0 carries the image, class 1 a threshold plane; the label map is (image < threshold)
@@ -149,7 +163,7 @@ def test_moving_averages_take_the_unbiased_batch_variance(lib):
     eng.load_variables(W0)
     ho, wo = (H + 2) // 2, (2 * H + 2) // 2
     z = torch.empty((B, ho, wo, 32), device=DEV)
-    hip.check(lib.ams_k_stem_conv(P(torch.as_tensor(frames).to(DEV)), hip.DT_U8, B, H, 2 * H, P(dev(W0["MobilenetV2/Conv/weights:0"])), 32, None, None,
+    hip.check(lib.ams_k_stem_conv(P(devu8(frames)), hip.DT_U8, B, H, 2 * H, P(dev(W0["MobilenetV2/Conv/weights:0"])), 32, None, None,
                                   hip.ACT_NONE, float(np.float32(S.PIXEL_SCALE)), P(z), stream()))
     zz = z.cpu().numpy().astype(np.float64).reshape(-1, 32)
     n = zz.shape[0]

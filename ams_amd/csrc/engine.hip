@@ -61,6 +61,7 @@ struct LayerRt {
     // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
+    float* blk_vecs = nullptr;             // expand layer of a whole-block kernel: [13][cout] table of BN vectors + depthwise taps (freeze)
 };
 
 struct Carver {
@@ -188,6 +189,12 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.wlo = l.whi ? l.whi + plane : nullptr;
             l.wlo3 = l.whi ? l.whi + 2 * plane : nullptr;
         }
+    }
+    for (int i = 2; i + 2 <= s->n_backbone; ++i) {      // whole-block kernels: packed per-channel tables, filled by freeze
+        LayerRt& l = s->L[i];
+        if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[i + 2].d.role == AMS_ROLE_PROJECT &&
+            block_fused_supported(l.d.cin, l.d.cout, s->L[i + 2].d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate, s->L[i + 2].d.residual_from != 0))
+            l.blk_vecs = cv.take<float>((size_t)13 * l.d.cout);
     }
     // BN sync region: loss (2 doubles) then per layer fwd sums [2][C], bwd sums [2][C]
     s->bn_sync_doubles = 2 + 4 * sum_c;
@@ -480,7 +487,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
                                         9.0 * ld.d.cin + (double)lj.d.cin * lj.d.cout);
             RUNK(i + 2, bytes, launch_block_fused(cur, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                   P + ld.d.w_off, ld.d.stride, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale, lj.fshift,
-                                                  lj.d.act, lj.d.cout, res, s->act[o], st));
+                                                  lj.d.act, lj.d.cout, res, s->act[o], st, le.blk_vecs));
             cur = s->act[o]; cur_i = o; i += 3;
             cur_parts = nullptr;
             continue;
@@ -930,6 +937,11 @@ int ams_student_freeze(ams_student* s, void* stream) {
         if (l.d.bn_eps < 0) continue;
         RUN(launch_bn_fold(s->fparams + l.d.gamma_off, s->fparams + l.d.beta_off, s->fstats + l.d.mean_off, s->fstats + l.d.var_off,
                            s->cfg.bn_eps_frozen, l.d.cout, l.fscale, l.fshift, st));
+    }
+    for (int i = 2; i + 1 <= s->n_backbone; ++i) {
+        LayerRt& l = s->L[i];
+        LayerRt& ld = s->L[i + 1];
+        if (l.blk_vecs) RUN(launch_block_pack(l.fscale, l.fshift, ld.fscale, ld.fshift, s->fparams + ld.d.w_off, l.d.cout, l.blk_vecs, st));
     }
     for (int i = 2; i <= s->cfg.n_layers; ++i) {
         LayerRt& l = s->L[i];

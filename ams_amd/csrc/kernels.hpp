@@ -95,7 +95,9 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
 bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bool residual);
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
                        const float* w_dw, int stride, const float* sc_d, const float* sh_d, int act_d, const float* w_pj, const float* sc_p,
-                       const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st);
+                       const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs = nullptr);
+// vecs: optional [13][Cexp] table (sc_e | sh_e | sc_d | sh_d | w_dw[9]) built once by launch_block_pack (the engine: at freeze)
+int launch_block_pack(const float* sc_e, const float* sh_e, const float* sc_d, const float* sh_d, const float* w_dw, int Cexp, float* out, hipStream_t st);
 
 // ---- k_xdw_stream.hip : the same fusion for the stride-16 blocks (Cin 64 / 96 / 160, stride 1, rate 1 | 2): raster-order
 // streaming through an LDS ring, split-bf16 products from the expand layer's bf16 panels (np = 2 | 3 parts, `plane` apart)

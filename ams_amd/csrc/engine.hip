@@ -126,7 +126,10 @@ struct ams_student {
     int fuse_dw_project = 0;                   // frozen inference: depthwise + project in one kernel on the stride-16 blocks.
                                                // Off by default: measured equal to the two kernels at B = 8 (LDS-read bound:
                                                // 60 b128 reads per wave and 32 channels) and slower at B = 1 (45 blocks)
-    int fuse_first_block = 1;                  // frozen inference: stem + depthwise + project of the first block in one kernel
+    int fuse_first_block = 1;                  // frozen inference: stem + depthwise + project of the first block in one kernel:
+                                               // 0 three kernels, 1 tile per block (k_first_block.hip), 2 tile per wave (k_block.hip:
+                                               // same bits, measured slower here: 488 vs 428 us at 32 frames — the 27-tap byte gather
+                                               // per wave outweighs the barriers it saves)
     int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
                                                // in one streaming kernel (k_xdw_stream.hip): 0 never, 1 where measured
                                                // faster (Cin 64 / 96, >= 16384 rows), 2 also the 160-channel blocks
@@ -190,6 +193,7 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.wlo3 = l.whi ? l.whi + 2 * plane : nullptr;
         }
     }
+    if (s->n_backbone >= 3 && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE) s->L[1].blk_vecs = cv.take<float>(13 * 32);
     for (int i = 2; i + 2 <= s->n_backbone; ++i) {      // whole-block kernels: packed per-channel tables, filled by freeze
         LayerRt& l = s->L[i];
         if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[i + 2].d.role == AMS_ROLE_PROJECT &&
@@ -443,9 +447,14 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             !lj.d.residual_from) {
             // stem + depthwise + project of the first block in one kernel: the 32-channel half-resolution tensor stays in LDS
             const double bytes = in_bytes + 4.0 * B * lj.px_out * lj.d.cout + 4.0 * (27 * 32 + 9 * 32 + 32 * 16);
-            RUNK(3, bytes, launch_first_block(frames, dtype, B, c.height, c.width, c.pixel_scale, P + l.d.w_off, l.fscale, l.fshift,
-                                              l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
-                                              lj.fshift, lj.d.act, cur, st));
+            if (s->fuse_first_block >= 2)
+                RUNK(3, bytes, launch_first_block_tiles(frames, dtype, B, c.height, c.width, c.pixel_scale, P + l.d.w_off, l.fscale, l.fshift,
+                                                        l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
+                                                        lj.fshift, lj.d.act, cur, st, l.blk_vecs));
+            else
+                RUNK(3, bytes, launch_first_block(frames, dtype, B, c.height, c.width, c.pixel_scale, P + l.d.w_off, l.fscale, l.fshift,
+                                                  l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
+                                                  lj.fshift, lj.d.act, cur, st));
             i = 4;
         } else {
             const double bytes = in_bytes + 4.0 * B * l.px_out * l.d.cout;
@@ -938,7 +947,7 @@ int ams_student_freeze(ams_student* s, void* stream) {
         RUN(launch_bn_fold(s->fparams + l.d.gamma_off, s->fparams + l.d.beta_off, s->fstats + l.d.mean_off, s->fstats + l.d.var_off,
                            s->cfg.bn_eps_frozen, l.d.cout, l.fscale, l.fshift, st));
     }
-    for (int i = 2; i + 1 <= s->n_backbone; ++i) {
+    for (int i = 1; i + 1 <= s->n_backbone; ++i) {
         LayerRt& l = s->L[i];
         LayerRt& ld = s->L[i + 1];
         if (l.blk_vecs) RUN(launch_block_pack(l.fscale, l.fshift, ld.fscale, ld.fshift, s->fparams + ld.d.w_off, l.d.cout, l.blk_vecs, st));
@@ -1055,7 +1064,7 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_FIRST_BLOCK) {
-        s->fuse_first_block = value != 0;
+        s->fuse_first_block = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_DW_PROJECT) {

@@ -20,6 +20,8 @@
 // After the last chunk: BN of the project layer, residual (= the block input at the output pixel), float4 stores.
 // Products, k order and tap order are those of the kernels it replaces (pw_gemm_f32_s walks k in 16-wide chunks, 4 MFMA steps
 // each, k = 16c + 4q + j; so does phase 3 across the channel chunks): the result is bit-identical to the layer-by-layer plan.
+#include <type_traits>
+
 #include "pw_common.hpp"
 
 namespace ams {
@@ -40,10 +42,29 @@ struct BlkArgs {
     int Ho, Wo, pt, pl;
     int tiles_x, tiles_y, chunks;
     const float* vecs;       // optional: sc_e | sh_e | sc_d | sh_d | w_dw[9] already packed as [13][Cexp] (the engine packs at freeze)
+    // STEM form (first block of the network): x = the frames [B, fH, fW, 3] (uint8 or float); the "expand" layer is the stem conv
+    // (pad 127.5, x * ps - 1, dense 3x3 stride 2: K = 27 taps gathered per position), H x W = the stem's output grid
+    int fH, fW, spt, spl;
+    float ps;
 };
 
-template <int S, int KC, int NTO, int TH, int TW>
+// value of the normalised, 127.5-padded frame at (iy, ix, ch) in padded coordinates; outside of it the stem's SAME zero padding
+template <typename TIn>
+__device__ __forceinline__ float blk_frame_value(const TIn* img, int H, int W, int iy, int ix, int ch, float ps) {
+    const bool inside = iy >= 0 && ix >= 0 && iy <= H && ix <= W;
+    const bool pad = iy >= H || ix >= W;
+    const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    const int ixc = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+    float raw = (float)img[((int64_t)iyc * W + ixc) * 3 + ch];
+    raw = pad ? 127.5f : raw;
+    const float v = __fsub_rn(__fmul_rn(raw, ps), 1.0f);
+    return inside ? v : 0.f;
+}
+
+// TIn = void: the block input is an f32 activation tensor; uint8_t / float: STEM form, the input is the frame batch
+template <int S, int KC, int NTO, int TH, int TW, typename TIn = void>
 __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntiles) {
+    constexpr bool STEM = !std::is_void<TIn>::value;
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NPIX = IH * IW;
     constexpr int NRG = (NPIX + 15) / 16;             // 16-pixel row groups of the wave's input tile (halo included)
@@ -77,14 +98,61 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - a.pt, ix0 = ox0 * S - a.pl;
 
-    // ---- the wave's input fragments, requested up front and kept for all chunks (clamped addresses, branch-free)
     // BN + activation = one fma and one v_med3_f32 per value: clamp to [lo, hi] with wave-uniform bounds; an input-tile position
     // outside the image gets hi = lo = 0 (the depthwise conv's SAME padding) instead of four selects
     const float lo_e = a.act_e == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_e = a.act_e == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     const float lo_d = a.act_d == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_d = a.act_d == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
-    const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
+    // ---- the wave's input fragments, requested up front and kept for all chunks (clamped addresses, branch-free)
+    const float* xb = STEM ? nullptr : a.x + (int64_t)b * a.H * a.W * a.Cin;
     float4 areg[NRG][KC];
     unsigned inside_mask = 0;
+    if constexpr (STEM) {
+        // this lane's taps: k = 16c + 4q + j -> (dy, dx, channel) of the 3x3x3 receptive field, k >= 27 padding (value 0)
+        typedef typename std::conditional<STEM, TIn, float>::type TI;
+        const TI* img = reinterpret_cast<const TI*>(a.x) + (int64_t)b * a.fH * a.fW * 3;
+        int toff[KC][4], tdy[KC][4], tdx[KC][4], tch[KC][4];
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * c + 4 * q + j, tap = k / 3;
+                tch[c][j] = k < 27 ? k - tap * 3 : -1;
+                tdy[c][j] = tap / 3;
+                tdx[c][j] = tap - tdy[c][j] * 3;
+                toff[c][j] = k < 27 ? (tdy[c][j] * a.fW + tdx[c][j]) * 3 + tch[c][j] : 0;
+            }
+        // interior tiles: every stem position of the halo tile exists and every tap lies inside the frame (wave-uniform)
+        const bool interior = iy0 >= 0 && iy0 + IH <= a.H && ix0 >= 0 && ix0 + IW <= a.W && iy0 * 2 - a.spt >= 0 &&
+                              (iy0 + IH - 1) * 2 - a.spt + 2 <= a.fH - 1 && ix0 * 2 - a.spl >= 0 && (ix0 + IW - 1) * 2 - a.spl + 2 <= a.fW - 1;
+#pragma unroll
+        for (int rg = 0; rg < NRG; ++rg) {
+            int m = rg * 16 + l15;
+            const bool in_tile = m < NPIX;
+            if (m > NPIX - 1) m = NPIX - 1;
+            const int ty_i = m / IW, tx_i = m - ty_i * IW;
+            const int sy = iy0 + ty_i, sx = ix0 + tx_i;                  // position in the stem's output grid
+            if (in_tile && sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) inside_mask |= 1u << rg;
+            const int fy = sy * 2 - a.spt, fx = sx * 2 - a.spl;
+            float t[KC][4];
+            if (interior) {
+                const TI* p0 = img + ((int64_t)fy * a.fW + fx) * 3;
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[c][j] = __fsub_rn(__fmul_rn((float)p0[toff[c][j]], a.ps), 1.0f);
+            } else {
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        t[c][j] = blk_frame_value(img, a.fH, a.fW, fy + tdy[c][j], fx + tdx[c][j], tch[c][j] < 0 ? 0 : tch[c][j], a.ps);
+            }
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                areg[rg][c] = make_float4(tch[c][0] >= 0 ? t[c][0] : 0.f, tch[c][1] >= 0 ? t[c][1] : 0.f, tch[c][2] >= 0 ? t[c][2] : 0.f,
+                                          tch[c][3] >= 0 ? t[c][3] : 0.f);
+        }
+    } else {
 #pragma unroll
     for (int rg = 0; rg < NRG; ++rg) {
         const int m = rg * 16 + l15;
@@ -101,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
             const float4 v = ld4(px + koff);
             areg[rg][c] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
+    }
     }
     // ---- chunk weights in registers (weights = MFMA operand A: a lane needs w[k = 16c + 4q + j][n = l15] only): pointers are set
     // up once and bumped per chunk, the next chunk's values are requested as soon as the current ones have been consumed
@@ -230,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
             float4 v;
             v.x = apply_act(out[i][t][0] * sc.x + sh.x, a.act_p); v.y = apply_act(out[i][t][1] * sc.y + sh.y, a.act_p);
             v.z = apply_act(out[i][t][2] * sc.z + sh.z, a.act_p); v.w = apply_act(out[i][t][3] * sc.w + sh.w, a.act_p);
-            if (a.residual) {
+            if (!STEM && a.residual) {
                 const float4 r = ld4(xb + ((int64_t)oy * a.W + ox) * a.Cin + c4);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
@@ -239,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     }
 }
 
-template <int S, int KC, int NTO, int TH, int TW>
+template <int S, int KC, int NTO, int TH, int TW, typename TIn = void>
 static int launch_blk_k(BlkArgs a, hipStream_t st) {
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NRG = (IH * IW + 15) / 16;
@@ -251,9 +320,10 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
     const int64_t nblocks = cdiv64(ntiles, 4);
     AMS_REQUIRE(ntiles > 0 && ntiles < 0x7fffffffLL, "block kernel: bad grid");
     static const std::string nm = "block_kernel<" + std::to_string(S) + ", " + std::to_string(KC) + ", " + std::to_string(NTO) + ", " +
-                                  std::to_string(TH) + ", " + std::to_string(TW) + ">";
+                                  std::to_string(TH) + ", " + std::to_string(TW) +
+                                  (std::is_void<TIn>::value ? ", void>" : sizeof(typename std::conditional<std::is_void<TIn>::value, char, TIn>::type) == 1 ? ", unsigned char>" : ", float>");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((block_kernel<S, KC, NTO, TH, TW>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)ntiles);
+    hipLaunchKernelGGL((block_kernel<S, KC, NTO, TH, TW, TIn>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)ntiles);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -307,6 +377,25 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
 #undef BLK
     set_error("block kernel: no %dx%d tile for stride %d", th, tw, stride);
     return AMS_E_INVALID;
+}
+
+// First block of the network in the same form: frames -> pad 127.5 -> x * ps - 1 -> stem 3x3 s2 (3 -> 32) + BN + ReLU6 -> depthwise 3x3 (32)
+// + BN + ReLU6 -> project 1x1 (32 -> 16) + BN.  `vecs` = [13][32] table (stem BN | depthwise BN | depthwise taps) or null.
+int launch_first_block_tiles(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem, const float* sc_s,
+                             const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d, int act_d, const float* w_pj,
+                             const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st, const float* vecs) {
+    AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "first_block: frames must be uint8 or float32");
+    BlkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = reinterpret_cast<const float*>(frames); a.B = B; a.fH = H; a.fW = W; a.ps = pixel_scale; a.Cin = 27;
+    a.w_exp = w_stem; a.sc_e = sc_s; a.sh_e = sh_s; a.act_e = act_s; a.Cexp = 32;
+    a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.w_pj = w_pj; a.sc_p = sc_p; a.sh_p = sh_p; a.act_p = act_p; a.Cout = 16;
+    a.residual = 0; a.y = y; a.vecs = vecs;
+    same_pad(H + 1, 3, 2, 1, &a.H, &a.spt);           // the stem's output grid = the depthwise conv's input grid
+    same_pad(W + 1, 3, 2, 1, &a.W, &a.spl);
+    a.Ho = a.H; a.Wo = a.W; a.pt = 1; a.pl = 1;        // depthwise 3x3, stride 1, SAME
+    if (dtype == AMS_DT_U8) return launch_blk_k<1, 2, 1, 8, 8, uint8_t>(a, st);
+    return launch_blk_k<1, 2, 1, 8, 8, float>(a, st);
 }
 
 }  // namespace ams

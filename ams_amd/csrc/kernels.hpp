@@ -97,6 +97,9 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
                        const float* w_dw, int stride, const float* sc_d, const float* sh_d, int act_d, const float* w_pj, const float* sc_p,
                        const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs = nullptr);
 // vecs: optional [13][Cexp] table (sc_e | sh_e | sc_d | sh_d | w_dw[9]) built once by launch_block_pack (the engine: at freeze)
+int launch_first_block_tiles(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem, const float* sc_s,
+                             const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d, int act_d, const float* w_pj,
+                             const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st, const float* vecs = nullptr);
 int launch_block_pack(const float* sc_e, const float* sh_e, const float* sc_d, const float* sh_d, const float* w_dw, int Cexp, float* out, hipStream_t st);
 
 // ---- k_xdw_stream.hip : the same fusion for the stride-16 blocks (Cin 64 / 96 / 160, stride 1, rate 1 | 2): raster-order

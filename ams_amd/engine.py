@@ -202,9 +202,10 @@ class StudentEngine:
                   "ams_pack_masked_fp16")
         return out[:int(cnt.item())]
 
-    def set_fuse_first_block(self, on: bool) -> None:
-        """Frozen inference: stem + depthwise + project of the first block as one kernel (default on)."""
-        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_FIRST_BLOCK, int(bool(on))), "ams_student_set_option")
+    def set_fuse_first_block(self, on: int) -> None:
+        """Frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel with a tile per block
+        (k_first_block.hip; default), 2 one kernel with a tile per wave (k_block.hip; measured slower).  Same bits in all three."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_FIRST_BLOCK, int(on)), "ams_student_set_option")
 
     def set_fuse_dw_project(self, on: bool) -> None:
         """Frozen inference: depthwise + project of the stride-16 blocks as one kernel (default off: measured no faster than

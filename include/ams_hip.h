@@ -191,8 +191,8 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
 enum { AMS_OPT_FUSE_BLOCK = 6 /* frozen inference: 1 (default) every early inverted-residual block with Cin <= 32 (expand + depthwise +
                                  project [+ block input]) runs as ONE kernel: neither the 6x-expanded tensor nor the depthwise result reaches
                                  HBM; bit-identical to the layer-by-layer plan.  0: the per-layer / pairwise-fused kernels below */,
-       AMS_OPT_FUSE_FIRST_BLOCK = 4 /* frozen inference: 1 (default) stem + depthwise + project of the first block in one
-                                       kernel, 0 three kernels */,
+       AMS_OPT_FUSE_FIRST_BLOCK = 4 /* frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel
+                                       with a tile per block (default), 2 one kernel with a tile per wave (measured slower); same bits */,
        AMS_OPT_FUSE_DW_PROJECT = 3 /* frozen inference: 1 = depthwise + project of the stride-16 blocks in one kernel (needs
                                       AMS_MATMUL_SPLIT_BF16), 0 (default) separate kernels: measured no faster */,
        AMS_OPT_FUSE_EXPAND_DW_STREAM = 5 /* frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks in one

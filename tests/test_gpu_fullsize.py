@@ -153,6 +153,11 @@ def test_bench_batch_fused_equals_unfused(W0):
     assert rel(_lowres(eng, B), low) < 5e-5
     assert (lab1 != lab).float().mean().item() < 1e-4
     eng.set_fuse_block(True)
+    for mode in (2, 0):                                   # first block: tile per wave / three kernels — the same bits as the default
+        eng.set_fuse_first_block(mode)
+        labm = eng.predict(frames)
+        assert torch.equal(labm, lab) and np.array_equal(_lowres(eng, B), low), mode
+    eng.set_fuse_first_block(1)
     eng.predict(frames[5:6])
     assert rel(_lowres(eng, 1)[0], low[5]) < 1e-4
     eng.close()

@@ -423,6 +423,7 @@ static int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st,
     if (!parts) a.ysplit = nullptr;
     if (wrote_parts) *wrote_parts = parts;
     if (split && s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6) RUNK(layer, pw_bytes(a), launch_pointwise_split3(a, l.whi, l.wlo, l.wlo3, l.Kp, st));
+    else if (split && s->matmul_mode == AMS_MATMUL_BF16) RUNK(layer, pw_bytes(a), launch_pointwise_split1(a, l.whi, l.Kp, st));
     else if (split) RUNK(layer, pw_bytes(a), launch_pointwise_split(a, l.whi, l.wlo, l.Kp, st));
     else RUNK(layer, pw_bytes(a), launch_pointwise(a, st));
     return AMS_OK;
@@ -520,7 +521,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             LayerRt& le = s->L[i];
             LayerRt& ld = s->L[i + 1];
             const int o = other(cur_i, -1);
-            const int np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : 2;
+            const int np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : s->matmul_mode == AMS_MATMUL_BF16 ? 1 : 2;
             const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin + ld.px_out * ld.d.cout) + (double)le.d.cin * le.d.cout + 9.0 * ld.d.cin);
             const int64_t xplane = (int64_t)B * le.px_in * le.d.cin;
             if (le.d.cin > 96 && cur_parts)
@@ -584,7 +585,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             if (stream_ok(i + 1) && s->xsplit && (size_t)a.M * a.N <= s->xsplit_plane) {
                 // the next block streams: its expand GEMM takes this result as bf16 parts, written here once instead of being
                 // split by every channel-chunk block there
-                a.ysplit = s->xsplit; a.ysplit_plane = a.M * a.N; a.ysplit_np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : 2;
+                a.ysplit = s->xsplit; a.ysplit_plane = a.M * a.N; a.ysplit_np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : s->matmul_mode == AMS_MATMUL_BF16 ? 1 : 2;
             }
             RUN(frozen_pointwise(s, i, a, st, &wrote));
             cur_parts = wrote ? s->xsplit : nullptr;
@@ -1058,7 +1059,7 @@ int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frame
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     AMS_REQUIRE(s, "set_option: null student");
     if (option == AMS_OPT_MATMUL) {
-        AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16 || value == AMS_MATMUL_SPLIT_BF16_X6,
+        AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16 || value == AMS_MATMUL_SPLIT_BF16_X6 || value == AMS_MATMUL_BF16,
                     "set_option: unknown matmul mode %d", value);
         s->matmul_mode = value;
         return AMS_OK;

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
 #pragma unroll
                 for (int r = 0; r < RM; ++r) {
                     if (NP == 3) split8(abuf[d][r][0], abuf[d][r][1], x0[r], x1[r], x2[r]);
-                    else split8(abuf[d][r][0], abuf[d][r][1], x0[r], x1[r]);
+                    else if (NP == 2) split8(abuf[d][r][0], abuf[d][r][1], x0[r], x1[r]);
+                    else split8(abuf[d][r][0], abuf[d][r][1], x0[r]);
                 }
                 const unsigned short* bw = &sW[d & 1][0][l15 * PITCH + 8 * q];
                 // Per accumulator the six products arrive in a fixed order (smallest terms first), but consecutive MFMAs go to
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
                     for (int g = 0; g < TG; ++g) {
                         if (t0 + g >= NT) continue;
                         q0[g] = *reinterpret_cast<const bf16x8*>(bw + (t0 + g) * 16 * PITCH);
-                        q1[g] = *reinterpret_cast<const bf16x8*>(bw + (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
+                        if (NP >= 2) q1[g] = *reinterpret_cast<const bf16x8*>(bw + (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
                         if (NP == 3) q2[g] = *reinterpret_cast<const bf16x8*>(bw + 2 * (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
                     }
 #define AMS_X3_TERM(QA, XB)                                                                                          \
@@ -184,8 +185,10 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
                         AMS_X3_TERM(q0, x2)
                         AMS_X3_TERM(q1, x1)
                     }
-                    AMS_X3_TERM(q1, x0)
-                    AMS_X3_TERM(q0, x1)
+                    if (NP >= 2) {
+                        AMS_X3_TERM(q1, x0)
+                        AMS_X3_TERM(q0, x1)
+                    }
                     AMS_X3_TERM(q0, x0)
 #undef AMS_X3_TERM
                 }
@@ -218,6 +221,7 @@ template <int RM, int NT, int EPI>
 static int launch_pw_x3_e(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
     // D = 4 is no faster (measured): the stage loop is bound by the LDS hand-over of the weight pieces, not by HBM latency
     if (w.np == 3) return launch_pw_x3_d<RM, NT, EPI, 2, 3>(a, w, Kp, st);
+    if (w.np == 1) return launch_pw_x3_d<RM, NT, EPI, 2, 1>(a, w, Kp, st);
     return launch_pw_x3_d<RM, NT, EPI, 2, 2>(a, w, Kp, st);
 }
 
@@ -259,6 +263,12 @@ bool pointwise_split_writes_parts(const PwArgs& a) { return pw_pick_epi(a) != EP
 // y = epilogue(x @ w) with w given as pre-split bf16 hi/lo panels [N][Kp]; requires K % 8 == 0
 int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t* wlo, int Kp, hipStream_t st) {
     const SplitPanels w = {whi, (int64_t)(wlo - whi), 2};
+    return launch_pointwise_parts(a, w, Kp, st);
+}
+
+// one part: plain bf16 products (AMS_MATMUL_BF16, the opt-in bf16 inference variant): 1 MFMA per 32 k
+int launch_pointwise_split1(const PwArgs& a, const uint16_t* whi, int Kp, hipStream_t st) {
+    const SplitPanels w = {whi, 0, 1};
     return launch_pointwise_parts(a, w, Kp, st);
 }
 

@@ -179,11 +179,12 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                     for (int s = 0; s < KS; ++s) {
                         if constexpr (PRE) {
                             x0 = __builtin_bit_cast(bf16x8, rawp[s][0]);
-                            x1 = __builtin_bit_cast(bf16x8, rawp[s][1]);
+                            if (NP >= 2) x1 = __builtin_bit_cast(bf16x8, rawp[s][NP >= 2 ? 1 : 0]);
                             if (NP == 3) x2 = __builtin_bit_cast(bf16x8, rawp[s][NP - 1]);
                         } else {
                             if (NP == 3) split8(raw[s][0], raw[s][1], x0, x1, x2);
-                            else split8(raw[s][0], raw[s][1], x0, x1);
+                            else if (NP == 2) split8(raw[s][0], raw[s][1], x0, x1);
+                            else split8(raw[s][0], raw[s][1], x0);
                         }
                         load_stage(pn, s);
                         const u32x4* bw = sW + (s * 4 + q) * NC + l15;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
     #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) {
                             q0[tt] = *reinterpret_cast<const bf16x8*>(bw + 16 * tt);
-                            q1[tt] = *reinterpret_cast<const bf16x8*>(bw + KS * 4 * NC + 16 * tt);
+                            if (NP >= 2) q1[tt] = *reinterpret_cast<const bf16x8*>(bw + KS * 4 * NC + 16 * tt);
                             if (NP == 3) q2[tt] = *reinterpret_cast<const bf16x8*>(bw + 2 * KS * 4 * NC + 16 * tt);
                         }
                         if (NP == 3) {                                    // smallest terms first
@@ -202,10 +203,12 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
     #pragma unroll
                             for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x1, acc[tt], 0, 0, 0);
                         }
+                        if (NP >= 2) {
     #pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x0, acc[tt], 0, 0, 0);
+                            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[tt], x0, acc[tt], 0, 0, 0);
     #pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x1, acc[tt], 0, 0, 0);
+                            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x1, acc[tt], 0, 0, 0);
+                        }
     #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x0, acc[tt], 0, 0, 0);
                     }
@@ -478,8 +481,8 @@ static int launch_xds_f32(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
 
 template <int KS>
 static int launch_xds_ks(const XdsArgs& a, const XdsPlan& p, int np, hipStream_t st) {
-    if (p.nt == 4) return np == 3 ? launch_xds_w<KS, 4, 3>(a, p, st) : launch_xds_w<KS, 4, 2>(a, p, st);
-    return np == 3 ? launch_xds_w<KS, 2, 3>(a, p, st) : launch_xds_w<KS, 2, 2>(a, p, st);
+    if (p.nt == 4) return np == 3 ? launch_xds_w<KS, 4, 3>(a, p, st) : np == 1 ? launch_xds_w<KS, 4, 1>(a, p, st) : launch_xds_w<KS, 4, 2>(a, p, st);
+    return np == 3 ? launch_xds_w<KS, 2, 3>(a, p, st) : np == 1 ? launch_xds_w<KS, 2, 1>(a, p, st) : launch_xds_w<KS, 2, 2>(a, p, st);
 }
 
 // w_f32: the expand weights [Cin][Cexp] for the exact-f32 form (Cin <= 32; w_parts / np / x_parts are then unused).
@@ -491,7 +494,7 @@ int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_p
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int stride, int rate, const float* sc_d,
                             const float* sh_d, int act_d, float* y, hipStream_t st) {
     const bool f32 = Cin <= 32;
-    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, stride, rate) && (f32 ? w_f32 != nullptr : (w_parts && (np == 2 || np == 3))),
+    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, stride, rate) && (f32 ? w_f32 != nullptr : (w_parts && np >= 1 && np <= 3)),
                 "expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d", Cin, Cexp, rate);
     if (f32) { np = 0; x_parts = nullptr; }
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_stream: empty input");

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #pragma unroll
                         for (int rg = 0; rg < NRG; ++rg) {
                             x0[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + 0) * KS + s) * 64]);
-                            x1[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + 1) * KS + s) * 64]);
+                            if (NP >= 2) x1[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + (NP >= 2 ? 1 : 0)) * KS + s) * 64]);
                             if (NP == 3) x2[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + NP - 1) * KS + s) * 64]);
                         }
                         // per accumulator the products of pw_gemm_bf16x3_l in its order (smallest terms first); consecutive MFMAs
@@ -171,8 +171,10 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                             AMS_XWR_TERM(0, x2)
                             AMS_XWR_TERM(1, x1)
                         }
-                        AMS_XWR_TERM(1, x0)
-                        AMS_XWR_TERM(0, x1)
+                        if (NP >= 2) {
+                            AMS_XWR_TERM(NP >= 2 ? 1 : 0, x0)
+                            AMS_XWR_TERM(0, x1)
+                        }
                         AMS_XWR_TERM(0, x0)
 #undef AMS_XWR_TERM
                     }
@@ -315,7 +317,7 @@ static int launch_xwr_w(const XwrArgs& a, int nwe, int nrg, size_t lds, hipStrea
 int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane,
                           int np, const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
                           const float* sh_d, int act_d, float* y, hipStream_t st) {
-    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && Cin >= 64 && (np == 2 || np == 3) && x_parts, "expand_dw_wreg: unsupported shape Cin=%d Cexp=%d rate=%d",
+    AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && Cin >= 64 && np >= 1 && np <= 3 && x_parts, "expand_dw_wreg: unsupported shape Cin=%d Cexp=%d rate=%d",
                 Cin, Cexp, rate);
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_wreg: empty input");
     AMS_REQUIRE((int64_t)H * W * Cexp * 4 < 0x7fffffffLL, "expand_dw_wreg: a frame of the output exceeds 2 GiB");
@@ -352,9 +354,9 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     a.groups = (int)groups;
     const size_t lds = xwr_lds(Cin, np, nwe, nrg, ring);
     switch (Cin / 32) {
-        case 2: return np == 3 ? launch_xwr_w<2, 3>(a, nwe, nrg, lds, st) : launch_xwr_w<2, 2>(a, nwe, nrg, lds, st);
-        case 3: return np == 3 ? launch_xwr_w<3, 3>(a, nwe, nrg, lds, st) : launch_xwr_w<3, 2>(a, nwe, nrg, lds, st);
-        default: return np == 3 ? launch_xwr_w<5, 3>(a, nwe, nrg, lds, st) : launch_xwr_w<5, 2>(a, nwe, nrg, lds, st);
+        case 2: return np == 3 ? launch_xwr_w<2, 3>(a, nwe, nrg, lds, st) : np == 1 ? launch_xwr_w<2, 1>(a, nwe, nrg, lds, st) : launch_xwr_w<2, 2>(a, nwe, nrg, lds, st);
+        case 3: return np == 3 ? launch_xwr_w<3, 3>(a, nwe, nrg, lds, st) : np == 1 ? launch_xwr_w<3, 1>(a, nwe, nrg, lds, st) : launch_xwr_w<3, 2>(a, nwe, nrg, lds, st);
+        default: return np == 3 ? launch_xwr_w<5, 3>(a, nwe, nrg, lds, st) : np == 1 ? launch_xwr_w<5, 1>(a, nwe, nrg, lds, st) : launch_xwr_w<5, 2>(a, nwe, nrg, lds, st);
     }
 }
 

@@ -43,6 +43,7 @@ int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t*
 int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* mid, uint16_t* lo,
                           hipStream_t st);
 int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t* wmid, const uint16_t* wlo, int Kp, hipStream_t st);
+int launch_pointwise_split1(const PwArgs& a, const uint16_t* whi, int Kp, hipStream_t st);      // one part: plain bf16 products
 bool pointwise_split_writes_parts(const PwArgs& a);      // the split kernels will honour a.ysplit (vector epilogue)
 
 // dw[K,N] = x[M,K]^T @ dy[M,N];  scratch holds the per-split partial products.

@@ -160,7 +160,7 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
                 }
                 uint16_t* sp = a.ysplit + m * (int64_t)a.N + n0 + c4;
                 *reinterpret_cast<bf16x4*>(sp) = p0;
-                *reinterpret_cast<bf16x4*>(sp + a.ysplit_plane) = p1;
+                if (a.ysplit_np >= 2) *reinterpret_cast<bf16x4*>(sp + a.ysplit_plane) = p1;
                 if (a.ysplit_np == 3) *reinterpret_cast<bf16x4*>(sp + 2 * a.ysplit_plane) = p2;
             }
         }

@@ -9,6 +9,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // native vecto
 
 // 8 consecutive f32 -> bf16x8 parts (hi, mid, lo): successive bf16 roundings of the remainder.  Plain named vectors (an
 // array of vectors filled element-wise lands in scratch memory).
+__device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& p0) {     // one part: plain bf16 rounding
+    const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p0[j] = (__bf16)f[j];
+}
 __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& p0, bf16x8& p1) {
     const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 #pragma unroll

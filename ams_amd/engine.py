@@ -183,8 +183,9 @@ class StudentEngine:
 
     def set_matmul_mode(self, mode: int) -> None:
         """hip.MATMUL_SPLIT_BF16_X6 (default: late-layer products via 6 bf16 MFMAs on three-part splits, f32-level),
-        hip.MATMUL_SPLIT_BF16 (3 MFMAs on two-part splits in frozen inference: +5 % frames/s, logits 2e-4..5e-4) or
-        hip.MATMUL_F32 (exact f32 MFMA everywhere)."""
+        hip.MATMUL_SPLIT_BF16 (3 MFMAs on two-part splits in frozen inference: +5 % frames/s, logits 2e-4..5e-4),
+        hip.MATMUL_F32 (exact f32 MFMA everywhere) or hip.MATMUL_BF16 (the opt-in bf16 variant: one part, plain bf16 products in the
+        late layers of frozen inference; outside the f32 tolerance — bench.py reports its mismatch beside its speed)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_MATMUL, int(mode)), "ams_student_set_option")
 
     def pack_masked_fp16(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:

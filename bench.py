@@ -17,6 +17,7 @@ Extra legs on the same JSON line (none of them is `value`):
   stream         configs[2] as a workload / configs[3] at N > 1: per second of video 30 single-frame inferences with metric on the
                  edge model + one 8-frame fine-tune step + server->edge hand-off, sustained; every rank runs its own video
   roofline       dominant kernel of the inference step + whole-step fractions, HIP events on the launch stream over a profiled replay
+  bf16_variant   the opt-in AMS_MATMUL_BF16 plan: speed, label-mismatch fraction and mIoU delta against the default plan
   parity         HIP vs the CPU oracle on two 512x1024 frames: exact label-match fraction, logits error, mIoU against the teacher
   cpu_baseline   the CPU oracle (PyTorch-CPU restatement) on bounded samples, rank 0 / N = 1
 """
@@ -57,6 +58,7 @@ def parse_args():
     ap.add_argument("--no-stream", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-bf16", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--only-timed", action="store_true", help="warm-up + timed loop only (what the rocprofv3 --pmc passes wrap)")
     ap.add_argument("--dump-layers", action="store_true", help="print the per-launch profile of one step to stderr")
@@ -346,6 +348,34 @@ def main():
                   "loss": {"hip": round(float(lg[0] / lg[1]), 6), "oracle": round(float(loss_o), 6)},
                   "miou_vs_teacher": {"hip": round(miou_of(cm_g.cpu().numpy()), 6), "oracle": round(miou_of(cm_o), 6)},
                   "note": "synthetic weights and a procedural teacher: the mIoU values are small and only their AGREEMENT is meaningful"}
+    # ---- bf16 variant (BASELINE.json configs[1] says "bf16"; SURVEY 8 d6: "bf16 path: label mismatch fraction + mIoU delta") ------
+    # NOT the headline: one bf16 part per operand in the late 1x1 layers (plain bf16 products, f32 accumulate, f32 storage)
+    bf16_leg = None
+    if not args.no_bf16 and rank == 0 and n_gpus == 1:
+        lab_ref, cm_ref, _ = eng.predict_with_metric(frames, torch.from_numpy(labels_np[:B]).to(dev))
+        hl, wl = eng.lowres
+        low_ref = eng.logits_lowres.view(-1, hl, wl, 32)[:B, :, :, :19].clone()
+        eng.set_matmul_mode(hip.MATMUL_BF16)
+        for _ in range(args.warmup):
+            eng.predict(frames)
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            eng.predict(frames)
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter() - tb
+        lab_b, cm_b, _ = eng.predict_with_metric(frames, torch.from_numpy(labels_np[:B]).to(dev))
+        low_b = eng.logits_lowres.view(-1, hl, wl, 32)[:B, :, :, :19]
+        m_ref, m_b = miou_of(cm_ref.cpu().numpy()), miou_of(cm_b.cpu().numpy())
+        bf16_leg = {"frames_per_sec": round(B * args.steps / tb, 1), "ms_per_step": round(1e3 * tb / args.steps, 4),
+                    "label_mismatch_fraction_vs_default": float("%.3e" % (lab_b != lab_ref).float().mean().item()),
+                    "logits_max_rel_dev_vs_default": float("%.3e" % ((low_b - low_ref).abs().max() / low_ref.abs().max()).item()),
+                    "miou_vs_teacher": {"default": round(m_ref, 6), "bf16": round(m_b, 6), "delta_points": round(100 * (m_b - m_ref), 4)},
+                    "what": "AMS_MATMUL_BF16: output-stride-16 layers and head with ONE bf16 part per operand (1 MFMA per 32 k instead of 6); early "
+                            "blocks exact f32; activations stored f32",
+                    "note": "opt-in, outside the 1e-3 logits tolerance with the synthetic weights (random weights amplify rounding; a trained "
+                            "checkpoint would sit lower): reported beside the f32-level headline, never instead of it"}
+        eng.set_matmul_mode(hip.MATMUL_SPLIT_BF16_X6)
     eng.close()
     del eng
     torch.cuda.empty_cache()
@@ -540,6 +570,7 @@ def main():
             "stream": stream,
             "roofline": roofline,
             "parity": parity,
+            "bf16_variant": bf16_leg,
             "cpu_baseline": cpu,
             "kernels": kernels,
             "labels_checksum": checksum,

@@ -232,3 +232,25 @@ def test_fine_tune_step_config2_batch_against_f64_oracle(W0, clip):
         assert rel(got[scope + "/BatchNorm/moving_mean:0"], mm0 - (mm0 - mu) * omd) < 1e-4, scope
         assert rel(got[scope + "/BatchNorm/moving_variance:0"], mv0 - (mv0 - var_u) * omd) < 1e-4, scope
     eng.close()
+
+
+def test_bf16_variant_is_opt_in_and_close(W0, clip):
+    """AMS_MATMUL_BF16 (SURVEY 8 cfg 2 / d6): plain bf16 products in the late layers.  It must change nothing unless selected, stay
+    within a few percent of the default plan's logits (bf16 has 8 significand bits; 40 layers deep with random weights) and give
+    label maps that differ on a small fraction of pixels only; the fine-tune step ignores it."""
+    frames, labels = clip
+    B = 2
+    eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
+    eng.load_variables(W0)
+    eng.freeze()
+    lab = eng.predict(frames[:B])
+    low = _lowres(eng, B).copy()
+    eng.set_matmul_mode(hip.MATMUL_BF16)
+    lab_b = eng.predict(frames[:B])
+    dev_b = rel(_lowres(eng, B), low)
+    mism = (lab_b != lab).float().mean().item()
+    print("bf16 variant at 512x1024: logits max rel deviation %.3e, label mismatch fraction %.3e" % (dev_b, mism))
+    assert 1e-4 < dev_b < 0.2 and mism < 0.05
+    eng.set_matmul_mode(hip.MATMUL_SPLIT_BF16_X6)
+    assert torch.equal(eng.predict(frames[:B]), lab) and np.array_equal(_lowres(eng, B), low)
+    eng.close()

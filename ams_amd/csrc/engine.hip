@@ -133,6 +133,7 @@ struct ams_student {
     int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
                                                // in one streaming kernel (k_xdw_stream.hip): 0 never, 1 where measured
                                                // faster (Cin 64 / 96, >= 16384 rows), 2 also the 160-channel blocks
+    int late_subbatch = 0;                     // frozen inference: frames per pass of the output-stride-16 section (0 = the whole batch)
     int fuse_block = 1;                        // frozen inference: a whole early block (Cin <= 32: expand + depthwise + project
                                                // [+ input]) in one kernel, bit-identical to the layer-by-layer plan
     int fuse_expand_dw = 1;                    // frozen inference, expand + depthwise in one kernel: 0 never, 1 where it
@@ -432,8 +433,9 @@ static int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st,
 // =======================================================================================================
 // frozen inference (BN folded; what the edge device runs)
 // =======================================================================================================
-static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, hipStream_t st) {
+static int forward_frozen(ams_student* s, const void* frames, int dtype, const int Bfull, hipStream_t st) {
     const ams_student_config& c = s->cfg;
+    int B = Bfull;                             // frames of the current pass: the whole batch, or one sub-batch of the late section
     const float* P = s->fparams;
     float* cur = s->act[0];
     int cur_i = 0;
@@ -463,7 +465,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
                                        c.pixel_scale, cur, st));
         }
     }
-    auto other = [&](int avoid0, int avoid1) { for (int k = 0; k < 4; ++k) if (k != avoid0 && k != avoid1) return k; return -1; };
+    int reserved = -1;                         // buffer that holds the late section's input for ALL sub-batches: never a target there
+    auto other = [&](int avoid0, int avoid1) { for (int k = 0; k < 4; ++k) if (k != avoid0 && k != avoid1 && k != reserved) return k; return -1; };
     // layer k starts a block whose expand + depthwise run as the streaming kernel (stride-16 blocks, split-bf16 modes, a few
     // frames: below that the launch cannot fill the chip)
     auto stream_ok = [&](int k) {
@@ -478,7 +481,15 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
         return s->matmul_mode != AMS_MATMUL_F32 && s->L[k].whi && s->L[k].Kp == s->L[k].d.cin;
     };
     const uint16_t* cur_parts = nullptr;       // `cur` as bf16 parts (s->xsplit), when the GEMM that produced it wrote them
-    while (i <= s->n_backbone) {
+    // The output-stride-16 section (blocks 7-16 and the head) can run in sub-batches: its largest tensor, the depthwise result of
+    // the 960-channel blocks, is 264 MB at 32 frames — written by one kernel, read by the next, and larger than the 256 MB Infinity
+    // Cache.  At 16 frames the writer/reader pairs of that section meet in the cache (and every sub-batch reuses the same addresses).
+    int i_late = s->n_backbone + 1;
+    for (int k = 2; k <= s->n_backbone; ++k)
+        if (s->L[k].d.role == AMS_ROLE_EXPAND && s->L[k].px_in == (int64_t)s->h * s->w) { i_late = k; break; }
+    const int sub = (s->late_subbatch > 0 && Bfull > s->late_subbatch && i_late <= s->n_backbone) ? s->late_subbatch : Bfull;
+    auto run_blocks = [&](int i_stop) -> int {
+    while (i <= s->n_backbone && i < i_stop) {
         // one inverted-residual block: [expand] -> depthwise -> project (+ block input)
         const float* block_in = cur;
         const float* x = cur;
@@ -592,33 +603,59 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, int B, 
             cur = s->act[o]; cur_i = o; ++i;
         }
     }
+    return AMS_OK;
+    };
     // ---- head -------------------------------------------------------------------------------------------
     LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];
-    const int64_t HW = (int64_t)s->h * s->w, M = (int64_t)B * HW;
-    RUNK(s->iPool, 4.0 * M * lp.d.cin, launch_global_mean(cur, B, HW, lp.d.cin, s->pooled, s->scratch, st));
-    {   // image_pooling conv + BN + ReLU on the pooled vector
-        PwArgs a = pw_args(s->pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, s->pool_a, lp.d.cout);
-        a.scale = lp.fscale; a.shift = lp.fshift; a.act = lp.d.act;
-        RUNK(s->iPool, pw_bytes(a), launch_pointwise(a, st));
-        // the broadcast pool branch enters concat_projection as a per-image bias: W_proj[0:256]^T . pool
-        PwArgs b = pw_args(s->pool_a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, s->img_bias, lc.d.cout);
-        RUNK(s->iProj, pw_bytes(b), launch_pointwise(b, st));
-    }
-    const int o1 = other(cur_i, -1), o2 = other(cur_i, o1);
-    {
+    const int64_t HW = (int64_t)s->h * s->w;
+    auto run_head = [&](int B0) -> int {       // frames B0 .. B0 + B - 1 of the batch
+        const int64_t M = (int64_t)B * HW;
+        float* pooled = s->pooled + (int64_t)B0 * lp.d.cin;
+        float* pool_a = s->pool_a + (int64_t)B0 * lp.d.cout;
+        float* img_bias = s->img_bias + (int64_t)B0 * lc.d.cout;
+        RUNK(s->iPool, 4.0 * M * lp.d.cin, launch_global_mean(cur, B, HW, lp.d.cin, pooled, s->scratch, st));
+        {   // image_pooling conv + BN + ReLU on the pooled vector
+            PwArgs a = pw_args(pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, pool_a, lp.d.cout);
+            a.scale = lp.fscale; a.shift = lp.fshift; a.act = lp.d.act;
+            RUNK(s->iPool, pw_bytes(a), launch_pointwise(a, st));
+            // the broadcast pool branch enters concat_projection as a per-image bias: W_proj[0:256]^T . pool
+            PwArgs b = pw_args(pool_a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, img_bias, lc.d.cout);
+            RUNK(s->iProj, pw_bytes(b), launch_pointwise(b, st));
+        }
+        const int o1 = other(cur_i, -1), o2 = other(cur_i, o1);
         PwArgs a = pw_args(cur, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, s->act[o1], la.d.cout);
         a.scale = la.fscale; a.shift = la.fshift; a.act = la.d.act;
         RUN(frozen_pointwise(s, s->iAspp, a, st));
         PwArgs b = pw_args(s->act[o1], M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout,
                            s->act[o2], lc.d.cout);
-        b.img_bias = s->img_bias; b.rows_per_img = HW; b.scale = lc.fscale; b.shift = lc.fshift; b.act = lc.d.act;
+        b.img_bias = img_bias; b.rows_per_img = HW; b.scale = lc.fscale; b.shift = lc.fshift; b.act = lc.d.act;
         RUN(frozen_pointwise(s, s->iProj, b, st));
-        PwArgs d = pw_args(s->act[o2], M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits, 32);
+        PwArgs d = pw_args(s->act[o2], M, lc.d.cout, lc.d.cout, P + ll.d.w_off, ll.d.cout, s->logits + (int64_t)B0 * HW * 32, 32);
         d.shift = P + ll.d.gamma_off;      // biases
         RUN(frozen_pointwise(s, s->iLogits, d, st));
+        return AMS_OK;
+    };
+    if (sub >= Bfull) {
+        RUN(run_blocks(s->n_backbone + 1));
+        return run_head(0);
+    }
+    RUN(run_blocks(i_late));                   // early section: the whole batch
+    float* late_in = cur;
+    const int late_in_i = cur_i;
+    const int64_t late_in_frame = s->L[i_late].px_in * s->L[i_late].d.cin;
+    reserved = late_in_i;
+    for (int B0 = 0; B0 < Bfull; B0 += sub) {
+        B = Bfull - B0 < sub ? Bfull - B0 : sub;
+        cur = late_in + (int64_t)B0 * late_in_frame;
+        cur_i = late_in_i;
+        cur_parts = nullptr;
+        i = i_late;
+        RUN(run_blocks(s->n_backbone + 1));
+        RUN(run_head(B0));
     }
     return AMS_OK;
 }
+
 
 // =======================================================================================================
 // live forward: training-mode BN.  z = raw conv output, batch statistics -> (scale, shift), a = act(z*scale+shift)(+res)
@@ -902,6 +939,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
+    if (const char* e = getenv("AMS_LATE_SUB")) s->late_subbatch = atoi(e);                  // tuning knob (see AMS_OPT_LATE_SUBBATCH)
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     *out = s;
@@ -1074,6 +1112,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     }
     if (option == AMS_OPT_FUSE_EXPAND_DW_STREAM) {
         s->fuse_expand_dw_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_LATE_SUBBATCH) {
+        s->late_subbatch = value < 0 ? 0 : value;
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_BLOCK) {

@@ -213,6 +213,10 @@ class StudentEngine:
         the two kernels; split-bf16 mode only)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DW_PROJECT, int(bool(on))), "ams_student_set_option")
 
+    def set_late_subbatch(self, frames: int) -> None:
+        """Frozen inference: frames per pass of the output-stride-16 section (0 = the whole batch); same bits either way."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_LATE_SUBBATCH, int(frames)), "ams_student_set_option")
+
     def set_fuse_block(self, on: bool) -> None:
         """Frozen inference: every early block with Cin <= 32 as ONE kernel (expand + depthwise + project [+ input]; default on)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_BLOCK, int(bool(on))), "ams_student_set_option")

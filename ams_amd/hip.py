@@ -27,6 +27,7 @@ OPT_FUSE_DW_PROJECT = 3
 OPT_FUSE_FIRST_BLOCK = 4
 OPT_FUSE_EXPAND_DW_STREAM = 5
 OPT_FUSE_BLOCK = 6
+OPT_LATE_SUBBATCH = 7
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)

@@ -189,7 +189,10 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_FUSE_BLOCK = 6 /* frozen inference: 1 (default) every early inverted-residual block with Cin <= 32 (expand + depthwise +
+enum { AMS_OPT_LATE_SUBBATCH = 7 /* frozen inference: frames per pass of the output-stride-16 section (blocks 7-16 and the head); 0 = the whole
+                                    batch.  Same results bit for bit; a pass whose largest tensor fits the 256 MB Infinity Cache keeps the
+                                    writer / reader pairs of that section out of HBM */,
+       AMS_OPT_FUSE_BLOCK = 6 /* frozen inference: 1 (default) every early inverted-residual block with Cin <= 32 (expand + depthwise +
                                  project [+ block input]) runs as ONE kernel: neither the 6x-expanded tensor nor the depthwise result reaches
                                  HBM; bit-identical to the layer-by-layer plan.  0: the per-layer / pairwise-fused kernels below */,
        AMS_OPT_FUSE_FIRST_BLOCK = 4 /* frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel

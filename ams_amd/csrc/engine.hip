@@ -26,7 +26,7 @@ const char* last_error() { return g_err; }
 static thread_local const char* g_kname = nullptr;
 void note_kernel(const char* name) { if (!g_kname) g_kname = name; }
 
-struct ProfRec { std::string name; int layer; double bytes; hipEvent_t e0, e1; };
+struct ProfRec { std::string name; int layer; double bytes, flops; hipEvent_t e0, e1; };
 struct Profiler {
     bool on = false;
     std::vector<ProfRec> recs;
@@ -140,6 +140,7 @@ struct ams_student {
                                                // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
     hipEvent_t prof_e0 = nullptr;
+    double prof_flops = 0.0;         // algorithmic FLOPs of the NEXT profiled launch (set right before RUNK, consumed by it)
 };
 
 namespace ams {
@@ -359,7 +360,8 @@ static inline void prof_end(ams_student* s, hipStream_t st, int layer, double by
     if (!s->prof.on) return;
     hipEvent_t e1 = s->prof.get();
     (void)hipEventRecord(e1, st);
-    s->prof.recs.push_back(ProfRec{g_kname ? g_kname : "?", layer, bytes, s->prof_e0, e1});
+    s->prof.recs.push_back(ProfRec{g_kname ? g_kname : "?", layer, bytes, s->prof_flops, s->prof_e0, e1});
+    s->prof_flops = 0.0;
 }
 // launch + profile: LAYER = 1-based layer index (0 = not tied to a layer), BYTES = algorithmic HBM bytes of the launch
 #define RUNK(LAYER, BYTES, expr)                                   \
@@ -506,6 +508,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
             const bool res = lj.d.residual_from != 0;
             const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin * (res ? 2 : 1) + lj.px_out * lj.d.cout) + (double)le.d.cin * le.d.cout +
                                         9.0 * ld.d.cin + (double)lj.d.cin * lj.d.cout);
+            // algorithmic FLOPs (no halo, no padding): the kernel is bound by the exact-f32 matrix pipe, not by HBM
+            s->prof_flops = 2.0 * B * ((double)le.px_in * le.d.cin * le.d.cout + (double)ld.px_out * 9.0 * ld.d.cin + (double)lj.px_out * lj.d.cin * lj.d.cout);
             RUNK(i + 2, bytes, launch_block_fused(cur, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                   P + ld.d.w_off, ld.d.stride, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale, lj.fshift,
                                                   lj.d.act, lj.d.cout, res, s->act[o], st, le.blk_vecs));
@@ -1146,7 +1150,7 @@ int ams_student_profile_read(ams_student* s, char* buf, size_t cap, size_t* need
     for (auto& r : s->prof.recs) {
         float ms = 0.f;
         AMS_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-        snprintf(line, sizeof(line), "%s\t%d\t%.6f\t%.0f\n", r.name.c_str(), r.layer, ms, r.bytes);
+        snprintf(line, sizeof(line), "%s\t%d\t%.6f\t%.0f\t%.0f\n", r.name.c_str(), r.layer, ms, r.bytes, r.flops);
         out += line;
     }
     *needed = out.size() + 1;

@@ -213,7 +213,8 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value);
 
 /* ---- measurement hook (bench.py roofline leg) -----------------------------------------------------------
  * With profiling enabled every kernel launch of the engine is bracketed by HIP events on the launch stream.
- * ams_student_profile_read synchronises and writes one line per launch: "kernel\tlayer\tms\talgorithmic_bytes\n"
+ * ams_student_profile_read synchronises and writes one line per launch: "kernel\tlayer\tms\talgorithmic_bytes\talgorithmic_flops\n"
+ * (flops = 0 where the launch is priced by bytes only)
  * (kernel named as rocprofv3 prints it, without namespace and argument list).  `needed` receives the size. */
 int ams_student_profile(ams_student* s, int32_t enable);
 int ams_student_profile_read(ams_student* s, char* buf, size_t cap, size_t* needed);

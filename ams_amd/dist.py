@@ -57,11 +57,14 @@ class RcclComm:
     Construct on every rank after ``torch.cuda.set_device(local_rank)``; the 128-byte unique id travels from rank 0 through the
     default ``torch.distributed`` group (any backend).  ``world == 1`` gives a no-op communicator."""
 
-    def __init__(self, rank: int, world: int, device: Optional[torch.device] = None):
+    def __init__(self, rank: int, world: int, device: Optional[torch.device] = None, real_single_rank: bool = False):
         import ctypes as C
         self.lib = hip.lib()
         self.rank, self.world = int(rank), int(world)
         ident = (C.c_uint8 * 128)()
+        have_id = self.world > 1 or real_single_rank
+        if self.world == 1 and real_single_rank:      # a genuine one-rank RCCL communicator (tests): every call goes through librccl
+            hip.check(self.lib.ams_comm_unique_id(ident, 128), "ams_comm_unique_id")
         if self.world > 1:
             import torch.distributed as dist
             box = [None]
@@ -72,7 +75,7 @@ class RcclComm:
             C.memmove(ident, box[0], 128)
         handle = C.c_void_p()
         with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
-            hip.check(self.lib.ams_comm_create(ident, 128, self.rank, self.world, C.byref(handle)), "ams_comm_create")
+            hip.check(self.lib.ams_comm_create(ident if have_id else None, 128, self.rank, self.world, C.byref(handle)), "ams_comm_create")
         self._h = handle
 
     def stats(self) -> Tuple[int, int]:

@@ -444,3 +444,29 @@ def test_cross_confusion_matches_oracle(H, ci):
 def _frozen_graph_for(ci, H):
     from ams_amd.semantic_network import FrozenGraph
     return FrozenGraph(Wt.synthetic_weights(S.build_spec(), seed=0), ci, H, 19)
+
+
+def test_rccl_communicator_inside_the_engine(W0):
+    """The library's own RCCL communicator (comm.hip: librccl resolved with dlopen, PyTorch's copy reused) as a genuine ONE-rank
+    communicator: ncclCommInitRank, ncclAllReduce on the launch stream, and the fine-tune step with its 110 collectives issued by the
+    engine — which must equal the plain step bit for bit (a sum over one rank).  Multi-rank RCCL needs one GPU per rank (bench.py)."""
+    from ams_amd.dist import RcclComm
+    comm = RcclComm(0, 1, torch.device("cuda:0"), real_single_rank=True)
+    t = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+    want = t.clone()
+    comm.all_reduce(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
+    frames, labels = synth.SyntheticVideo(64, 2, CI, seed=4).clip()
+    outs = []
+    for use_comm in (False, True):
+        eng = StudentEngine(CI, 64, 128, max_batch=2, trainable=True)
+        eng.load_variables(W0)
+        ls = eng.train_step(frames, labels, 1e-3, comm=comm if use_comm else None, global_batch=2).cpu().numpy()
+        torch.cuda.synchronize()
+        outs.append((ls, eng.params.cpu().numpy().copy(), eng.stats.cpu().numpy().copy()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    calls, nbytes = comm.stats()
+    assert calls == 1 + 54 * 2 + 2 and nbytes > 4 * 2113043           # the probe above, BN forward + backward per layer, loss, gradients
+    comm.close()

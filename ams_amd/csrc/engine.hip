@@ -26,7 +26,7 @@ const char* last_error() { return g_err; }
 static thread_local const char* g_kname = nullptr;
 void note_kernel(const char* name) { if (!g_kname) g_kname = name; }
 
-struct ProfRec { std::string name; int layer; double bytes, flops; hipEvent_t e0, e1; };
+struct ProfRec { std::string name; int layer; double bytes, flops, flops_x6; hipEvent_t e0, e1; };
 struct Profiler {
     bool on = false;
     std::vector<ProfRec> recs;
@@ -133,6 +133,7 @@ struct ams_student {
     int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
                                                // in one streaming kernel (k_xdw_stream.hip): 0 never, 1 where measured
                                                // faster (Cin 64 / 96, >= 16384 rows), 2 also the 160-channel blocks
+    int block_x6 = 1;                          // whole-block kernels: expand products of the K = 24 / 32 blocks as six bf16 MFMAs (f32-level)
     int late_subbatch = 0;                     // frozen inference: frames per pass of the output-stride-16 section (0 = the whole batch)
     int fuse_block = 1;                        // frozen inference: a whole early block (Cin <= 32: expand + depthwise + project
                                                // [+ input]) in one kernel, bit-identical to the layer-by-layer plan
@@ -140,7 +141,8 @@ struct ams_student {
                                                // is measured faster (narrow inputs, stride-2 blocks), 2 wherever supported
     Profiler prof;
     hipEvent_t prof_e0 = nullptr;
-    double prof_flops = 0.0;         // algorithmic FLOPs of the NEXT profiled launch (set right before RUNK, consumed by it)
+    double prof_flops = 0.0;         // algorithmic FLOPs of the NEXT profiled launch on the exact-f32 pipe (set right before RUNK)
+    double prof_flops_x6 = 0.0;      // ... and those it forms as six bf16 MFMAs on three-part splits
 };
 
 namespace ams {
@@ -360,8 +362,9 @@ static inline void prof_end(ams_student* s, hipStream_t st, int layer, double by
     if (!s->prof.on) return;
     hipEvent_t e1 = s->prof.get();
     (void)hipEventRecord(e1, st);
-    s->prof.recs.push_back(ProfRec{g_kname ? g_kname : "?", layer, bytes, s->prof_flops, s->prof_e0, e1});
+    s->prof.recs.push_back(ProfRec{g_kname ? g_kname : "?", layer, bytes, s->prof_flops, s->prof_flops_x6, s->prof_e0, e1});
     s->prof_flops = 0.0;
+    s->prof_flops_x6 = 0.0;
 }
 // launch + profile: LAYER = 1-based layer index (0 = not tied to a layer), BYTES = algorithmic HBM bytes of the launch
 #define RUNK(LAYER, BYTES, expr)                                   \
@@ -509,10 +512,16 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
             const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin * (res ? 2 : 1) + lj.px_out * lj.d.cout) + (double)le.d.cin * le.d.cout +
                                         9.0 * ld.d.cin + (double)lj.d.cin * lj.d.cout);
             // algorithmic FLOPs (no halo, no padding): the kernel is bound by the exact-f32 matrix pipe, not by HBM
-            s->prof_flops = 2.0 * B * ((double)le.px_in * le.d.cin * le.d.cout + (double)ld.px_out * 9.0 * ld.d.cin + (double)lj.px_out * lj.d.cin * lj.d.cout);
+            // three-part split products for the expand layer when K >= 24 (not in the exact-f32 mode; the one- and two-part modes
+            // concern the late layers only: the early blocks keep f32-level products there too)
+            const bool x6 = s->block_x6 && s->matmul_mode != AMS_MATMUL_F32 && le.whi && le.Kp == 32 && le.d.cin > 16;
+            const double fl_e = 2.0 * B * (double)le.px_in * le.d.cin * le.d.cout;
+            s->prof_flops = 2.0 * B * ((double)ld.px_out * 9.0 * ld.d.cin + (double)lj.px_out * lj.d.cin * lj.d.cout) + (x6 ? 0.0 : fl_e);
+            s->prof_flops_x6 = x6 ? fl_e : 0.0;
             RUNK(i + 2, bytes, launch_block_fused(cur, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                   P + ld.d.w_off, ld.d.stride, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale, lj.fshift,
-                                                  lj.d.act, lj.d.cout, res, s->act[o], st, le.blk_vecs));
+                                                  lj.d.act, lj.d.cout, res, s->act[o], st, le.blk_vecs, x6 ? le.whi : nullptr,
+                                                  (int64_t)(le.wlo - le.whi)));
             cur = s->act[o]; cur_i = o; i += 3;
             cur_parts = nullptr;
             continue;
@@ -943,6 +952,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
+    if (const char* e = getenv("AMS_BLOCK_X6")) s->block_x6 = atoi(e);                       // tuning knob (see AMS_OPT_BLOCK_X6)
     if (const char* e = getenv("AMS_LATE_SUB")) s->late_subbatch = atoi(e);                  // tuning knob (see AMS_OPT_LATE_SUBBATCH)
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
@@ -1118,6 +1128,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         s->fuse_expand_dw_stream = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
     }
+    if (option == AMS_OPT_BLOCK_X6) {
+        s->block_x6 = value != 0;
+        return AMS_OK;
+    }
     if (option == AMS_OPT_LATE_SUBBATCH) {
         s->late_subbatch = value < 0 ? 0 : value;
         return AMS_OK;
@@ -1150,7 +1164,7 @@ int ams_student_profile_read(ams_student* s, char* buf, size_t cap, size_t* need
     for (auto& r : s->prof.recs) {
         float ms = 0.f;
         AMS_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-        snprintf(line, sizeof(line), "%s\t%d\t%.6f\t%.0f\t%.0f\n", r.name.c_str(), r.layer, ms, r.bytes, r.flops);
+        snprintf(line, sizeof(line), "%s\t%d\t%.6f\t%.0f\t%.0f\t%.0f\n", r.name.c_str(), r.layer, ms, r.bytes, r.flops, r.flops_x6);
         out += line;
     }
     *needed = out.size() + 1;
@@ -1250,10 +1264,18 @@ int ams_k_dw_project(const float* e, int32_t B, int32_t H, int32_t W, int32_t Cc
 
 int ams_k_block_fused(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e, const float* shift_e,
                       int32_t Cexp, const float* w_dw, int32_t stride, const float* scale_d, const float* shift_d, const float* w_proj, int32_t Cout,
-                      const float* scale_p, const float* shift_p, int32_t residual, float* y, void* stream) {
+                      const float* scale_p, const float* shift_p, int32_t residual, float* y, uint16_t* panels, size_t panel_elems, void* stream) {
     if (!block_fused_supported(Cin, Cexp, Cout, stride, 1, residual != 0)) { set_error("block_fused: unsupported shape"); return AMS_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t* wparts = nullptr;
+    const int64_t plane = (int64_t)Cexp * 32;
+    if (panels) {                                  // three-part split of the expand weights into [part][Cexp][32]
+        AMS_REQUIRE(Cin <= 32 && panel_elems >= (size_t)3 * plane, "block_fused: panel scratch too small (need %zu)", (size_t)3 * plane);
+        RUN(launch_split_weights3(w_exp, Cexp, 1, Cin, Cexp, 32, panels, panels + plane, panels + 2 * plane, st));
+        wparts = panels;
+    }
     return launch_block_fused(x, B, H, W, Cin, w_exp, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, stride, scale_d, shift_d, AMS_ACT_RELU6, w_proj,
-                              scale_p, shift_p, AMS_ACT_NONE, Cout, residual != 0, y, (hipStream_t)stream);
+                              scale_p, shift_p, AMS_ACT_NONE, Cout, residual != 0, y, st, nullptr, wparts, plane);
 }
 
 int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "pw_common.hpp"
+#include "split_bf16.hpp"
 
 namespace ams {
 
@@ -46,6 +47,11 @@ struct BlkArgs {
     // (pad 127.5, x * ps - 1, dense 3x3 stride 2: K = 27 taps gathered per position), H x W = the stem's output grid
     int fH, fW, spt, spl;
     float ps;
+    // X6 form (Cin 24 / 32): the expand products as six bf16 MFMAs on three-part splits (f32-level, cf. k_pw_x3.hip) instead of eight
+    // exact-f32 MFMAs of twice the latency: wparts = the expand layer's panels [part][Cexp][32] bf16 (k contiguous, zero-padded),
+    // parts `wplane` elements apart
+    const uint16_t* wparts;
+    int64_t wplane;
 };
 
 // value of the normalised, 127.5-padded frame at (iy, ix, ch) in padded coordinates; outside of it the stem's SAME zero padding
@@ -62,9 +68,10 @@ __device__ __forceinline__ float blk_frame_value(const TIn* img, int H, int W, i
 }
 
 // TIn = void: the block input is an f32 activation tensor; uint8_t / float: STEM form, the input is the frame batch
-template <int S, int KC, int NTO, int TH, int TW, typename TIn = void>
+template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false>
 __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntiles) {
     constexpr bool STEM = !std::is_void<TIn>::value;
+    static_assert(!(X6 && STEM), "the stem stays exact f32");
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NPIX = IH * IW;
     constexpr int NRG = (NPIX + 15) / 16;             // 16-pixel row groups of the wave's input tile (halo included)
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     const float lo_d = a.act_d == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_d = a.act_d == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     // ---- the wave's input fragments, requested up front and kept for all chunks (clamped addresses, branch-free)
     const float* xb = STEM ? nullptr : a.x + (int64_t)b * a.H * a.W * a.Cin;
-    float4 areg[NRG][KC];
+    float4 areg[X6 ? 1 : NRG][KC];
+    bf16x8 xp[X6 ? NRG : 1][3];                        // X6: the fragments as bf16 parts (k = 8q .. 8q + 7 of the lane's pixel), split once
     unsigned inside_mask = 0;
     if constexpr (STEM) {
         // this lane's taps: k = 16c + 4q + j -> (dy, dx, channel) of the 3x3x3 receptive field, k >= 27 padding (value 0)
@@ -161,13 +169,24 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
         if (m < NPIX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inside_mask |= 1u << rg;
         const int iyc = iy < 0 ? 0 : (iy > a.H - 1 ? a.H - 1 : iy), ixc = ix < 0 ? 0 : (ix > a.W - 1 ? a.W - 1 : ix);
         const float* px = xb + ((int64_t)iyc * a.W + ixc) * a.Cin;
+        if constexpr (X6) {
+            int k0 = 8 * q, k1 = 8 * q + 4;
+            const bool ok0 = k0 < a.Cin, ok1 = k1 < a.Cin;
+            if (k0 > a.Cin - 4) k0 = a.Cin - 4;
+            if (k1 > a.Cin - 4) k1 = a.Cin - 4;
+            float4 u = ld4(px + k0), v = ld4(px + k1);
+            u = make_float4(ok0 ? u.x : 0.f, ok0 ? u.y : 0.f, ok0 ? u.z : 0.f, ok0 ? u.w : 0.f);
+            v = make_float4(ok1 ? v.x : 0.f, ok1 ? v.y : 0.f, ok1 ? v.z : 0.f, ok1 ? v.w : 0.f);
+            split8(u, v, xp[rg][0], xp[rg][1], xp[rg][2]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            int koff = c * 16 + 4 * q;
-            const bool ok = koff < a.Cin;
-            if (koff > a.Cin - 4) koff = a.Cin - 4;
-            const float4 v = ld4(px + koff);
-            areg[rg][c] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            for (int c = 0; c < KC; ++c) {
+                int koff = c * 16 + 4 * q;
+                const bool ok = koff < a.Cin;
+                if (koff > a.Cin - 4) koff = a.Cin - 4;
+                const float4 v = ld4(px + koff);
+                areg[rg][c] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            }
         }
     }
     }
@@ -188,11 +207,18 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
 #pragma unroll
     for (int t = 0; t < NTO; ++t) ncl[t] = 16 * t + l15 < a.Cout ? 16 * t : 0;
     float wa[KC][4], wp[4][NTO];
+    bf16x8 wq[3];                                      // X6: this lane's expand-weight fragments (channel n0 + l15, k = 8q .. 8q + 7), three parts
+    const uint16_t* pwq = X6 ? a.wparts + (int64_t)l15 * 32 + 8 * q : nullptr;
     auto load_wa = [&](int n0) {
+        if constexpr (X6) {
 #pragma unroll
-        for (int c = 0; c < KC; ++c)
+            for (int pp = 0; pp < 3; ++pp) wq[pp] = *reinterpret_cast<const bf16x8*>(pwq + pp * a.wplane + (int64_t)n0 * 32);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wa[c][j] = pwa[c][j][n0];
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wa[c][j] = pwa[c][j][n0];
+        }
     };
     auto load_wp = [&](int n0) {
 #pragma unroll
@@ -220,12 +246,21 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
 #pragma unroll
             for (int rg = 0; rg < NRG; ++rg) {
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (X6) {                    // the six products of k_pw_x3.hip, smallest terms first
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[2], xp[rg][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0], xp[rg][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[1], xp[rg][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[1], xp[rg][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0], xp[rg][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0], xp[rg][0], acc, 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int c = 0; c < KC; ++c) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][0], areg[rg][c].x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][1], areg[rg][c].y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][2], areg[rg][c].z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][3], areg[rg][c].w, acc, 0, 0, 0);
+                    for (int c = 0; c < KC; ++c) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][0], areg[rg][c].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][1], areg[rg][c].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][2], areg[rg][c].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][3], areg[rg][c].w, acc, 0, 0, 0);
+                    }
                 }
                 const bool inside = (inside_mask >> rg) & 1u;
                 const float lo = inside ? lo_e : 0.f, hi = inside ? hi_e : 0.f;
@@ -308,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     }
 }
 
-template <int S, int KC, int NTO, int TH, int TW, typename TIn = void>
+template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false>
 static int launch_blk_k(BlkArgs a, hipStream_t st) {
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NRG = (IH * IW + 15) / 16;
@@ -321,9 +356,10 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
     AMS_REQUIRE(ntiles > 0 && ntiles < 0x7fffffffLL, "block kernel: bad grid");
     static const std::string nm = "block_kernel<" + std::to_string(S) + ", " + std::to_string(KC) + ", " + std::to_string(NTO) + ", " +
                                   std::to_string(TH) + ", " + std::to_string(TW) +
-                                  (std::is_void<TIn>::value ? ", void>" : sizeof(typename std::conditional<std::is_void<TIn>::value, char, TIn>::type) == 1 ? ", unsigned char>" : ", float>");
+                                  (std::is_void<TIn>::value ? ", void" : sizeof(typename std::conditional<std::is_void<TIn>::value, char, TIn>::type) == 1 ? ", unsigned char" : ", float") +
+                                  (X6 ? ", true>" : ", false>");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((block_kernel<S, KC, NTO, TH, TW, TIn>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)ntiles);
+    hipLaunchKernelGGL((block_kernel<S, KC, NTO, TH, TW, TIn, X6>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)ntiles);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -332,6 +368,7 @@ template <int S, int TH, int TW>
 static int launch_blk_t(const BlkArgs& a, hipStream_t st) {
     const bool k1 = (a.Cin + 15) / 16 == 1, o2 = a.Cout <= 32;
     if (k1) return o2 ? launch_blk_k<S, 1, 2, TH, TW>(a, st) : launch_blk_k<S, 1, 4, TH, TW>(a, st);
+    if (a.wparts) return o2 ? launch_blk_k<S, 2, 2, TH, TW, void, true>(a, st) : launch_blk_k<S, 2, 4, TH, TW, void, true>(a, st);
     return o2 ? launch_blk_k<S, 2, 2, TH, TW>(a, st) : launch_blk_k<S, 2, 4, TH, TW>(a, st);
 }
 
@@ -357,7 +394,8 @@ bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bo
 
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
                        const float* w_dw, int stride, const float* sc_d, const float* sh_d, int act_d, const float* w_pj, const float* sc_p,
-                       const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs) {
+                       const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs, const uint16_t* wparts,
+                       int64_t wplane) {
     AMS_REQUIRE(block_fused_supported(Cin, Cexp, Cout, stride, 1, residual), "block kernel: unsupported shape Cin=%d Cexp=%d Cout=%d s=%d", Cin, Cexp,
                 Cout, stride);
     BlkArgs a;
@@ -365,6 +403,7 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
     a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.w_exp = w_exp; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e; a.Cexp = Cexp;
     a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.w_pj = w_pj; a.sc_p = sc_p; a.sh_p = sh_p; a.act_p = act_p; a.Cout = Cout;
     a.residual = residual ? 1 : 0; a.y = y; a.vecs = vecs;
+    if (wparts && Cin > 16) { a.wparts = wparts; a.wplane = wplane; }      // X6 pays from K = 24 on (at K = 16 half of every bf16 MFMA is padding)
     same_pad(H, 3, stride, 1, &a.Ho, &a.pt);
     same_pad(W, 3, stride, 1, &a.Wo, &a.pl);
     // tile of output pixels per WAVE

@@ -96,7 +96,10 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
 bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bool residual);
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
                        const float* w_dw, int stride, const float* sc_d, const float* sh_d, int act_d, const float* w_pj, const float* sc_p,
-                       const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs = nullptr);
+                       const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs = nullptr,
+                       const uint16_t* wparts = nullptr, int64_t wplane = 0);
+// wparts: optional three-part bf16 panels [part][Cexp][32] of the expand weights (parts `wplane` apart): with them the expand products of
+// a block with Cin 24 / 32 run as six bf16 MFMAs (f32-level) instead of eight exact-f32 MFMAs
 // vecs: optional [13][Cexp] table (sc_e | sh_e | sc_d | sh_d | w_dw[9]) built once by launch_block_pack (the engine: at freeze)
 int launch_first_block_tiles(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem, const float* sc_s,
                              const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d, int act_d, const float* w_pj,

@@ -213,6 +213,11 @@ class StudentEngine:
         the two kernels; split-bf16 mode only)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DW_PROJECT, int(bool(on))), "ams_student_set_option")
 
+    def set_block_x6(self, on: bool) -> None:
+        """Whole-block kernels: expand products of the K = 24 / 32 blocks as six bf16 MFMAs on three-part splits (default on, f32-level)
+        or as exact f32 MFMAs (bit-identical to the layer-by-layer plan)."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_BLOCK_X6, int(bool(on))), "ams_student_set_option")
+
     def set_late_subbatch(self, frames: int) -> None:
         """Frozen inference: frames per pass of the output-stride-16 section (0 = the whole batch); same bits either way."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_LATE_SUBBATCH, int(frames)), "ams_student_set_option")

@@ -28,6 +28,7 @@ OPT_FUSE_FIRST_BLOCK = 4
 OPT_FUSE_EXPAND_DW_STREAM = 5
 OPT_FUSE_BLOCK = 6
 OPT_LATE_SUBBATCH = 7
+OPT_BLOCK_X6 = 8
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)
@@ -88,7 +89,7 @@ SIGNATURES = {
     "ams_k_pointwise_split3": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "ams_ingest_resize_u8": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "ams_k_dw_project": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "ams_k_block_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "ams_k_block_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_expand_dw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ams_k_expand_dw_stream": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _i32, _i32, _vp]),
     "ams_k_global_mean": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _sz, _vp]),

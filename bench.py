@@ -42,6 +42,7 @@ from ams_amd import hip, spec as S, synth, weights as Wt  # noqa: E402
 from ams_amd.engine import StudentEngine  # noqa: E402
 
 CI = [0, 1, 2, 10, 11, 13]          # exp 25 (Cityscapes) class subset, reference exp_configs.py:86-89
+BF16_MFMA_PEAK_TF = 2500.0          # dense bf16 matrix pipe (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3            # exact-f32 matrix pipe (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -105,8 +106,8 @@ def read_profile(eng):
     hip.check(eng.lib.ams_student_profile_read(eng._h, buf, len(buf), C.byref(need)))
     rows = []
     for line in buf.value.decode().splitlines():
-        name, layer, ms, nbytes, flops = line.split("\t")
-        rows.append((name, int(layer), float(ms), float(nbytes), float(flops)))
+        name, layer, ms, nbytes, flops, flops_x6 = line.split("\t")
+        rows.append((name, int(layer), float(ms), float(nbytes), float(flops), float(flops_x6)))
     return rows
 
 
@@ -275,25 +276,26 @@ def main():
         hip.check(eng.lib.ams_student_profile(eng._h, 0))
         if args.dump_layers:
             per = len(rows) // n_prof
-            for name, layer, ms, nbytes, flops in rows[-per:]:
-                print("%3d %-28s %8.1f us %8.1f GB/s %10.0f KB %7.1f TFLOP/s" % (layer, name, 1e3 * ms, nbytes / ms / 1e6, nbytes / 1e3, flops / ms / 1e9),
+            for name, layer, ms, nbytes, flops, fx6 in rows[-per:]:
+                print("%3d %-28s %8.1f us %8.1f GB/s %10.0f KB %7.1f TFLOP/s" % (layer, name, 1e3 * ms, nbytes / ms / 1e6, nbytes / 1e3, (flops + fx6) / ms / 1e9),
                       file=sys.stderr)
-        agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
-        for name, layer, ms, nbytes, flops in rows:
+        agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0.0])
+        for name, layer, ms, nbytes, flops, fx6 in rows:
             a = agg[name]
             a[0] += 1
             a[1] += ms
             a[2] += nbytes
             a[3] += flops
+            a[4] += fx6
         total_ms = sum(a[1] for a in agg.values())
         total_bytes = sum(a[2] for a in agg.values())
-        for name, (cnt, ms, nbytes, flops) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        for name, (cnt, ms, nbytes, flops, fx6) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             kernels[name] = {"launches": cnt, "avg_us": round(1e3 * ms / cnt, 2), "share": round(ms / total_ms, 4),
                              "alg_GBps": round(nbytes / ms / 1e6, 1)}
-            if flops:
-                kernels[name]["alg_TFLOPs"] = round(flops / ms / 1e9, 1)
+            if flops + fx6:
+                kernels[name]["alg_TFLOPs"] = round((flops + fx6) / ms / 1e9, 1)
         dom = max(agg.items(), key=lambda kv: kv[1][1])
-        cnt, ms, nbytes, flops = dom[1]
+        cnt, ms, nbytes, flops, fx6 = dom[1]
         achieved = nbytes / ms / 1e6          # bytes / ms -> GB/s
         step_ms = 1e3 * elapsed / args.steps
         hbm_view = {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -302,10 +304,16 @@ def main():
             # The whole-block kernels move only block inputs and outputs; what bounds them is the EXACT-f32 matrix pipe
             # (v_mfma_f32_16x16x4_f32: 157.3 TFLOP/s = 1/16 of the bf16 rate, MI355X_MICROARCH.md), so that is the roof they are priced
             # against; the HBM view of the same launches sits beside it
-            tf = flops / ms / 1e9
-            roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(tf, 1), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(tf / F32_MFMA_PEAK_TF, 4), "traffic": None,
-                        "alg_flops_per_launch": round(flops / cnt), "dtype_of_the_pipe": "f32 in / f32 accumulate (exact f32 products)",
+            # FLOPs formed as exact-f32 MFMAs are priced at 157.3 TFLOP/s, those formed as six bf16 MFMAs on three-part splits at a
+            # sixth of the dense bf16 peak: `peak` is the blend for this kernel's mix (alg. FLOPs / matrix-pipe floor time)
+            tf = (flops + fx6) / ms / 1e9
+            floor_ms = 1e3 * (flops / (F32_MFMA_PEAK_TF * 1e12) + 6.0 * fx6 / (BF16_MFMA_PEAK_TF * 1e12))
+            peak_tf = (flops + fx6) / floor_ms / 1e9
+            roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(tf, 1), "peak": round(peak_tf, 1), "unit": "TFLOP/s",
+                        "frac": round(tf / peak_tf, 4), "traffic": None,
+                        "alg_flops_per_launch": round((flops + fx6) / cnt),
+                        "pipe_mix": {"exact_f32_mfma_flops": round(flops / cnt), "split_bf16_x6_flops": round(fx6 / cnt),
+                                     "f32_peak": F32_MFMA_PEAK_TF, "bf16_peak": BF16_MFMA_PEAK_TF},
                         "hbm": hbm_view}
         else:
             roofline = {"bound": "hbm", "kernel": dom[0], "traffic": None}

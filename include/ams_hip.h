@@ -189,7 +189,10 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_LATE_SUBBATCH = 7 /* frozen inference: frames per pass of the output-stride-16 section (blocks 7-16 and the head); 0 = the whole
+enum { AMS_OPT_BLOCK_X6 = 8 /* whole-block kernels: 1 (default) the expand products of the blocks with 24 / 32 input channels run as six bf16
+                               MFMAs on three-part splits (f32-level, 96 instead of 256 matrix-pipe cycles per 16x16 tile); 0 exact f32 MFMA
+                               (bit-identical to the layer-by-layer plan).  Always exact f32 under AMS_MATMUL_F32. */,
+       AMS_OPT_LATE_SUBBATCH = 7 /* frozen inference: frames per pass of the output-stride-16 section (blocks 7-16 and the head); 0 = the whole
                                     batch.  Same results bit for bit; a pass whose largest tensor fits the 256 MB Infinity Cache keeps the
                                     writer / reader pairs of that section out of HBM */,
        AMS_OPT_FUSE_BLOCK = 6 /* frozen inference: 1 (default) every early inverted-residual block with Cin <= 32 (expand + depthwise +
@@ -274,10 +277,12 @@ int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin
 
 /* A whole early block in one kernel (k_block.hip): y = bn_p(relu6(bn_d(dw3x3(relu6(bn_e(x @ w_exp))))) @ w_proj) (+ x when residual != 0:
  * stride 1 and Cout == Cin only).  Cin in {16, 24, 32}, Cexp % 32 == 0 or % 48 == 0, Cout % 4 == 0 and <= 64, stride 1|2, rate 1.
- * Exact f32 products in the k order of ams_k_pointwise: the same bits as ams_k_expand_dw followed by ams_k_pointwise. */
+ * panels == NULL: exact f32 products in the k order of ams_k_pointwise — the same bits as ams_k_expand_dw followed by ams_k_pointwise.
+ * panels != NULL (scratch of >= 3*Cexp*32 uint16) and Cin > 16: the EXPAND products as six bf16 MFMAs on three-part splits (all 24
+ * significand bits, f32-level: what the engine does by default, AMS_OPT_BLOCK_X6); depthwise and project stay exact f32. */
 int ams_k_block_fused(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e, const float* shift_e,
                       int32_t Cexp, const float* w_dw, int32_t stride, const float* scale_d, const float* shift_d, const float* w_proj, int32_t Cout,
-                      const float* scale_p, const float* shift_p, int32_t residual, float* y, void* stream);
+                      const float* scale_p, const float* shift_p, int32_t residual, float* y, uint16_t* panels, size_t panel_elems, void* stream);
 
 /* K4+K3 fused, streaming form for the stride-16 blocks (Cin in {64, 96, 160}, stride 1, rate 1|2, Cexp % 32 == 0): the same
  * result as ams_k_pointwise_split (parts = 2) / the three-part split (parts = 3) followed by ams_k_depthwise3x3, bit for bit,

@@ -271,7 +271,7 @@ def test_whole_block_kernel(lib, H, W, Cin, Cexp, Cout, stride, res):
     sed, hed, sdd, hdd, spd, hpd = dev(se), dev(he), dev(sd), dev(hd), dev(sp), dev(hp)
     y = torch.full((B, Ho, Wo, Cout), np.nan, device=DEV)
     hip.check(lib.ams_k_block_fused(P(xd), B, H, W, Cin, P(wed), P(sed), P(hed), Cexp, P(wdd), stride, P(sdd), P(hdd), P(wpd), Cout, P(spd), P(hpd),
-                                    int(res), P(y), stream()))
+                                    int(res), P(y), None, 0, stream()))
     e = np.clip((x.astype(np.float64) @ we.astype(np.float64)) * se + he, 0, 6)
     et = torch.as_tensor(e).permute(0, 3, 1, 2)
     raw = F.conv2d(F.pad(et, (pl, pr, pt, pb)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), stride=stride, groups=Cexp)
@@ -289,6 +289,16 @@ def test_whole_block_kernel(lib, H, W, Cin, Cexp, Cout, stride, res):
     hip.check(lib.ams_k_pointwise(P(dmid), B * Ho * Wo, Cexp, P(wpd), Cout, 0, None, 1, P(spd), P(hpd), hip.ACT_NONE, P(xd) if res else None, P(y2),
                                   stream()))
     assert torch.equal(y, y2), "max abs diff %g" % (y - y2).abs().max().item()
+    # the default form of the engine for K >= 24: expand products as six bf16 MFMAs on three-part splits (f32-level, not the same bits)
+    panels = torch.zeros(3 * Cexp * 32, dtype=torch.int16, device=DEV)
+    y3 = torch.full((B, Ho, Wo, Cout), np.nan, device=DEV)
+    hip.check(lib.ams_k_block_fused(P(xd), B, H, W, Cin, P(wed), P(sed), P(hed), Cexp, P(wdd), stride, P(sdd), P(hdd), P(wpd), Cout, P(spd), P(hpd),
+                                    int(res), P(y3), P(panels), panels.numel(), stream()))
+    assert rel_err(y3.cpu().numpy(), ref) < 2e-5
+    if Cin > 16:
+        assert not torch.equal(y3, y) and rel_err(y3.cpu().numpy(), got) < 2e-6
+    else:
+        assert torch.equal(y3, y)                      # K = 16: the exact-f32 form either way
 
 
 @pytest.mark.parametrize("H,W,Cin,Cexp,rate,parts", [(33, 65, 64, 384, 1, 3), (33, 65, 96, 576, 1, 2), (33, 65, 160, 960, 2, 3),

@@ -23,10 +23,14 @@ se, sd, sp = (torch.rand(n, device=dev) + 0.5 for n in (Cexp, Cexp, Cout))
 he, hd, hp = (torch.randn(n, device=dev) for n in (Cexp, Cexp, Cout))
 Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
 y = torch.empty(B, Ho, Wo, Cout, device=dev)
+import os
+X6 = os.environ.get("BLK_X6", "1") == "1"
+panels = torch.zeros(3 * Cexp * 32, dtype=torch.int16, device=dev)
 
 
 def run():
-    hip.check(lib.ams_k_block_fused(P(x), B, H, W, Cin, P(we), P(se), P(he), Cexp, P(wd), stride, P(sd), P(hd), P(wp), Cout, P(sp), P(hp), res, P(y), st))
+    hip.check(lib.ams_k_block_fused(P(x), B, H, W, Cin, P(we), P(se), P(he), Cexp, P(wd), stride, P(sd), P(hd), P(wp), Cout, P(sp), P(hp), res, P(y),
+                                    P(panels) if X6 else None, panels.numel(), st))
 
 
 for _ in range(2):

@@ -66,6 +66,8 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int oy0 = ty * TH, ox0 = tx * TW;
+    const float lo_s = a.act_s == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_s = a.act_s == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+    const float lo_d = a.act_d == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_d = a.act_d == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
 
     for (int e = tid; e < 28 * 32; e += 256) {
         const int kk = e >> 5, nn = e & 31;
@@ -155,11 +157,13 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
             for (int t = 0; t < 2; ++t) {
                 const int n4 = 16 * t + 4 * q;
                 const float4 sc = ld4(sAff + n4), sh = ld4(sAff + 32 + n4);
+                // one v_med3 per value: clamp to the activation's bounds, both 0 outside the feature map (the depthwise conv's padding)
+                const float lo = live[i] ? lo_s : 0.f, hi = live[i] ? hi_s : 0.f;
                 float4 o;
-                o.x = live[i] ? apply_act(acc[t][0] * sc.x + sh.x, a.act_s) : 0.f;
-                o.y = live[i] ? apply_act(acc[t][1] * sc.y + sh.y, a.act_s) : 0.f;
-                o.z = live[i] ? apply_act(acc[t][2] * sc.z + sh.z, a.act_s) : 0.f;
-                o.w = live[i] ? apply_act(acc[t][3] * sc.w + sh.w, a.act_s) : 0.f;
+                o.x = __builtin_amdgcn_fmed3f(acc[t][0] * sc.x + sh.x, lo, hi);
+                o.y = __builtin_amdgcn_fmed3f(acc[t][1] * sc.y + sh.y, lo, hi);
+                o.z = __builtin_amdgcn_fmed3f(acc[t][2] * sc.z + sh.z, lo, hi);
+                o.w = __builtin_amdgcn_fmed3f(acc[t][3] * sc.w + sh.w, lo, hi);
                 if (rg * 16 + l15 < NPIX) st4(sS + (rg * 16 + l15) * P + n4, o);
             }
         }
@@ -200,8 +204,8 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             float4 o;
-            o.x = apply_act(acc[r].x * sc.x + sh.x, a.act_d); o.y = apply_act(acc[r].y * sc.y + sh.y, a.act_d);
-            o.z = apply_act(acc[r].z * sc.z + sh.z, a.act_d); o.w = apply_act(acc[r].w * sc.w + sh.w, a.act_d);
+            o.x = __builtin_amdgcn_fmed3f(acc[r].x * sc.x + sh.x, lo_d, hi_d); o.y = __builtin_amdgcn_fmed3f(acc[r].y * sc.y + sh.y, lo_d, hi_d);
+            o.z = __builtin_amdgcn_fmed3f(acc[r].z * sc.z + sh.z, lo_d, hi_d); o.w = __builtin_amdgcn_fmed3f(acc[r].w * sc.w + sh.w, lo_d, hi_d);
             st4(sD + ((g * RG + r) * TW + lx) * P + c4, o);
         }
     }

@@ -28,12 +28,12 @@ __device__ __forceinline__ void pw_stage_affine(const PwArgs& a, float* sSc, flo
 
 template <int RM, int NT>
 __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x4 (&acc)[RM][NT], int64_t m_base, int n0, int l15, int q,
-                                            const float* sSc, const float* sSh) {
+                                            const float* sSc, const float* sSh, int nrg = RM) {
     const bool y_vec = (a.ldy & 3) == 0, r_vec = (a.ldr & 3) == 0, n_vec = (a.N & 3) == 0;
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
         const int64_t m = m_base + r * 16 + l15;
-        if (m >= a.M) continue;
+        if (m >= a.M || r >= nrg) continue;
         float4 add[NT];                                   // residual + per-image bias contributions, gathered first
         bool has_add = false;
         if (a.res || a.img_bias) {
@@ -93,12 +93,13 @@ enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_BIAS = 2, EPI_GENERIC = 3 };
 // successive roundings of split8), so that the next block's expand GEMM loads its operand ready-made.
 template <int RM, int NT, int EPI, bool SPLIT_OUT = false>
 __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][NT], int64_t m_base, int n0, int lane,
-                                              const float* sSc, const float* sSh, float* sOut) {
+                                              const float* sSc, const float* sSh, float* sOut, int nrg = RM) {
     constexpr int OP = 16 * NT + 4;
     constexpr int V4 = 4 * NT;                 // float4 per slab row
     const int l15 = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
+        if (r >= nrg) break;                   // wave-uniform: a half-height block (k_pw_x3.hip) owns fewer row groups
         const int64_t m0 = m_base + r * 16;
         if (EPI == EPI_BIAS) {                 // added before scale/shift; row = this lane's pixel
             int64_t m = m0 + l15;

@@ -515,3 +515,39 @@ def test_adam_matches_tf1_form(lib):
     got = pd.cpu().numpy()
     assert np.array_equal(got[mask == 0], p[mask == 0])                # reverted entries keep their bits
     assert np.abs(got[mask == 1] - wn[mask == 1]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_split_gemm_half_height_tail_blocks():
+    """68640 x 64 -> 320 runs 160-wide tiles at two blocks per CU: 1074 full-height blocks would need 2.1 rounds, so the launcher ends the
+    launch with half-height blocks (pw_plan_tail, k_pw_x3.hip).  Same products in the same order per output as the all-full plan: the
+    two launches must agree bit for bit, and with a float64 product to the f32 level."""
+    import ctypes as C
+    import os
+    lib = hip.lib()
+    M, K, N = 68640, 64, 320
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(K, N, generator=g) / K ** 0.5).cuda()
+    sc = (torch.rand(N, generator=g) + 0.5).cuda()
+    sh = torch.randn(N, generator=g).cuda()
+    panels = torch.zeros(3 * N * 64, dtype=torch.int16, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run():
+        y = torch.full((M, N), float("nan"), device="cuda")
+        hip.check(lib.ams_k_pointwise_split3(P(x), M, K, P(w), N, P(sc), P(sh), hip.ACT_NONE, None, P(y), P(panels), panels.numel(), st))
+        torch.cuda.synchronize()
+        return y
+
+    y_tail = run()
+    os.environ["AMS_PWX_NO_TAIL"] = "1"
+    try:
+        y_full = run()
+    finally:
+        del os.environ["AMS_PWX_NO_TAIL"]
+    assert not torch.isnan(y_tail).any()
+    assert torch.equal(y_tail, y_full)
+    want = (x.double() @ w.double()) * sc.double() + sh.double()
+    assert ((y_tail.double() - want).abs().max() / want.abs().max()).item() < 2e-6

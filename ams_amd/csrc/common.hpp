@@ -57,11 +57,13 @@ static inline void same_pad(int in, int k, int stride, int rate, int* out, int* 
 constexpr int kNumXcd = 8;   // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
 
 // ---- device helpers --------------------------------------------------------------------------------
-// branch-free: the activation is a clamp to [lo, hi] with wave-uniform bounds (scalar selects, two VALU ops per value)
+// branch-free: the activation is a clamp to [lo, hi] with wave-uniform bounds (scalar selects) — ONE v_med3_f32 per value (the
+// fminf(fmaxf()) form is two instructions: hipcc cannot prove lo <= hi for run-time bounds; VALU instructions beside MFMAs are not
+// free on this chip, tools/probes/README.md)
 __device__ __forceinline__ float apply_act(float v, int act) {
     const float lo = act == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f;
     const float hi = act == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
-    return fminf(fmaxf(v, lo), hi);
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
 }
 
 // XCD-aware block remap: consecutive *logical* ids land on the same XCD (same private L2), so blocks that

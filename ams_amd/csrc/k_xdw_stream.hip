@@ -220,10 +220,12 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                     for (int tt = 0; tt < NT; ++tt) {
                         const float4 sc = ld4(sAff + 16 * tt + 4 * q), sh = ld4(sAff + NC + 16 * tt + 4 * q);
                         float4 v;
-                        v.x = apply_act(acc[tt][0] * sc.x + sh.x, a.act_e); v.y = apply_act(acc[tt][1] * sc.y + sh.y, a.act_e);
-                        v.z = apply_act(acc[tt][2] * sc.z + sh.z, a.act_e); v.w = apply_act(acc[tt][3] * sc.w + sh.w, a.act_e);
-                        // positions outside the image hold 0: SAME padding of the depthwise conv, halo outside the sub-image
-                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        // one v_med3 per value: the activation's bounds, both 0 for positions outside the image (SAME padding of the
+                        // depthwise conv, halo outside the sub-image)
+                        const float lo = inside ? (a.act_e == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f) : 0.f;
+                        const float hi = inside ? (a.act_e == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf()) : 0.f;
+                        v.x = __builtin_amdgcn_fmed3f(acc[tt][0] * sc.x + sh.x, lo, hi); v.y = __builtin_amdgcn_fmed3f(acc[tt][1] * sc.y + sh.y, lo, hi);
+                        v.z = __builtin_amdgcn_fmed3f(acc[tt][2] * sc.z + sh.z, lo, hi); v.w = __builtin_amdgcn_fmed3f(acc[tt][3] * sc.w + sh.w, lo, hi);
                         st4(dst + 16 * tt, v);
                         // the first MIRROR slots of the ring are repeated after its end: a D-thread's run of taps never wraps
                         if (mirror) st4(dst + R * PITCH + 16 * tt, v);

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) { esc[tt] = ld4(a.sc_e + n0c + 16 * tt + 4 * q); esh[tt] = ld4(a.sh_e + n0c + 16 * tt + 4 * q); }
         const int ring_lane = l15 * PITCH + 32 * wave + 4 * q;
+        const float lo_e = a.act_e == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_e = a.act_e == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
         // loader duty: pixel (lrg, l15) of a step is shared by TPP threads; thread lj of them takes pieces lj, lj + TPP, ...
         // (piece j = part * KS * 4 + s * 4 + qq).  Source offsets (elements, relative to the pixel) and LDS slots are fixed.
         const int lrg = NRG == 2 ? (q & 1) : 0;
@@ -181,16 +182,18 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 }
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg) {
-                    const unsigned keep = in_cur[rg] ? 0xffffffffu : 0u;
+                    // one v_med3 per value: the activation's bounds, both 0 for a position outside the feature map (the depthwise
+                    // conv's zero padding)
+                    const float lo = in_cur[rg] ? lo_e : 0.f, hi = in_cur[rg] ? hi_e : 0.f;
                     float* dst = ring + (sbase + 16 * rg) * PITCH + ring_lane;
                     const bool mirror = sbase == 0 && rg == 0 && l15 < MIRROR;
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         float4 v;
-                        v.x = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][0] * esc[tt].x + esh[tt].x, a.act_e)) & keep);
-                        v.y = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][1] * esc[tt].y + esh[tt].y, a.act_e)) & keep);
-                        v.z = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][2] * esc[tt].z + esh[tt].z, a.act_e)) & keep);
-                        v.w = __uint_as_float(__float_as_uint(apply_act(acc[rg][tt][3] * esc[tt].w + esh[tt].w, a.act_e)) & keep);
+                        v.x = __builtin_amdgcn_fmed3f(acc[rg][tt][0] * esc[tt].x + esh[tt].x, lo, hi);
+                        v.y = __builtin_amdgcn_fmed3f(acc[rg][tt][1] * esc[tt].y + esh[tt].y, lo, hi);
+                        v.z = __builtin_amdgcn_fmed3f(acc[rg][tt][2] * esc[tt].z + esh[tt].z, lo, hi);
+                        v.w = __builtin_amdgcn_fmed3f(acc[rg][tt][3] * esc[tt].w + esh[tt].w, lo, hi);
                         st4(dst + 16 * tt, v);
                         if (mirror) st4(dst + R * PITCH + 16 * tt, v);
                     }

@@ -579,7 +579,8 @@ def main():
             "precision_note": "f32 storage and accumulation everywhere; products of the late 1x1 layers (output stride 16 + head) are "
                               "formed as 6 bf16 MFMAs on three-part splits of the f32 operands (all 24 significand bits: f32-level; "
                               "512x1024 logits 4e-5 from the f64 oracle, same as exact f32 MFMA and as the f32 CPU oracle: "
-                              "tools/logit_error.py); AMS_MATMUL_SPLIT_BF16 (3 MFMAs, two parts) is +5 % frames/s at 2e-4..5e-4",
+                              "tools/logit_error.py); the expand products of the early blocks with 24 / 32 input channels likewise (AMS_OPT_BLOCK_X6), everything "
+                              "else exact f32 MFMA / VALU; AMS_MATMUL_SPLIT_BF16 (3 MFMAs, two parts) is +5 % frames/s at 2e-4..5e-4",
             "config": {"workload": "student infer only, %dx%d synthetic clip, frozen BN, uint8 frames resident in HBM, "
                                    "int32 label maps out (BASELINE.json configs[1])" % (H, 2 * H),
                        "frames_per_step_per_gpu": B, "class_subset": CI, "weights": "synthetic seed 0",

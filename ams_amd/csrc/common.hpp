@@ -54,6 +54,26 @@ static inline void same_pad(int in, int k, int stride, int rate, int* out, int* 
     *before = total / 2;
 }
 
+// acc += v * w on 4 channels as two v_pk_fma_f32 (per element the same single rounding as fmaf): half the VALU issue slots of four
+// v_fma_f32.  For VALU phases that are NOT interleaved instruction by instruction with MFMAs (tools/probes/README.md: packed f32
+// between a wave's own MFMAs is slower than scalar).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fma4_pk(float4& acc, const float4& v, const float4& w) {
+    f32x2_t a0 = {acc.x, acc.y}, a1 = {acc.z, acc.w};
+    const f32x2_t v0 = {v.x, v.y}, v1 = {v.z, v.w}, w0 = {w.x, w.y}, w1 = {w.z, w.w};
+    a0 = __builtin_elementwise_fma(v0, w0, a0);
+    a1 = __builtin_elementwise_fma(v1, w1, a1);
+    acc = make_float4(a0.x, a0.y, a1.x, a1.y);
+}
+
+// v * sc + sh with the two roundings of an unfused multiply and add, as v_pk_mul_f32 + v_pk_add_f32 (two instructions for four values)
+__device__ __forceinline__ float4 muladd4_pk(const float4& v, const float4& sc, const float4& sh) {
+    const f32x2_t v0 = {v.x, v.y}, v1 = {v.z, v.w}, s0 = {sc.x, sc.y}, s1 = {sc.z, sc.w}, h0 = {sh.x, sh.y}, h1 = {sh.z, sh.w};
+    const f32x2_t m0 = v0 * s0, m1 = v1 * s1;
+    const f32x2_t r0 = m0 + h0, r1 = m1 + h1;
+    return make_float4(r0.x, r0.y, r1.x, r1.y);
+}
+
 constexpr int kNumXcd = 8;   // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
 
 // ---- device helpers --------------------------------------------------------------------------------

@@ -70,6 +70,7 @@ __device__ __forceinline__ float blk_frame_value(const TIn* img, int H, int W, i
 // TIn = void: the block input is an f32 activation tensor; uint8_t / float: STEM form, the input is the frame batch
 template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false>
 __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntiles) {
+    constexpr bool PKDW = S == 1 || TH == 2;          // packed f32 in the depthwise phase (see there)
     constexpr bool STEM = !std::is_void<TIn>::value;
     static_assert(!(X6 && STEM), "the stem stays exact f32");
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
@@ -300,12 +301,19 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    acc.x = fmaf(tp9[k].x, w9[k].x, acc.x); acc.y = fmaf(tp9[k].y, w9[k].y, acc.y);
-                    acc.z = fmaf(tp9[k].z, w9[k].z, acc.z); acc.w = fmaf(tp9[k].w, w9[k].w, acc.w);
+                    // packed f32 halves the issue slots of the depthwise phase; the 4 x 8 stride-2 tile of the split form has no
+                    // registers left for the aligned pairs (60 spilled VGPRs, 159 -> 254 us): scalar there
+                    if (PKDW) fma4_pk(acc, tp9[k], w9[k]);
+                    else {
+                        acc.x = fmaf(tp9[k].x, w9[k].x, acc.x); acc.y = fmaf(tp9[k].y, w9[k].y, acc.y);
+                        acc.z = fmaf(tp9[k].z, w9[k].z, acc.z); acc.w = fmaf(tp9[k].w, w9[k].w, acc.w);
+                    }
                 }
                 float dv[4];
-                dv[0] = __builtin_amdgcn_fmed3f(acc.x * scd.x + shd.x, lo_d, hi_d); dv[1] = __builtin_amdgcn_fmed3f(acc.y * scd.y + shd.y, lo_d, hi_d);
-                dv[2] = __builtin_amdgcn_fmed3f(acc.z * scd.z + shd.z, lo_d, hi_d); dv[3] = __builtin_amdgcn_fmed3f(acc.w * scd.w + shd.w, lo_d, hi_d);
+                const float4 bn = PKDW ? muladd4_pk(acc, scd, shd)
+                                       : make_float4(acc.x * scd.x + shd.x, acc.y * scd.y + shd.y, acc.z * scd.z + shd.z, acc.w * scd.w + shd.w);
+                dv[0] = __builtin_amdgcn_fmed3f(bn.x, lo_d, hi_d); dv[1] = __builtin_amdgcn_fmed3f(bn.y, lo_d, hi_d);
+                dv[2] = __builtin_amdgcn_fmed3f(bn.z, lo_d, hi_d); dv[3] = __builtin_amdgcn_fmed3f(bn.w, lo_d, hi_d);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll

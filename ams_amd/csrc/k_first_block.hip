@@ -194,9 +194,7 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
                     float4& o = acc[u - i];
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        const float4 ww = w[i * 3 + j];
-                        o.x = fmaf(x3[j].x, ww.x, o.x); o.y = fmaf(x3[j].y, ww.y, o.y);
-                        o.z = fmaf(x3[j].z, ww.z, o.z); o.w = fmaf(x3[j].w, ww.w, o.w);
+                        fma4_pk(o, x3[j], w[i * 3 + j]);          // this phase is barrier-separated from the MFMA phases: packed f32 pays
                     }
                 }
             }
@@ -204,8 +202,9 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             float4 o;
-            o.x = __builtin_amdgcn_fmed3f(acc[r].x * sc.x + sh.x, lo_d, hi_d); o.y = __builtin_amdgcn_fmed3f(acc[r].y * sc.y + sh.y, lo_d, hi_d);
-            o.z = __builtin_amdgcn_fmed3f(acc[r].z * sc.z + sh.z, lo_d, hi_d); o.w = __builtin_amdgcn_fmed3f(acc[r].w * sc.w + sh.w, lo_d, hi_d);
+            const float4 bn = muladd4_pk(acc[r], sc, sh);
+            o.x = __builtin_amdgcn_fmed3f(bn.x, lo_d, hi_d); o.y = __builtin_amdgcn_fmed3f(bn.y, lo_d, hi_d);
+            o.z = __builtin_amdgcn_fmed3f(bn.z, lo_d, hi_d); o.w = __builtin_amdgcn_fmed3f(bn.w, lo_d, hi_d);
             st4(sD + ((g * RG + r) * TW + lx) * P + c4, o);
         }
     }

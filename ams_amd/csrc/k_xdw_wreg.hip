@@ -16,6 +16,14 @@
 
 namespace ams {
 
+// the depthwise FMAs of the D-waves: scalar.  -DAMS_XDW_PK makes them v_pk_fma_f32 — measured neutral here (the D-waves share their SIMD
+// with an E-wave that issues MFMAs all the time), unlike the whole-block kernel whose depthwise phase is its own phase
+#ifdef AMS_XDW_PK
+#define AMS_DW_FMA4(A_, V_, W_) fma4_pk(A_, V_, W_)
+#else
+#define AMS_DW_FMA4(A_, V_, W_) do { A_.x = fmaf(V_.x, W_.x, A_.x); A_.y = fmaf(V_.y, W_.y, A_.y); A_.z = fmaf(V_.z, W_.z, A_.z); A_.w = fmaf(V_.w, W_.w, A_.w); } while (0)
+#endif
+
 struct XwrArgs {
     const unsigned short* xs;        // operand as bf16 parts [part][B*H*W][Cin], part p at xs + p * xs_plane
     int64_t xs_plane;
@@ -260,8 +268,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                             for (int j = 0; j < 3; ++j) {
                                 const float4 vv = v[i][u + j];
                                 const float4 w4 = wv[i * 3 + j];
-                                acc4.x = fmaf(vv.x, w4.x, acc4.x); acc4.y = fmaf(vv.y, w4.y, acc4.y);
-                                acc4.z = fmaf(vv.z, w4.z, acc4.z); acc4.w = fmaf(vv.w, w4.w, acc4.w);
+                                AMS_DW_FMA4(acc4, vv, w4);
                             }
                         float4 o;
                         o.x = apply_act(acc4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(acc4.y * dsc.y + dsh.y, a.act_d);

@@ -23,17 +23,31 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
         p1[j] = (__bf16)(f[j] - (float)h);
     }
 }
+// Three parts, written pair by pair so that every conversion is one v_cvt_pk_bf16_f32 on two values and every remainder one
+// v_pk_add_f32 (9 instructions per pair; the element-wise form compiled to ~12 with single-value conversions and byte permutes).
+// Same roundings: hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid), the subtractions are exact.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2s_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const f32x2s_t f = {a, b};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+    const f32x2s_t hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    const f32x2s_t r1 = f - hf;
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_t));
+    const f32x2s_t mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    const f32x2s_t r2 = r1 - mf;
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+}
 __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-    const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)f[j];
-        const float r1 = f[j] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        p0[j] = h;
-        p1[j] = m;
-        p2[j] = (__bf16)(r1 - (float)m);
-    }
+    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    split_pair(u.x, u.y, h0, m0, l0);
+    split_pair(u.z, u.w, h1, m1, l1);
+    split_pair(v.x, v.y, h2, m2, l2);
+    split_pair(v.z, v.w, h3, m3, l3);
+    const u32x4 h = {h0, h1, h2, h3}, m = {m0, m1, m2, m3}, l = {l0, l1, l2, l3};
+    p0 = __builtin_bit_cast(bf16x8, h);
+    p1 = __builtin_bit_cast(bf16x8, m);
+    p2 = __builtin_bit_cast(bf16x8, l);
 }
 
 }  // namespace ams

@@ -130,6 +130,7 @@ struct ams_student {
                                                // 0 three kernels, 1 tile per block (k_first_block.hip), 2 tile per wave (k_block.hip:
                                                // same bits, measured slower here: 488 vs 428 us at 32 frames — the 27-tap byte gather
                                                // per wave outweighs the barriers it saves)
+    int64_t stream_min_rows = 16384;           // rows (frames x pixels at the block's resolution) from which the streaming kernels run
     int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
                                                // in one streaming kernel (k_xdw_stream.hip): 0 never, 1 where measured
                                                // faster (Cin 64 / 96, >= 16384 rows), 2 also the 160-channel blocks
@@ -476,7 +477,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
     // frames: below that the launch cannot fill the chip)
     auto stream_ok = [&](int k) {
         if (!(s->fuse_expand_dw_stream && k + 1 <= s->n_backbone && s->L[k].d.role == AMS_ROLE_EXPAND && s->L[k + 1].d.role == AMS_ROLE_DEPTHWISE &&
-              (int64_t)B * s->L[k].px_in >= 16384 && (int64_t)s->L[k + 1].px_out * s->L[k + 1].d.cout * 4 < 0x7fffffffLL &&
+              (int64_t)B * s->L[k].px_in >= s->stream_min_rows && (int64_t)s->L[k + 1].px_out * s->L[k + 1].d.cout * 4 < 0x7fffffffLL &&
               expand_dw_stream_supported(s->L[k].d.cin, s->L[k].d.cout, s->L[k + 1].d.stride, s->L[k + 1].d.rate)))
             return false;
         // stride 2 on the streaming kernel is correct and tested but measured no faster than the tiled kernel (the expand runs at
@@ -954,6 +955,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     s->arena_bytes = arena_bytes;
     if (const char* e = getenv("AMS_BLOCK_X6")) s->block_x6 = atoi(e);                       // tuning knob (see AMS_OPT_BLOCK_X6)
     if (const char* e = getenv("AMS_LATE_SUB")) s->late_subbatch = atoi(e);                  // tuning knob (see AMS_OPT_LATE_SUBBATCH)
+    if (const char* e = getenv("AMS_STREAM_MIN_ROWS")) s->stream_min_rows = atoll(e);        // tuning knob
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     *out = s;

@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
                     else split8(abuf[d][r][0], abuf[d][r][1], x0[r]);
                 }
                 const unsigned short* bw = &sW[d & 1][0][l15 * PITCH + 8 * (q ^ ((l15 >> 3) << 1))];
-                // Column tiles are taken TG at a time (TG * NP weight fragments live).
+                // Per accumulator the six products arrive in a fixed order (smallest terms first), but consecutive MFMAs go to
+                // DIFFERENT accumulators: a dependent MFMA waits for its predecessor's 8 passes (~2.5 issue slots), and hipcc
+                // keeps the source order.  Column tiles are taken TG at a time (TG * RM chains in flight, TG * NP fragments live).
                 constexpr int TG = (NT >= 2 && RM <= 2) ? 2 : 1;        // an odd NT ends with a group of one
 #pragma unroll
                 for (int t0 = 0; t0 < NT; t0 += TG) {
@@ -190,28 +192,22 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
                         if (NP >= 2) q1[g] = *reinterpret_cast<const bf16x8*>(bw + (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
                         if (NP == 3) q2[g] = *reinterpret_cast<const bf16x8*>(bw + 2 * (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
                     }
-                    // The products of one accumulator back to back, smallest terms first.  A bf16 MFMA that reuses the accumulator of
-                    // its predecessor issues at the pipe rate (7.4 ns); rotating over four accumulators costs 8.1-8.9 ns each
-                    // (tools/probes/mfma_chain_probe.hip) — the hardware forwards the accumulator, there is no dependency stall to hide.
-#pragma unroll
-                    for (int g = 0; g < TG; ++g) {
-                        if (t0 + g >= NT) continue;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            f32x4 c = acc[r][t0 + g];
-                            if (NP == 3) {
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[g], x0[r], c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[g], x2[r], c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[g], x1[r], c, 0, 0, 0);
-                            }
-                            if (NP >= 2) {
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1[g], x0[r], c, 0, 0, 0);
-                                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[g], x1[r], c, 0, 0, 0);
-                            }
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[g], x0[r], c, 0, 0, 0);
-                            acc[r][t0 + g] = c;
-                        }
+#define AMS_X3_TERM(QA, XB)                                                                                          \
+    _Pragma("unroll") for (int g = 0; g < TG; ++g)                                                                   \
+        _Pragma("unroll") for (int r = 0; r < R; ++r)                                                                \
+            if (t0 + g < NT)                                                                                         \
+                acc[r][t0 + g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(QA[g], XB[r], acc[r][t0 + g], 0, 0, 0);
+                    if (NP == 3) {           // smallest terms first
+                        AMS_X3_TERM(q2, x0)
+                        AMS_X3_TERM(q0, x2)
+                        AMS_X3_TERM(q1, x1)
                     }
+                    if (NP >= 2) {
+                        AMS_X3_TERM(q1, x0)
+                        AMS_X3_TERM(q0, x1)
+                    }
+                    AMS_X3_TERM(q0, x0)
+#undef AMS_X3_TERM
                 }
             }
             store_stage((d + 1) & 1, wring[(d + 1) % D]);

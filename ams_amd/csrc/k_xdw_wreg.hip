@@ -160,14 +160,25 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 for (int rg = 0; rg < NRG; ++rg) { acc[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
                 if (active) {
                     const u32x4* ap = sA + par * AUNITS + q * 16 + l15;
+                    // the operand fragments of k-step s + 1 are requested before the MFMAs of k-step s: with one E-wave per SIMD nothing
+                    // else hides the LDS round trip (five exposed waits per step otherwise)
+                    bf16x8 xa[2][NP][NRG];
+                    auto load_x = [&](int s, bf16x8 (&dst)[NP][NRG]) {
+#pragma unroll
+                        for (int rg = 0; rg < NRG; ++rg)
+#pragma unroll
+                            for (int pp = 0; pp < NP; ++pp) dst[pp][rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + pp) * KS + s) * 64]);
+                    };
+                    load_x(0, xa[0]);
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
+                        if (s + 1 < KS) load_x(s + 1, xa[(s + 1) & 1]);
                         bf16x8 x0[NRG], x1[NRG], x2[NRG];
 #pragma unroll
                         for (int rg = 0; rg < NRG; ++rg) {
-                            x0[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + 0) * KS + s) * 64]);
-                            if (NP >= 2) x1[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + (NP >= 2 ? 1 : 0)) * KS + s) * 64]);
-                            if (NP == 3) x2[rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + NP - 1) * KS + s) * 64]);
+                            x0[rg] = xa[s & 1][0][rg];
+                            if (NP >= 2) x1[rg] = xa[s & 1][NP >= 2 ? 1 : 0][rg];
+                            if (NP == 3) x2[rg] = xa[s & 1][NP - 1][rg];
                         }
                         // per accumulator the products of pw_gemm_bf16x3_l in its order (smallest terms first); consecutive MFMAs
                         // go to different accumulators

@@ -35,6 +35,11 @@ struct ClassTable {
     int32_t lut[256];        // teacher id -> subset index, -1 = ignored
 };
 
+// KMAX > 0: K <= KMAX and the K horizontally interpolated values of the two source rows live in registers while the thread walks
+// DOWN its column through a band of consecutive output rows — they change only when the source row does (every ~16 output rows at
+// 512 from 33), so an output pixel costs K vertical lerps + the argmax instead of 4K loads and 3K lerps.  Same arithmetic in the same
+// order per pixel (horizontal, then vertical, unfused): bit-identical labels.  KMAX = 0: any K <= kMaxK, everything per pixel.
+template <int KMAX>
 __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __restrict__ logits, HeadGeom g, ClassTable ct,
                                                               const uint8_t* __restrict__ teacher,
                                                               int32_t* __restrict__ labels,
@@ -53,9 +58,14 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
     int x0 = 0, x1 = 0; float tx = 0.f;
     if (x < g.W) src_tap(x, g.sx, g.w, x0, x1, tx);
     const float* base = logits + (int64_t)b * g.h * g.w * g.ld;
-    // a block walks rows blockIdx.y, blockIdx.y + gridDim.y, ...: the confusion counts and the loss leave the block once
-    // (the global atomics on a handful of addresses were the cost of the metric path with one row per block)
-    for (int y = blockIdx.y; y < g.H; y += gridDim.y) {
+    // a block walks a band of consecutive rows: the confusion counts and the loss leave the block once (the global atomics on a
+    // handful of addresses were the cost of the metric path with one row per block)
+    const int band = (g.H + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int ybeg = blockIdx.y * band, yend = ybeg + band < g.H ? ybeg + band : g.H;
+    constexpr int KR = KMAX > 0 ? KMAX : 1;
+    float top[KR], bot[KR];
+    int cur_y0 = -1;
+    for (int y = ybeg; y < yend; ++y) {
         if (x >= g.W) break;
         int y0, y1; float ty;
         src_tap(y, g.sy, g.h, y0, y1, ty);
@@ -63,14 +73,21 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
         const float* ptr = base + ((int64_t)y0 * g.w + x1) * g.ld;
         const float* pbl = base + ((int64_t)y1 * g.w + x0) * g.ld;
         const float* pbr = base + ((int64_t)y1 * g.w + x1) * g.ld;
+        if (KMAX > 0 && y0 != cur_y0) {               // block-uniform (one output row per iteration)
+            cur_y0 = y0;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int c = ct.idx[k < g.K ? k : 0];
+                top[k] = __fadd_rn(ptl[c], __fmul_rn(__fsub_rn(ptr[c], ptl[c]), tx));
+                bot[k] = __fadd_rn(pbl[c], __fmul_rn(__fsub_rn(pbr[c], pbl[c]), tx));
+            }
+        }
         const int64_t pix = ((int64_t)b * g.H + y) * g.W + x;
         int target = -1;
         if (metric) target = ct.lut[teacher[pix]];
         float best = 0.f, zt = 0.f, zmax = 0.f, ssum = 0.f;
         int arg = 0;
-        for (int k = 0; k < g.K; ++k) {
-            const int c = ct.idx[k];
-            const float v = bilerp(ptl[c], ptr[c], pbl[c], pbr[c], tx, ty);
+        auto visit = [&](int k, float v) {
             if (k == 0 || v > best) { best = v; arg = k; }        // first maximum wins (tf.argmax)
             if (target >= 0) {
                 // streaming log-sum-exp: keep the running max, rescale the running sum
@@ -78,6 +95,16 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
                 else if (v > zmax) { ssum = ssum * __expf(zmax - v) + 1.f; zmax = v; }
                 else ssum += __expf(v - zmax);
                 if (k == target) zt = v;
+            }
+        };
+        if (KMAX > 0) {
+#pragma unroll
+            for (int k = 0; k < KR; ++k)
+                if (k < g.K) visit(k, __fadd_rn(top[k], __fmul_rn(__fsub_rn(bot[k], top[k]), ty)));
+        } else {
+            for (int k = 0; k < g.K; ++k) {
+                const int c = ct.idx[k];
+                visit(k, bilerp(ptl[c], ptr[c], pbl[c], pbr[c], tx, ty));
             }
         }
         if (labels) labels[pix] = arg;
@@ -136,9 +163,15 @@ int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, con
     }
     const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
     note_kernel("upsample_argmax_kernel");
-    const int rows_y = teacher ? (H < 32 ? H : 32) : H;          // metric path: 32 row-walkers per column strip and image
-    hipLaunchKernelGGL(upsample_argmax_kernel, dim3(cdiv(W, 256), rows_y, B), dim3(256), 0, st, logits, g, ct, teacher, labels,
-                       (unsigned long long*)conf, loss);
+    // bands of consecutive rows per block: 32 per column strip and image, fewer rows per band when that leaves the chip short of blocks
+    int rows_y = H < 32 ? H : 32;
+    while (rows_y < H && (int64_t)cdiv(W, 256) * rows_y * B < 2048) rows_y *= 2;
+    if (rows_y > H) rows_y = H;
+    const dim3 grid(cdiv(W, 256), rows_y, B);
+    if (K <= 8)
+        hipLaunchKernelGGL(upsample_argmax_kernel<8>, grid, dim3(256), 0, st, logits, g, ct, teacher, labels, (unsigned long long*)conf, loss);
+    else
+        hipLaunchKernelGGL(upsample_argmax_kernel<0>, grid, dim3(256), 0, st, logits, g, ct, teacher, labels, (unsigned long long*)conf, loss);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

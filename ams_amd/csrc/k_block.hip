@@ -266,10 +266,11 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
                 const bool inside = (inside_mask >> rg) & 1u;
                 const float lo = inside ? lo_e : 0.f, hi = inside ? hi_e : 0.f;
                 float4 v;
-                v.x = __builtin_amdgcn_fmed3f(acc[0] * sc.x + sh.x, lo, hi);
-                v.y = __builtin_amdgcn_fmed3f(acc[1] * sc.y + sh.y, lo, hi);
-                v.z = __builtin_amdgcn_fmed3f(acc[2] * sc.z + sh.z, lo, hi);
-                v.w = __builtin_amdgcn_fmed3f(acc[3] * sc.w + sh.w, lo, hi);
+                const float4 bn = muladd4_pk(make_float4(acc[0], acc[1], acc[2], acc[3]), sc, sh);      // v_pk_mul + v_pk_add: two roundings
+                v.x = __builtin_amdgcn_fmed3f(bn.x, lo, hi);
+                v.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
+                v.z = __builtin_amdgcn_fmed3f(bn.z, lo, hi);
+                v.w = __builtin_amdgcn_fmed3f(bn.w, lo, hi);
                 st4(sAct + (rg * 16 + l15) * AP + 4 * q, v);
             }
         }
@@ -340,8 +341,9 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
             if (c4 >= a.Cout) continue;
             const float4 sc = ld4(a.sc_p + c4), sh = ld4(a.sh_p + c4);
             float4 v;
-            v.x = apply_act(out[i][t][0] * sc.x + sh.x, a.act_p); v.y = apply_act(out[i][t][1] * sc.y + sh.y, a.act_p);
-            v.z = apply_act(out[i][t][2] * sc.z + sh.z, a.act_p); v.w = apply_act(out[i][t][3] * sc.w + sh.w, a.act_p);
+            const float4 bn = muladd4_pk(make_float4(out[i][t][0], out[i][t][1], out[i][t][2], out[i][t][3]), sc, sh);
+            v.x = apply_act(bn.x, a.act_p); v.y = apply_act(bn.y, a.act_p);
+            v.z = apply_act(bn.z, a.act_p); v.w = apply_act(bn.w, a.act_p);
             if (!STEM && a.residual) {
                 const float4 r = ld4(xb + ((int64_t)oy * a.W + ox) * a.Cin + c4);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;

@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
                 // one v_med3 per value: clamp to the activation's bounds, both 0 outside the feature map (the depthwise conv's padding)
                 const float lo = live[i] ? lo_s : 0.f, hi = live[i] ? hi_s : 0.f;
                 float4 o;
-                o.x = __builtin_amdgcn_fmed3f(acc[t][0] * sc.x + sh.x, lo, hi);
-                o.y = __builtin_amdgcn_fmed3f(acc[t][1] * sc.y + sh.y, lo, hi);
-                o.z = __builtin_amdgcn_fmed3f(acc[t][2] * sc.z + sh.z, lo, hi);
-                o.w = __builtin_amdgcn_fmed3f(acc[t][3] * sc.w + sh.w, lo, hi);
+                const float4 bn = muladd4_pk(make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]), sc, sh);
+                o.x = __builtin_amdgcn_fmed3f(bn.x, lo, hi);
+                o.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
+                o.z = __builtin_amdgcn_fmed3f(bn.z, lo, hi);
+                o.w = __builtin_amdgcn_fmed3f(bn.w, lo, hi);
                 if (rg * 16 + l15 < NPIX) st4(sS + (rg * 16 + l15) * P + n4, o);
             }
         }
@@ -227,8 +228,9 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
         }
         const float4 sc = ld4(sAff + 128 + 4 * q), sh = ld4(sAff + 144 + 4 * q);
         float4 o;
-        o.x = apply_act(acc[0] * sc.x + sh.x, a.act_p); o.y = apply_act(acc[1] * sc.y + sh.y, a.act_p);
-        o.z = apply_act(acc[2] * sc.z + sh.z, a.act_p); o.w = apply_act(acc[3] * sc.w + sh.w, a.act_p);
+        const float4 bn = muladd4_pk(make_float4(acc[0], acc[1], acc[2], acc[3]), sc, sh);
+        o.x = apply_act(bn.x, a.act_p); o.y = apply_act(bn.y, a.act_p);
+        o.z = apply_act(bn.z, a.act_p); o.w = apply_act(bn.w, a.act_p);
         const int oy = oy0 + row, ox = ox0 + l15;
         if (oy < a.Ho && ox < a.Wo) st4(yb + ((int64_t)oy * a.Wo + ox) * 16 + 4 * q, o);
     }

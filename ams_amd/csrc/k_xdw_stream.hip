@@ -232,8 +232,9 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                         // depthwise conv, halo outside the sub-image)
                         const float lo = inside ? (a.act_e == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f) : 0.f;
                         const float hi = inside ? (a.act_e == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf()) : 0.f;
-                        v.x = __builtin_amdgcn_fmed3f(acc[tt][0] * sc.x + sh.x, lo, hi); v.y = __builtin_amdgcn_fmed3f(acc[tt][1] * sc.y + sh.y, lo, hi);
-                        v.z = __builtin_amdgcn_fmed3f(acc[tt][2] * sc.z + sh.z, lo, hi); v.w = __builtin_amdgcn_fmed3f(acc[tt][3] * sc.w + sh.w, lo, hi);
+                        const float4 bn = muladd4_pk(make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]), sc, sh);
+                        v.x = __builtin_amdgcn_fmed3f(bn.x, lo, hi); v.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
+                        v.z = __builtin_amdgcn_fmed3f(bn.z, lo, hi); v.w = __builtin_amdgcn_fmed3f(bn.w, lo, hi);
                         st4(dst + 16 * tt, v);
                         // the first MIRROR slots of the ring are repeated after its end: a D-thread's run of taps never wraps
                         if (mirror) st4(dst + R * PITCH + 16 * tt, v);

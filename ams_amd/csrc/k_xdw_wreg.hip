@@ -209,10 +209,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         float4 v;
-                        v.x = __builtin_amdgcn_fmed3f(acc[rg][tt][0] * esc[tt].x + esh[tt].x, lo, hi);
-                        v.y = __builtin_amdgcn_fmed3f(acc[rg][tt][1] * esc[tt].y + esh[tt].y, lo, hi);
-                        v.z = __builtin_amdgcn_fmed3f(acc[rg][tt][2] * esc[tt].z + esh[tt].z, lo, hi);
-                        v.w = __builtin_amdgcn_fmed3f(acc[rg][tt][3] * esc[tt].w + esh[tt].w, lo, hi);
+                        const float4 bn = muladd4_pk(make_float4(acc[rg][tt][0], acc[rg][tt][1], acc[rg][tt][2], acc[rg][tt][3]), esc[tt], esh[tt]);
+                        v.x = __builtin_amdgcn_fmed3f(bn.x, lo, hi);
+                        v.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
+                        v.z = __builtin_amdgcn_fmed3f(bn.z, lo, hi);
+                        v.w = __builtin_amdgcn_fmed3f(bn.w, lo, hi);
                         st4(dst + 16 * tt, v);
                         if (mirror) st4(dst + R * PITCH + 16 * tt, v);
                     }

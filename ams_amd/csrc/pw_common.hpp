@@ -66,8 +66,9 @@ __device__ __forceinline__ void pw_epilogue(const PwArgs& a, f32x4 (&acc)[RM][NT
             if (n4 >= a.N) continue;
             const float4 sc = ld4(sSc + c4), sh = ld4(sSh + c4);
             float4 v;
-            v.x = apply_act(acc[r][t][0] * sc.x + sh.x, a.act); v.y = apply_act(acc[r][t][1] * sc.y + sh.y, a.act);
-            v.z = apply_act(acc[r][t][2] * sc.z + sh.z, a.act); v.w = apply_act(acc[r][t][3] * sc.w + sh.w, a.act);
+            const float4 bn = muladd4_pk(make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]), sc, sh);   // packed, two roundings
+            v.x = apply_act(bn.x, a.act); v.y = apply_act(bn.y, a.act);
+            v.z = apply_act(bn.z, a.act); v.w = apply_act(bn.w, a.act);
             if (has_add && a.res) { v.x += add[t].x; v.y += add[t].y; v.z += add[t].z; v.w += add[t].w; }
             float* yp = a.y + m * a.ldy + n4;
             if (n4 + 3 < a.N && y_vec) st4(yp, v);
@@ -120,8 +121,9 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
             const int c4 = 16 * t + 4 * q;
             const float4 sc = ld4(sSc + c4), sh = ld4(sSh + c4);
             float4 v;
-            v.x = apply_act(acc[r][t][0] * sc.x + sh.x, a.act); v.y = apply_act(acc[r][t][1] * sc.y + sh.y, a.act);
-            v.z = apply_act(acc[r][t][2] * sc.z + sh.z, a.act); v.w = apply_act(acc[r][t][3] * sc.w + sh.w, a.act);
+            const float4 bn = muladd4_pk(make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]), sc, sh);   // packed, two roundings
+            v.x = apply_act(bn.x, a.act); v.y = apply_act(bn.y, a.act);
+            v.z = apply_act(bn.z, a.act); v.w = apply_act(bn.w, a.act);
             st4(sOut + l15 * OP + c4, v);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -198,7 +198,14 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.wlo3 = l.whi ? l.whi + 2 * plane : nullptr;
         }
     }
-    if (s->n_backbone >= 3 && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE) s->L[1].blk_vecs = cv.take<float>(13 * 32);
+    if (s->n_backbone >= 3 && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE) {
+        LayerRt& l1 = s->L[1];
+        l1.blk_vecs = cv.take<float>(13 * 32);
+        l1.Kp = 32;                                        // stem weights as three bf16 parts [32][32] for the first-block kernel's split form
+        l1.whi = cv.take<uint16_t>(3 * 32 * 32);
+        l1.wlo = l1.whi ? l1.whi + 32 * 32 : nullptr;
+        l1.wlo3 = l1.whi ? l1.whi + 2 * 32 * 32 : nullptr;
+    }
     for (int i = 2; i + 2 <= s->n_backbone; ++i) {      // whole-block kernels: packed per-channel tables, filled by freeze
         LayerRt& l = s->L[i];
         if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE && s->L[i + 2].d.role == AMS_ROLE_PROJECT &&
@@ -460,10 +467,12 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
                 RUNK(3, bytes, launch_first_block_tiles(frames, dtype, B, c.height, c.width, c.pixel_scale, P + l.d.w_off, l.fscale, l.fshift,
                                                         l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
                                                         lj.fshift, lj.d.act, cur, st, l.blk_vecs));
-            else
+            else {
+                const bool x6 = s->block_x6 && s->matmul_mode != AMS_MATMUL_F32 && l.whi;
                 RUNK(3, bytes, launch_first_block(frames, dtype, B, c.height, c.width, c.pixel_scale, P + l.d.w_off, l.fscale, l.fshift,
                                                   l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
-                                                  lj.fshift, lj.d.act, cur, st));
+                                                  lj.fshift, lj.d.act, cur, st, x6 ? l.whi : nullptr, 32 * 32));
+            }
             i = 4;
         } else {
             const double bytes = in_bytes + 4.0 * B * l.px_out * l.d.cout;
@@ -1007,6 +1016,8 @@ int ams_student_freeze(ams_student* s, void* stream) {
         LayerRt& ld = s->L[i + 1];
         if (l.blk_vecs) RUN(launch_block_pack(l.fscale, l.fshift, ld.fscale, ld.fshift, s->fparams + ld.d.w_off, l.d.cout, l.blk_vecs, st));
     }
+    if (s->L[1].whi)        // stem: [27][32] -> parts [32][32], k = tap * 3 + channel
+        RUN(launch_split_weights3(s->fparams + s->L[1].d.w_off, 32, 1, 27, 32, 32, s->L[1].whi, s->L[1].wlo, s->L[1].wlo3, st));
     for (int i = 2; i <= s->cfg.n_layers; ++i) {
         LayerRt& l = s->L[i];
         if (!l.whi) continue;

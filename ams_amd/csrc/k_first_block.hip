@@ -14,6 +14,7 @@
 //            consecutive pixels per lane group: full lines without a transpose).
 // Arithmetic per element is the same as in the three separate kernels (same tap order, same MFMA chunking).
 #include "pw_common.hpp"
+#include "split_bf16.hpp"
 
 namespace ams {
 
@@ -30,7 +31,19 @@ struct FirstBlockArgs {
     float* y;                               // [B,Ho,Wo,16]
     int Ho, Wo, pt, pl;                     // stem output size and its SAME padding on the 127.5-padded frame
     int tiles_x, tiles_y;
+    const uint16_t* w_parts;                // X6 form: stem weights as three bf16 parts [part][32 channels][32 k], parts w_plane apart
+    int64_t w_plane;
 };
+
+// X6 form: index into the normalisation table of the tap (0..255 the byte, 256 the 127.5 padding row / column, 257 = zero: outside)
+__device__ __forceinline__ int fb_frame_index(const uint8_t* img, int H, int W, int iy, int ix, int ch) {
+    const bool inside = iy >= 0 && ix >= 0 && iy <= H && ix <= W;
+    const bool pad = iy >= H || ix >= W;
+    const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    const int ixc = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+    const int raw = img[((int64_t)iyc * W + ixc) * 3 + ch];
+    return inside ? (pad ? 256 : raw) : 257;
+}
 
 template <typename TIn>
 __device__ __forceinline__ float fb_frame_value(const TIn* img, int H, int W, int iy, int ix, int ch, float ps) {
@@ -45,8 +58,14 @@ __device__ __forceinline__ float fb_frame_value(const TIn* img, int H, int W, in
     return inside ? v : 0.f;
 }
 
-template <typename TIn>
+// X6 (uint8 frames only): the stem's products as six bf16 MFMAs on three-part splits, like the late layers and the other early blocks
+// (96 instead of 256 matrix-pipe cycles per 16 positions x 16 channels).  A frame value has 256 possible inputs (+ the 127.5 padding
+// and the zero outside the padded frame), so the three parts of x * ps - 1 come from a 258-entry LDS table built per block: a tap
+// costs one byte load, one shift and one ds_read_b64 instead of convert + multiply + subtract + split.  Not bit-identical to the
+// exact-f32 stem (f32-level: the dropped terms are <= 2^-24 relative).
+template <typename TIn, bool X6 = false>
 __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsigned nblocks) {
+    constexpr bool TAB = X6 && sizeof(TIn) == 1;      // float frames: the same parts by splitting in registers (same bits, more VALU)
     constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
     constexpr int NRG = (NPIX + 15) / 16;             // 12 row groups of stem positions
     constexpr int P = 36;                             // pitch of the 32-channel rows (stride 144 B: conflict-free b128 passes)
@@ -57,6 +76,7 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     __shared__ __attribute__((aligned(16))) float sDw[9 * 32];
     __shared__ __attribute__((aligned(16))) float sWp[32 * PW];
     __shared__ __attribute__((aligned(16))) float sAff[32 * 4 + 16 * 2];      // sc_s, sh_s, sc_d, sh_d, sc_p, sh_p
+    __shared__ __attribute__((aligned(8))) uint2 sTab[TAB ? 258 : 1];          // X6: {hi | mid << 16, lo} bf16 parts of the normalised value
 
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     const int tx = lb % a.tiles_x;
@@ -69,9 +89,19 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     const float lo_s = a.act_s == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_s = a.act_s == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     const float lo_d = a.act_d == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_d = a.act_d == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
 
-    for (int e = tid; e < 28 * 32; e += 256) {
-        const int kk = e >> 5, nn = e & 31;
-        sW[kk * P + nn] = kk < 27 ? a.w_stem[kk * 32 + nn] : 0.f;
+    if constexpr (TAB) {
+        for (int e = tid; e < 258; e += 256) {
+            const float raw = e < 256 ? (float)e : 127.5f;
+            const float val = e < 257 ? __fsub_rn(__fmul_rn(raw, a.ps), 1.0f) : 0.f;
+            unsigned h, m, l;
+            split_pair(val, 0.f, h, m, l);
+            sTab[e] = make_uint2((h & 0xffffu) | (m << 16), l & 0xffffu);
+        }
+    } else if constexpr (!X6) {
+        for (int e = tid; e < 28 * 32; e += 256) {
+            const int kk = e >> 5, nn = e & 31;
+            sW[kk * P + nn] = kk < 27 ? a.w_stem[kk * 32 + nn] : 0.f;
+        }
     }
     for (int e = tid; e < 9 * 32; e += 256) sDw[e] = a.w_dw[e];
     for (int e = tid; e < 32 * 16; e += 256) sWp[(e >> 4) * PW + (e & 15)] = a.w_pj[e];
@@ -85,7 +115,7 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     int tdy[8], tdx[8], tch[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int k = 16 * (u >> 2) + 4 * q + (u & 3);
+        const int k = X6 ? 8 * q + u : 16 * (u >> 2) + 4 * q + (u & 3);      // X6: one bf16 MFMA covers k = 8q .. 8q + 7
         const int tap = k / 3;
         tch[u] = k < 27 ? k - tap * 3 : -1;
         tdy[u] = tap / 3;
@@ -93,8 +123,17 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     }
     const TIn* img = reinterpret_cast<const TIn*>(a.frames) + (int64_t)b * a.H * a.W * 3;
     constexpr int MRG = (NRG + 3) / 4;
-    float v[MRG][8];
+    float v[TAB ? 1 : MRG][8];
+    int vi[TAB ? MRG : 1][8];                         // table form: table indices of the taps
     bool live[MRG];
+    bf16x8 wq[2][3];                                  // X6: this lane's stem-weight fragments (channel 16 t + l15, k = 8q .. 8q + 7), three parts
+    if constexpr (X6) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+                wq[t][pp] = *reinterpret_cast<const bf16x8*>(a.w_parts + pp * a.w_plane + (int64_t)(16 * t + l15) * 32 + 8 * q);
+    }
     // Interior tiles (all but the outermost ring): every stem position of the halo tile exists and every tap lies inside the
     // H x W frame, so a tap is one add, one byte load and the two-rounding normalisation — no clamps, no pad selects (the
     // border arithmetic was a quarter of the kernel's issue cycles).  Block-uniform branch.
@@ -117,8 +156,13 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
             const TIn* p0 = img + ((int64_t)iy0 * a.W + ix0) * 3;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float t = __fsub_rn(__fmul_rn((float)p0[toff[u]], a.ps), 1.0f);
-                v[i][u] = tch[u] >= 0 ? t : 0.f;
+                if constexpr (TAB) {
+                    const int raw = p0[toff[u]];
+                    vi[i][u] = tch[u] >= 0 ? raw : 257;
+                } else {
+                    const float t = __fsub_rn(__fmul_rn((float)p0[toff[u]], a.ps), 1.0f);
+                    v[i][u] = tch[u] >= 0 ? t : 0.f;
+                }
             }
         }
     } else {
@@ -133,8 +177,13 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
             const int iy0 = sy * 2 - a.pt, ix0 = sx * 2 - a.pl;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float t = fb_frame_value(img, a.H, a.W, iy0 + tdy[u], ix0 + tdx[u], tch[u] < 0 ? 0 : tch[u], a.ps);
-                v[i][u] = tch[u] >= 0 ? t : 0.f;
+                if constexpr (TAB) {
+                    const int idx = fb_frame_index(reinterpret_cast<const uint8_t*>(img), a.H, a.W, iy0 + tdy[u], ix0 + tdx[u], tch[u] < 0 ? 0 : tch[u]);
+                    vi[i][u] = tch[u] >= 0 ? idx : 257;
+                } else {
+                    const float t = fb_frame_value(img, a.H, a.W, iy0 + tdy[u], ix0 + tdx[u], tch[u] < 0 ? 0 : tch[u], a.ps);
+                    v[i][u] = tch[u] >= 0 ? t : 0.f;
+                }
             }
         }
     }
@@ -146,12 +195,42 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
             f32x4 acc[2];
             acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (X6) {
+                uint2 e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if constexpr (TAB) e[u] = sTab[vi[i][u]];
+                    else {
+                        unsigned h, m, l;
+                        split_pair(v[i][u], 0.f, h, m, l);
+                        e[u] = make_uint2((h & 0xffffu) | (m << 16), l & 0xffffu);
+                    }
+                }
+                u32x4 p0, p1, p2;                                          // the lane's 8 taps as bf16 parts: element u of part p
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    p0[j] = __builtin_amdgcn_perm(e[2 * j + 1].x, e[2 * j].x, 0x05040100u);
+                    p1[j] = __builtin_amdgcn_perm(e[2 * j + 1].x, e[2 * j].x, 0x07060302u);
+                    p2[j] = __builtin_amdgcn_perm(e[2 * j + 1].y, e[2 * j].y, 0x05040100u);
+                }
+                const bf16x8 x0 = __builtin_bit_cast(bf16x8, p0), x1 = __builtin_bit_cast(bf16x8, p1), x2 = __builtin_bit_cast(bf16x8, p2);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {                              // smallest terms first, as in the split GEMM
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t][2], x0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t][0], x2, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t][1], x1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t][1], x0, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t][0], x1, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[t][0], x0, acc[t], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = 16 * (u >> 2) + 4 * q + (u & 3);
                 const float* sB = sW + (k < 27 ? k : 27) * P + l15;
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[0], v[i][u], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sB[16], v[i][u], acc[1], 0, 0, 0);
+            }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -238,7 +317,8 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
 
 int launch_first_block(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem,
                        const float* sc_s, const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d,
-                       int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st) {
+                       int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st,
+                       const uint16_t* w_parts, int64_t w_plane) {
     AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "first_block: frames must be uint8 or float32");
     FirstBlockArgs a;
     memset(&a, 0, sizeof(a));
@@ -246,12 +326,20 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
     a.w_stem = w_stem; a.sc_s = sc_s; a.sh_s = sh_s; a.act_s = act_s;
     a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d;
     a.w_pj = w_pj; a.sc_p = sc_p; a.sh_p = sh_p; a.act_p = act_p; a.y = y;
+    a.w_parts = w_parts; a.w_plane = w_plane;
     same_pad(H + 1, 3, 2, 1, &a.Ho, &a.pt);
     same_pad(W + 1, 3, 2, 1, &a.Wo, &a.pl);
     a.tiles_x = cdiv(a.Wo, 16);
     a.tiles_y = cdiv(a.Ho, 8);
     const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * B;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "first_block: bad grid");
+    if (w_parts) {                                  // three-part split products in the stem (see the kernel)
+        note_kernel(dtype == AMS_DT_U8 ? "first_block_kernel<unsigned char, true>" : "first_block_kernel<float, true>");
+        if (dtype == AMS_DT_U8) hipLaunchKernelGGL((first_block_kernel<uint8_t, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
+        else hipLaunchKernelGGL((first_block_kernel<float, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
+        AMS_CHECK_LAUNCH();
+        return AMS_OK;
+    }
     note_kernel(dtype == AMS_DT_U8 ? "first_block_kernel<unsigned char>" : "first_block_kernel<float>");
     if (dtype == AMS_DT_U8) hipLaunchKernelGGL(first_block_kernel<uint8_t>, dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
     else hipLaunchKernelGGL(first_block_kernel<float>, dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);

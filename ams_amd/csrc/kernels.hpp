@@ -68,7 +68,10 @@ int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st);
 // ---- k_first_block.hip : stem + depthwise + project of the first block in one kernel (frozen inference; 3 -> 32 -> 32 -> 16)
 int launch_first_block(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem,
                        const float* sc_s, const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d,
-                       int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st);
+                       int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st,
+                       const uint16_t* w_parts = nullptr, int64_t w_plane = 0);
+// w_parts: optional three-part bf16 panels [part][32][32] of the stem weights (k = tap * 3 + channel, zero-padded 27 -> 32): with them and
+// uint8 frames the stem's products run as six bf16 MFMAs, operands from a 258-entry table of the normalised byte values (f32-level)
 
 // ---- k_ingest.hip : frame / label resize on the device (run.py:179-183)
 int launch_resize_u8(const uint8_t* src, int Hs, int Ws, int C, int mode, int swap_rb, uint8_t* dst, int H, int W, hipStream_t st);

@@ -205,7 +205,8 @@ class StudentEngine:
 
     def set_fuse_first_block(self, on: int) -> None:
         """Frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel with a tile per block
-        (k_first_block.hip; default), 2 one kernel with a tile per wave (k_block.hip; measured slower).  Same bits in all three."""
+        (k_first_block.hip; default), 2 one kernel with a tile per wave (k_block.hip; measured slower).  Forms 0 and 2 keep an exact-f32 stem;
+        form 1 runs the stem as six bf16 products on three-part splits while set_block_x6 is on (default; f32-level), else the same bits."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_FIRST_BLOCK, int(on)), "ams_student_set_option")
 
     def set_fuse_dw_project(self, on: bool) -> None:
@@ -215,7 +216,7 @@ class StudentEngine:
 
     def set_block_x6(self, on: bool) -> None:
         """Whole-block kernels: expand products of the K = 24 / 32 blocks as six bf16 MFMAs on three-part splits (default on, f32-level)
-        or as exact f32 MFMAs (bit-identical to the layer-by-layer plan)."""
+        or as exact f32 MFMAs (bit-identical to the layer-by-layer plan).  Also selects the stem's products in the one-kernel first block."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_BLOCK_X6, int(bool(on))), "ams_student_set_option")
 
     def set_late_subbatch(self, frames: int) -> None:

@@ -189,7 +189,8 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_BLOCK_X6 = 8 /* whole-block kernels: 1 (default) the expand products of the blocks with 24 / 32 input channels run as six bf16
+enum { AMS_OPT_BLOCK_X6 = 8 /* whole-block kernels: 1 (default) the expand products of the blocks with 24 / 32 input channels, and the stem's
+                               products in the one-kernel first block (operands from a 258-entry table of the normalised byte values), run as six bf16
                                MFMAs on three-part splits (f32-level, 96 instead of 256 matrix-pipe cycles per 16x16 tile); 0 exact f32 MFMA
                                (bit-identical to the layer-by-layer plan).  Always exact f32 under AMS_MATMUL_F32. */,
        AMS_OPT_LATE_SUBBATCH = 7 /* frozen inference: frames per pass of the output-stride-16 section (blocks 7-16 and the head); 0 = the whole

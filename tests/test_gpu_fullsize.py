@@ -102,10 +102,18 @@ def test_full_size_properties(W0, clip):
     cm = np.zeros((len(CI), len(CI)), np.int64)
     np.add.at(cm, (t[valid], lab.cpu().numpy()[valid]), 1)
     assert np.array_equal(conf.cpu().numpy(), cm)
-    # the fused first block does the arithmetic of the three kernels it replaces in the same order: identical bits
+    # the fused first block: by default its stem runs as six bf16 products on table-looked-up parts (f32-level, like the early blocks'
+    # expand); with exact-f32 products (block_x6 off) it does the arithmetic of the three kernels it replaces in the same order: identical bits
     eng.set_fuse_first_block(False)
     eng.predict(frames)
-    assert np.array_equal(_lowres(eng, B), low)
+    assert rel(_lowres(eng, B), low) < 5e-5
+    eng.set_block_x6(False)
+    eng.predict(frames)
+    low_exact = _lowres(eng, B).copy()
+    eng.set_fuse_first_block(True)
+    eng.predict(frames)
+    assert np.array_equal(_lowres(eng, B), low_exact)
+    eng.set_block_x6(True)
     # so does the streaming expand+depthwise kernel of the stride-16 blocks (engaged at this batch: 8 x 2145 rows), in the
     # three-part and the two-part split
     for mode in (0, 2):          # never / every supported block (the 160-channel blocks too)
@@ -153,10 +161,19 @@ def test_bench_batch_fused_equals_unfused(W0):
     assert rel(_lowres(eng, B), low) < 5e-5
     assert (lab1 != lab).float().mean().item() < 1e-4
     eng.set_fuse_block(True)
-    for mode in (2, 0):                                   # first block: tile per wave / three kernels — the same bits as the default
+    for mode in (2, 0):                                   # first block: tile per wave / three kernels — exact-f32 stems: f32-level from the default
         eng.set_fuse_first_block(mode)
         labm = eng.predict(frames)
-        assert torch.equal(labm, lab) and np.array_equal(_lowres(eng, B), low), mode
+        assert rel(_lowres(eng, B), low) < 5e-5 and (labm != lab).float().mean().item() < 1e-4, mode
+    eng.set_block_x6(False)                               # exact-f32 products everywhere in the early section: the three forms agree bit for bit
+    eng.set_fuse_first_block(1)
+    lab_e = eng.predict(frames)
+    low_e = _lowres(eng, B).copy()
+    for mode in (2, 0):
+        eng.set_fuse_first_block(mode)
+        labm = eng.predict(frames)
+        assert torch.equal(labm, lab_e) and np.array_equal(_lowres(eng, B), low_e), mode
+    eng.set_block_x6(True)
     eng.set_fuse_first_block(1)
     eng.predict(frames[5:6])
     assert rel(_lowres(eng, 1)[0], low[5]) < 1e-4

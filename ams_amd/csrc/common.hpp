@@ -74,6 +74,22 @@ __device__ __forceinline__ float4 muladd4_pk(const float4& v, const float4& sc, 
     return make_float4(r0.x, r0.y, r1.x, r1.y);
 }
 
+__device__ __forceinline__ float4 add4_pk(const float4& a, const float4& b) {
+    const f32x2_t a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    const f32x2_t r0 = a0 + b0, r1 = a1 + b1;
+    return make_float4(r0.x, r0.y, r1.x, r1.y);
+}
+__device__ __forceinline__ float4 sub4_pk(const float4& a, const float4& b) {
+    const f32x2_t a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    const f32x2_t r0 = a0 - b0, r1 = a1 - b1;
+    return make_float4(r0.x, r0.y, r1.x, r1.y);
+}
+__device__ __forceinline__ float4 mul4_pk(const float4& a, const float4& b) {
+    const f32x2_t a0 = {a.x, a.y}, a1 = {a.z, a.w}, b0 = {b.x, b.y}, b1 = {b.z, b.w};
+    const f32x2_t r0 = a0 * b0, r1 = a1 * b1;
+    return make_float4(r0.x, r0.y, r1.x, r1.y);
+}
+
 constexpr int kNumXcd = 8;   // MI355X: 8 XCDs, block b is dispatched to XCD b % 8 (speed only, never correctness)
 
 // ---- device helpers --------------------------------------------------------------------------------

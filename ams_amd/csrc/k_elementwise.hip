@@ -37,8 +37,8 @@ struct OpStats {          // q0 = z - center, q1 = (z - center)^2
     __device__ __forceinline__ void prepare(int c0) { c = center ? ld4(center + c0) : make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
         const float4 v = ld4(z + row * ld + c0);
-        q0 = make_float4(v.x - c.x, v.y - c.y, v.z - c.z, v.w - c.w);
-        q1 = make_float4(q0.x * q0.x, q0.y * q0.y, q0.z * q0.z, q0.w * q0.w);
+        q0 = sub4_pk(v, c);                  // packed f32: the same IEEE operations, half the instructions
+        q1 = mul4_pk(q0, q0);
     }
 };
 
@@ -54,10 +54,10 @@ struct OpBnBwd {          // q0 = dy, q1 = dy * xhat ; dy = da * act'(z*scale+sh
     __device__ __forceinline__ void prepare(int c0) { sc = ld4(scale + c0); sh = ld4(shift + c0); mu = ld4(mean + c0); rs = ld4(rstd + c0); }
     __device__ __forceinline__ void operator()(int64_t row, int c0, int ld, float4& q0, float4& q1) const {
         const float4 g = ld4(da + row * ld + c0), v = ld4(z + row * ld + c0);
-        q0.x = g.x * act_grad_mask(v.x * sc.x + sh.x, act); q0.y = g.y * act_grad_mask(v.y * sc.y + sh.y, act);
-        q0.z = g.z * act_grad_mask(v.z * sc.z + sh.z, act); q0.w = g.w * act_grad_mask(v.w * sc.w + sh.w, act);
-        q1.x = q0.x * (v.x - mu.x) * rs.x; q1.y = q0.y * (v.y - mu.y) * rs.y;
-        q1.z = q0.z * (v.z - mu.z) * rs.z; q1.w = q0.w * (v.w - mu.w) * rs.w;
+        const float4 y = muladd4_pk(v, sc, sh);
+        const float4 mk = make_float4(act_grad_mask(y.x, act), act_grad_mask(y.y, act), act_grad_mask(y.z, act), act_grad_mask(y.w, act));
+        q0 = mul4_pk(g, mk);
+        q1 = mul4_pk(mul4_pk(q0, sub4_pk(v, mu)), rs);
     }
 };
 
@@ -91,15 +91,15 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(Op op, ColGeom g, float
             for (int u = 0; u < 4; ++u) op(base + r + u * g.slots, c0, g.ldx, q0[u], q1[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                a0.x += q0[u].x; a0.y += q0[u].y; a0.z += q0[u].z; a0.w += q0[u].w;
-                if (NQ > 1) { a1.x += q1[u].x; a1.y += q1[u].y; a1.z += q1[u].z; a1.w += q1[u].w; }
+                a0 = add4_pk(a0, q0[u]);
+                if (NQ > 1) a1 = add4_pk(a1, q1[u]);
             }
         }
         for (; r < r_end; r += g.slots) {
             float4 q0, q1;
             op(base + r, c0, g.ldx, q0, q1);
-            a0.x += q0.x; a0.y += q0.y; a0.z += q0.z; a0.w += q0.w;
-            if (NQ > 1) { a1.x += q1.x; a1.y += q1.y; a1.z += q1.z; a1.w += q1.w; }
+            a0 = add4_pk(a0, q0);
+            if (NQ > 1) a1 = add4_pk(a1, q1);
         }
         st4(sred + ((int64_t)slot * NQ + 0) * g.C + c0, a0);
         if (NQ > 1) st4(sred + ((int64_t)slot * NQ + 1) * g.C + c0, a1);
@@ -405,13 +405,9 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ z
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % C4) * 4;
         const float4 v = ld4(z + i * 4), sc = ld4(scale + c0), sh = ld4(shift + c0);
-        float4 o;
-        o.x = apply_act(v.x * sc.x + sh.x, act); o.y = apply_act(v.y * sc.y + sh.y, act);
-        o.z = apply_act(v.z * sc.z + sh.z, act); o.w = apply_act(v.w * sc.w + sh.w, act);
-        if (res) {
-            const float4 r = ld4(res + i * 4);
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
+        const float4 y = muladd4_pk(v, sc, sh);            // packed f32: the same IEEE operations, half the instructions
+        float4 o = make_float4(apply_act(y.x, act), apply_act(y.y, act), apply_act(y.z, act), apply_act(y.w, act));
+        if (res) o = add4_pk(o, ld4(res + i * 4));
         st4(a + i * 4, o);
     }
 }
@@ -442,11 +438,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int c0 = (int)(i % C4) * 4;
         const float4 g = ld4(da + i * 4), v = ld4(z + i * 4);
         const float4 sc = ld4(scale + c0), sh = ld4(shift + c0), A = ld4(cA + c0), Bc = ld4(cB + c0), Cc = ld4(cC + c0);
-        float4 o;
-        o.x = A.x * (g.x * act_grad_mask(v.x * sc.x + sh.x, act)) + Bc.x + Cc.x * v.x;
-        o.y = A.y * (g.y * act_grad_mask(v.y * sc.y + sh.y, act)) + Bc.y + Cc.y * v.y;
-        o.z = A.z * (g.z * act_grad_mask(v.z * sc.z + sh.z, act)) + Bc.z + Cc.z * v.z;
-        o.w = A.w * (g.w * act_grad_mask(v.w * sc.w + sh.w, act)) + Bc.w + Cc.w * v.w;
+        // A * (g * mask) + B + C * v, evaluated left to right as written (packed f32: the same IEEE operations)
+        const float4 y = muladd4_pk(v, sc, sh);
+        const float4 mk = make_float4(act_grad_mask(y.x, act), act_grad_mask(y.y, act), act_grad_mask(y.z, act), act_grad_mask(y.w, act));
+        const float4 o = add4_pk(add4_pk(mul4_pk(A, mul4_pk(g, mk)), Bc), mul4_pk(Cc, v));
         st4(dz + i * 4, o);
     }
 }

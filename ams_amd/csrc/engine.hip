@@ -109,10 +109,14 @@ struct ams_student {
     float* dz2 = nullptr;
     float* scratch2 = nullptr;
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_wg[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_head = nullptr;
+    int overlap_head = 0;            // frozen inference: image-pooling branch on the side stream beside the aspp0 GEMM (AMS_OVERLAP_HEAD).
+                                     // Off: measured 3.63 vs 3.61 ms at 32 frames and 1.90 k vs 2.01 k frames/s at one — the fork / join events
+                                     // cost more than the three small launches they hide
     int overlap_wgrad = 1;
     ~ams_student() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_head) (void)hipEventDestroy(ev_head);
         for (auto& e : ev_wg) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
     }
@@ -636,19 +640,34 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
         float* pooled = s->pooled + (int64_t)B0 * lp.d.cin;
         float* pool_a = s->pool_a + (int64_t)B0 * lp.d.cout;
         float* img_bias = s->img_bias + (int64_t)B0 * lc.d.cout;
-        RUNK(s->iPool, 4.0 * M * lp.d.cin, launch_global_mean(cur, B, HW, lp.d.cin, pooled, s->scratch, st));
+        // The image-pooling branch (global mean -> 1x1 + BN + ReLU -> its share of concat_projection as a per-image bias) is three
+        // latency-bound launches on a handful of rows (58 us at 32 frames, 22 us at one).  With overlap_head it runs on the side stream
+        // beside the aspp0 GEMM and joins before concat_projection (off by default, see the flag).
+        const bool fork = s->overlap_head && !s->prof.on;
+        hipStream_t ps = st;
+        if (fork) {
+            if (!s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+            if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+            if (!s->ev_head) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
+            AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+            AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+            ps = s->side;
+        }
+        RUNK(s->iPool, 4.0 * M * lp.d.cin, launch_global_mean(cur, B, HW, lp.d.cin, pooled, s->scratch, ps));
         {   // image_pooling conv + BN + ReLU on the pooled vector
             PwArgs a = pw_args(pooled, B, lp.d.cin, lp.d.cin, P + lp.d.w_off, lp.d.cout, pool_a, lp.d.cout);
             a.scale = lp.fscale; a.shift = lp.fshift; a.act = lp.d.act;
-            RUNK(s->iPool, pw_bytes(a), launch_pointwise(a, st));
+            RUNK(s->iPool, pw_bytes(a), launch_pointwise(a, ps));
             // the broadcast pool branch enters concat_projection as a per-image bias: W_proj[0:256]^T . pool
             PwArgs b = pw_args(pool_a, B, lp.d.cout, lp.d.cout, P + lc.d.w_off, lc.d.cout, img_bias, lc.d.cout);
-            RUNK(s->iProj, pw_bytes(b), launch_pointwise(b, st));
+            RUNK(s->iProj, pw_bytes(b), launch_pointwise(b, ps));
         }
+        if (fork) AMS_CHECK_HIP(hipEventRecord(s->ev_head, s->side));
         const int o1 = other(cur_i, -1), o2 = other(cur_i, o1);
         PwArgs a = pw_args(cur, M, la.d.cin, la.d.cin, P + la.d.w_off, la.d.cout, s->act[o1], la.d.cout);
         a.scale = la.fscale; a.shift = la.fshift; a.act = la.d.act;
         RUN(frozen_pointwise(s, s->iAspp, a, st));
+        if (fork) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_head, 0));
         PwArgs b = pw_args(s->act[o1], M, la.d.cout, la.d.cout, P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, lc.d.cout,
                            s->act[o2], lc.d.cout);
         b.img_bias = img_bias; b.rows_per_img = HW; b.scale = lc.fscale; b.shift = lc.fshift; b.act = lc.d.act;
@@ -864,9 +883,9 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     // and share the chip well).  dz alternates between two buffers; the main stream waits for the weight gradient that read a
     // buffer two layers ago before it overwrites it.
     const bool overlap = s->overlap_wgrad && !s->prof.on && s->dz2 && s->scratch2;
-    if (overlap && !s->side) {
-        AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-        AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    if (overlap && !s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    if (overlap && !s->ev_wg[0]) {
+        if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         for (auto& e : s->ev_wg) AMS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     bool wg_pending[2] = {false, false};
@@ -965,6 +984,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (const char* e = getenv("AMS_BLOCK_X6")) s->block_x6 = atoi(e);                       // tuning knob (see AMS_OPT_BLOCK_X6)
     if (const char* e = getenv("AMS_LATE_SUB")) s->late_subbatch = atoi(e);                  // tuning knob (see AMS_OPT_LATE_SUBBATCH)
     if (const char* e = getenv("AMS_STREAM_MIN_ROWS")) s->stream_min_rows = atoll(e);        // tuning knob
+    if (const char* e = getenv("AMS_OVERLAP_HEAD")) s->overlap_head = atoi(e);              // tuning knob
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     *out = s;

@@ -29,6 +29,8 @@ namespace ams {
 #define AMS_DW_FMA4(A_, V_, W_) do { A_.x = fmaf(V_.x, W_.x, A_.x); A_.y = fmaf(V_.y, W_.y, A_.y); A_.z = fmaf(V_.z, W_.z, A_.z); A_.w = fmaf(V_.w, W_.w, A_.w); } while (0)
 #endif
 
+constexpr int xds_pitch(int nc) { return nc == 32 ? 48 : nc == 64 ? 80 : nc == 96 ? 112 : nc + 4; }
+
 struct XdsArgs {
     const float* x;                  // [B, H, W, Cin]
     const unsigned short* xs;        // PRE: the same tensor as bf16 parts [part][B*H*W][Cin] (written by the producing GEMM), part p at xs + p * xs_plane
@@ -71,7 +73,10 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
     constexpr int PX = STEP * CG / (64 * NWD);       // consecutive centres per D-thread
     static_assert(PX * 64 * NWD == STEP * CG && PX >= 1, "D-step mapping");
     static_assert(!(F32 && PRE), "the exact-f32 form splits nothing");
-    constexpr int PITCH = NC + 4;                    // ring row pitch in floats (odd number of 16-byte units)
+    // ring row pitch in floats, chosen for the D-waves' tap reads (12 ds_read_b128 per thread and step against the E-waves' few stores):
+    // under the real lane groups of ds_read_b128 (MI355X_MICROARCH.md) NC + 4 is 2- to 3-way conflicted, these pitches are conflict-free
+    // for the reads and 2-way for the stores (brute-forced over the lane -> (pixel group, channel group) map of the D-step)
+    constexpr int PITCH = xds_pitch(NC);
     constexpr int MIRROR = 4;                        // ring slots repeated after the end (a run of taps is <= 4 slots)
     constexpr int Kp = F32 ? KS * 16 : KS * 32;
     constexpr int WPF = NC + 4;                      // F32: pitch of the weight rows [k][n]
@@ -383,7 +388,7 @@ struct XdsPlan { int nt, nwe, nwd, SH, SW, nsy, nsx, ring, groups; size_t lds; }
 static size_t xds_lds(int Kp, int nt, int np, int ring) {
     const int NC = 16 * nt;
     const size_t w = np == 0 ? (size_t)Kp * (NC + 4) * 4 : (size_t)np * Kp * NC * 2;
-    return w + 2 * NC * 4 + (size_t)(ring + 4) * (NC + 4) * 4;      // + the mirrored slots
+    return w + 2 * NC * 4 + (size_t)(ring + 4) * xds_pitch(NC) * 4;      // + the mirrored slots
 }
 static int xds_ring(int SW, int step) { return (2 * (SW + 2) + 2 + 2 * step + step - 1) / step * step; }
 

@@ -68,6 +68,8 @@ __device__ __forceinline__ float blk_frame_value(const TIn* img, int H, int W, i
 }
 
 // TIn = void: the block input is an f32 activation tensor; uint8_t / float: STEM form, the input is the frame batch
+constexpr int blk_act_pitch(int s, int tw) { return s == 1 && tw == 16 ? 24 : 20; }
+
 template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false>
 __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntiles) {
     constexpr bool PKDW = S == 1 || TH == 2;          // packed f32 in the depthwise phase (see there)
@@ -76,7 +78,10 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NPIX = IH * IW;
     constexpr int NRG = (NPIX + 15) / 16;             // 16-pixel row groups of the wave's input tile (halo included)
-    constexpr int AP = 20;                            // pitch of a 16-channel row: 80 B, conflict-free for ds_read_b128 over 16 pixels
+    // pitch of a 16-channel row of the wave's tile.  With 16 consecutive positions per row group (4 x 16 tile) 96 bytes are conflict-free
+    // for the tap reads and the expand stores under the real lane groups of ds_read_b128 / ds_write_b128; 80 bytes are 2-way conflicted on
+    // three of sixteen lanes, and so is every pitch for the other tile shapes (brute-forced)
+    constexpr int AP = blk_act_pitch(S, TW);
     constexpr int MRO = TH * TW / 16;                 // output row groups of the wave's tile
     static_assert(TH * TW % 16 == 0, "whole output row groups");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -359,7 +364,7 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
     constexpr int NRG = (IH * IW + 15) / 16;
     a.tiles_x = cdiv(a.Wo, TW);
     a.tiles_y = cdiv(a.Ho, TH);
-    const size_t lds = ((size_t)13 * a.Cexp + (size_t)4 * NRG * 16 * 20) * sizeof(float);
+    const size_t lds = ((size_t)13 * a.Cexp + (size_t)4 * NRG * 16 * blk_act_pitch(S, TW)) * sizeof(float);
     AMS_REQUIRE(lds <= 64 * 1024, "block kernel: needs %zu bytes of LDS", lds);
     const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.B;
     const int64_t nblocks = cdiv64(ntiles, 4);

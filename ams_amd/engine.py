@@ -219,6 +219,11 @@ class StudentEngine:
         or as exact f32 MFMAs (bit-identical to the layer-by-layer plan).  Also selects the stem's products in the one-kernel first block."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_BLOCK_X6, int(bool(on))), "ams_student_set_option")
 
+    def set_dual_stream(self, mode: int) -> None:
+        """Frozen inference as two half-batches on two streams: 0 never, 1 decided per batch size by timing both plans in the first call
+        (default), n >= 2 always from n frames on."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_DUAL_STREAM, int(mode)), "ams_student_set_option")
+
     def set_late_subbatch(self, frames: int) -> None:
         """Frozen inference: frames per pass of the output-stride-16 section (0 = the whole batch); same bits either way."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_LATE_SUBBATCH, int(frames)), "ams_student_set_option")

@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=float, default=0.3, help="seconds of untimed inference before the warm-up steps (plan choice + clocks)")
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (throughput saturates at ~24)")
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--train-batch", type=int, default=8)
@@ -211,6 +212,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # Set-up, before the W warm-up steps: the first call with this batch size times the engine's two plans (one stream / two half-batches
+    # on two streams) and keeps the faster; then the clocks settle under load (a cold chip measures ~3 % low over the first 20 steps:
+    # 9.15 k vs 9.44 k frames/s steady state).  Both are part of bringing the engine up, like weight upload and freeze; `settle_s` is in the line.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        eng.predict(frames)
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         eng.predict(frames)
     barrier()
@@ -572,7 +580,7 @@ def main():
     if rank == 0:
         result = {
             "metric": "frames/sec student infer (DeeplabV3+MobileNetV2, 512x1024) + distill-steps/sec",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,

@@ -327,7 +327,9 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom[0], "traffic": None}
             roofline.update(hbm_view)
         roofline.update({"avg_launch_us": round(1e3 * ms / cnt, 2), "launches": cnt, "step_kernel_ms": round(total_ms / n_prof, 3),
-                         "note": "HIP events on the launch stream around every kernel of a profiled replay of the timed step; algorithmic bytes = "
+                         "note": "HIP events on the launch stream around every kernel of a profiled replay of the timed step on ONE stream (under the profiler the engine "
+                                 "does not split the batch over two streams: the headline may run the same kernels as two half-size launches side by side, "
+                                 "AMS_OPT_DUAL_STREAM; profiles/*_infer_kernel_stats.csv is taken with AMS_DUAL_STREAM=0 likewise); algorithmic bytes = "
                                  "f32 operands read once + results written once, algorithmic FLOPs = 2 x MACs of the block without halo or "
                                  "padding (DESIGN.md); launches of one kernel symbol are pooled (sum of work / sum of time)"})
         roofline.update(pmc_traffic(dom[0], B, H))

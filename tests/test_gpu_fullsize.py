@@ -271,3 +271,36 @@ def test_bf16_variant_is_opt_in_and_close(W0, clip):
     eng.set_matmul_mode(hip.MATMUL_SPLIT_BF16_X6)
     assert torch.equal(eng.predict(frames[:B]), lab) and np.array_equal(_lowres(eng, B), low)
     eng.close()
+
+
+def test_two_stream_plan_is_two_half_batches(W0):
+    """AMS_OPT_DUAL_STREAM: a 32-frame call run as two halves on two streams gives every frame the bits of a 16-frame call (same kernels in
+    half-size launches, second half of every buffer), the automatic mode settles on one plan in its first call and then repeats its bits, and
+    metrics computed after the join see the whole batch."""
+    frames, labels = synth.SyntheticVideo(H, 32, CI, seed=5).clip()
+    B = 32
+    eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
+    eng.load_variables(W0)
+    eng.freeze()
+    eng.set_dual_stream(0)
+    lab_a = eng.predict(frames[:16]).clone()
+    low_a = _lowres(eng, 16).copy()
+    lab_b = eng.predict(frames[16:]).clone()
+    low_b = _lowres(eng, 16).copy()
+    eng.set_dual_stream(2)                                # always two streams
+    lab2 = eng.predict(frames)
+    low2 = _lowres(eng, B).copy()
+    assert torch.equal(lab2[:16], lab_a) and torch.equal(lab2[16:], lab_b)
+    assert np.array_equal(low2[:16], low_a) and np.array_equal(low2[16:], low_b)
+    lab_m, conf, loss = eng.predict_with_metric(frames, labels)
+    assert torch.equal(lab_m, lab2)
+    assert conf.sum().item() == int(np.isin(labels, CI).sum())
+    eng.set_dual_stream(0)
+    lab1 = eng.predict(frames)                            # one stream: the 32-frame plan, f32-level from the half-size plan
+    assert rel(_lowres(eng, B), low2) < 1e-4 and (lab1 != lab2).float().mean().item() < 1e-4
+    eng.set_dual_stream(1)                                # decided by timing in the first call; the same bits from then on
+    first = eng.predict(frames).clone()
+    for _ in range(3):
+        assert torch.equal(eng.predict(frames), first)
+    assert torch.equal(first, lab1) or torch.equal(first, lab2)
+    eng.close()

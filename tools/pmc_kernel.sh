@@ -6,7 +6,8 @@ ctrs=("$@")
 [ ${#ctrs[@]} -eq 0 ] && ctrs=(SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmck_$tag
-rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d gpurun_out/pmck_$tag -o p -- python3 bench.py --steps 2 --warmup 1 --only-timed > gpurun_out/pmck_$tag.log 2>&1
+export AMS_DUAL_STREAM=0      # per-kernel counters of the one-stream plan (the two-stream plan runs the same kernels in half-size launches)
+rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d gpurun_out/pmck_$tag -o p -- python3 bench.py --steps 2 --warmup 1 --settle 0 --only-timed > gpurun_out/pmck_$tag.log 2>&1
 f=$(find gpurun_out/pmck_$tag -name "*counter_collection.csv" | head -1)
 python3 - "$f" "$pat" <<'PY'
 import csv, sys, collections

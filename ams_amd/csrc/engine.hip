@@ -115,7 +115,10 @@ struct ams_student {
     // batch size by timing both plans inside the first call with that batch size (>= 16 frames), n >= 2 always from n frames on.
     // Whether it pays is a matter of grid quantisation: at 512x1024 it is +3.5 % at 32-36 frames and -1..-5 % at 24-30 and 40.
     int dual_stream = 1;
-    std::map<int, int> dual_choice;  // batch -> 0 one stream, 1 two
+    int dual_parts = 2;              // parts when dual_stream >= 2 forces the split (AMS_DUAL_PARTS, 2 .. 4)
+    hipStream_t part_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t part_done[3] = {nullptr, nullptr, nullptr};
+    std::map<int, int> dual_choice;  // batch -> number of parts (1 = one stream)
     int overlap_head = 0;            // frozen inference: image-pooling branch on the side stream beside the aspp0 GEMM (AMS_OVERLAP_HEAD).
                                      // Off: measured 3.63 vs 3.61 ms at 32 frames and 1.90 k vs 2.01 k frames/s at one — the fork / join events
                                      // cost more than the three small launches they hide
@@ -123,6 +126,8 @@ struct ams_student {
     ~ams_student() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_head) (void)hipEventDestroy(ev_head);
+        for (auto& e : part_done) if (e) (void)hipEventDestroy(e);
+        for (auto& t : part_stream) if (t) (void)hipStreamDestroy(t);
         for (auto& e : ev_wg) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
     }
@@ -990,6 +995,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (const char* e = getenv("AMS_BLOCK_X6")) s->block_x6 = atoi(e);                       // tuning knob (see AMS_OPT_BLOCK_X6)
     if (const char* e = getenv("AMS_LATE_SUB")) s->late_subbatch = atoi(e);                  // tuning knob (see AMS_OPT_LATE_SUBBATCH)
     if (const char* e = getenv("AMS_STREAM_MIN_ROWS")) s->stream_min_rows = atoll(e);        // tuning knob
+    if (const char* e = getenv("AMS_DUAL_PARTS")) s->dual_parts = atoi(e);                  // tuning knob
     if (const char* e = getenv("AMS_DUAL_STREAM")) s->dual_stream = atoi(e);                // tuning knob (see AMS_OPT_DUAL_STREAM)
     if (const char* e = getenv("AMS_OVERLAP_HEAD")) s->overlap_head = atoi(e);              // tuning knob
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
@@ -1067,37 +1073,45 @@ static int check_call(const ams_student* s, const void* frames, int dtype, int b
 // on the student's side stream, one fork and one join per step), each in its own half of every activation buffer.  A launch of this
 // network rarely fills the chip to the end — tails of 1.05- or 2.1-round grids, latency-bound chains on a few blocks per CU — and the
 // other half's kernels fill those gaps.  Every frame is computed exactly as in a batch of half the size.
-static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, int batch, hipStream_t st) {
+static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, int batch, hipStream_t st, int nparts = 2) {
     const ams_student_config& c = s->cfg;
-    const int B0 = batch / 2, B1 = batch - B0;
-    if (!s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    if (nparts < 2) nparts = 2;
+    if (nparts > 4) nparts = 4;
+    if (nparts > batch) nparts = batch;
     if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    if (!s->ev_head) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
-    AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
-    AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-    int rc = forward_frozen(s, frames, dtype, B0, st);
-    if (!rc) {
-        // half 1: the second half of every buffer (sized for max_batch >= batch frames)
-        LayerRt& lp = s->L[s->iPool]; LayerRt& lc = s->L[s->iProj];
-        const size_t frame_bytes = (size_t)c.height * c.width * 3 * (dtype == AMS_DT_U8 ? 1 : 4);
-        float* act0[4] = {s->act[0], s->act[1], s->act[2], s->act[3]};
-        uint16_t* xs0 = s->xsplit; const size_t xp0 = s->xsplit_plane;
-        float *pooled0 = s->pooled, *pool_a0 = s->pool_a, *img_bias0 = s->img_bias, *logits0 = s->logits, *scratch0 = s->scratch;
-        const size_t per_frame = s->act_elems / c.max_batch;
-        for (int k = 0; k < 4; ++k) s->act[k] = act0[k] + (size_t)B0 * per_frame;
-        if (s->xsplit) { s->xsplit = xs0 + 3 * (xp0 / c.max_batch) * B0; s->xsplit_plane = (xp0 / c.max_batch) * B1; }
-        s->pooled = pooled0 + (size_t)B0 * lp.d.cin;
-        s->pool_a = pool_a0 + (size_t)B0 * lp.d.cout;
-        s->img_bias = img_bias0 + (size_t)B0 * lc.d.cout;
-        s->logits = logits0 + (size_t)B0 * s->h * s->w * 32;
-        s->scratch = scratch0 + image_colsum_scratch(B0, lp.d.cin);
-        rc = forward_frozen(s, (const char*)frames + (size_t)B0 * frame_bytes, dtype, B1, s->side);
-        for (int k = 0; k < 4; ++k) s->act[k] = act0[k];
-        s->xsplit = xs0; s->xsplit_plane = xp0;
-        s->pooled = pooled0; s->pool_a = pool_a0; s->img_bias = img_bias0; s->logits = logits0; s->scratch = scratch0;
+    for (int p = 1; p < nparts; ++p) {
+        if (!s->part_stream[p - 1]) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->part_stream[p - 1], hipStreamNonBlocking));
+        if (!s->part_done[p - 1]) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->part_done[p - 1], hipEventDisableTiming));
     }
-    AMS_CHECK_HIP(hipEventRecord(s->ev_head, s->side));
-    AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_head, 0));
+    AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+    LayerRt& lp = s->L[s->iPool]; LayerRt& lc = s->L[s->iProj];
+    const size_t frame_bytes = (size_t)c.height * c.width * 3 * (dtype == AMS_DT_U8 ? 1 : 4);
+    float* act0[4] = {s->act[0], s->act[1], s->act[2], s->act[3]};
+    uint16_t* xs0 = s->xsplit; const size_t xp0 = s->xsplit_plane;
+    float *pooled0 = s->pooled, *pool_a0 = s->pool_a, *img_bias0 = s->img_bias, *logits0 = s->logits, *scratch0 = s->scratch;
+    const size_t per_frame = s->act_elems / c.max_batch;
+    int rc = AMS_OK;
+    int b0 = 0;
+    for (int p = 0; p < nparts && !rc; ++p) {
+        const int bp = batch / nparts + (p < batch % nparts ? 1 : 0);
+        hipStream_t ps = p == 0 ? st : s->part_stream[p - 1];
+        if (p > 0) AMS_CHECK_HIP(hipStreamWaitEvent(ps, s->ev_fork, 0));
+        // part p: its own slice of every buffer (sized for max_batch >= batch frames)
+        for (int k = 0; k < 4; ++k) s->act[k] = act0[k] + (size_t)b0 * per_frame;
+        if (xs0) { s->xsplit = xs0 + 3 * (xp0 / c.max_batch) * b0; s->xsplit_plane = (xp0 / c.max_batch) * bp; }
+        s->pooled = pooled0 + (size_t)b0 * lp.d.cin;
+        s->pool_a = pool_a0 + (size_t)b0 * lp.d.cout;
+        s->img_bias = img_bias0 + (size_t)b0 * lc.d.cout;
+        s->logits = logits0 + (size_t)b0 * s->h * s->w * 32;
+        s->scratch = scratch0 + image_colsum_scratch(b0, lp.d.cin);
+        rc = forward_frozen(s, (const char*)frames + (size_t)b0 * frame_bytes, dtype, bp, ps);
+        if (p > 0) AMS_CHECK_HIP(hipEventRecord(s->part_done[p - 1], ps));
+        b0 += bp;
+    }
+    for (int k = 0; k < 4; ++k) s->act[k] = act0[k];
+    s->xsplit = xs0; s->xsplit_plane = xp0;
+    s->pooled = pooled0; s->pool_a = pool_a0; s->img_bias = img_bias0; s->logits = logits0; s->scratch = scratch0;
+    for (int p = 1; p < nparts; ++p) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->part_done[p - 1], 0));
     return rc;
 }
 
@@ -1105,7 +1119,7 @@ static int run_forward(ams_student* s, const void* frames, int dtype, int batch,
     if (mode == AMS_MODE_FROZEN) {
         if (!s->frozen_ready) { set_error("predict: ams_student_freeze has not been called"); return AMS_E_STATE; }
         if (s->dual_stream == 0 || s->prof.on || s->late_subbatch != 0 || batch < 2) return forward_frozen(s, frames, dtype, batch, st);
-        if (s->dual_stream >= 2) return batch >= s->dual_stream ? forward_frozen_dual(s, frames, dtype, batch, st) : forward_frozen(s, frames, dtype, batch, st);
+        if (s->dual_stream >= 2) return batch >= s->dual_stream ? forward_frozen_dual(s, frames, dtype, batch, st, s->dual_parts) : forward_frozen(s, frames, dtype, batch, st);
         if (batch < 16) return forward_frozen(s, frames, dtype, batch, st);
         auto it = s->dual_choice.find(batch);
         if (it == s->dual_choice.end()) {
@@ -1117,23 +1131,27 @@ static int run_forward(ams_student* s, const void* frames, int dtype, int batch,
             hipEvent_t e0, e1;
             AMS_CHECK_HIP(hipEventCreate(&e0));
             AMS_CHECK_HIP(hipEventCreate(&e1));
-            float ms[2] = {0.f, 0.f};
+            float ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // ms[n]: the batch in n parts (n = 1: one stream)
             int rc = AMS_OK;
-            for (int plan = 0; plan < 2 && !rc; ++plan) {
+            const int max_parts = batch >= 32 ? 4 : batch >= 24 ? 3 : 2;       // parts of at least 8 frames
+            for (int n = 1; n <= max_parts && !rc; ++n) {
                 for (int rep = 0; rep < 2 && !rc; ++rep) {
                     if (rep == 1) (void)hipEventRecord(e0, st);
-                    rc = plan ? forward_frozen_dual(s, frames, dtype, batch, st) : forward_frozen(s, frames, dtype, batch, st);
+                    rc = n > 1 ? forward_frozen_dual(s, frames, dtype, batch, st, n) : forward_frozen(s, frames, dtype, batch, st);
                 }
                 (void)hipEventRecord(e1, st);
                 (void)hipEventSynchronize(e1);
-                (void)hipEventElapsedTime(&ms[plan], e0, e1);
+                (void)hipEventElapsedTime(&ms[n], e0, e1);
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (rc) return rc;
-            it = s->dual_choice.emplace(batch, ms[1] < 0.985f * ms[0] ? 1 : 0).first;
+            int best = 1;
+            for (int n = 2; n <= max_parts; ++n)
+                if (ms[n] < 0.985f * ms[1] && (best == 1 || ms[n] < ms[best])) best = n;
+            it = s->dual_choice.emplace(batch, best).first;
         }
-        return it->second ? forward_frozen_dual(s, frames, dtype, batch, st) : forward_frozen(s, frames, dtype, batch, st);
+        return it->second > 1 ? forward_frozen_dual(s, frames, dtype, batch, st, it->second) : forward_frozen(s, frames, dtype, batch, st);
     }
     if (mode == AMS_MODE_LIVE) return forward_live(s, frames, dtype, batch, batch, /*update_ema=*/false, nullptr, st);
     set_error("predict: unknown mode %d", mode);

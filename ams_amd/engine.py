@@ -220,8 +220,8 @@ class StudentEngine:
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_BLOCK_X6, int(bool(on))), "ams_student_set_option")
 
     def set_dual_stream(self, mode: int) -> None:
-        """Frozen inference as two half-batches on two streams: 0 never, 1 decided per batch size by timing both plans in the first call
-        (default), n >= 2 always from n frames on."""
+        """Frozen inference as two to four part-batches on as many streams: 0 never, 1 decided per batch size by timing the plans in the
+        first call (default), n >= 2 always two parts from n frames on."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_DUAL_STREAM, int(mode)), "ams_student_set_option")
 
     def set_late_subbatch(self, frames: int) -> None:

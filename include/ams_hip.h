@@ -189,10 +189,10 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_DUAL_STREAM = 10 /* frozen inference: a batch as two halves on two streams (the caller's and one the student owns; one fork and
-                                   one join per call), each frame computed exactly as in a batch of half the size.  0 never; 1 (default) decided
-                                   per batch size (>= 16 frames) by timing both plans inside the first call with that batch size; n >= 2 always
-                                   from n frames on.  It pays where the single-stream grids quantise badly (512x1024: +3.5 % at 32-36 frames). */,
+enum { AMS_OPT_DUAL_STREAM = 10 /* frozen inference: a batch as two to four parts on as many streams (the caller's and up to three the student
+                                   owns; one fork and one join per call), each frame computed exactly as in a batch of the part's size.  0 never;
+                                   1 (default) decided per batch size (>= 16 frames) by timing the one-stream plan and the 2-, 3- and 4-part
+                                   plans inside the first call with that batch size; n >= 2 always two parts from n frames on.  It pays where the single-stream grids quantise badly (512x1024: +3.5 % at 32-36 frames). */,
        AMS_OPT_BLOCK_X6 = 8 /* whole-block kernels: 1 (default) the expand products of the blocks with 24 / 32 input channels, and the stem's
                                products in the one-kernel first block (operands from a 258-entry table of the normalised byte values), run as six bf16
                                MFMAs on three-part splits (f32-level, 96 instead of 256 matrix-pipe cycles per 16x16 tile); 0 exact f32 MFMA

@@ -1090,6 +1090,14 @@ static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, in
     uint16_t* xs0 = s->xsplit; const size_t xp0 = s->xsplit_plane;
     float *pooled0 = s->pooled, *pool_a0 = s->pool_a, *img_bias0 = s->img_bias, *logits0 = s->logits, *scratch0 = s->scratch;
     const size_t per_frame = s->act_elems / c.max_batch;
+    struct Restore {                                  // the student's buffer pointers come back whatever way this function is left
+        ams_student* s; float* act0[4]; uint16_t* xs0; size_t xp0; float *pooled0, *pool_a0, *img_bias0, *logits0, *scratch0;
+        ~Restore() {
+            for (int k = 0; k < 4; ++k) s->act[k] = act0[k];
+            s->xsplit = xs0; s->xsplit_plane = xp0;
+            s->pooled = pooled0; s->pool_a = pool_a0; s->img_bias = img_bias0; s->logits = logits0; s->scratch = scratch0;
+        }
+    } restore{s, {act0[0], act0[1], act0[2], act0[3]}, xs0, xp0, pooled0, pool_a0, img_bias0, logits0, scratch0};
     int rc = AMS_OK;
     int b0 = 0;
     for (int p = 0; p < nparts && !rc; ++p) {
@@ -1108,9 +1116,6 @@ static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, in
         if (p > 0) AMS_CHECK_HIP(hipEventRecord(s->part_done[p - 1], ps));
         b0 += bp;
     }
-    for (int k = 0; k < 4; ++k) s->act[k] = act0[k];
-    s->xsplit = xs0; s->xsplit_plane = xp0;
-    s->pooled = pooled0; s->pool_a = pool_a0; s->img_bias = img_bias0; s->logits = logits0; s->scratch = scratch0;
     for (int p = 1; p < nparts; ++p) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->part_done[p - 1], 0));
     return rc;
 }

@@ -1,0 +1,110 @@
+// Probe: a BN backward pass (column sums of dy and dy*xhat over [M, C], per-channel coefficients, then dz = A*dy + B + C*z) as ONE cooperative
+// launch with two grid barriers, against the same work as three launches.  Timing experiment; sums in f32 per block + f64 combine.
+// build: hipcc --offload-arch=gfx950 -O3 coop_bn_probe.hip -o coop_bn_probe ; run under `timeout 60`
+#include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
+#include <cstdio>
+#include <vector>
+namespace cg = cooperative_groups;
+
+struct Args { const float* da; const float* z; float* dz; float* part; float* coef; long M; int C; };
+
+__device__ void reduce_phase(const Args& a, int nblk, int bid) {
+    // block = 256 threads: CG = C/4 column groups x slots rows in flight
+    const int CG = a.C / 4, slots = 256 / CG;
+    const int cg_i = threadIdx.x % CG, slot = threadIdx.x / CG;
+    const long rows_per = (a.M + nblk - 1) / nblk;
+    const long r0 = (long)bid * rows_per, r1 = r0 + rows_per < a.M ? r0 + rows_per : a.M;
+    float4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    if (slot < slots)
+        for (long r = r0 + slot; r < r1; r += slots) {
+            const float4 g = *(const float4*)(a.da + r * a.C + cg_i * 4), v = *(const float4*)(a.z + r * a.C + cg_i * 4);
+            const float m0 = v.x > 0.f && v.x < 6.f, m1 = v.y > 0.f && v.y < 6.f, m2 = v.z > 0.f && v.z < 6.f, m3 = v.w > 0.f && v.w < 6.f;
+            s0.x += g.x * m0; s0.y += g.y * m1; s0.z += g.z * m2; s0.w += g.w * m3;
+            s1.x += g.x * m0 * v.x; s1.y += g.y * m1 * v.y; s1.z += g.z * m2 * v.z; s1.w += g.w * m3 * v.w;
+        }
+    __shared__ float sred[256 * 8];
+    *(float4*)(sred + threadIdx.x * 8) = s0; *(float4*)(sred + threadIdx.x * 8 + 4) = s1;
+    __syncthreads();
+    if (threadIdx.x < CG) {
+        float4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+        for (int u = threadIdx.x; u < CG * slots; u += CG) {
+            const float4 x0 = *(float4*)(sred + u * 8), x1 = *(float4*)(sred + u * 8 + 4);
+            t0.x += x0.x; t0.y += x0.y; t0.z += x0.z; t0.w += x0.w; t1.x += x1.x; t1.y += x1.y; t1.z += x1.z; t1.w += x1.w;
+        }
+        float* out = a.part + (long)bid * 2 * a.C + threadIdx.x * 4;
+        *(float4*)out = t0; *(float4*)(out + a.C) = t1;
+    }
+    __syncthreads();
+}
+__device__ void finalize_phase(const Args& a, int nblk, int bid, int nb_total) {
+    // columns distributed over the blocks: block b takes columns b, b + nb_total, ...
+    for (int c = bid * 256 + threadIdx.x; c < a.C; c += nb_total * 256) {
+        double t0 = 0, t1 = 0;
+        for (int k = 0; k < nblk; ++k) { t0 += a.part[(long)k * 2 * a.C + c]; t1 += a.part[(long)k * 2 * a.C + a.C + c]; }
+        a.coef[c] = 1.0f; a.coef[a.C + c] = (float)(-t0 / (double)a.M); a.coef[2 * a.C + c] = (float)(-t1 / (double)a.M * 1e-3);
+    }
+}
+__device__ void apply_phase(const Args& a, int nblk, int bid) {
+    const long n4 = a.M * a.C / 4, per = (n4 + nblk - 1) / nblk;
+    const long i0 = (long)bid * per, i1 = i0 + per < n4 ? i0 + per : n4;
+    const int C4 = a.C / 4;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int c0 = (int)(i % C4) * 4;
+        const float4 g = *(const float4*)(a.da + i * 4), v = *(const float4*)(a.z + i * 4);
+        const float4 A = *(const float4*)(a.coef + c0), B = *(const float4*)(a.coef + a.C + c0), Cc = *(const float4*)(a.coef + 2 * a.C + c0);
+        float4 o;
+        o.x = A.x * (g.x * (v.x > 0.f && v.x < 6.f)) + B.x + Cc.x * v.x; o.y = A.y * (g.y * (v.y > 0.f && v.y < 6.f)) + B.y + Cc.y * v.y;
+        o.z = A.z * (g.z * (v.z > 0.f && v.z < 6.f)) + B.z + Cc.z * v.z; o.w = A.w * (g.w * (v.w > 0.f && v.w < 6.f)) + B.w + Cc.w * v.w;
+        *(float4*)(a.dz + i * 4) = o;
+    }
+}
+__global__ __launch_bounds__(256) void k_reduce(Args a) { reduce_phase(a, gridDim.x, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_finalize(Args a, int nblk) { finalize_phase(a, nblk, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void k_apply(Args a) { apply_phase(a, gridDim.x, blockIdx.x); }
+__global__ __launch_bounds__(256) void k_coop(Args a) {
+    cg::grid_group grid = cg::this_grid();
+    reduce_phase(a, gridDim.x, blockIdx.x);
+    grid.sync();
+    finalize_phase(a, gridDim.x, blockIdx.x, gridDim.x);
+    grid.sync();
+    apply_phase(a, gridDim.x, blockIdx.x);
+}
+
+int main() {
+    int dev = 0; hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, dev);
+    int per_cu = 0; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_coop, 256, 0);
+    const int nblk = per_cu * prop.multiProcessorCount > 1024 ? 1024 : per_cu * prop.multiProcessorCount;
+    printf("cooperative grid: %d blocks (%d per CU possible)\n", nblk, per_cu);
+    struct Shape { long M; int C; } shapes[] = {{17160, 960}, {17160, 160}, {68904, 192}, {265224, 144}, {1054728, 96}};
+    for (auto sh : shapes) {
+        const size_t n = (size_t)sh.M * sh.C;
+        float *da, *z, *dz, *part, *coef;
+        (void)hipMalloc(&da, n * 4); (void)hipMalloc(&z, n * 4); (void)hipMalloc(&dz, n * 4); (void)hipMalloc(&part, (size_t)1024 * 2 * sh.C * 4); (void)hipMalloc(&coef, 3 * sh.C * 4);
+        (void)hipMemset(da, 0, n * 4); (void)hipMemset(z, 0, n * 4);
+        Args a{da, z, dz, part, coef, sh.M, sh.C};
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        float ms3 = 0, msc = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 20; ++it) {
+                hipLaunchKernelGGL(k_reduce, dim3(nblk), dim3(256), 0, 0, a);
+                hipLaunchKernelGGL(k_finalize, dim3((sh.C + 255) / 256), dim3(256), 0, 0, a, nblk);
+                hipLaunchKernelGGL(k_apply, dim3(nblk), dim3(256), 0, 0, a);
+            }
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms3, e0, e1);
+        }
+        void* params[] = {&a};
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 20; ++it) {
+                hipError_t rc = hipLaunchCooperativeKernel((const void*)k_coop, dim3(nblk), dim3(256), params, 0, 0);
+                if (rc != hipSuccess) { printf("cooperative launch failed: %s\n", hipGetErrorString(rc)); return 1; }
+            }
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&msc, e0, e1);
+        }
+        printf("M=%7ld C=%4d (%6.1f MB x 2 in, 1 out): three launches %7.1f us   one cooperative launch %7.1f us\n", sh.M, sh.C, n * 4 / 1e6, ms3 * 1e3 / 20, msc * 1e3 / 20);
+        (void)hipFree(da); (void)hipFree(z); (void)hipFree(dz); (void)hipFree(part); (void)hipFree(coef);
+    }
+    return 0;
+}

@@ -16,12 +16,24 @@ __device__ void reduce_phase(const Args& a, int nblk, int bid) {
     const long rows_per = (a.M + nblk - 1) / nblk;
     const long r0 = (long)bid * rows_per, r1 = r0 + rows_per < a.M ? r0 + rows_per : a.M;
     float4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+#ifdef FULL_MATH
+    const float4 sc = *(const float4*)(a.coef + cg_i * 4), sh = *(const float4*)(a.coef + a.C + cg_i * 4), mu = *(const float4*)(a.coef + 2 * a.C + cg_i * 4), rs = sc;
+#endif
     if (slot < slots)
         for (long r = r0 + slot; r < r1; r += slots) {
             const float4 g = *(const float4*)(a.da + r * a.C + cg_i * 4), v = *(const float4*)(a.z + r * a.C + cg_i * 4);
+#ifdef FULL_MATH
+            // the engine's OpBnBwd arithmetic: dy = da * [0 < z*scale+shift < 6], xhat = (z - mean) * rstd
+            const float y0 = v.x * sc.x + sh.x, y1 = v.y * sc.y + sh.y, y2 = v.z * sc.z + sh.z, y3 = v.w * sc.w + sh.w;
+            const float m0 = y0 > 0.f && y0 < 6.f, m1 = y1 > 0.f && y1 < 6.f, m2 = y2 > 0.f && y2 < 6.f, m3 = y3 > 0.f && y3 < 6.f;
+            const float q0 = g.x * m0, q1 = g.y * m1, q2 = g.z * m2, q3 = g.w * m3;
+            s0.x += q0; s0.y += q1; s0.z += q2; s0.w += q3;
+            s1.x += q0 * (v.x - mu.x) * rs.x; s1.y += q1 * (v.y - mu.y) * rs.y; s1.z += q2 * (v.z - mu.z) * rs.z; s1.w += q3 * (v.w - mu.w) * rs.w;
+#else
             const float m0 = v.x > 0.f && v.x < 6.f, m1 = v.y > 0.f && v.y < 6.f, m2 = v.z > 0.f && v.z < 6.f, m3 = v.w > 0.f && v.w < 6.f;
             s0.x += g.x * m0; s0.y += g.y * m1; s0.z += g.z * m2; s0.w += g.w * m3;
             s1.x += g.x * m0 * v.x; s1.y += g.y * m1 * v.y; s1.z += g.z * m2 * v.z; s1.w += g.w * m3 * v.w;
+#endif
         }
     __shared__ float sred[256 * 8];
     *(float4*)(sred + threadIdx.x * 8) = s0; *(float4*)(sred + threadIdx.x * 8 + 4) = s1;
@@ -38,12 +50,23 @@ __device__ void reduce_phase(const Args& a, int nblk, int bid) {
     __syncthreads();
 }
 __device__ void finalize_phase(const Args& a, int nblk, int bid, int nb_total) {
-    // columns distributed over the blocks: block b takes columns b, b + nb_total, ...
-    for (int c = bid * 256 + threadIdx.x; c < a.C; c += nb_total * 256) {
-        double t0 = 0, t1 = 0;
-        for (int k = 0; k < nblk; ++k) { t0 += a.part[(long)k * 2 * a.C + c]; t1 += a.part[(long)k * 2 * a.C + a.C + c]; }
-        a.coef[c] = 1.0f; a.coef[a.C + c] = (float)(-t0 / (double)a.M); a.coef[2 * a.C + c] = (float)(-t1 / (double)a.M * 1e-3);
+    // columns spread over ALL blocks (cpb per block); a column's nblk partial rows are summed by 256 / cpb threads in f64, fixed order
+    const int cpb = (a.C + nb_total - 1) / nb_total;            // 1 .. a few
+    const int tpc = 256 / cpb;                                   // threads per column
+    const int lc = threadIdx.x / tpc, lt = threadIdx.x % tpc;
+    const int c = bid * cpb + lc;
+    __shared__ double sacc[2][256];
+    double t0 = 0, t1 = 0;
+    if (lc < cpb && c < a.C)
+        for (int k = lt; k < nblk; k += tpc) { t0 += a.part[(long)k * 2 * a.C + c]; t1 += a.part[(long)k * 2 * a.C + a.C + c]; }
+    sacc[0][threadIdx.x] = t0; sacc[1][threadIdx.x] = t1;
+    __syncthreads();
+    if (lt == 0 && lc < cpb && c < a.C) {
+        double u0 = 0, u1 = 0;
+        for (int k = 0; k < tpc; ++k) { u0 += sacc[0][lc * tpc + k]; u1 += sacc[1][lc * tpc + k]; }
+        a.coef[c] = 1.0f; a.coef[a.C + c] = (float)(-u0 / (double)a.M); a.coef[2 * a.C + c] = (float)(-u1 / (double)a.M * 1e-3);
     }
+    __syncthreads();
 }
 __device__ void apply_phase(const Args& a, int nblk, int bid) {
     const long n4 = a.M * a.C / 4, per = (n4 + nblk - 1) / nblk;
@@ -62,6 +85,24 @@ __device__ void apply_phase(const Args& a, int nblk, int bid) {
 __global__ __launch_bounds__(256) void k_reduce(Args a) { reduce_phase(a, gridDim.x, blockIdx.x); }
 __global__ __launch_bounds__(256) void k_finalize(Args a, int nblk) { finalize_phase(a, nblk, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(256) void k_apply(Args a) { apply_phase(a, gridDim.x, blockIdx.x); }
+// hand-made grid barrier: every block of the grid must be resident (grid <= what the chip holds at once); counter zeroed before the launch
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(4);
+        __threadfence();
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_manual(Args a, unsigned* counter) {
+    reduce_phase(a, gridDim.x, blockIdx.x);
+    grid_barrier(counter, gridDim.x);
+    finalize_phase(a, gridDim.x, blockIdx.x, gridDim.x);
+    grid_barrier(counter, 2 * gridDim.x);
+    apply_phase(a, gridDim.x, blockIdx.x);
+}
 __global__ __launch_bounds__(256) void k_coop(Args a) {
     cg::grid_group grid = cg::this_grid();
     reduce_phase(a, gridDim.x, blockIdx.x);
@@ -81,18 +122,47 @@ int main() {
         const size_t n = (size_t)sh.M * sh.C;
         float *da, *z, *dz, *part, *coef;
         (void)hipMalloc(&da, n * 4); (void)hipMalloc(&z, n * 4); (void)hipMalloc(&dz, n * 4); (void)hipMalloc(&part, (size_t)1024 * 2 * sh.C * 4); (void)hipMalloc(&coef, 3 * sh.C * 4);
-        (void)hipMemset(da, 0, n * 4); (void)hipMemset(z, 0, n * 4);
+        (void)hipMemset(da, 0x3c, n * 4); (void)hipMemset(z, 0x3f, n * 4);
         Args a{da, z, dz, part, coef, sh.M, sh.C};
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         float ms3 = 0, msc = 0;
         for (int rep = 0; rep < 2; ++rep) {
             (void)hipEventRecord(e0);
             for (int it = 0; it < 20; ++it) {
-                hipLaunchKernelGGL(k_reduce, dim3(nblk), dim3(256), 0, 0, a);
-                hipLaunchKernelGGL(k_finalize, dim3((sh.C + 255) / 256), dim3(256), 0, 0, a, nblk);
-                hipLaunchKernelGGL(k_apply, dim3(nblk), dim3(256), 0, 0, a);
+                hipLaunchKernelGGL(k_reduce, dim3(512), dim3(256), 0, 0, a);
+                hipLaunchKernelGGL(k_finalize, dim3(512), dim3(256), 0, 0, a, 512);
+                hipLaunchKernelGGL(k_apply, dim3(512), dim3(256), 0, 0, a);
             }
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms3, e0, e1);
+        }
+        {   // the same with cold caches: 512 MB are overwritten before every launch, only the kernel is timed
+            static char* flush = nullptr;
+            if (!flush) (void)hipMalloc(&flush, (size_t)512 << 20);
+            float mr = 0, ma = 0, t;
+            for (int it = 0; it < 8; ++it) {
+                (void)hipMemsetAsync(flush, it, (size_t)512 << 20, 0);
+                (void)hipEventRecord(e0);
+                hipLaunchKernelGGL(k_reduce, dim3(512), dim3(256), 0, 0, a);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&t, e0, e1); mr += t;
+                (void)hipMemsetAsync(flush, it, (size_t)512 << 20, 0);
+                (void)hipEventRecord(e0);
+                hipLaunchKernelGGL(k_apply, dim3(512), dim3(256), 0, 0, a);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&t, e0, e1); ma += t;
+            }
+            printf("   cold: reduce %6.1f us  apply %6.1f us\n", mr * 125, ma * 125);
+        }
+        {   // the three phases one at a time
+            float mr = 0, mf = 0, ma = 0;
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(k_reduce, dim3(512), dim3(256), 0, 0, a);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&mr, e0, e1);
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(k_finalize, dim3(512), dim3(256), 0, 0, a, 512);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&mf, e0, e1);
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(k_apply, dim3(512), dim3(256), 0, 0, a);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ma, e0, e1);
+            printf("   reduce %6.1f us  finalize %5.1f us  apply %6.1f us (each 20 back to back)\n", mr * 50, mf * 50, ma * 50);
         }
         void* params[] = {&a};
         for (int rep = 0; rep < 2; ++rep) {
@@ -103,6 +173,19 @@ int main() {
             }
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&msc, e0, e1);
         }
+        float msm = 0;
+        unsigned* counter; (void)hipMalloc(&counter, 4);
+        const int nman = nblk > 512 ? 512 : nblk;               // two blocks per CU: resident with room to spare
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(e0);
+            for (int it = 0; it < 20; ++it) {
+                (void)hipMemsetAsync(counter, 0, 4, 0);
+                hipLaunchKernelGGL(k_manual, dim3(nman), dim3(256), 0, 0, a, counter);
+            }
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&msm, e0, e1);
+        }
+        printf("   hand-made barrier, %d blocks: %7.1f us\n", nman, msm * 1e3 / 20);
+        (void)hipFree(counter);
         printf("M=%7ld C=%4d (%6.1f MB x 2 in, 1 out): three launches %7.1f us   one cooperative launch %7.1f us\n", sh.M, sh.C, n * 4 / 1e6, ms3 * 1e3 / 20, msc * 1e3 / 20);
         (void)hipFree(da); (void)hipFree(z); (void)hipFree(dz); (void)hipFree(part); (void)hipFree(coef);
     }

@@ -178,9 +178,11 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
                     else split8(abuf[d][r][0], abuf[d][r][1], x0[r]);
                 }
                 const unsigned short* bw = &sW[d & 1][0][l15 * PITCH + 8 * (q ^ ((l15 >> 3) << 1))];
-                // Per accumulator the six products arrive in a fixed order (smallest terms first), but consecutive MFMAs go to
-                // DIFFERENT accumulators: a dependent MFMA waits for its predecessor's 8 passes (~2.5 issue slots), and hipcc
-                // keeps the source order.  Column tiles are taken TG at a time (TG * RM chains in flight, TG * NP fragments live).
+                // Per accumulator the six products arrive in a fixed order (smallest terms first); consecutive MFMAs rotate over the
+                // TG * RM accumulators of a group.  (The rotation is not needed against a dependency stall — a bf16 MFMA on its
+                // predecessor's accumulator issues at the pipe rate, tools/probes/mfma_chain_probe.hip — but issuing an accumulator's six
+                // products back to back measured no faster here and slower in the streaming kernels, where the next accumulator's first
+                // product then waits for its LDS fragments with nothing else to issue.)  TG * NP weight fragments live.
                 constexpr int TG = (NT >= 2 && RM <= 2) ? 2 : 1;        // an odd NT ends with a group of one
 #pragma unroll
                 for (int t0 = 0; t0 < NT; t0 += TG) {

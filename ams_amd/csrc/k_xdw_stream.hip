@@ -176,8 +176,8 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                 const int64_t pn = next_pixel();                      // pixel of step t + 1
                 // Operands are split stage by stage (12 registers live instead of 12 * KS) and a stage's registers are refilled
                 // with the next step's operands as soon as they are split: those loads have the rest of the step to land.
-                // Products in the order of pw_gemm_bf16x3_l per accumulator; consecutive MFMAs go to different accumulators
-                // (a dependent MFMA waits ~2.5 issue slots for its predecessor).
+                // Products in the order of pw_gemm_bf16x3_l per accumulator; consecutive MFMAs go to different accumulators (see there:
+                // chaining one accumulator's products measured 2-3 % slower in this kernel).
                 if constexpr (F32) {
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {

@@ -41,6 +41,8 @@ void note_kernel(const char* name);
         }                                                                                     \
     } while (0)
 
+#define RUN_RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -97,7 +97,16 @@ struct ams_student {
     float* logits = nullptr;         // [B,h,w,32]
     uint16_t* xsplit = nullptr; size_t xsplit_plane = 0;         // bf16 parts of a stride-16 block's input (written by the project GEMM before it)
     uint16_t* panel_scratch = nullptr; size_t panel_elems = 0;   // live (training) weights split per launch: hi | lo
+    // live weight panels of every 1x1 layer in both orientations (forward [cout][Kp], input gradient [cin][Np]), refreshed by ONE
+    // launch at the start of a live forward instead of one small launch per GEMM (47 per step)
+    std::vector<SplitJob> tp_jobs;
+    std::map<std::pair<const float*, int>, int> tp_index;        // (weight pointer, w_sk == 1) -> job
+    SplitJob* tp_jobs_dev = nullptr;
+    uint16_t* tp_panels = nullptr; size_t tp_elems = 0;
+    int64_t tp_blocks = 0;
+    bool tp_fresh = false;                                       // panels hold the split of the CURRENT parameters (this step)
     float* dlogits = nullptr;
+    float* ce_scratch = nullptr;       // unnormalised CE gradient planes of the one-pass loss kernel (k_head.hip)
     float* act[4] = {nullptr, nullptr, nullptr, nullptr};   // inference ping-pong pool
     size_t act_elems = 0;
     float *pooled = nullptr, *pool_a = nullptr, *img_bias = nullptr;          // [B,cin_head], [B,256], [B,256]
@@ -162,6 +171,39 @@ struct ams_student {
 };
 
 namespace ams {
+
+// the live weight panels: every 1x1 layer a split GEMM may run on, forward and input-gradient orientation.  p0 holds the element
+// offset inside tp_panels until the arena is known (create turns it into a pointer).
+static void plan_train_panels(ams_student* s) {
+    s->tp_jobs.clear();
+    s->tp_elems = 0;
+    s->tp_blocks = 0;
+    if (!s->cfg.trainable) return;
+    auto add = [&](int64_t w_off, int64_t sk, int64_t sn, int K, int N) {
+        if (K < 32 || K % 8 != 0) return;                  // split_pays() never takes these
+        SplitJob j;
+        memset(&j, 0, sizeof(j));
+        j.w = (const float*)(uintptr_t)w_off;              // offset for now
+        j.sk = sk; j.sn = sn; j.K = K; j.N = N; j.Kp = (K + 31) / 32 * 32;
+        j.plane = (int64_t)N * j.Kp;
+        j.p0 = (uint16_t*)(uintptr_t)s->tp_elems;
+        j.first_block = s->tp_blocks;
+        s->tp_elems += 3 * (size_t)j.plane;
+        s->tp_elems = (s->tp_elems + 127) & ~(size_t)127;
+        s->tp_blocks += (j.plane + 255) / 256;
+        s->tp_jobs.push_back(j);
+    };
+    for (int i = 2; i <= s->cfg.n_layers; ++i) {
+        const LayerRt& l = s->L[i];
+        if (l.d.role == AMS_ROLE_DEPTHWISE || l.d.role == AMS_ROLE_POOL_CONV) continue;
+        int64_t w_off = l.d.w_off;
+        int K = l.d.cin;
+        const int N = l.d.cout;
+        if (l.d.role == AMS_ROLE_CONCAT_PROJ) { const int k0 = s->L[s->iPool].d.cout; w_off += (int64_t)k0 * N; K -= k0; }
+        add(w_off, N, 1, K, N);                             // forward: element (k, n) at w[k*N + n]
+        if (l.d.role != AMS_ROLE_LOGITS) add(w_off, 1, N, N, K);      // input gradient: B operand (k' = n, n' = k) = w[k][n]
+    }
+}
 
 static int layout(ams_student* s, void* arena, size_t* bytes_out) {
     const ams_student_config& c = s->cfg;
@@ -287,9 +329,13 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
         }
         s->panel_elems = pe;
         s->panel_scratch = cv.take<uint16_t>(pe);
+        plan_train_panels(s);
+        s->tp_panels = cv.take<uint16_t>(s->tp_elems);
+        s->tp_jobs_dev = cv.take<SplitJob>(s->tp_jobs.size());
     }
     if (c.trainable) {
         s->dlogits = cv.take<float>((size_t)B * s->h * s->w * 32);
+        s->ce_scratch = cv.take<float>(ce_loss_grad_scratch(B, s->h, s->w, c.n_selected));
         s->d_img_bias = cv.take<float>((size_t)B * aspp_c);
         s->d_pool_a = cv.take<float>((size_t)B * aspp_c);
         s->d_pool_z = cv.take<float>((size_t)B * aspp_c);
@@ -436,6 +482,14 @@ static int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
     // split of the frozen path would put the step outside the f32 error class
     const int Kp = (a.K + 31) / 32 * 32;
     const size_t plane = (size_t)a.N * Kp;
+    if (s->tp_fresh) {                                  // split once per step (forward_live) instead of once per launch
+        auto it = s->tp_index.find({a.w, a.w_sk == 1 ? 1 : 0});
+        if (it != s->tp_index.end()) {
+            const SplitJob& j = s->tp_jobs[it->second];
+            if (j.K == a.K && j.N == a.N && j.sk == a.w_sk && j.sn == a.w_sn)
+                return launch_pointwise_split3(a, j.p0, j.p0 + j.plane, j.p0 + 2 * j.plane, j.Kp, st);
+        }
+    }
     AMS_REQUIRE(3 * plane <= s->panel_elems, "live_pointwise: panel scratch too small");
     uint16_t* p0 = s->panel_scratch;
     int rc = launch_split_weights3(a.w, a.w_sk, a.w_sn, a.K, a.N, Kp, p0, p0 + plane, p0 + 2 * plane, st);
@@ -740,6 +794,12 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
     const ams_student_config& c = s->cfg;
     AMS_REQUIRE(c.trainable, "live forward needs a trainable student (activations are not allocated)");
     const float* P = s->params;
+    // the parameters may have changed since the last call (Adam, restore): all live weight panels in one launch
+    s->tp_fresh = false;
+    if (s->matmul_mode != AMS_MATMUL_F32 && !s->tp_jobs.empty()) {
+        RUNK(0, 0.0, launch_split_batch(s->tp_jobs_dev, (int)s->tp_jobs.size(), s->tp_blocks, st));
+        s->tp_fresh = true;
+    }
     {
         LayerRt& l = s->L[1];
         RUN(launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, nullptr, nullptr, AMS_ACT_NONE,
@@ -838,8 +898,11 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     const double nHW = (double)global_B * HW;
     const int NC = c.num_classes;
     // d loss / d logits (already divided by the global number of valid pixels)
-    RUN(launch_ce_grad(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher, NC, s->loss_buf,
-                       s->dlogits, 32, st));
+    if (ce_loss_grad_supported(s->w, c.width))           // second pass of the one-pass loss kernel (train_step_impl ran the first)
+        RUNK(0, 0.0, launch_ce_combine(B, s->h, s->w, c.class_indices, c.n_selected, NC, s->loss_buf, s->ce_scratch, s->dlogits, 32, st));
+    else
+        RUNK(0, 0.0, launch_ce_grad(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher, NC, s->loss_buf,
+                                    s->dlogits, 32, st));
     // logits layer: bias, weights, input gradient
     RUN(launch_colsum(s->dlogits, M, 32, 32, s->tmp_c, s->scratch, st));
     RUN(launch_copy(G + ll.d.gamma_off, s->tmp_c, NC, st));
@@ -947,6 +1010,12 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
 
 static int loss_forward(ams_student* s, const uint8_t* teacher, int B, int32_t* labels, hipStream_t st) {
     const ams_student_config& c = s->cfg;
+    if (!labels && ce_loss_grad_supported(s->w, c.width)) {
+        // the fine-tune step: loss sums and the unnormalised gradient in one pass over the pixels
+        RUNK(0, 0.0, launch_ce_loss_grad(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher, c.num_classes,
+                                         s->loss_buf, s->ce_scratch, st));
+        return AMS_OK;
+    }
     return launch_upsample_argmax(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher,
                                   c.num_classes, labels, s->conf_buf, s->loss_buf, st);
 }
@@ -992,6 +1061,16 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
+    if (!s->tp_jobs.empty()) {
+        for (size_t k = 0; k < s->tp_jobs.size(); ++k) {
+            SplitJob& j = s->tp_jobs[k];
+            j.w = s->params + (int64_t)(uintptr_t)j.w;
+            j.p0 = s->tp_panels + (size_t)(uintptr_t)j.p0;
+            s->tp_index[{j.w, j.sk == 1 ? 1 : 0}] = (int)k;
+        }
+        const hipError_t e = hipMemcpy(s->tp_jobs_dev, s->tp_jobs.data(), s->tp_jobs.size() * sizeof(SplitJob), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_error("create: uploading the panel table -> %s", hipGetErrorString(e)); delete s; return AMS_E_HIP; }
+    }
     if (const char* e = getenv("AMS_BLOCK_X6")) s->block_x6 = atoi(e);                       // tuning knob (see AMS_OPT_BLOCK_X6)
     if (const char* e = getenv("AMS_LATE_SUB")) s->late_subbatch = atoi(e);                  // tuning knob (see AMS_OPT_LATE_SUBBATCH)
     if (const char* e = getenv("AMS_STREAM_MIN_ROWS")) s->stream_min_rows = atoll(e);        // tuning knob
@@ -1217,6 +1296,7 @@ static int train_step_impl(ams_student* s, const void* frames_dev, int32_t frame
     // beta1 / beta2 are f32 tensors in the TF graph (0.9f, 0.999f), and so are their running powers
     const double b1 = (double)0.9f, b2 = (double)0.999f;
     const double lr_t = (double)lr * sqrt(1.0 - pow(b2, (double)s->adam_t)) / (1.0 - pow(b1, (double)s->adam_t));
+    s->tp_fresh = false;                               // the update below invalidates the live weight panels
     return launch_adam(s->params, s->grads, s->adam_m, s->adam_v, mask_dev, s->cfg.n_trainable, (float)lr_t, 0.9f, 0.999f, 1e-8f, st);
 }
 
@@ -1472,6 +1552,18 @@ int ams_k_ce_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t 
                   int32_t W, const uint8_t* teacher, const double* loss_and_count_dev, float* dlogits, void* stream) {
     return launch_ce_grad(logits, NC, B, h, w, class_idx_host, K, H, W, teacher, NC, loss_and_count_dev, dlogits, NC,
                           (hipStream_t)stream);
+}
+
+size_t ams_k_ce_loss_grad_scratch(int32_t B, int32_t h, int32_t w, int32_t K) { return ce_loss_grad_scratch(B, h, w, K); }
+
+int ams_k_ce_loss_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t NC, const int32_t* class_idx_host, int32_t K, int32_t H,
+                       int32_t W, const uint8_t* teacher, double* loss_dev, float* dlogits, float* scratch, size_t scratch_floats, void* stream) {
+    AMS_REQUIRE(ce_loss_grad_supported(w, W), "ce_loss_grad: %d output columns on %d source columns is outside the one-pass kernel", W, w);
+    AMS_REQUIRE(scratch && scratch_floats >= ce_loss_grad_scratch(B, h, w, K), "ce_loss_grad: scratch too small (need %zu floats)",
+                ce_loss_grad_scratch(B, h, w, K));
+    hipStream_t st = (hipStream_t)stream;
+    RUN(launch_ce_loss_grad(logits, NC, B, h, w, class_idx_host, K, H, W, teacher, NC, loss_dev, scratch, st));
+    return launch_ce_combine(B, h, w, class_idx_host, K, NC, loss_dev, scratch, dlogits, NC, st);
 }
 
 size_t ams_k_pointwise_wgrad_scratch(int64_t M, int32_t K, int32_t N) { return pointwise_wgrad_scratch(M, K, N); }

@@ -426,7 +426,7 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
     // project layer is 64 wide (four accumulator tiles per row group: the smaller tile keeps the registers of two waves per SIMD)
     int th = stride == 1 ? 8 : (Cout > 32 ? 2 : 4), tw = 8;
     if (stride == 1 && a.wparts) { th = 4; tw = 16; }   // X6 form: 4 x 16 (no spills, conflict-free tap reads along a row): 327 vs 337 us on block 2
-    if (const char* e = getenv("AMS_BLK_TILE")) sscanf(e, "%dx%d", &th, &tw);          // tuning knob (tools/block_one.py)
+    if (knobs().blk_th > 0) { th = knobs().blk_th; tw = knobs().blk_tw; }              // tuning knob AMS_BLK_TILE (tools/block_one.py)
 #define BLK(S_, TH_, TW_) if (stride == S_ && th == TH_ && tw == TW_) return launch_blk_t<S_, TH_, TW_>(a, st);
     BLK(1, 8, 8) BLK(1, 4, 16) BLK(1, 4, 8) BLK(2, 4, 8) BLK(2, 2, 8) BLK(2, 4, 4)
 #undef BLK

@@ -655,9 +655,10 @@ int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W,
     // never launch more blocks than fit at once
     const void* fn = stride == 2 ? (const void*)dw3x3_wgrad_kernel<2, 1> : rate == 2 ? (const void*)dw3x3_wgrad_kernel<1, 2>
                                                                                    : (const void*)dw3x3_wgrad_kernel<1, 1>;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    int per_cu = 1, cus = 256;
+    RUN_RC(func_blocks_per_cu(fn, threads, lds, &per_cu));
+    RUN_RC(device_cus(&cus));
+    if (blocks > cus * per_cu) blocks = cus * per_cu;
     const int64_t ppb = cdiv64(total, blocks);
     note_kernel(stride == 2 ? "dw3x3_wgrad_kernel<2, 1>" : rate == 2 ? "dw3x3_wgrad_kernel<1, 2>" : "dw3x3_wgrad_kernel<1, 1>");
     if (stride == 1 && rate == 1)

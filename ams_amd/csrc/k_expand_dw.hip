@@ -204,12 +204,7 @@ static int launch_xdw_k(XdwArgs a, hipStream_t st) {
     constexpr int Kpad = KC * 16;
     const size_t lds = ((size_t)Kpad * (CC + 4) + 4 * CC + 9 * CC + (size_t)NRG * 16 * (CC + 4)) * sizeof(float);
     AMS_REQUIRE(lds <= 150 * 1024, "expand_dw: tile needs %zu bytes of LDS", lds);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)expand_dw_kernel<S, R, NT, TH, TW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          150 * 1024));
-        attr_set = true;
-    }
+    RUN_RC(func_allow_lds((const void*)expand_dw_kernel<S, R, NT, TH, TW, KC>, lds > 64 * 1024 ? 150 * 1024 : lds));
     // all chunks in one block when there are enough tiles to fill the chip (measured: from ~2000 tiles on, ~1000 with 4+ chunks), else one block
     // per (tile, chunk) for parallelism
     const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.B;

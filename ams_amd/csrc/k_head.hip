@@ -276,6 +276,206 @@ int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32
     return AMS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Loss AND its gradient in one pass over the full-resolution pixels (the fine-tune step: replaces upsample_argmax (loss only) +
+// ce_grad, which evaluates every pixel's softmax once per low-resolution cell it touches: four times).
+// Block = (CB cell columns, one source-row band, image): the band of source row i0 is every output row y with floor(y * sy) == i0; a
+// thread owns one output column and walks down the band with the K horizontally interpolated values of the two source rows in
+// registers (as the forward kernel does), evaluates the softmax once per pixel and accumulates (softmax - onehot) weighted by
+// (1 - ty) for cell row i0 and by ty for cell row i0 + 1.  The columns are then folded into the block's cell columns in a fixed
+// order through LDS (weights 1 - tx / tx); a block also walks the pixel columns of the cell column to its left, so every cell it
+// owns is complete in x.  Two partial planes come out — T[b][i0][j] and B[b][i0 + 1][j], each element written exactly once (no
+// atomics: run-to-run identical) — and ce_combine_kernel adds them, applies 1 / (valid pixels) and scatters to the class columns.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kCeCB = 8;              // cell columns per block
+
+template <int KMAX>
+__global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restrict__ logits, HeadGeom g, ClassTable ct,
+                                                           const uint8_t* __restrict__ teacher, double* __restrict__ loss,
+                                                           float* __restrict__ partT, float* __restrict__ partB) {
+    __shared__ float s_val[192][2 * KMAX + 1];
+    __shared__ float s_wx[192][2];            // weight of the column towards its left / right source column
+    __shared__ int s_x0[192];
+    __shared__ float s_loss[3];
+    __shared__ int s_cnt[3];
+    const int b = blockIdx.z, i0 = blockIdx.y, j_lo = blockIdx.x * kCeCB;
+    const int i1 = i0 + 1 < g.h ? i0 + 1 : g.h - 1;
+    // pixel rows of the band: floor(y * sy) == i0 (sy = 0: a single source row holds every output row)
+    int ybeg, yend;
+    {
+        const float inv = g.sy > 0.f ? 1.f / g.sy : 0.f;
+        int y = g.sy > 0.f ? (int)(i0 * inv) - 2 : 0;
+        if (y < 0) y = 0;
+        while (y < g.H && (int)floorf(__fmul_rn((float)y, g.sy)) < i0) ++y;
+        ybeg = y;
+        while (y < g.H && (int)floorf(__fmul_rn((float)y, g.sy)) == i0) ++y;
+        yend = y;
+    }
+    // pixel columns: those whose left source column x0 lies in [j_lo - 1, j_lo + CB - 1]
+    int xbeg;
+    {
+        const float inv = g.sx > 0.f ? 1.f / g.sx : 0.f;
+        const int jl = j_lo - 1 < 0 ? 0 : j_lo - 1;
+        int x = g.sx > 0.f ? (int)(jl * inv) - 2 : 0;
+        if (x < 0) x = 0;
+        while (x < g.W && (int)floorf(__fmul_rn((float)x, g.sx)) < jl) ++x;
+        xbeg = x;
+    }
+    const int x = xbeg + threadIdx.x;
+    int x0 = 0, x1 = 0; float tx = 0.f;
+    bool live = x < g.W;
+    if (live) { src_tap(x, g.sx, g.w, x0, x1, tx); live = x0 <= j_lo + kCeCB - 1; }
+    float gt[KMAX], gb[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { gt[k] = 0.f; gb[k] = 0.f; }
+    float my_loss = 0.f;
+    int my_cnt = 0;
+    if (live) {
+        const float* base = logits + (int64_t)b * g.h * g.w * g.ld;
+        const float* ptl = base + ((int64_t)i0 * g.w + x0) * g.ld;
+        const float* ptr = base + ((int64_t)i0 * g.w + x1) * g.ld;
+        const float* pbl = base + ((int64_t)i1 * g.w + x0) * g.ld;
+        const float* pbr = base + ((int64_t)i1 * g.w + x1) * g.ld;
+        float top[KMAX], bot[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int c = ct.idx[k < g.K ? k : 0];
+            top[k] = __fadd_rn(ptl[c], __fmul_rn(__fsub_rn(ptr[c], ptl[c]), tx));
+            bot[k] = __fadd_rn(pbl[c], __fmul_rn(__fsub_rn(pbr[c], pbl[c]), tx));
+        }
+        // only columns whose x0 is an OWNED cell column count towards the loss (the overlap column belongs to the block on the left)
+        const bool own = x0 >= j_lo;
+        for (int y = ybeg; y < yend; ++y) {
+            const int target = ct.lut[teacher[((int64_t)b * g.H + y) * g.W + x]];
+            if (target < 0) continue;
+            const float src = __fmul_rn((float)y, g.sy);
+            const float ty = __fsub_rn(src, floorf(src));
+            float z[KMAX];
+            float zmax = -3.0e38f, zt = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                z[k] = __fadd_rn(top[k], __fmul_rn(__fsub_rn(bot[k], top[k]), ty));
+                if (k < g.K) zmax = fmaxf(zmax, z[k]);
+                if (k == target) zt = z[k];
+            }
+            float ssum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < g.K) { z[k] = __expf(z[k] - zmax); ssum += z[k]; }
+            const float rs = 1.f / ssum;
+            if (own) { my_loss += (zmax + __logf(ssum)) - zt; my_cnt += 1; }
+            const float wt = 1.f - ty;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < g.K) {
+                    const float d = z[k] * rs - (k == target ? 1.f : 0.f);
+                    gt[k] += wt * d;
+                    gb[k] += ty * d;
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { s_val[threadIdx.x][k] = gt[k]; s_val[threadIdx.x][KMAX + k] = gb[k]; }
+    s_x0[threadIdx.x] = live ? x0 : -2;
+    s_wx[threadIdx.x][0] = 1.f - tx;
+    s_wx[threadIdx.x][1] = x1 != x0 ? tx : 0.f;       // clamped right neighbour (last source column): tx is 0 there anyway
+    my_loss = wave_sum(my_loss);
+    my_cnt = (int)wave_sum((float)my_cnt);
+    if ((threadIdx.x & 63) == 0) { s_loss[threadIdx.x >> 6] = my_loss; s_cnt[threadIdx.x >> 6] = my_cnt; }
+    __syncthreads();
+    // fold the pixel columns into the cell columns: entry e = (cell column jj, plane tb, class k), columns in ascending order
+    for (int e = threadIdx.x; e < kCeCB * 2 * KMAX; e += blockDim.x) {
+        const int jj = e / (2 * KMAX), r = e - jj * (2 * KMAX);
+        const int j = j_lo + jj;
+        const int tb = r / KMAX, k = r - tb * KMAX;
+        if (j >= g.w || k >= g.K) continue;
+        float s = 0.f;
+        for (int t = 0; t < (int)blockDim.x; ++t) {
+            const int c0 = s_x0[t];
+            if (c0 == j) s += s_wx[t][0] * s_val[t][r];
+            else if (c0 == j - 1) s += s_wx[t][1] * s_val[t][r];
+        }
+        if (tb == 0) partT[(((int64_t)b * g.h + i0) * g.w + j) * KMAX + k] = s;
+        else if (i0 + 1 < g.h) partB[(((int64_t)b * g.h + i0 + 1) * g.w + j) * KMAX + k] = s;
+    }
+    if (threadIdx.x == 0) {
+        double ls = 0; int cn = 0;
+        for (int i = 0; i < 3; ++i) { ls += s_loss[i]; cn += s_cnt[i]; }
+        if (cn) { atomicAdd(&loss[0], ls); atomicAdd(&loss[1], (double)cn); }
+    }
+}
+
+// dlogits[b][i][j][c] = (T + B)[b][i][j][k(c)] / valid pixels; class columns outside the subset and the pad columns get 0
+template <int KMAX>
+__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ partT, const float* __restrict__ partB, int64_t cells,
+                                                         int w_cells, int h_cells, ClassTable ct, int K,
+                                                         const double* __restrict__ loss_and_count, float* __restrict__ dlogits, int ldd) {
+    const double nvalid = loss_and_count[1];
+    const float inv_n = nvalid > 0.5 ? (float)(1.0 / nvalid) : 0.f;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < cells * ldd; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = e / ldd;
+        const int c = (int)(e - cell * ldd);
+        const int k = c < 256 ? ct.lut[c] : -1;
+        float v = 0.f;
+        if (k >= 0) {
+            const int i = (int)((cell / w_cells) % h_cells);
+            const float t = partT[cell * KMAX + k];
+            v = (i > 0 ? t + partB[cell * KMAX + k] : t) * inv_n;          // row 0 has no band above it
+        }
+        dlogits[e] = v;
+    }
+}
+
+bool ce_loss_grad_supported(int w, int W) {
+    const int per_cell = w > 1 ? (W - 1 + w - 2) / (w - 1) + 1 : W;      // output columns per source column, rounded up, + 1
+    return (kCeCB + 1) * per_cell + 2 <= 192;
+}
+
+size_t ce_loss_grad_scratch(int B, int h, int w, int K) { return (size_t)2 * B * h * w * (K <= 8 ? 8 : K <= 20 ? 20 : 32); }
+
+// pass 1: loss[0] += CE sum, loss[1] += valid pixels (loss zeroed here), unnormalised gradient planes into scratch
+int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W, const uint8_t* teacher,
+                        int NC, double* loss, float* scratch, hipStream_t st) {
+    ClassTable ct;
+    int rc = fill_class_table(cls, K, NC, &ct);
+    if (rc) return rc;
+    AMS_REQUIRE(teacher && loss && scratch, "ce_loss_grad: null pointer");
+    const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
+    // a block's pixel columns: (CB + 1) source columns' worth
+    const int per_cell = w > 1 ? (W - 1 + w - 2) / (w - 1) + 1 : W;
+    AMS_REQUIRE((kCeCB + 1) * per_cell + 2 <= 192, "ce_loss_grad: %d output columns per source column do not fit a block", per_cell);
+    AMS_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double) * 2, st));
+    const int KM = K <= 8 ? 8 : K <= 20 ? 20 : 32;
+    float* partT = scratch;
+    float* partB = scratch + (size_t)B * h * w * KM;
+    const dim3 grid(cdiv(w, kCeCB), h, B);
+    note_kernel("ce_loss_grad_kernel");
+    if (KM == 8) hipLaunchKernelGGL(ce_loss_grad_kernel<8>, grid, dim3(192), 0, st, logits, g, ct, teacher, loss, partT, partB);
+    else if (KM == 20) hipLaunchKernelGGL(ce_loss_grad_kernel<20>, grid, dim3(192), 0, st, logits, g, ct, teacher, loss, partT, partB);
+    else hipLaunchKernelGGL(ce_loss_grad_kernel<32>, grid, dim3(192), 0, st, logits, g, ct, teacher, loss, partT, partB);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// pass 2 (after the valid-pixel count is final, i.e. after its cross-rank sum in a data-parallel step)
+int launch_ce_combine(int B, int h, int w, const int32_t* cls, int K, int NC, const double* loss_and_count, const float* scratch,
+                      float* dlogits, int ldd, hipStream_t st) {
+    ClassTable ct;
+    int rc = fill_class_table(cls, K, NC, &ct);
+    if (rc) return rc;
+    AMS_REQUIRE(ldd >= NC && ldd <= 256, "ce_combine: ldd=%d must hold %d classes", ldd, NC);
+    const int KM = K <= 8 ? 8 : K <= 20 ? 20 : 32;
+    const int64_t cells = (int64_t)B * h * w;
+    const float* partT = scratch;
+    const float* partB = scratch + (size_t)cells * KM;
+    const int grid = (int)(cdiv64(cells * ldd, 256) < 2048 ? cdiv64(cells * ldd, 256) : 2048);
+    if (KM == 8) hipLaunchKernelGGL(ce_combine_kernel<8>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd);
+    else if (KM == 20) hipLaunchKernelGGL(ce_combine_kernel<20>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd);
+    else hipLaunchKernelGGL(ce_combine_kernel<32>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 // phi-score confusion matrix between two teacher label maps (SemanticNetwork.py:124-139): pixels whose label is in the
 // subset in BOTH maps count 1 at [before][after].
 __global__ __launch_bounds__(256) void cross_conf_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int64_t n,

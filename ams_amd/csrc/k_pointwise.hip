@@ -65,9 +65,8 @@ int launch_pointwise(const PwArgs& a, hipStream_t st) {
         AMS_CHECK_LAUNCH();
         return AMS_OK;
     }
-    char force = 0;
-    int frm = 0, fnt = 0;
-    if (const char* e = getenv("AMS_PW_FORCE")) sscanf(e, "%c,%d,%d", &force, &frm, &fnt);     // tuning knob: "<s|l>,<RM>,<NT>"
+    const char force = knobs().pw_force;                  // tuning knob AMS_PW_FORCE = "<s|l>,<RM>,<NT>"
+    const int frm = knobs().pw_rm, fnt = knobs().pw_nt;
     if ((a.M >= 32768 && force != 'l') || force == 's') {
         bool handled = false;
         const int rc = launch_pointwise_stream(a, frm, force == 's' ? fnt : 0, &handled, st);

@@ -82,19 +82,12 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     int64_t blocks = cdiv64(n_groups, 4);
     // persistent grid: exactly the blocks that are co-resident (work is pre-partitioned by grid-stride, so any block that
     // has to wait for a slot would run its whole share on a half-empty chip)
-    static int per_cu_cache = -1;
-    static size_t per_cu_lds = 0;
-    if (per_cu_cache < 0 || per_cu_lds != lds) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pw_gemm_f32_s<RM, NT, EPI>, 256, lds) != hipSuccess || nb < 1) nb = 1;
-        per_cu_cache = nb;
-        per_cu_lds = lds;
-    }
-    int per_cu = per_cu_cache;
-    if (const char* e = getenv("AMS_PW_PERCU")) per_cu = atoi(e);          // tuning knob (tools/bench_kernel.py)
-    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-    if (lds > 64 * 1024)
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)pw_gemm_f32_s<RM, NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1, cus = 256;
+    RUN_RC(func_allow_lds((const void*)pw_gemm_f32_s<RM, NT, EPI>, lds));
+    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f32_s<RM, NT, EPI>, 256, lds, &per_cu));
+    RUN_RC(device_cus(&cus));
+    if (knobs().pw_percu > 0) per_cu = knobs().pw_percu;                  // tuning knob AMS_PW_PERCU (tools/bench_kernel.py)
+    if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
     static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ">";
     note_kernel(nm.c_str());
     hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT, EPI>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, a, n_tiles_n, n_groups);

@@ -41,6 +41,33 @@ __global__ void split_w_kernel(const float* __restrict__ w, int64_t sk, int64_t 
     if (lo) lo[i] = bf16_rne_bits(r1 - __uint_as_float((unsigned)m << 16));
 }
 
+// every live (training) weight panel of the student in ONE launch: job j owns blocks [first_block_j, first_block_{j+1})
+__global__ void split_batch_kernel(const SplitJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                          // last job whose first block is <= blockIdx.x (block-uniform search)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const SplitJob j = jobs[lo];
+    const int64_t i = ((int64_t)blockIdx.x - j.first_block) * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)j.N * j.Kp) return;
+    const int n = (int)(i / j.Kp), k = (int)(i % j.Kp);
+    const float v = k < j.K ? j.w[k * j.sk + n * j.sn] : 0.f;
+    const unsigned short h = bf16_rne_bits(v);
+    const float r1 = v - __uint_as_float((unsigned)h << 16);
+    const unsigned short m = bf16_rne_bits(r1);
+    j.p0[i] = h;
+    j.p0[i + j.plane] = m;
+    j.p0[i + 2 * j.plane] = bf16_rne_bits(r1 - __uint_as_float((unsigned)m << 16));
+}
+
+int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st) {
+    if (njobs <= 0) return AMS_OK;
+    hipLaunchKernelGGL(split_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs_dev, njobs);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 int launch_split_weights(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st) {
     const int64_t n = (int64_t)N * Kp;
     hipLaunchKernelGGL(split_w_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, sk, sn, K, N, Kp, hi, lo, (unsigned short*)nullptr);
@@ -236,7 +263,7 @@ static int64_t pw_plan_tail(int64_t M, int rm, int n_tiles_n, int slots, int64_t
     const int64_t rows_full = 64 * rm, rows_half = 32 * rm;
     const int64_t full_all = cdiv64(M, rows_full);
     *half_strips_out = 0;
-    if (rm < 2 || slots <= 0 || getenv("AMS_PWX_NO_TAIL")) return full_all;
+    if (rm < 2 || slots <= 0 || knobs().pwx_no_tail) return full_all;
     const int64_t spr = slots / n_tiles_n > 0 ? slots / n_tiles_n : 1;          // strips per round
     auto rounds = [&](int64_t strips) {
         const int64_t whole = strips / spr, rest = strips % spr;
@@ -256,15 +283,10 @@ static int64_t pw_plan_tail(int64_t M, int rm, int n_tiles_n, int slots, int64_t
 template <int RM, int NT, int EPI, int D, int NP>
 static int launch_pw_x3_d(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
-    static int slots = 0;                          // resident blocks of this instantiation on the whole chip
-    if (!slots) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        AMS_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pw_gemm_bf16x3_l<RM, NT, EPI, D, NP>, 256, 0));
-        AMS_CHECK_HIP(hipGetDevice(&dev));
-        AMS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        slots = per_cu * prop.multiProcessorCount;
-    }
+    int per_cu = 1, cus = 256;                     // resident blocks of this instantiation on the whole chip (per device)
+    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_bf16x3_l<RM, NT, EPI, D, NP>, 256, 0, &per_cu));
+    RUN_RC(device_cus(&cus));
+    const int slots = per_cu * cus;
     int64_t half_strips = 0;
     const int64_t full_strips = pw_plan_tail(a.M, RM, n_tiles_n, slots, &half_strips);
     const int64_t n_full = full_strips * n_tiles_n;
@@ -309,7 +331,7 @@ static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp,
         if (a.N == 96 || a.N == 960) nt = 6;
         else if (a.N == 320) nt = 10;
     }
-    if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &rm, &nt);       // tuning knob
+    if (knobs().pwx_rm > 0) { rm = knobs().pwx_rm; nt = knobs().pwx_nt; }            // tuning knob AMS_PWX_FORCE
 #define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, w, Kp, st);
     PW_X(4, 4) PW_X(4, 3) PW_X(4, 5)
     PW_X(2, 10) PW_X(2, 8)

@@ -214,11 +214,7 @@ static int launch_wg6_t(const WgArgs& a, int splits, hipStream_t st) {
     int64_t rows = cdiv64(a.M, splits);
     rows = (rows + 31) / 32 * 32;
     const size_t lds = (size_t)3 * 32 * (wg_pitch(16 * KT) + wg_pitch(16 * NW)) * sizeof(unsigned short);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)pw_wgrad_bf16x6<KT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    RUN_RC(func_allow_lds((const void*)pw_wgrad_bf16x6<KT, NW>, lds));
     static const std::string nm = "pw_wgrad_bf16x6<" + std::to_string(KT) + ", " + std::to_string(NW) + ">";
     note_kernel(nm.c_str());
     hipLaunchKernelGGL((pw_wgrad_bf16x6<KT, NW>), dim3(splits, tiles_k * tiles_n), dim3(256), lds, st, a, tiles_n, rows);

@@ -437,7 +437,7 @@ static bool xds_plan(int B, int H, int W, int Cin, int Cexp, int rate, int np, X
     // measured on MI355X at 32 frames (tools/bench_xds.py): 32-channel chunks and two blocks per CU for Cin 64 / 96; Cin 160 is
     // bound by the operand re-reads of its 30 chunk blocks (L1 / TA rate), 64-channel chunks halve them
     int nt = Cin >= 128 ? 4 : 2, nsy_force = 0, nsx_force = 0, nwe = 4, nwd = 4, groups_force = 0;
-    if (const char* e = getenv("AMS_XDS_FORCE")) sscanf(e, "%d,%d,%d,%d,%d,%d", &nt, &nsy_force, &nsx_force, &nwe, &nwd, &groups_force);
+    if (knobs().xds_set) { const int* f = knobs().xds; nt = f[0]; nsy_force = f[1]; nsx_force = f[2]; nwe = f[3]; nwd = f[4]; groups_force = f[5]; }
     if (nt != 2 && nt != 4) nt = Cin >= 128 ? 4 : 2;
     if (np == 0) { nwe = 4; nwd = 4; }               // the exact-f32 form is built for 4 + 4 waves
     if (!((nwe == 4 && (nwd == 2 || nwd == 4)) || (nwe == 8 && nwd == 4))) { nwe = 4; nwd = 4; }
@@ -457,12 +457,7 @@ bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate) {
 
 template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32 = false, int S = 1>
 static int launch_xds_p(XdsArgs a, const XdsPlan& p, hipStream_t st) {
-    static size_t attr_lds = 0;
-    if (p.lds > 64 * 1024 && p.lds > attr_lds) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)p.lds));
-        attr_lds = p.lds;
-    }
+    RUN_RC(func_allow_lds((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S>, p.lds));
     const int64_t nblocks = (int64_t)a.groups * a.chunks;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_stream: bad grid");
     static const std::string nm = "xdw_stream_kernel<" + std::to_string(KS) + ", " + std::to_string(NT) + ", " + std::to_string(NP) + ", " +

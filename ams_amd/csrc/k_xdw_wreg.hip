@@ -312,11 +312,7 @@ static size_t xwr_lds(int Kp, int np, int nwe, int nrg, int ring) {
 
 template <int KS, int NP, int NWE, int NWD, int NRG>
 static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
-    static size_t attr_lds = 0;
-    if (lds > 64 * 1024 && lds > attr_lds) {
-        AMS_CHECK_HIP(hipFuncSetAttribute((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG>, lds));
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");
     static const std::string nm = "xdw_wreg_kernel<" + std::to_string(KS) + ", " + std::to_string(NP) + ", " + std::to_string(NWE) + ", " +
@@ -344,7 +340,7 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_wreg: empty input");
     AMS_REQUIRE((int64_t)H * W * Cexp * 4 < 0x7fffffffLL, "expand_dw_wreg: a frame of the output exceeds 2 GiB");
     int nwe = 4, nsy_force = 0, nsx_force = 0, groups_force = 0, nrg = 2;
-    if (const char* e = getenv("AMS_XWR_FORCE")) sscanf(e, "%d,%d,%d,%d,%d", &nwe, &nsy_force, &nsx_force, &groups_force, &nrg);
+    if (knobs().xwr_set) { const int* f = knobs().xwr; nwe = f[0]; nsy_force = f[1]; nsx_force = f[2]; groups_force = f[3]; nrg = f[4]; }
     if (nwe != 4 && nwe != 8) nwe = 4;
     if (nrg != 1 && nrg != 2) nrg = 2;
     if (nwe == 8) nrg = 1;

@@ -6,6 +6,25 @@ struct ams_comm;
 
 namespace ams {
 
+// ---- runtime.hip : per-device launch bookkeeping, environment knobs (read once) --------------------------
+// allow `lds` bytes of dynamic LDS for kernel `fn` on the CURRENT device (no-op up to 64 KB; set once per device and size)
+int func_allow_lds(const void* fn, size_t lds);
+// resident blocks per CU of `fn` on the current device (cached per device / block size / LDS)
+int func_blocks_per_cu(const void* fn, int threads, size_t lds, int* per_cu);
+int device_cus(int* cus);
+// pure bookkeeping behind func_allow_lds (CPU-testable): true the first time (device, kernel) needs a limit >= lds
+bool launch_table_needs_attr(int device, const void* fn, size_t lds);
+struct Knobs {                   // tuning knobs of tools/*: environment variables, read at first use, never on the launch path
+    int blk_th = 0, blk_tw = 0;                  // AMS_BLK_TILE=<th>x<tw>
+    char pw_force = 0; int pw_rm = 0, pw_nt = 0; // AMS_PW_FORCE=<s|l>,<RM>,<NT>
+    int pw_percu = 0;                            // AMS_PW_PERCU
+    bool pwx_no_tail = false;                    // AMS_PWX_NO_TAIL
+    int pwx_rm = 0, pwx_nt = 0;                  // AMS_PWX_FORCE=<RM>,<NT>
+    bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE
+    bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
+};
+const Knobs& knobs();
+
 // ---- comm.hip : RCCL communicator (resolved at run time) ------------------------------------------------
 int comm_allreduce(ams_comm* c, void* p, size_t n, int dtype, hipStream_t st);
 
@@ -43,6 +62,10 @@ int launch_pointwise_split(const PwArgs& a, const uint16_t* whi, const uint16_t*
 int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* mid, uint16_t* lo,
                           hipStream_t st);
 int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t* wmid, const uint16_t* wlo, int Kp, hipStream_t st);
+// all live weight panels of a student in one launch (three-part split): job j splits w (element (k, n) at w[k*sk + n*sn]) into
+// p0 | p0 + plane | p0 + 2*plane as [N][Kp]; it owns the 256-thread blocks [first_block, first_block + ceil(N*Kp / 256))
+struct SplitJob { const float* w; int64_t sk, sn; int K, N, Kp; uint16_t* p0; int64_t plane; int64_t first_block; };
+int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st);
 int launch_pointwise_split1(const PwArgs& a, const uint16_t* whi, int Kp, hipStream_t st);      // one part: plain bf16 products
 bool pointwise_split_writes_parts(const PwArgs& a);      // the split kernels will honour a.ysplit (vector epilogue)
 
@@ -176,6 +199,14 @@ int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, con
                            const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st);
 int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
                    const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st);
+// loss + gradient in one pass (fine-tune step): pass 1 leaves the CE sum / valid count in loss[2] and the unnormalised gradient in
+// scratch (ce_loss_grad_scratch floats); pass 2 scales by 1 / count (after its cross-rank sum) and writes dlogits [B*h*w, ldd]
+bool ce_loss_grad_supported(int w, int W);
+size_t ce_loss_grad_scratch(int B, int h, int w, int K);
+int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W, const uint8_t* teacher,
+                        int NC, double* loss, float* scratch, hipStream_t st);
+int launch_ce_combine(int B, int h, int w, const int32_t* cls, int K, int NC, const double* loss_and_count, const float* scratch,
+                      float* dlogits, int ldd, hipStream_t st);
 int launch_cross_confusion(const uint8_t* a, const uint8_t* b, int64_t n, const int32_t* lut /*[256] -> subset idx or -1*/,
                            int K, int64_t* conf, hipStream_t st);
 

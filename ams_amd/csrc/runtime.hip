@@ -1,0 +1,100 @@
+// Process-wide launch bookkeeping shared by every kernel launcher:
+//   * per-DEVICE one-time function attributes and occupancy figures (hipFuncSetAttribute / hipOccupancy* are per device: a process
+//     that holds a server student on one GPU and an edge student on another must set them on both), behind one mutex;
+//   * the tuning knobs of the environment, read ONCE (a frame at a time the hot path is ~47 launches: no getenv on it).
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "kernels.hpp"
+
+namespace ams {
+
+namespace {
+std::mutex g_mu;
+std::map<std::pair<int, const void*>, size_t> g_attr;                       // (device, kernel) -> dynamic LDS limit set so far
+std::map<std::tuple<int, const void*, int, size_t>, int> g_occ;             // (device, kernel, threads, lds) -> blocks per CU
+std::map<int, int> g_cus;                                                   // device -> compute units
+}  // namespace
+
+bool launch_table_needs_attr(int device, const void* fn, size_t lds) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t& have = g_attr[{device, fn}];
+    if (lds <= have) return false;
+    have = lds;
+    return true;
+}
+
+void launch_table_forget(int device, const void* fn) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_attr.erase({device, fn});
+}
+
+int func_allow_lds(const void* fn, size_t lds) {
+    if (lds <= 64 * 1024) return AMS_OK;
+    int dev = 0;
+    AMS_CHECK_HIP(hipGetDevice(&dev));
+    if (!launch_table_needs_attr(dev, fn, lds)) return AMS_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        launch_table_forget(dev, fn);                    // not set: the next launch must try again
+        set_error("hipFuncSetAttribute(dynamic LDS %zu) -> %s", lds, hipGetErrorString(e));
+        return AMS_E_HIP;
+    }
+    return AMS_OK;
+}
+
+int func_blocks_per_cu(const void* fn, int threads, size_t lds, int* per_cu) {
+    int dev = 0;
+    AMS_CHECK_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_occ.find({dev, fn, threads, lds});
+        if (it != g_occ.end()) { *per_cu = it->second; return AMS_OK; }
+    }
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds) != hipSuccess || nb < 1) nb = 1;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_occ[{dev, fn, threads, lds}] = nb;
+    *per_cu = nb;
+    return AMS_OK;
+}
+
+int device_cus(int* cus) {
+    int dev = 0;
+    AMS_CHECK_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_cus.find(dev);
+        if (it != g_cus.end()) { *cus = it->second; return AMS_OK; }
+    }
+    int n = 0;
+    AMS_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cus[dev] = n;
+    *cus = n;
+    return AMS_OK;
+}
+
+const Knobs& knobs() {
+    static const Knobs k = [] {
+        Knobs v;
+        if (const char* e = getenv("AMS_BLK_TILE")) sscanf(e, "%dx%d", &v.blk_th, &v.blk_tw);
+        if (const char* e = getenv("AMS_PW_FORCE")) sscanf(e, "%c,%d,%d", &v.pw_force, &v.pw_rm, &v.pw_nt);
+        if (const char* e = getenv("AMS_PW_PERCU")) v.pw_percu = atoi(e);
+        v.pwx_no_tail = getenv("AMS_PWX_NO_TAIL") != nullptr;
+        if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &v.pwx_rm, &v.pwx_nt);
+        if (const char* e = getenv("AMS_XDS_FORCE")) { v.xds_set = true; sscanf(e, "%d,%d,%d,%d,%d,%d", &v.xds[0], &v.xds[1], &v.xds[2], &v.xds[3], &v.xds[4], &v.xds[5]); }
+        if (const char* e = getenv("AMS_XWR_FORCE")) { v.xwr_set = true; sscanf(e, "%d,%d,%d,%d,%d", &v.xwr[0], &v.xwr[1], &v.xwr[2], &v.xwr[3], &v.xwr[4]); }
+        return v;
+    }();
+    return k;
+}
+
+}  // namespace ams
+
+extern "C" int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_t lds) {
+    return ams::launch_table_needs_attr(device, (const void*)(uintptr_t)kernel_key, lds) ? 1 : 0;
+}

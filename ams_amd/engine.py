@@ -105,8 +105,12 @@ class StudentEngine:
         h, w = C.c_int32(), C.c_int32()
         hip.check(self.lib.ams_student_lowres_size(self._h, C.byref(h), C.byref(w)))
         self.lowres = (h.value, w.value)
-        self._conf = torch.zeros(self.K * self.K, dtype=torch.int64, device=self.device)
-        self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
+        # one output block for the host-returning calls: [conf int64 K*K | loss f64[2] | labels int32 B*H*W], mirrored in pinned
+        # host memory, so a call costs ONE device -> host copy and no allocation (SemanticNetwork.predict_with_metric)
+        self._out_meta = (self.K * self.K + 2) * 8
+        nbytes = self._out_meta + self.max_batch * self.height * self.width * 4
+        self._out_dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self._out_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
         self._keepalive = []
 
     # ------------------------------------------------------------------ plumbing
@@ -269,6 +273,36 @@ class StudentEngine:
             self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()), C.c_void_p(out.data_ptr()),
             C.c_void_p(conf.data_ptr()), C.c_void_p(loss.data_ptr()), self._stream()), "ams_student_predict_with_metric")
         return out, conf.view(self.K, self.K), loss
+
+    def _fetch_outputs(self, b: int):
+        """labels / conf / loss of the last host-returning call: one async copy into the pinned mirror, one stream sync."""
+        n = self._out_meta + b * self.height * self.width * 4
+        self._out_host[:n].copy_(self._out_dev[:n], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        host = self._out_host.numpy()
+        kk = self.K * self.K
+        conf = host[:kk * 8].view(np.int64).reshape(self.K, self.K).copy()
+        loss = host[kk * 8:self._out_meta].view(np.float64).copy()
+        labels = host[self._out_meta:n].view(np.int32).reshape(b, self.height, self.width).copy()
+        return labels, conf, loss
+
+    def predict_host(self, frames, mode: int = hip.MODE_FROZEN) -> np.ndarray:
+        """predict() with the label maps returned as a fresh int32 ndarray (one device -> host copy, preallocated buffers)."""
+        t, dt, b = self._frames_to_device(frames)
+        lab_ptr = self._out_dev.data_ptr() + self._out_meta
+        hip.check(self.lib.ams_student_predict(self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab_ptr), self._stream()),
+                  "ams_student_predict")
+        return self._fetch_outputs(b)[0]
+
+    def predict_with_metric_host(self, frames, labels_teacher, mode: int = hip.MODE_FROZEN):
+        """predict_with_metric() -> (labels int32 [B,H,W], conf_mat int64 [K,K], loss_sum_count f64[2]) as fresh ndarrays."""
+        t, dt, b = self._frames_to_device(frames)
+        lab = self._labels_to_device(labels_teacher, b)
+        base = self._out_dev.data_ptr()
+        hip.check(self.lib.ams_student_predict_with_metric(
+            self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()), C.c_void_p(base + self._out_meta),
+            C.c_void_p(base), C.c_void_p(base + self.K * self.K * 8), self._stream()), "ams_student_predict_with_metric")
+        return self._fetch_outputs(b)
 
     def cross_confusion(self, labels_pair) -> torch.Tensor:
         a = np.asarray(labels_pair)

@@ -9,11 +9,14 @@ committed; the defects listed in SURVEY.md Appendix D are resolved towards their
   * sampling and training fire ONCE per matching second (reference: once per frame of that second);
   * ``label_memory.append`` (reference ``extend`` pushes rows);
   * first training at ceil(100 / train_period) * train_period seconds, then every ``train_period`` (int range);
-  * ``send_rate`` is the uplink sampling rate in frames per SECOND: ``fps / sampling_period`` at the start (1.0 with the
-    defaults 30 / 30, the value the reference's ``sampling_period / fps`` also gives there), clipped to [0.1, 1] under ASR
-    as in the reference; ``choose_frames`` receives ``send_rate / fps`` as the fraction of the bucket, so the replay memory
-    of ``memory_len / sampling_period * fps`` entries spans ``memory_len`` seconds (the reference passes ``send_rate``
-    itself as the fraction, which uploads every frame and shrinks the memory's span to a few seconds);
+  * uplink sampling follows the reference by default (``--sampling reference``): ``send_rate = sampling_period / fps``
+    (run.py:115; 1.0 at the defaults 30 / 30) is handed to ``choose_frames`` as the FRACTION of the bucket (run.py:175), so at
+    the defaults every bucketed frame is uploaded and the replay memory of ``memory_len / sampling_period * fps`` entries
+    spans a few seconds; ASR moves it inside [0.1, 1] (run.py:287-288).  ``--sampling per_second`` is the evident intent of
+    the flag names instead: ``send_rate`` counts frames per SECOND (``fps / sampling_period`` at the start, started inside
+    ASR's [0.1, 1] when ASR is on), ``choose_frames`` receives ``send_rate / fps``, and the replay memory spans
+    ``memory_len`` seconds.  ``*_fps_client.npy``, the uplink byte counts, ``*_update.txt`` totals and the replay-memory
+    contents (hence the fine-tuned models) differ between the two settings; INTEGRATION.md lists them;
   * samples are uploaded every ``train_period`` seconds (the reference's last ``train_model`` argument, run.py:600-601);
   * a training event that finds the replay memory empty still publishes the current model for that time, so that the edge
     has a model to load (the reference would fail inside ``mini_batch``).
@@ -76,6 +79,9 @@ def build_parser() -> argparse.ArgumentParser:
     # additions (not in the reference): make short synthetic runs possible
     p.add_argument("--length", type=int, default=None, help="override exp_configs.test_length (seconds)")
     p.add_argument("--first_train_time", type=int, default=None, help="override ceil(100/train_period)*train_period")
+    p.add_argument("--sampling", default="reference", choices=["reference", "per_second"],
+                   help="uplink sampling: 'reference' = run.py:115/175 (send_rate = send_period / fps is the fraction of the bucket "
+                        "that is uploaded), 'per_second' = send_rate counts frames per second (fps / send_period)")
     p.add_argument("--horizon_k1s", default="16,32,64,128,256,512", help="horizon mode: training-window lengths in seconds (reference: hard-coded)")
     p.add_argument("--horizon_k2", type=int, default=256, help="horizon mode: evaluation window in seconds (reference: 256)")
     p.add_argument("--horizon_points", type=int, default=3, help="horizon mode: number of evaluation points (reference: 3)")
@@ -200,7 +206,13 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
     train_end_frame = min(train_end * fps, len(ctx.source))
     i = train_start * fps
     update_count = 0
-    send_rate = min(float(fps), fps / float(sampling_period))      # frames per second uploaded (module docstring)
+    per_second = getattr(FLAGS, "sampling", "reference") == "per_second"
+    if per_second:
+        send_rate = min(float(fps), fps / float(sampling_period))  # frames per second uploaded (module docstring)
+        if FLAGS.enable_ASR:
+            send_rate = float(np.clip(send_rate, 0.1, 1))          # start inside ASR's range: its first update must not jump
+    else:
+        send_rate = sampling_period / fps                          # reference run.py:115: the fraction of the bucket
     sample_per_period, up_bw_per_period, down_bw_per_period = [], [], []
     frame_label_bucket = []
     num_unseen_frames = 0
@@ -235,7 +247,7 @@ def train_model(ctx: Context, train_start, train_end, sampling_period, gpu_id, r
             print_process("%d seconds elapsed" % second, second)
 
         if second % sample_send_period == 0:
-            frames_chosen, labels_chosen = choose_frames(frame_label_bucket, min(1.0, send_rate / fps))
+            frames_chosen, labels_chosen = choose_frames(frame_label_bucket, min(1.0, send_rate / fps if per_second else send_rate))
             size_images = 0.0
             for fr, label in zip(frames_chosen, labels_chosen):
                 fr, label_resized = _to_size(fr, label, ctx.size, ctx.ingest)

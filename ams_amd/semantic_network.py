@@ -114,9 +114,14 @@ class SemanticNetwork(object):
         max_batch = kwargs.pop("max_batch", None)
         assert not kwargs, "unknown arguments: %s" % sorted(kwargs)
 
+        # gpu_id is the reference's visible_device_list string (SemanticNetwork.py:74): an ordinal among the devices this process
+        # can see.  An ordinal that does not exist is an error, as it is for tf.ConfigProto (no silent fallback to device 0);
+        # mem_frac (per_process_gpu_memory_fraction, :73) has no counterpart: the engine allocates exactly its arena.
         device = "cuda:%d" % int(str(gpu_id).split(",")[0]) if not str(gpu_id).startswith("cuda") else str(gpu_id)
         if torch.cuda.is_available() and int(device.split(":")[1]) >= torch.cuda.device_count():
-            device = "cuda:0"       # one process per GPU: the launcher already narrowed visibility (run.py:28)
+            raise ValueError("gpu_id %r: this process sees %d GPU(s) (ordinals are relative to the visible devices, "
+                             "cf. HIP_VISIBLE_DEVICES)" % (gpu_id, torch.cuda.device_count()))
+        assert 0 < float(mem_frac) <= 1, "mem_frac must be in (0, 1]"
         if self.frozen:
             if frozen_graph is None:
                 with open(meta_dir + ".pb", 'rb') as pb_file:
@@ -181,7 +186,7 @@ class SemanticNetwork(object):
     def predict_input(self, frames):
         self.process_lock.acquire()
         try:
-            labels_ = self.engine.predict(frames, self._mode()).cpu().numpy()
+            labels_ = self.engine.predict_host(frames, self._mode())
             assert labels_.shape == tuple(frames.shape[:-1] if hasattr(frames, 'shape') else np.shape(frames)[:-1])
         finally:
             self.process_lock.release()
@@ -204,10 +209,9 @@ class SemanticNetwork(object):
     def predict_with_metric(self, frames, labels_teacher):
         self.process_lock.acquire()
         try:
-            labels_dev, conf_dev, loss_dev = self.engine.predict_with_metric(frames, labels_teacher, self._mode())
-            labels_student = labels_dev.cpu().numpy()
-            conf_mat_ = conf_dev.cpu().numpy().astype(np.float64)
-            ls = loss_dev.cpu().numpy()
+            # one device -> host copy for labels + confusion matrix + loss (they share one preallocated output block)
+            labels_student, conf_i64, ls = self.engine.predict_with_metric_host(frames, labels_teacher, self._mode())
+            conf_mat_ = conf_i64.astype(np.float64)
             loss_ = np.float32(ls[0] / ls[1]) if ls[1] > 0 else np.float32(np.nan)
             assert labels_student.shape == tuple(frames.shape[:-1] if hasattr(frames, 'shape') else np.shape(frames)[:-1])
             iou_ = calculate_miou(conf_mat_, nan=True)

@@ -335,6 +335,16 @@ int ams_k_ce_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t 
                   int32_t K, int32_t H, int32_t W, const uint8_t* teacher, const double* loss_and_count_dev,
                   float* dlogits, void* stream);
 
+/* K11 forward + backward in ONE pass over the pixels (what the fine-tune step runs; replaces graph_utils.py:403-408 and its
+ * gradient): loss_dev[0] = CE sum over valid pixels, loss_dev[1] = their number, dlogits [B*h*w, NC] = d(mean CE) / d low-res
+ * logits (zeros for unselected classes).  Every pixel's softmax is evaluated once; no atomics touch the gradient (run-to-run
+ * identical).  scratch: >= ams_k_ce_loss_grad_scratch floats.  AMS_E_INVALID when one source column spans more than ~20 output
+ * columns (callers then use ams_k_upsample_argmax + ams_k_ce_grad). */
+int ams_k_ce_loss_grad(const float* logits, int32_t B, int32_t h, int32_t w, int32_t NC, const int32_t* class_idx_host,
+                       int32_t K, int32_t H, int32_t W, const uint8_t* teacher, double* loss_dev, float* dlogits,
+                       float* scratch, size_t scratch_floats, void* stream);
+size_t ams_k_ce_loss_grad_scratch(int32_t B, int32_t h, int32_t w, int32_t K);
+
 /* K13: weight gradient of a 1x1 conv: dw[K,N] = x[M,K]^T @ dy[M,N]. scratch: >= ams_k_pointwise_wgrad_scratch floats */
 int ams_k_pointwise_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw,
                           float* scratch, size_t scratch_floats, void* stream);
@@ -355,6 +365,11 @@ int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t
 /* K14-K16: fused Adam + coordinate-descent mask over a flat arena (TF1 Adam, Appendix C.10). */
 int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t,
                float beta1, float beta2, float eps, void* stream);
+
+/* Test hook (no GPU needed): the per-DEVICE bookkeeping behind the one-time kernel attributes (dynamic LDS limits).  Returns 1
+ * when (device, kernel_key) has not yet been granted `lds` bytes — i.e. the launcher would call hipFuncSetAttribute now — and
+ * records the grant; 0 otherwise.  Two students on two GPUs of one process each get their attributes set. */
+int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_t lds);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ from ams_amd import run as R  # noqa: E402
 from oracle.oracle_network import OracleSemanticNetwork  # noqa: E402
 
 ARGS = ["--input_video", "synthetic:25-synth:seconds=6:fps=4", "--student_checkpoint", "synthetic:0", "--gpu", "0", "--mode", "simple",
-        "--height", "64", "--batch_size", "4", "--iter", "1", "--send_period", "1", "--train_period", "2", "--first_train_time", "2",
+        "--height", "64", "--batch_size", "4", "--iter", "1", "--send_period", "2", "--train_period", "2", "--first_train_time", "2",
         "--memory_len", "4", "--train_strategy", "full_model"]
 SEED = 5
 

@@ -20,7 +20,7 @@ def _results(out, suffix):
     return np.load(hits[0])
 
 
-def case_asr_atr_control_loop(tmp_path, network_cls=None):
+def case_asr_atr_control_loop(tmp_path, network_cls=None, sampling="reference"):
     """--enable_ASR --enable_ATR (run.py:279-307): the phi-score of the newly uploaded teacher labels moves the sampling rate by
     -0.2*tanh((phi-0.6)*20), clipped to [0.1, 1]; a low recent rate hibernates training (train period +2 s per event, up to 6x).
     The logged trajectory must follow exactly those formulas, and the publishing times must follow the logged period."""
@@ -29,12 +29,14 @@ def case_asr_atr_control_loop(tmp_path, network_cls=None):
     random.seed(1)
     summary = _main(network_cls, ["--input_video", "synthetic:25-synth:seconds=200:fps=1", "--student_checkpoint", "synthetic:0", "--output_dir", out,
                       "--gpu", "0", "--mode", "simple", "--height", "32", "--batch_size", "2", "--iter", "1", "--send_period", "1",
-                      "--train_period", "10", "--first_train_time", "10", "--memory_len", "50", "--enable_ASR", "--enable_ATR"])
+                      "--train_period", "10", "--first_train_time", "10", "--memory_len", "50", "--enable_ASR", "--enable_ATR", "--sampling", sampling])
     assert summary["frames"] == 200
     ctl = _results(out, "_control.npy")                  # second, phi, send_rate, train_period_current, hibernating
     times = _results(out, "_model_update_times.npy")
     assert ctl.shape[1] == 5 and len(ctl) == len(times) - 1 and np.array_equal(ctl[:, 0], times[1:])
-    rate, deq, period, hib = 1.0, [], 10, False          # send_rate starts at fps / sampling_period = 1 / 1
+    # send_rate starts at sampling_period / fps = 1 / 1 (reference run.py:115) = fps / sampling_period (per_second): at 1 fps the two
+    # settings upload the same frames, so the trajectory below holds for both
+    rate, deq, period, hib = 1.0, [], 10, False
     for sec, phi, got_rate, got_period, got_hib in ctl:
         if not np.isnan(phi):
             rate = float(np.clip(rate - 0.2 * np.tanh((phi - 0.6) * 20), 0.1, 1))
@@ -60,15 +62,18 @@ def case_asr_atr_control_loop(tmp_path, network_cls=None):
     assert samples[:6].tolist() == [10, 8, 6, 4, 2, 1] and samples[-1] == 1     # send_rate frames per second x 10 s, then the 0.1 floor
 
 
-def case_upload_period_is_the_train_period(tmp_path, network_cls=None):
+def case_upload_period_is_the_train_period(tmp_path, network_cls=None, sampling="reference"):
     """The last argument of train_model is FLAGS.train_period (run.py:600-601): samples arrive every train_period seconds even when
     --send_period (the frame sampling period, 1 sample per send_period frames) is a different number."""
     out = str(tmp_path / "out") + "/"
     _main(network_cls, ["--input_video", "synthetic:25-synth:seconds=9:fps=6", "--student_checkpoint", "synthetic:0", "--output_dir", out, "--gpu", "0",
             "--mode", "simple", "--height", "32", "--batch_size", "2", "--iter", "1", "--send_period", "3", "--train_period", "2",
-            "--first_train_time", "4", "--memory_len", "6"])
+            "--first_train_time", "4", "--memory_len", "6", "--sampling", sampling])
     samples = _results(out, "_fps_client.npy")
-    assert samples.tolist() == [4, 4, 4, 4]               # uploads at 2, 4, 6, 8 s: fps / send_period = 2 frames per second x 2 s
+    if sampling == "per_second":
+        assert samples.tolist() == [4, 4, 4, 4]           # uploads at 2, 4, 6, 8 s: fps / send_period = 2 frames per second x 2 s
+    else:
+        assert samples.tolist() == [6, 6, 6, 6]           # reference run.py:115,175: the fraction send_period / fps = 0.5 of each 12-frame bucket
     assert _results(out, "_model_update_times.npy").tolist() == [0.0, 4.0, 6.0, 8.0]
 
 
@@ -78,7 +83,8 @@ def case_other_scheduler_modes(tmp_path, mode, network_cls=None):
     import glob
     out = str(tmp_path / "out") + "/"
     common = ["--input_video", "synthetic:25-synth:seconds=12:fps=4", "--student_checkpoint", "synthetic:0", "--output_dir", out, "--gpu", "0",
-              "--height", "32", "--batch_size", "2", "--iter", "1", "--send_period", "4", "--train_period", "2", "--memory_len", "4"]
+              "--height", "32", "--batch_size", "2", "--iter", "1", "--send_period", "4", "--train_period", "2", "--memory_len", "4",
+              "--sampling", "per_second"]
     if mode == "early":
         summary = _main(network_cls, common + ["--mode", "early", "--early_cutoff_time", "4"])
         assert summary["frames"] == 48
@@ -99,3 +105,24 @@ def case_other_scheduler_modes(tmp_path, mode, network_cls=None):
             assert len(np.load(glob.glob(out + lab + "_results*_mious.npy")[0])) == n
         # a window shorter than the upload period still publishes a model for its event time (the edge loads it)
         assert summary["frames"] == 12
+
+
+def case_reference_sampling_default(tmp_path, network_cls=None):
+    """Default uplink sampling = the reference's (run.py:115, :136-137, :175): send_rate = send_period / fps is the fraction of the
+    bucket handed to choose_frames, the replay memory holds int(memory_len / send_period * fps) entries.  At send_period == fps every
+    bucketed frame is uploaded; the per_second setting uploads one frame per second from the same buckets."""
+    import glob
+    outs = {}
+    for tag, extra in (("ref", []), ("sec", ["--sampling", "per_second"])):
+        out = str(tmp_path / tag) + "/"
+        np.random.seed(3)
+        random.seed(3)
+        _main(network_cls, ["--input_video", "synthetic:25-synth:seconds=6:fps=4", "--student_checkpoint", "synthetic:0", "--output_dir", out,
+                            "--gpu", "0", "--mode", "simple", "--height", "32", "--batch_size", "2", "--iter", "1", "--send_period", "4",
+                            "--train_period", "2", "--first_train_time", "2", "--memory_len", "4"] + extra)
+        outs[tag] = out
+    assert _results(outs["ref"], "_fps_client.npy").tolist() == [8, 8, 8]      # fraction 4 / 4 = 1: all 8 frames of each 2-second bucket
+    assert _results(outs["sec"], "_fps_client.npy").tolist() == [2, 2, 2]      # 1 frame per second
+    for tag, total in (("ref", 24), ("sec", 6)):
+        txt = open(glob.glob(outs[tag] + "*_results*_update.txt")[0]).read().split()
+        assert int(txt[4]) == total

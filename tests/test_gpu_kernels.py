@@ -483,6 +483,20 @@ def test_upsample_argmax_metrics_and_ce_grad(lib, h, w, H, W, cls):
     assert rel_err(dl.cpu().numpy(), lt.grad.numpy()) < 2e-5
     unsel = [c for c in range(NC) if c not in cls]
     assert np.all(dl.cpu().numpy()[..., unsel] == 0)
+    # ---- loss and gradient in ONE pass (what the fine-tune step runs): same loss sums, same gradient, identical bits run to run
+    n = lib.ams_k_ce_loss_grad_scratch(B, h, w, K)
+    scr = torch.full((n,), np.nan, device=DEV)
+    outs = []
+    for _ in range(2):
+        loss1 = torch.full((2,), np.nan, dtype=torch.float64, device=DEV)
+        dl1 = torch.full((B, h, w, NC), np.nan, device=DEV)
+        hip.check(lib.ams_k_ce_loss_grad(P(ld), B, h, w, NC, ci, K, H, W, P(td), P(loss1), P(dl1), P(scr), n, stream()))
+        outs.append((loss1.cpu().numpy(), dl1.cpu().numpy()))
+    got1, d1 = outs[0]
+    assert got1[1] == valid.sum() and got1[0] / got1[1] == pytest.approx(pix[valid].mean(), rel=1e-5)
+    assert rel_err(d1, lt.grad.numpy()) < 2e-5
+    assert np.all(d1[..., unsel] == 0)
+    assert np.array_equal(d1, outs[1][1])
 
 
 def test_upsample_all_ignored_gives_zero_count(lib):

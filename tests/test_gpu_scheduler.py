@@ -15,7 +15,7 @@ def test_simple_mode_on_synthetic_clip(tmp_path):
     summary = R.main(["--input_video", "synthetic:25-synth:seconds=8:fps=8", "--student_checkpoint", "synthetic:0",
                       "--output_dir", out, "--gpu", "0", "--mode", "simple", "--height", "256", "--batch_size", "4",
                       "--iter", "3", "--send_period", "1", "--train_period", "2", "--first_train_time", "2",
-                      "--memory_len", "4", "--train_strategy", "coord_desc_rand"])
+                      "--memory_len", "4", "--train_strategy", "coord_desc_rand", "--sampling", "per_second"])
     assert summary["frames"] == 64 and np.isfinite(summary["mean_miou"]) and summary["frames_per_sec"] > 30
     import glob
     files = {f.split("_results_")[-1].split("_256_")[-1] if "_256_" in f else f for f in glob.glob(out + "*_results*")}
@@ -66,7 +66,7 @@ def test_directory_source_with_gpu_ingest_equals_host_resize(tmp_path):
         random.seed(11)
         R.main(["--input_video", str(src), "--gt_video", str(src), "--student_checkpoint", "synthetic:0", "--output_dir", out,
                 "--gpu", "0", "--mode", "simple", "--height", str(H), "--batch_size", "2", "--iter", "2", "--send_period", "1",
-                "--train_period", "1", "--first_train_time", "1", "--memory_len", "2", "--length", str(seconds)] + extra)
+                "--train_period", "1", "--first_train_time", "1", "--memory_len", "2", "--length", str(seconds), "--sampling", "per_second"] + extra)
         outs[tag] = out
     a = np.load(glob.glob(outs["host"] + "*_mioucats.npy")[0])
     b = np.load(glob.glob(outs["dev"] + "*_mioucats.npy")[0])
@@ -76,7 +76,7 @@ def test_directory_source_with_gpu_ingest_equals_host_resize(tmp_path):
     np.testing.assert_allclose(la, lb, rtol=1e-5)
 
 
-from sched_cases import _results, case_asr_atr_control_loop, case_other_scheduler_modes, case_upload_period_is_the_train_period
+from sched_cases import _results, case_asr_atr_control_loop, case_other_scheduler_modes, case_reference_sampling_default, case_upload_period_is_the_train_period
 
 
 def test_scheduler_matches_the_oracle_backed_run(tmp_path, golden_dir):
@@ -112,12 +112,18 @@ def test_scheduler_matches_the_oracle_backed_run(tmp_path, golden_dir):
     assert loss[-8:].mean() < 0.75 * loss[:8].mean()                    # the published models are picked up and help
 
 
-def test_asr_atr_control_loop(tmp_path):
-    case_asr_atr_control_loop(tmp_path)
+@pytest.mark.parametrize("sampling", ["reference", "per_second"])
+def test_asr_atr_control_loop(tmp_path, sampling):
+    case_asr_atr_control_loop(tmp_path, None, sampling=sampling)
 
 
-def test_upload_period_is_the_train_period_not_the_send_period(tmp_path):
-    case_upload_period_is_the_train_period(tmp_path)
+@pytest.mark.parametrize("sampling", ["reference", "per_second"])
+def test_upload_period_is_the_train_period_not_the_send_period(tmp_path, sampling):
+    case_upload_period_is_the_train_period(tmp_path, None, sampling=sampling)
+
+
+def test_default_sampling_is_the_reference_fraction(tmp_path):
+    case_reference_sampling_default(tmp_path)
 
 
 @pytest.mark.parametrize("mode", ["early", "pretrained", "horizon"])

@@ -4,15 +4,21 @@ path."""
 import pytest
 
 from oracle.oracle_network import OracleSemanticNetwork
-from sched_cases import case_asr_atr_control_loop, case_other_scheduler_modes, case_upload_period_is_the_train_period
+from sched_cases import case_asr_atr_control_loop, case_other_scheduler_modes, case_reference_sampling_default, case_upload_period_is_the_train_period
 
 
-def test_asr_atr_control_loop(tmp_path):
-    case_asr_atr_control_loop(tmp_path, OracleSemanticNetwork)
+@pytest.mark.parametrize("sampling", ["reference", "per_second"])
+def test_asr_atr_control_loop(tmp_path, sampling):
+    case_asr_atr_control_loop(tmp_path, OracleSemanticNetwork, sampling=sampling)
 
 
-def test_upload_period_is_the_train_period_not_the_send_period(tmp_path):
-    case_upload_period_is_the_train_period(tmp_path, OracleSemanticNetwork)
+@pytest.mark.parametrize("sampling", ["reference", "per_second"])
+def test_upload_period_is_the_train_period_not_the_send_period(tmp_path, sampling):
+    case_upload_period_is_the_train_period(tmp_path, OracleSemanticNetwork, sampling=sampling)
+
+
+def test_default_sampling_is_the_reference_fraction(tmp_path):
+    case_reference_sampling_default(tmp_path, OracleSemanticNetwork)
 
 
 @pytest.mark.parametrize("mode", ["early", "pretrained", "horizon"])

@@ -63,6 +63,7 @@ struct LayerRt {
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
     float* blk_vecs = nullptr;             // expand layer of a whole-block kernel: [13][cout] table of BN vectors + depthwise taps (freeze)
+    float* xx_g0 = nullptr;                // expand layer of a recompute block (training): sum x x^T [KP][KP] | sum x [KP] of the last live forward
 };
 
 struct Carver {
@@ -107,6 +108,10 @@ struct ams_student {
     bool tp_fresh = false;                                       // panels hold the split of the CURRENT parameters (this step)
     float* dlogits = nullptr;
     float* ce_scratch = nullptr;       // unnormalised CE gradient planes of the one-pass loss kernel (k_head.hip)
+    // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
+    int train_recompute = 1;
+    float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
+    float *vec_ones = nullptr, *vec_zeros = nullptr;             // [1024] each: identity BN for a fused kernel's raw output
     float* act[4] = {nullptr, nullptr, nullptr, nullptr};   // inference ping-pong pool
     size_t act_elems = 0;
     float *pooled = nullptr, *pool_a = nullptr, *img_bias = nullptr;          // [B,cin_head], [B,256], [B,256]
@@ -336,6 +341,27 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
     if (c.trainable) {
         s->dlogits = cv.take<float>((size_t)B * s->h * s->w * 32);
         s->ce_scratch = cv.take<float>(ce_loss_grad_scratch(B, s->h, s->w, c.n_selected));
+        size_t xt = 0;
+        for (int i = 2; i + 1 <= s->n_backbone; ++i) {
+            const LayerRt& l = s->L[i];
+            if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
+                xdw_train_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate)) {
+                const size_t need = xdw_train_scratch(B, l.Hin, l.Win, l.d.cin, l.d.cout);
+                if (need > xt) xt = need;
+            }
+        }
+        s->xt_floats = xt;
+        s->xt_scratch = cv.take<float>(xt);
+        for (int i = 2; i + 1 <= s->n_backbone; ++i) {
+            LayerRt& l = s->L[i];
+            if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
+                xdw_train_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate)) {
+                const int KP = (l.d.cin + 15) / 16 * 16;
+                l.xx_g0 = cv.take<float>((size_t)KP * KP + KP);
+            }
+        }
+        s->vec_ones = cv.take<float>(1024);
+        s->vec_zeros = cv.take<float>(1024);
         s->d_img_bias = cv.take<float>((size_t)B * aspp_c);
         s->d_pool_a = cv.take<float>((size_t)B * aspp_c);
         s->d_pool_z = cv.take<float>((size_t)B * aspp_c);
@@ -767,6 +793,16 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
 // =======================================================================================================
 // live forward: training-mode BN.  z = raw conv output, batch statistics -> (scale, shift), a = act(z*scale+shift)(+res)
 // =======================================================================================================
+// layer i opens an early block whose fine-tune step runs without the expanded tensors (k_xdw_train.hip)
+static bool train_recompute_block(const ams_student* s, int i) {
+    if (!s->train_recompute || !s->xt_scratch || i < 2 || i + 1 > s->n_backbone) return false;
+    const LayerRt& l = s->L[i];
+    const LayerRt& ld = s->L[i + 1];
+    return l.xx_g0 && l.d.role == AMS_ROLE_EXPAND && ld.d.role == AMS_ROLE_DEPTHWISE && xdw_train_supported(l.d.cin, l.d.cout, ld.d.stride, ld.d.rate) &&
+           expand_dw_supported(l.d.cin, l.d.cout, ld.d.stride, ld.d.rate) && l.d.cout <= 1024 &&
+           xdw_train_scratch(s->cfg.max_batch, l.Hin, l.Win, l.d.cin, l.d.cout) <= s->xt_floats;
+}
+
 static int bn_train(ams_student* s, LayerRt& l, int64_t M_local, double n_global, bool update_ema, const SyncCtx* sc,
                     const float* res, hipStream_t st) {
     const ams_student_config& c = s->cfg;
@@ -809,6 +845,40 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
     for (int i = 2; i <= s->n_backbone; ++i) {
         LayerRt& l = s->L[i];
         const float* x = s->L[i - 1].a;
+        if (train_recompute_block(s, i)) {
+            // early block: neither z_e nor a_e is written.  Statistics of z_e = x . W_e straight from x, then the inference kernel
+            // expand + BN + ReLU6 + depthwise with the batch statistics -> the depthwise layer's raw output
+            LayerRt& ld = s->L[i + 1];
+            const float* center = s->stats + l.d.mean_off;
+            const float omd = 1.0f - c.bn_decay;
+            float* mm = update_ema ? s->stats + l.d.mean_off : nullptr;
+            float* mv = update_ema ? s->stats + l.d.var_off : nullptr;
+            const double n_e = (double)global_B * l.px_out;
+            int rows = 0;
+            int64_t fstride = 0;
+            RUNK(i, 4.0 * B * l.px_in * l.d.cin,
+                 launch_xdw_fwd_stats(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.cout, center, s->xt_scratch, &rows, &fstride, st));
+            {   // sums of x and x x^T over this rank's pixels, kept for the expand weight gradient
+                const int KP = (l.d.cin + 15) / 16 * 16;
+                RUN(launch_reduce_splits(s->xt_scratch + 2 * (int64_t)l.d.cout, rows, (int64_t)KP * KP + KP, l.xx_g0, st, fstride));
+            }
+            if (!sc || !sc->cb) {
+                RUN(launch_bn_fwd_finalize_partials(s->xt_scratch, rows, fstride, l.d.cout, l.fsums, n_e, center,
+                                                    s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd, mm, mv, l.scale,
+                                                    l.shift, l.mean, l.rstd, st));
+            } else {
+                RUN(launch_partials_to_sums(s->xt_scratch, rows, fstride, l.d.cout, l.fsums, st));
+                RUN(sync_doubles(sc, l.fsums, 2 * (size_t)l.d.cout, st));
+                RUN(launch_bn_finalize(l.fsums, n_e, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
+                                       mm, mv, l.scale, l.shift, l.mean, l.rstd, st));
+            }
+            RUNK(i + 1, 4.0 * ((double)B * (l.px_in * l.d.cin + ld.px_out * ld.d.cout)),
+                 launch_expand_dw(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.scale, l.shift, l.d.act, l.d.cout, P + ld.d.w_off, ld.d.stride,
+                                  ld.d.rate, s->vec_ones, s->vec_zeros, AMS_ACT_NONE, ld.z, st));
+            RUN(bn_train(s, ld, (int64_t)B * ld.px_out, (double)global_B * ld.px_out, update_ema, sc, nullptr, st));
+            ++i;
+            continue;
+        }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, nullptr, nullptr,
                                                      AMS_ACT_NONE, l.z, st));
@@ -970,6 +1040,41 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         float* dz = overlap && zb ? s->dz2 : s->dz;
         if (overlap && wg_pending[zb]) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_wg[zb], 0)); wg_pending[zb] = false; }
         RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz));
+        if (l.d.role == AMS_ROLE_DEPTHWISE && train_recompute_block(s, i - 1)) {
+            // early block: from dz of the depthwise layer straight to the gradient of the block input; da_e / dz_e / a_e are recomputed
+            // from the block input inside the kernels and never stored (k_xdw_train.hip)
+            LayerRt& le = s->L[i - 1];
+            LayerRt& lin = s->L[i - 2];
+            const float* x = lin.a;
+            int rows = 0;
+            int64_t stride = 0;
+            RUNK(i, 4.0 * ((double)B * (le.px_in * le.d.cin + l.px_out * l.d.cout)),
+                 launch_xdw_bwd_reduce(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.d.cout, le.scale, le.shift, le.mean, le.rstd, le.d.act,
+                                       P + l.d.w_off, l.d.stride, dz, s->xt_scratch, &rows, &stride, st));
+            const double n_e = (double)global_B * le.px_out;
+            if (!sc || !sc->cb) {
+                RUN(launch_bn_bwd_finalize_partials(s->xt_scratch, rows, stride, le.d.cout, le.bsums, n_e, P + le.d.gamma_off, le.mean, le.rstd,
+                                                    le.cA, le.cB, le.cC, G + le.d.gamma_off, G + le.d.beta_off, st));
+            } else {
+                RUN(launch_partials_to_sums(s->xt_scratch, rows, stride, le.d.cout, le.bsums, st));
+                RUN(launch_bn_param_grads(le.bsums, le.d.cout, G + le.d.gamma_off, G + le.d.beta_off, st));
+                RUN(sync_doubles(sc, le.bsums, 2 * (size_t)le.d.cout, st));
+                RUN(launch_bn_bwd_coef(le.bsums, n_e, le.d.cout, P + le.d.gamma_off, le.mean, le.rstd, le.cA, le.cB, le.cC, nullptr, nullptr, st));
+            }
+            const float* skip = (i + 1 <= s->n_backbone && s->L[i + 1].d.residual_from == i - 2) ? s->L[i + 1].da : nullptr;
+            RUNK(i - 1, 4.0 * ((double)B * (le.px_in * le.d.cin * (skip ? 3 : 2) + l.px_out * l.d.cout)),
+                 launch_xdw_bwd_dx(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.d.cout, le.scale, le.shift, le.d.act, P + l.d.w_off,
+                                   l.d.stride, dz, le.cA, le.cB, le.cC, skip, lin.da, st));
+            // weight gradients from the partial rows: depthwise taps, then the expand weights from (G1 | XX | g0)
+            const int KP = (le.d.cin + 15) / 16 * 16;
+            const int64_t n_dw = 9 * (int64_t)le.d.cout, n_g = (int64_t)KP * le.d.cout;
+            float* reduced = s->xt_scratch + (int64_t)rows * stride;
+            RUN(launch_reduce_splits(s->xt_scratch + 2 * (int64_t)le.d.cout, rows, n_dw, G + l.d.w_off, st, stride));
+            RUN(launch_reduce_splits(s->xt_scratch + 11 * (int64_t)le.d.cout, rows, n_g, reduced, st, stride));
+            RUN(launch_xdw_dwe(reduced, le.xx_g0, le.d.cin, le.d.cout, P + le.d.w_off, le.cA, le.cB, le.cC, G + le.d.w_off, st));
+            --i;                                       // the expand layer is done
+            continue;
+        }
         if (l.d.role == AMS_ROLE_STEM) {
             RUN(launch_stem_im2col(frames, dtype, B, c.height, c.width, c.pixel_scale, s->im2col, st));
             RUN(pw_wgrad(s, s->im2col, 32, 27, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, st));
@@ -1061,6 +1166,12 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
+    if (s->vec_ones) {
+        std::vector<float> ones(1024, 1.0f), zeros(1024, 0.0f);
+        hipError_t e = hipMemcpy(s->vec_ones, ones.data(), 1024 * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s->vec_zeros, zeros.data(), 1024 * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_error("create: uploading constants -> %s", hipGetErrorString(e)); delete s; return AMS_E_HIP; }
+    }
     if (!s->tp_jobs.empty()) {
         for (size_t k = 0; k < s->tp_jobs.size(); ++k) {
             SplitJob& j = s->tp_jobs[k];
@@ -1079,6 +1190,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (const char* e = getenv("AMS_OVERLAP_HEAD")) s->overlap_head = atoi(e);              // tuning knob
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
+    if (const char* e = getenv("AMS_TRAIN_RECOMPUTE")) s->train_recompute = atoi(e);       // tuning knob (see AMS_OPT_TRAIN_RECOMPUTE)
     *out = s;
     return AMS_OK;
 }
@@ -1357,6 +1469,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     }
     if (option == AMS_OPT_FUSE_EXPAND_DW) {
         s->fuse_expand_dw = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_TRAIN_RECOMPUTE) {
+        s->train_recompute = value != 0;
         return AMS_OK;
     }
     set_error("set_option: unknown option %d", option);

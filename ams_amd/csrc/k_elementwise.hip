@@ -188,13 +188,13 @@ struct BnBwdFin {
 
 template <class Fin>
 __global__ __launch_bounds__(512) void col_finalize_bn_kernel(const float* __restrict__ part, int chunks, int C,
-                                                              double* __restrict__ sums, Fin fin) {
+                                                              double* __restrict__ sums, Fin fin, int64_t row_stride = 0) {
     __shared__ double sacc[2][16][17];
     const int col = threadIdx.x & 15, kpart = (threadIdx.x >> 4) & 15, q = threadIdx.x >> 8;
     const int c = blockIdx.x * 16 + col;
     double s = 0.0;
     if (c < C) {
-        const int64_t per = 2 * (int64_t)C;
+        const int64_t per = row_stride > 0 ? row_stride : 2 * (int64_t)C;       // floats between the partial rows
         const float* p = part + (int64_t)q * C + c;
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int k = kpart;
@@ -250,7 +250,7 @@ static int run_col_reduce_bn(Op op, int64_t M, int C, float* scratch, double* su
     const size_t lds = (size_t)g.slots * 2 * C * sizeof(float);
     hipLaunchKernelGGL((col_reduce_kernel<2, Op>), dim3(g.chunks, 1), dim3(g.CG * g.slots), lds, st, op, g, scratch);
     AMS_CHECK_LAUNCH();
-    hipLaunchKernelGGL((col_finalize_bn_kernel<Fin>), dim3(cdiv(C, 16)), dim3(512), 0, st, scratch, g.chunks, C, sums, fin);
+    hipLaunchKernelGGL((col_finalize_bn_kernel<Fin>), dim3(cdiv(C, 16)), dim3(512), 0, st, scratch, g.chunks, C, sums, fin, (int64_t)0);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -263,6 +263,31 @@ int launch_colstats_bn(const float* z, int64_t M, int C, const float* center, do
     note_kernel("col_reduce_kernel<2, OpStats>");
     const BnFwdFin fin{n, center, gamma, beta, eps, one_minus_decay, moving_mean, moving_var, scale, shift, save_mean, save_rstd};
     return run_col_reduce_bn(op, M, C, scratch, sums, fin, st);
+}
+
+// second stages alone, over partial rows [rows][2][C] that another kernel produced (k_xdw_train.hip), `row_stride` floats apart
+int launch_bn_fwd_finalize_partials(const float* part, int rows, int64_t row_stride, int C, double* sums, double n, const float* center,
+                                    const float* gamma, const float* beta, float eps, float one_minus_decay, float* moving_mean,
+                                    float* moving_var, float* scale, float* shift, float* save_mean, float* save_rstd, hipStream_t st) {
+    const BnFwdFin fin{n, center, gamma, beta, eps, one_minus_decay, moving_mean, moving_var, scale, shift, save_mean, save_rstd};
+    hipLaunchKernelGGL((col_finalize_bn_kernel<BnFwdFin>), dim3(cdiv(C, 16)), dim3(512), 0, st, part, rows, C, sums, fin, row_stride);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+int launch_bn_bwd_finalize_partials(const float* part, int rows, int64_t row_stride, int C, double* sums, double n, const float* gamma,
+                                    const float* mean, const float* rstd, float* coefA, float* coefB, float* coefC, float* dgamma,
+                                    float* dbeta, hipStream_t st) {
+    const BnBwdFin fin{n, gamma, mean, rstd, coefA, coefB, coefC, dgamma, dbeta};
+    hipLaunchKernelGGL((col_finalize_bn_kernel<BnBwdFin>), dim3(cdiv(C, 16)), dim3(512), 0, st, part, rows, C, sums, fin, row_stride);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+struct SumsOnlyFin { __device__ void operator()(int, int, double, double) const {} };
+// sums[2][C] (f64) only: the data-parallel step all-reduces them before the per-channel arithmetic
+int launch_partials_to_sums(const float* part, int rows, int64_t row_stride, int C, double* sums, hipStream_t st) {
+    hipLaunchKernelGGL((col_finalize_bn_kernel<SumsOnlyFin>), dim3(cdiv(C, 16)), dim3(512), 0, st, part, rows, C, sums, SumsOnlyFin{}, row_stride);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
 }
 
 // launch_bn_bwd_reduce + launch_bn_param_grads + launch_bn_bwd_coef in two launches instead of four
@@ -489,7 +514,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mas
 // at (t >> 4); the 16 f64 partials of an output are added in a fixed order (deterministic, and ~16x shorter dependent
 // load chains than one thread per output: with ~1000 splits the serial form cost > 100 us per call).
 __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, int splits, int64_t n,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int64_t stride) {
     __shared__ double sacc[16][17];
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
     const int kpart = threadIdx.x >> 4;
@@ -497,8 +522,8 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
     if (i < n) {
         double s0 = 0, s1 = 0;
         int k = kpart;
-        for (; k + 16 < splits; k += 32) { s0 += part[(int64_t)k * n + i]; s1 += part[(int64_t)(k + 16) * n + i]; }
-        if (k < splits) s0 += part[(int64_t)k * n + i];
+        for (; k + 16 < splits; k += 32) { s0 += part[(int64_t)k * stride + i]; s1 += part[(int64_t)(k + 16) * stride + i]; }
+        if (k < splits) s0 += part[(int64_t)k * stride + i];
         s = s0 + s1;
     }
     sacc[kpart][threadIdx.x & 15] = s;
@@ -510,8 +535,8 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
     }
 }
 
-int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, splits, n, out);
+int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st, int64_t stride) {
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, splits, n, out, stride > 0 ? stride : n);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

@@ -118,6 +118,27 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
                      int Cexp, const float* w_dw, int stride, int rate, const float* sc_d, const float* sh_d, int act_d, float* y,
                      hipStream_t st);
 
+// ---- k_xdw_train.hip : fine-tune step of the early blocks (Cin <= 32) without the 6x-expanded tensors: every consumer recomputes
+// z_e = x . W_e from the block input (see the file header)
+bool xdw_train_supported(int Cin, int Cexp, int stride, int rate);
+size_t xdw_train_scratch(int B, int H, int W, int Cin, int Cexp);      // floats: partial rows of the passes below + one reduced row
+int xdw_train_blocks(int B, int H, int W);
+// forward statistics: partial rows  S [2][Cexp] (sum(z - center), sum((z - center)^2)) | XX [KP][KP] = x^T x | g0 [KP] = sum x
+// (KP = Cin rounded up to 16) -> scratch
+int launch_xdw_fwd_stats(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* center, float* scratch,
+                         int* rows_out, int64_t* stride_out, hipStream_t st);
+// backward pass 1 (given dz_d): partial rows  S [2][Cexp] | dWd [9][Cexp] | G1 [KP][Cexp]
+int launch_xdw_bwd_reduce(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* sc_e, const float* sh_e,
+                          const float* mean_e, const float* rstd_e, int act_e, const float* w_dw, int stride, const float* dz_d, float* scratch,
+                          int* rows_out, int64_t* stride_out, hipStream_t st);
+// backward pass 2: dx = (cA dy_e + cB + cC z_e) . W_e^T (+ res)
+int launch_xdw_bwd_dx(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* sc_e, const float* sh_e,
+                      int act_e, const float* w_dw, int stride, const float* dz_d, const float* cA, const float* cB, const float* cC,
+                      const float* res, float* dx, hipStream_t st);
+// dW_e from the reduced G1 [KP][Cexp], the forward pass's (XX | g0) and the BN-backward coefficients
+int launch_xdw_dwe(const float* G1, const float* xx_g0, int Cin, int Cexp, const float* w_exp, const float* cA, const float* cB, const float* cC,
+                   float* dw, hipStream_t st);
+
 // ---- k_block.hip : a whole early inverted-residual block (expand -> depthwise -> project [+ input]) in one kernel ----
 bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bool residual);
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
@@ -188,7 +209,16 @@ int launch_colsum(const float* x, int64_t M, int C, int ldx, float* out, float* 
 int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t, float b1,
                 float b2, float eps, hipStream_t st);
 // out[i] = sum_k part[k*n + i], k ascending (deterministic second stage of split reductions)
-int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st);
+// stride: floats between the partial rows (0 = n: dense)
+int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st, int64_t stride = 0);
+// the second (per-channel) stages of the BN reductions over partial rows [rows][2][C] produced elsewhere, row_stride floats apart
+int launch_bn_fwd_finalize_partials(const float* part, int rows, int64_t row_stride, int C, double* sums, double n, const float* center,
+                                    const float* gamma, const float* beta, float eps, float one_minus_decay, float* moving_mean,
+                                    float* moving_var, float* scale, float* shift, float* save_mean, float* save_rstd, hipStream_t st);
+int launch_bn_bwd_finalize_partials(const float* part, int rows, int64_t row_stride, int C, double* sums, double n, const float* gamma,
+                                    const float* mean, const float* rstd, float* coefA, float* coefB, float* coefC, float* dgamma,
+                                    float* dbeta, hipStream_t st);
+int launch_partials_to_sums(const float* part, int rows, int64_t row_stride, int C, double* sums, hipStream_t st);
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
 int launch_copy(float* dst, const float* src, int64_t n, hipStream_t st);
 size_t pack_fp16_scratch(int64_t n);

@@ -207,6 +207,10 @@ class StudentEngine:
                   "ams_pack_masked_fp16")
         return out[:int(cnt.item())]
 
+    def set_train_recompute(self, on: bool) -> None:
+        """Fine-tune step of the early blocks without their 6x-expanded tensors (default on); off = every tensor materialised."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_TRAIN_RECOMPUTE, int(bool(on))), "ams_student_set_option")
+
     def set_fuse_first_block(self, on: int) -> None:
         """Frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel with a tile per block
         (k_first_block.hip; default), 2 one kernel with a tile per wave (k_block.hip; measured slower).  Forms 0 and 2 keep an exact-f32 stem;

@@ -30,6 +30,7 @@ OPT_FUSE_BLOCK = 6
 OPT_LATE_SUBBATCH = 7
 OPT_BLOCK_X6 = 8
 OPT_DUAL_STREAM = 10
+OPT_TRAIN_RECOMPUTE = 11
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)

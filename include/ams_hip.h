@@ -189,7 +189,10 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_DUAL_STREAM = 10 /* frozen inference: a batch as two to four parts on as many streams (the caller's and up to three the student
+enum { AMS_OPT_TRAIN_RECOMPUTE = 11 /* fine-tune step: 1 (default) the early blocks (block input <= 32 channels) run without their 6x-expanded
+                                       tensors — every consumer recomputes z_e = x . W_e from the block input (k_xdw_train.hip); 0 the
+                                       layer-by-layer step (every tensor materialised).  Same mathematics, f32-level differences (summation order). */,
+       AMS_OPT_DUAL_STREAM = 10 /* frozen inference: a batch as two to four parts on as many streams (the caller's and up to three the student
                                    owns; one fork and one join per call), each frame computed exactly as in a batch of the part's size.  0 never;
                                    1 (default) decided per batch size (>= 16 frames) by timing the one-stream plan and the 2-, 3- and 4-part
                                    plans inside the first call with that batch size; n >= 2 always two parts from n frames on.  It pays where the single-stream grids quantise badly (512x1024: +3.5 % at 32-36 frames). */,

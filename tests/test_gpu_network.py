@@ -376,7 +376,10 @@ def test_data_parallel_step_equals_single_process(W0, tmp_path):
     eng.load_variables(W0)
     ls = eng.train_step(frames, labels, 1e-3).cpu().numpy()
     dp_ls = np.load(tmp_path / "dp_loss.npy")
-    assert dp_ls[1] == ls[1] and dp_ls[0] == pytest.approx(ls[0], rel=1e-6)      # global CE sum and valid count
+    # global CE sum and valid count: the count is exact; the sum carries the f32 summation order of the ranks' BN statistics (two ranks
+    # add their halves, a single process adds block partials): measured 1.3e-6 with the early blocks' statistics taken from the block
+    # input (k_xdw_train.hip), 2e-7 layer by layer
+    assert dp_ls[1] == ls[1] and dp_ls[0] == pytest.approx(ls[0], rel=1e-5)
     g, dg = eng.grads.cpu().numpy().astype(np.float64), np.load(tmp_path / "dp_grads.npy").astype(np.float64)
     cos = float(g @ dg / (np.linalg.norm(g) * np.linalg.norm(dg)))
     assert cos > 0.99999, cos

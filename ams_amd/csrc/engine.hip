@@ -130,9 +130,11 @@ struct ams_student {
     // Whether it pays is a matter of grid quantisation: at 512x1024 it is +3.5 % at 32-36 frames and -1..-5 % at 24-30 and 40.
     int dual_stream = 1;
     int dual_parts = 2;              // parts when dual_stream >= 2 forces the split (AMS_DUAL_PARTS, 2 .. 4)
+    int dual_autotune = 0;           // AMS_OPT_DUAL_AUTOTUNE: time the plans in the first call per batch size (synchronises; opt-in)
     hipStream_t part_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t part_done[3] = {nullptr, nullptr, nullptr};
-    std::map<int, int> dual_choice;  // batch -> number of parts (1 = one stream)
+    hipEvent_t ev_fork_dual = nullptr;
+    std::map<int, int> dual_choice;  // batch -> number of parts (1 = one stream), filled by the autotune
     int overlap_head = 0;            // frozen inference: image-pooling branch on the side stream beside the aspp0 GEMM (AMS_OVERLAP_HEAD).
                                      // Off: measured 3.63 vs 3.61 ms at 32 frames and 1.90 k vs 2.01 k frames/s at one — the fork / join events
                                      // cost more than the three small launches they hide
@@ -142,6 +144,7 @@ struct ams_student {
         if (ev_head) (void)hipEventDestroy(ev_head);
         for (auto& e : part_done) if (e) (void)hipEventDestroy(e);
         for (auto& t : part_stream) if (t) (void)hipStreamDestroy(t);
+        if (ev_fork_dual) (void)hipEventDestroy(ev_fork_dual);
         for (auto& e : ev_wg) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
     }
@@ -1166,6 +1169,13 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (rc) { delete s; return rc; }
     s->arena = (char*)arena_dev;
     s->arena_bytes = arena_bytes;
+    {   // events are free; STREAMS are not: the runtime multiplexes them onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by
+        // default), and two streams that land on one queue serialise.  A student therefore owns only the streams it uses: the part
+        // streams appear with the first multi-part call (never inside a graph capture: ensure_part_streams).
+        hipError_t e = hipEventCreateWithFlags(&s->ev_fork_dual, hipEventDisableTiming);
+        for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&s->part_done[k], hipEventDisableTiming);
+        if (e != hipSuccess) { set_error("create: events -> %s", hipGetErrorString(e)); delete s; return AMS_E_HIP; }
+    }
     if (s->vec_ones) {
         std::vector<float> ones(1024, 1.0f), zeros(1024, 0.0f);
         hipError_t e = hipMemcpy(s->vec_ones, ones.data(), 1024 * sizeof(float), hipMemcpyHostToDevice);
@@ -1187,6 +1197,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (const char* e = getenv("AMS_STREAM_MIN_ROWS")) s->stream_min_rows = atoll(e);        // tuning knob
     if (const char* e = getenv("AMS_DUAL_PARTS")) s->dual_parts = atoi(e);                  // tuning knob
     if (const char* e = getenv("AMS_DUAL_STREAM")) s->dual_stream = atoi(e);                // tuning knob (see AMS_OPT_DUAL_STREAM)
+    if (const char* e = getenv("AMS_DUAL_AUTOTUNE")) s->dual_autotune = atoi(e);            // tuning knob (see AMS_OPT_DUAL_AUTOTUNE)
     if (const char* e = getenv("AMS_OVERLAP_HEAD")) s->overlap_head = atoi(e);              // tuning knob
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
@@ -1260,42 +1271,18 @@ static int check_call(const ams_student* s, const void* frames, int dtype, int b
     return AMS_OK;
 }
 
-// Frozen inference on two streams: the batch's halves run the same layer sequence side by side (half 0 on the caller's stream, half 1
-// on the student's side stream, one fork and one join per step), each in its own half of every activation buffer.  A launch of this
-// network rarely fills the chip to the end — tails of 1.05- or 2.1-round grids, latency-bound chains on a few blocks per CU — and the
-// other half's kernels fill those gaps.  Every frame is computed exactly as in a batch of half the size.
-static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, int batch, hipStream_t st, int nparts = 2) {
-    const ams_student_config& c = s->cfg;
-    if (nparts < 2) nparts = 2;
-    if (nparts > 4) nparts = 4;
-    if (nparts > batch) nparts = batch;
-    if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    for (int p = 1; p < nparts; ++p) {
-        if (!s->part_stream[p - 1]) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->part_stream[p - 1], hipStreamNonBlocking));
-        if (!s->part_done[p - 1]) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->part_done[p - 1], hipEventDisableTiming));
-    }
-    AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
-    LayerRt& lp = s->L[s->iPool]; LayerRt& lc = s->L[s->iProj];
-    const size_t frame_bytes = (size_t)c.height * c.width * 3 * (dtype == AMS_DT_U8 ? 1 : 4);
-    float* act0[4] = {s->act[0], s->act[1], s->act[2], s->act[3]};
-    uint16_t* xs0 = s->xsplit; const size_t xp0 = s->xsplit_plane;
-    float *pooled0 = s->pooled, *pool_a0 = s->pool_a, *img_bias0 = s->img_bias, *logits0 = s->logits, *scratch0 = s->scratch;
-    const size_t per_frame = s->act_elems / c.max_batch;
-    struct Restore {                                  // the student's buffer pointers come back whatever way this function is left
-        ams_student* s; float* act0[4]; uint16_t* xs0; size_t xp0; float *pooled0, *pool_a0, *img_bias0, *logits0, *scratch0;
-        ~Restore() {
-            for (int k = 0; k < 4; ++k) s->act[k] = act0[k];
-            s->xsplit = xs0; s->xsplit_plane = xp0;
-            s->pooled = pooled0; s->pool_a = pool_a0; s->img_bias = img_bias0; s->logits = logits0; s->scratch = scratch0;
-        }
-    } restore{s, {act0[0], act0[1], act0[2], act0[3]}, xs0, xp0, pooled0, pool_a0, img_bias0, logits0, scratch0};
-    int rc = AMS_OK;
-    int b0 = 0;
-    for (int p = 0; p < nparts && !rc; ++p) {
-        const int bp = batch / nparts + (p < batch % nparts ? 1 : 0);
-        hipStream_t ps = p == 0 ? st : s->part_stream[p - 1];
-        if (p > 0) AMS_CHECK_HIP(hipStreamWaitEvent(ps, s->ev_fork, 0));
-        // part p: its own slice of every buffer (sized for max_batch >= batch frames)
+// A slice of the student's frozen-inference buffers: frames b0 .. b0 + bp - 1 of every activation / head buffer (all sized for max_batch
+// frames).  While the guard lives, forward_frozen works inside that slice; the pointers come back whatever way the scope is left.
+struct SliceGuard {
+    ams_student* s;
+    float* act0[4]; uint16_t* xs0; size_t xp0; float *pooled0, *pool_a0, *img_bias0, *logits0, *scratch0;
+    SliceGuard(ams_student* s_, int b0, int bp) : s(s_) {
+        const ams_student_config& c = s->cfg;
+        for (int k = 0; k < 4; ++k) act0[k] = s->act[k];
+        xs0 = s->xsplit; xp0 = s->xsplit_plane;
+        pooled0 = s->pooled; pool_a0 = s->pool_a; img_bias0 = s->img_bias; logits0 = s->logits; scratch0 = s->scratch;
+        const LayerRt& lp = s->L[s->iPool]; const LayerRt& lc = s->L[s->iProj];
+        const size_t per_frame = s->act_elems / c.max_batch;
         for (int k = 0; k < 4; ++k) s->act[k] = act0[k] + (size_t)b0 * per_frame;
         if (xs0) { s->xsplit = xs0 + 3 * (xp0 / c.max_batch) * b0; s->xsplit_plane = (xp0 / c.max_batch) * bp; }
         s->pooled = pooled0 + (size_t)b0 * lp.d.cin;
@@ -1303,12 +1290,74 @@ static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, in
         s->img_bias = img_bias0 + (size_t)b0 * lc.d.cout;
         s->logits = logits0 + (size_t)b0 * s->h * s->w * 32;
         s->scratch = scratch0 + image_colsum_scratch(b0, lp.d.cin);
-        rc = forward_frozen(s, (const char*)frames + (size_t)b0 * frame_bytes, dtype, bp, ps);
-        if (p > 0) AMS_CHECK_HIP(hipEventRecord(s->part_done[p - 1], ps));
+    }
+    ~SliceGuard() {
+        for (int k = 0; k < 4; ++k) s->act[k] = act0[k];
+        s->xsplit = xs0; s->xsplit_plane = xp0;
+        s->pooled = pooled0; s->pool_a = pool_a0; s->img_bias = img_bias0; s->logits = logits0; s->scratch = scratch0;
+    }
+};
+
+// Frozen inference as two to four parts on as many streams: the parts run the same layer sequence side by side (part 0 on the caller's
+// stream, the others on streams the student owns; one fork and one join per step), each in its own slice of every activation buffer.
+// A launch of this network rarely fills the chip to the end — tails of 1.05- or 2.1-round grids, latency-bound chains on a few blocks
+// per CU — and the other parts' kernels fill those gaps.  Every frame is computed exactly as in a batch of the part's size.
+// Whatever happens inside, every part stream is joined back into `st` before this returns.
+// the part streams of an n-part plan exist (created on first use, outside any graph capture); false: run the one-stream plan instead
+static bool ensure_part_streams(ams_student* s, int nparts, hipStream_t st) {
+    bool missing = false;
+    for (int p = 1; p < nparts; ++p) missing = missing || !s->part_stream[p - 1];
+    if (!missing) return true;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;      // nothing is created inside a capture
+    for (int p = 1; p < nparts; ++p)
+        if (!s->part_stream[p - 1] && hipStreamCreateWithFlags(&s->part_stream[p - 1], hipStreamNonBlocking) != hipSuccess) return false;
+    return true;
+}
+
+static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, int batch, hipStream_t st, int nparts = 2) {
+    const ams_student_config& c = s->cfg;
+    if (nparts < 2) nparts = 2;
+    if (nparts > 4) nparts = 4;
+    if (nparts > batch) nparts = batch;
+    if (nparts < 2 || !ensure_part_streams(s, nparts, st)) return forward_frozen(s, frames, dtype, batch, st);
+    AMS_REQUIRE(s->ev_fork_dual && s->part_stream[nparts - 2] && s->part_done[nparts - 2], "dual plan: part streams were not created");
+    AMS_CHECK_HIP(hipEventRecord(s->ev_fork_dual, st));
+    const size_t frame_bytes = (size_t)c.height * c.width * 3 * (dtype == AMS_DT_U8 ? 1 : 4);
+    int rc = AMS_OK;
+    int b0 = 0, forked = 0;
+    for (int p = 0; p < nparts && !rc; ++p) {
+        const int bp = batch / nparts + (p < batch % nparts ? 1 : 0);
+        hipStream_t ps = p == 0 ? st : s->part_stream[p - 1];
+        if (p > 0) {
+            if (hipStreamWaitEvent(ps, s->ev_fork_dual, 0) != hipSuccess) { set_error("dual plan: fork failed"); rc = AMS_E_HIP; break; }
+            forked = p;
+        }
+        {
+            SliceGuard slice(s, b0, bp);
+            rc = forward_frozen(s, (const char*)frames + (size_t)b0 * frame_bytes, dtype, bp, ps);
+        }
         b0 += bp;
     }
-    for (int p = 1; p < nparts; ++p) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->part_done[p - 1], 0));
+    // join every stream that was forked, error or not: no part may still be writing the student's buffers after the return
+    for (int p = 1; p <= forked; ++p) {
+        if (hipEventRecord(s->part_done[p - 1], s->part_stream[p - 1]) != hipSuccess ||
+            hipStreamWaitEvent(st, s->part_done[p - 1], 0) != hipSuccess) {
+            (void)hipStreamSynchronize(s->part_stream[p - 1]);        // last resort: a host wait keeps the guarantee
+            if (!rc) { set_error("dual plan: join failed"); rc = AMS_E_HIP; }
+        }
+    }
     return rc;
+}
+
+// Parts of the static rule (AMS_OPT_DUAL_STREAM = 1): where the one-stream grids quantise badly at 512 x 1024 (round-2 sweep on MI355X:
+// two parts +3.5 % at 32-36 frames and at 64, three at 48; a loss of 1-5 % at 24-30 and 40; nothing either way elsewhere).  A fixed
+// function of the batch size: the same call always runs the same plan, and nothing is timed inside a call.
+static int dual_parts_static(int batch) {
+    if (batch >= 32 && batch <= 36) return 2;
+    if (batch == 48) return 3;
+    if (batch == 64) return 2;
+    return 1;
 }
 
 static int run_forward(ams_student* s, const void* frames, int dtype, int batch, int mode, hipStream_t st) {
@@ -1316,32 +1365,43 @@ static int run_forward(ams_student* s, const void* frames, int dtype, int batch,
         if (!s->frozen_ready) { set_error("predict: ams_student_freeze has not been called"); return AMS_E_STATE; }
         if (s->dual_stream == 0 || s->prof.on || s->late_subbatch != 0 || batch < 2) return forward_frozen(s, frames, dtype, batch, st);
         if (s->dual_stream >= 2) return batch >= s->dual_stream ? forward_frozen_dual(s, frames, dtype, batch, st, s->dual_parts) : forward_frozen(s, frames, dtype, batch, st);
+        if (!s->dual_autotune) {
+            const int n = dual_parts_static(batch);
+            return n > 1 ? forward_frozen_dual(s, frames, dtype, batch, st, n) : forward_frozen(s, frames, dtype, batch, st);
+        }
         if (batch < 16) return forward_frozen(s, frames, dtype, batch, st);
         auto it = s->dual_choice.find(batch);
         if (it == s->dual_choice.end()) {
-            // first call with this batch size: time both plans on these very frames (each after a warm-up pass), keep the faster one — two
-            // streams only when they win by more than the timing noise — and finish with a pass of the chosen plan, whose result is returned
+            // AMS_OPT_DUAL_AUTOTUNE (opt-in; this branch synchronises the host): the first call with this batch size times the one-stream
+            // plan and the 2- to 4-part plans on these very frames — median of three timed passes each, after a warm-up pass — keeps a
+            // multi-part plan only when it wins by more than the timing noise, and finishes with a pass of the chosen plan
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             (void)hipStreamIsCapturing(st, &cap);
             if (cap != hipStreamCaptureStatusNone) return forward_frozen(s, frames, dtype, batch, st);      // no timing inside a capture
-            hipEvent_t e0, e1;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
             AMS_CHECK_HIP(hipEventCreate(&e0));
-            AMS_CHECK_HIP(hipEventCreate(&e1));
+            if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); set_error("autotune: hipEventCreate failed"); return AMS_E_HIP; }
             float ms[5] = {0.f, 0.f, 0.f, 0.f, 0.f};          // ms[n]: the batch in n parts (n = 1: one stream)
             int rc = AMS_OK;
+            hipError_t he = hipSuccess;
             const int max_parts = batch >= 32 ? 4 : batch >= 24 ? 3 : 2;       // parts of at least 8 frames
-            for (int n = 1; n <= max_parts && !rc; ++n) {
-                for (int rep = 0; rep < 2 && !rc; ++rep) {
-                    if (rep == 1) (void)hipEventRecord(e0, st);
+            for (int n = 1; n <= max_parts && !rc && he == hipSuccess; ++n) {
+                float t[3] = {0.f, 0.f, 0.f};
+                rc = n > 1 ? forward_frozen_dual(s, frames, dtype, batch, st, n) : forward_frozen(s, frames, dtype, batch, st);      // warm-up
+                for (int rep = 0; rep < 3 && !rc && he == hipSuccess; ++rep) {
+                    he = hipEventRecord(e0, st);
                     rc = n > 1 ? forward_frozen_dual(s, frames, dtype, batch, st, n) : forward_frozen(s, frames, dtype, batch, st);
+                    if (he == hipSuccess) he = hipEventRecord(e1, st);
+                    if (he == hipSuccess) he = hipEventSynchronize(e1);
+                    if (he == hipSuccess) he = hipEventElapsedTime(&t[rep], e0, e1);
                 }
-                (void)hipEventRecord(e1, st);
-                (void)hipEventSynchronize(e1);
-                (void)hipEventElapsedTime(&ms[n], e0, e1);
+                const float lo = t[0] < t[1] ? t[0] : t[1], hi = t[0] < t[1] ? t[1] : t[0];
+                ms[n] = t[2] < lo ? lo : (t[2] > hi ? hi : t[2]);                                  // median of three
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (rc) return rc;
+            if (he != hipSuccess) { set_error("autotune: event timing failed: %s", hipGetErrorString(he)); return AMS_E_HIP; }
             int best = 1;
             for (int n = 2; n <= max_parts; ++n)
                 if (ms[n] < 0.985f * ms[1] && (best == 1 || ms[n] < ms[best])) best = n;
@@ -1375,6 +1435,18 @@ int ams_student_predict_with_metric(ams_student* s, const void* frames_dev, int3
     const ams_student_config& c = s->cfg;
     return launch_upsample_argmax(s->logits, 32, batch, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher_dev,
                                   c.num_classes, labels_out_dev, conf_mat_dev, loss_dev, st);
+}
+
+int ams_student_predict_frames(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch, int32_t mode, const uint8_t* teacher_dev,
+                               int32_t* labels_out_dev, int64_t* conf_mats_dev, double* losses_dev, void* stream) {
+    RUN(check_call(s, frames_dev, frames_dtype, batch));
+    AMS_REQUIRE(labels_out_dev, "predict_frames: null output");
+    AMS_REQUIRE(teacher_dev == nullptr || (conf_mats_dev && losses_dev), "predict_frames: metrics need conf and loss buffers");
+    hipStream_t st = (hipStream_t)stream;
+    RUN(run_forward(s, frames_dev, frames_dtype, batch, mode, st));
+    const ams_student_config& c = s->cfg;
+    return launch_upsample_argmax(s->logits, 32, batch, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher_dev, c.num_classes,
+                                  labels_out_dev, teacher_dev ? conf_mats_dev : nullptr, teacher_dev ? losses_dev : nullptr, st, /*per_frame=*/1);
 }
 
 int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t n_pixels, int64_t* conf_mat_dev, void* stream) {
@@ -1432,10 +1504,20 @@ int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frame
 
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     AMS_REQUIRE(s, "set_option: null student");
+    s->dual_choice.clear();                            // any option may change the plans the autotune compared
     if (option == AMS_OPT_MATMUL) {
         AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16 || value == AMS_MATMUL_SPLIT_BF16_X6 || value == AMS_MATMUL_BF16,
                     "set_option: unknown matmul mode %d", value);
         s->matmul_mode = value;
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_DUAL_AUTOTUNE) {
+        s->dual_autotune = value != 0;
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_DUAL_PARTS) {
+        AMS_REQUIRE(value >= 2 && value <= 4, "set_option: AMS_OPT_DUAL_PARTS must be 2 .. 4");
+        s->dual_parts = value;
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_FIRST_BLOCK) {

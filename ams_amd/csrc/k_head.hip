@@ -12,6 +12,7 @@ constexpr int kMaxK = 32;
 
 struct HeadGeom {
     int B, h, w, ld, K, H, W, NC;
+    int per_frame;         // metrics per frame: conf [B][K][K], loss [B][2] instead of the batch totals
     float sy, sx;          // (h-1)/(H-1), (w-1)/(W-1) as f32 (TF: CalculateResizeScale with align_corners)
 };
 
@@ -45,15 +46,19 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
                                                               int32_t* __restrict__ labels,
                                                               unsigned long long* __restrict__ conf, double* __restrict__ loss) {
     __shared__ int s_conf[kMaxK * kMaxK];
-    __shared__ float s_loss[4];
+    __shared__ double s_loss[4];
     __shared__ int s_cnt[4];
     const bool metric = teacher != nullptr;
     if (metric)
         for (int e = threadIdx.x; e < g.K * g.K; e += blockDim.x) s_conf[e] = 0;
     const int b = blockIdx.z;
+    if (g.per_frame && metric) { conf += (size_t)b * g.K * g.K; loss += 2 * b; }
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (metric) __syncthreads();
-    float my_loss = 0.f;
+    // A pixel's loss enters the sums as an integer multiple of 2^-20 (held in f64: exact up to 2^33): every partial sum is then exact,
+    // so the total does not depend on how pixels are dealt to threads, blocks or batches, nor on the order of the atomics below — the
+    // loss of a frame is the same bits in a one-frame call and inside a 32-frame call.  The rounding is <= 5e-7 per pixel (~1e-10 of the sum).
+    double my_loss = 0.0;
     int my_cnt = 0;
     int x0 = 0, x1 = 0; float tx = 0.f;
     if (x < g.W) src_tap(x, g.sx, g.w, x0, x1, tx);
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
         }
         if (labels) labels[pix] = arg;
         if (target >= 0) {
-            my_loss += (zmax + __logf(ssum)) - zt;
+            my_loss += rint((double)((zmax + __logf(ssum)) - zt) * 1048576.0);
             my_cnt += 1;
             atomicAdd(&s_conf[target * g.K + arg], 1);
         }
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
         const int nw = (blockDim.x + 63) >> 6;
         double ls = 0; int cn = 0;
         for (int i = 0; i < nw; ++i) { ls += s_loss[i]; cn += s_cnt[i]; }
-        if (cn) { atomicAdd(&loss[0], ls); atomicAdd(&loss[1], (double)cn); }
+        if (cn) { atomicAdd(&loss[0], ls * (1.0 / 1048576.0)); atomicAdd(&loss[1], (double)cn); }
     }
 }
 
@@ -144,7 +149,7 @@ static int fill_class_table(const int32_t* cls_host, int K, int NC, ClassTable* 
 
 static HeadGeom head_geom(int ld, int B, int h, int w, int K, int H, int W, int NC) {
     HeadGeom g;
-    g.B = B; g.h = h; g.w = w; g.ld = ld; g.K = K; g.H = H; g.W = W; g.NC = NC;
+    g.B = B; g.h = h; g.w = w; g.ld = ld; g.K = K; g.H = H; g.W = W; g.NC = NC; g.per_frame = 0;
     g.sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     g.sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     return g;
@@ -152,16 +157,18 @@ static HeadGeom head_geom(int ld, int B, int h, int w, int K, int H, int W, int 
 
 // cls: HOST pointer to the K selected class ids (they travel to the kernel by value)
 int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
-                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st) {
+                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st, int per_frame) {
     ClassTable ct;
     int rc = fill_class_table(cls, K, NC, &ct);
     if (rc) return rc;
     AMS_REQUIRE(teacher == nullptr || (conf != nullptr && loss != nullptr), "head: metrics need conf and loss buffers");
+    const int nm = per_frame ? B : 1;
     if (teacher) {
-        AMS_CHECK_HIP(hipMemsetAsync(conf, 0, sizeof(int64_t) * K * K, st));
-        AMS_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double) * 2, st));
+        AMS_CHECK_HIP(hipMemsetAsync(conf, 0, sizeof(int64_t) * K * K * nm, st));
+        AMS_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double) * 2 * nm, st));
     }
-    const HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
+    HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
+    g.per_frame = per_frame;
     note_kernel("upsample_argmax_kernel");
     // bands of consecutive rows per block: 32 per column strip and image, fewer rows per band when that leaves the chip short of blocks
     int rows_y = H < 32 ? H : 32;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
     __shared__ float s_val[192][2 * KMAX + 1];
     __shared__ float s_wx[192][2];            // weight of the column towards its left / right source column
     __shared__ int s_x0[192];
-    __shared__ float s_loss[3];
+    __shared__ double s_loss[3];
     __shared__ int s_cnt[3];
     const int b = blockIdx.z, i0 = blockIdx.y, j_lo = blockIdx.x * kCeCB;
     const int i1 = i0 + 1 < g.h ? i0 + 1 : g.h - 1;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
     float gt[KMAX], gb[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { gt[k] = 0.f; gb[k] = 0.f; }
-    float my_loss = 0.f;
+    double my_loss = 0.0;                     // integer multiples of 2^-20 per pixel: exact, order-independent sums (upsample_argmax_kernel)
     int my_cnt = 0;
     if (live) {
         const float* base = logits + (int64_t)b * g.h * g.w * g.ld;
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
             for (int k = 0; k < KMAX; ++k)
                 if (k < g.K) { z[k] = __expf(z[k] - zmax); ssum += z[k]; }
             const float rs = 1.f / ssum;
-            if (own) { my_loss += (zmax + __logf(ssum)) - zt; my_cnt += 1; }
+            if (own) { my_loss += rint((double)((zmax + __logf(ssum)) - zt) * 1048576.0); my_cnt += 1; }
             const float wt = 1.f - ty;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
     if (threadIdx.x == 0) {
         double ls = 0; int cn = 0;
         for (int i = 0; i < 3; ++i) { ls += s_loss[i]; cn += s_cnt[i]; }
-        if (cn) { atomicAdd(&loss[0], ls); atomicAdd(&loss[1], (double)cn); }
+        if (cn) { atomicAdd(&loss[0], ls * (1.0 / 1048576.0)); atomicAdd(&loss[1], (double)cn); }
     }
 }
 

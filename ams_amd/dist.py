@@ -85,6 +85,13 @@ class RcclComm:
         hip.check(self.lib.ams_comm_stats(self._h, None, None, C.byref(calls), C.byref(nbytes)), "ams_comm_stats")
         return int(calls.value), int(nbytes.value)
 
+    def rank_world(self) -> Tuple[int, int]:
+        """(rank, world size) as the library's communicator sees them (RCCL's own view, not the launcher's environment)."""
+        import ctypes as C
+        r, w = C.c_int32(), C.c_int32()
+        hip.check(self.lib.ams_comm_stats(self._h, C.byref(r), C.byref(w), None, None), "ams_comm_stats")
+        return int(r.value), int(w.value)
+
     def all_reduce(self, t: torch.Tensor) -> None:
         """Sum ``t`` (float32 / float64, contiguous, on this rank's GPU) in place across ranks on torch's current stream."""
         import ctypes as C

@@ -108,7 +108,7 @@ class StudentEngine:
         # one output block for the host-returning calls: [conf int64 K*K | loss f64[2] | labels int32 B*H*W], mirrored in pinned
         # host memory, so a call costs ONE device -> host copy and no allocation (SemanticNetwork.predict_with_metric)
         self._out_meta = (self.K * self.K + 2) * 8
-        nbytes = self._out_meta + self.max_batch * self.height * self.width * 4
+        nbytes = self._out_meta * self.max_batch + self.max_batch * self.height * self.width * 4      # room for per-frame metrics too
         self._out_dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self._out_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
         self._keepalive = []
@@ -227,10 +227,15 @@ class StudentEngine:
         or as exact f32 MFMAs (bit-identical to the layer-by-layer plan).  Also selects the stem's products in the one-kernel first block."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_BLOCK_X6, int(bool(on))), "ams_student_set_option")
 
-    def set_dual_stream(self, mode: int) -> None:
-        """Frozen inference as two to four part-batches on as many streams: 0 never, 1 decided per batch size by timing the plans in the
-        first call (default), n >= 2 always two parts from n frames on."""
+    def set_dual_stream(self, mode: int, parts: Optional[int] = None, autotune: Optional[bool] = None) -> None:
+        """Frozen inference as two to four part-batches on as many streams: 0 never, 1 (default) a fixed function of the batch size
+        (never synchronises), n >= 2 always ``parts`` parts from n frames on.  ``autotune=True`` (with mode 1): time the plans inside the
+        first call per batch size instead of the static rule (that call synchronises)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_DUAL_STREAM, int(mode)), "ams_student_set_option")
+        if parts is not None:
+            hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_DUAL_PARTS, int(parts)), "ams_student_set_option")
+        if autotune is not None:
+            hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_DUAL_AUTOTUNE, int(bool(autotune))), "ams_student_set_option")
 
     def set_late_subbatch(self, frames: int) -> None:
         """Frozen inference: frames per pass of the output-stride-16 section (0 = the whole batch); same bits either way."""
@@ -307,6 +312,39 @@ class StudentEngine:
             self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()), C.c_void_p(base + self._out_meta),
             C.c_void_p(base), C.c_void_p(base + self.K * self.K * 8), self._stream()), "ams_student_predict_with_metric")
         return self._fetch_outputs(b)
+
+    def predict_frames(self, frames, labels_teacher=None, mode: int = hip.MODE_FROZEN):
+        """Per-FRAME results of one batched pass (ams_student_predict_frames): device tensors labels int32 [B,H,W], conf int64 [B,K,K],
+        loss f64 [B,2] (views of the engine's output block, valid until the next host-returning / predict_frames call).  Nothing is
+        synchronised; ``fetch_frames`` brings them to the host."""
+        t, dt, b = self._frames_to_device(frames)
+        lab = self._labels_to_device(labels_teacher, b) if labels_teacher is not None else None
+        kk = self.K * self.K
+        base = self._out_dev.data_ptr()
+        meta = self._out_meta * b
+        hip.check(self.lib.ams_student_predict_frames(
+            self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()) if lab is not None else None, C.c_void_p(base + meta),
+            C.c_void_p(base), C.c_void_p(base + kk * 8 * b), self._stream()), "ams_student_predict_frames")
+        self._keepalive = [t, lab]
+        self._frames_b = b
+        conf = self._out_dev[:kk * 8 * b].view(torch.int64).view(b, self.K, self.K)
+        loss = self._out_dev[kk * 8 * b:meta].view(torch.float64).view(b, 2)
+        labels = self._out_dev[meta:meta + b * self.height * self.width * 4].view(torch.int32).view(b, self.height, self.width)
+        return labels, conf, loss
+
+    def fetch_frames(self):
+        """(labels [B,H,W] int32, conf [B,K,K] int64, loss [B,2] f64) of the last ``predict_frames`` as fresh ndarrays: one copy, one sync."""
+        b = self._frames_b
+        kk = self.K * self.K
+        meta = self._out_meta * b
+        n = meta + b * self.height * self.width * 4
+        self._out_host[:n].copy_(self._out_dev[:n], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        host = self._out_host.numpy()
+        conf = host[:kk * 8 * b].view(np.int64).reshape(b, self.K, self.K).copy()
+        loss = host[kk * 8 * b:meta].view(np.float64).reshape(b, 2).copy()
+        labels = host[meta:n].view(np.int32).reshape(b, self.height, self.width).copy()
+        return labels, conf, loss
 
     def cross_confusion(self, labels_pair) -> torch.Tensor:
         a = np.asarray(labels_pair)

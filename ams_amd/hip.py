@@ -31,6 +31,8 @@ OPT_LATE_SUBBATCH = 7
 OPT_BLOCK_X6 = 8
 OPT_DUAL_STREAM = 10
 OPT_TRAIN_RECOMPUTE = 11
+OPT_DUAL_AUTOTUNE = 12
+OPT_DUAL_PARTS = 13
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)
@@ -68,6 +70,7 @@ SIGNATURES = {
     "ams_student_freeze": (C.c_int, [_vp, _vp]),
     "ams_student_predict": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ams_student_predict_with_metric": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ams_student_predict_frames": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ams_cross_confusion": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "ams_student_train_step": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _vp]),
     "ams_student_train_step_dp": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, ALLREDUCE_CB, _vp, _vp]),

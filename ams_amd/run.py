@@ -79,6 +79,10 @@ def build_parser() -> argparse.ArgumentParser:
     # additions (not in the reference): make short synthetic runs possible
     p.add_argument("--length", type=int, default=None, help="override exp_configs.test_length (seconds)")
     p.add_argument("--first_train_time", type=int, default=None, help="override ceil(100/train_period)*train_period")
+    p.add_argument("--edge_pipeline", type=int, default=1, choices=[1, 2, 3, 4],
+                   help="edge: frames per inference pass (extra flag; 1 = the reference's synchronous per-frame call).  With n >= 2 the edge "
+                        "holds n frames and labels them in ONE pass (a one-frame pass leaves most of the chip idle), while the previous pass's "
+                        "results are being consumed; per-frame outputs are identical")
     p.add_argument("--sampling", default="reference", choices=["reference", "per_second"],
                    help="uplink sampling: 'reference' = run.py:115/175 (send_rate = send_period / fps is the fraction of the bucket "
                         "that is uploaded), 'per_second' = send_rate counts frames per second (fps / send_period)")
@@ -344,26 +348,54 @@ def infer_output(ctx: Context, inf_start, inf_end, gpu_id, run_label, gt_path, e
     final_save_dir = ctx.save_dir(run_label + "_results")
     load_times = set(float(t) for t in load_range)
     t_infer = 0.0
-    while i < inf_end_frame:
-        if i / fps in load_times:
-            save_dir = ctx.save_dir(run_label + "_%d" % (i // fps))
-            if semantic_network is not None:
-                semantic_network.close_model()
-            semantic_network = ctx.network_cls(meta_dir=save_dir + "_final", class_weights_exp=class_weights(exp_num),
-                                               height=FLAGS.height, gpu_id=gpu_id, mem_frac=1, frozen=True)
-        frame, gt_frame = _to_size(*ctx.source.read(i), ctx.size, ctx.ingest)
-        t0 = time.time()
-        labels_, conf_mat_, _, miou_, loss_ = semantic_network.predict_with_metric(_batch1(frame), _batch1(gt_frame))
-        t_infer += time.time() - t0
+    depth = int(getattr(FLAGS, "edge_pipeline", 1))
+    in_flight = deque()               # tickets of submitted frames (depth >= 2), oldest first
+
+    def record(result, n_done):
+        _labels, conf_mat_, _, miou_, loss_ = result
         loss_s.append(loss_)
         miou_cats.append(np.array(conf_mat_))
         miou_s.append(miou_)
         confusion_matrix_memory.append(conf_mat_)
         miou_mem_s.append(np.nanmean(calculate_miou(np.sum(list(confusion_matrix_memory), axis=0), nan=True)))
-        i += 1
-        if i % fps == 0:
+        if n_done % fps == 0:
             miou = np.nanmean(calculate_miou(np.sum(miou_cats[-fps:], axis=0), nan=True))
-            print_process("miou at %03d secs: %.1f%%" % (i / fps, float(miou) * 100), i / fps)
+            print_process("miou at %03d secs: %.1f%%" % (n_done / fps, float(miou) * 100), n_done / fps)
+
+    done = inf_start * fps
+    while i < inf_end_frame:
+        if i / fps in load_times:
+            while in_flight:                           # the frames still in flight belong to the model that is about to be replaced
+                t0 = time.time()
+                res = semantic_network.collect(in_flight.popleft())
+                t_infer += time.time() - t0
+                done += 1
+                record(res, done)
+            save_dir = ctx.save_dir(run_label + "_%d" % (i // fps))
+            if semantic_network is not None:
+                semantic_network.close_model()
+            kw = {"pipeline_depth": depth} if depth > 1 else {}
+            semantic_network = ctx.network_cls(meta_dir=save_dir + "_final", class_weights_exp=class_weights(exp_num),
+                                               height=FLAGS.height, gpu_id=gpu_id, mem_frac=1, frozen=True, **kw)
+        frame, gt_frame = _to_size(*ctx.source.read(i), ctx.size, ctx.ingest)
+        t0 = time.time()
+        if depth > 1:
+            in_flight.append(semantic_network.predict_with_metric_async(_batch1(frame), _batch1(gt_frame)))
+            # up to two passes of `depth` frames in flight: the one on the GPU and the one being filled
+            res = semantic_network.collect(in_flight.popleft()) if len(in_flight) >= 2 * depth else None
+        else:
+            res = semantic_network.predict_with_metric(_batch1(frame), _batch1(gt_frame))
+        t_infer += time.time() - t0
+        i += 1
+        if res is not None:
+            done += 1
+            record(res, done)
+    while in_flight:
+        t0 = time.time()
+        res = semantic_network.collect(in_flight.popleft())
+        t_infer += time.time() - t0
+        done += 1
+        record(res, done)
     np.save('%s_loss.npy' % final_save_dir, loss_s)
     np.save('%s_mioucats.npy' % final_save_dir, miou_cats)
     np.save('%s_mious.npy' % final_save_dir, miou_s)

@@ -240,6 +240,7 @@ def main():
 
     # ---- latency mode + hipGraph replay (single GPU only: they say nothing about scaling) -------------------------
     fps_b1 = graph_fps = graph_fps_b1 = None
+    b1_micro = {}
     if n_gpus == 1:
         one = frames[:1].contiguous()
         for _ in range(3):
@@ -251,6 +252,23 @@ def main():
             eng.predict(one)
         torch.cuda.synchronize(dev)
         fps_b1 = n1 / (time.perf_counter() - t1)
+        # the same one-frame RESULTS, several frames per pass: bit-identical per frame to the one-frame call (tests/test_gpu_fullsize.py)
+        for mb in (2, 3, 4):                              # n frames in ONE pass with per-frame metrics (ams_student_predict_frames)
+            pe = StudentEngine(CI, H, 2 * H, max_batch=mb, trainable=False, device=dev)
+            pe.load_variables(W0)
+            pe.freeze()
+            fmb = frames[:mb].contiguous()
+            for _ in range(3):
+                pe.predict_frames(fmb)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                lab_mb, _c, _l = pe.predict_frames(fmb)
+            torch.cuda.synchronize(dev)
+            b1_micro[mb] = mb * n1 / (time.perf_counter() - t1)
+            assert torch.equal(lab_mb[:1], eng.predict(one)), "a frame of a %d-frame pass differs from its one-frame call" % mb
+            pe.close()
+            del pe
         try:
             gp = eng.graphed_predict(B)
             gp1 = eng.graphed_predict(1)
@@ -332,6 +350,12 @@ def main():
                                  "AMS_OPT_DUAL_STREAM; profiles/*_infer_kernel_stats.csv is taken with AMS_DUAL_STREAM=0 likewise); algorithmic bytes = "
                                  "f32 operands read once + results written once, algorithmic FLOPs = 2 x MACs of the block without halo or "
                                  "padding (DESIGN.md); launches of one kernel symbol are pooled (sum of work / sum of time)"})
+        parts_timed = {True: 1}.get(B < 2, 2 if (32 <= B <= 36 or B == 64) else 3 if B == 48 else 1)
+        if os.environ.get("AMS_DUAL_STREAM") == "0":
+            parts_timed = 1
+        roofline["plan"] = "one stream (the engine's per-launch profiler replays the step on ONE stream)"
+        roofline["timed_plan"] = ("%d parts of the batch on %d streams (AMS_OPT_DUAL_STREAM static rule); rocprofv3 trace of this plan: "
+                                  "profiles/r03_infer_kernel_stats_dual.csv" % (parts_timed, parts_timed)) if parts_timed > 1 else "one stream"
         roofline.update(pmc_traffic(dom[0], B, H))
         # the whole step against the three denominators of SURVEY 8 d4, over the TIMED step (not the profiled replay)
         as_built = total_bytes / n_prof
@@ -346,6 +370,20 @@ def main():
             "blockfused_f32": {"alg_bytes": round(B * blockfused_b), "achieved_GBps": round(B * blockfused_b / step_ms / 1e6, 1),
                                "frac": round(B * blockfused_b / step_ms / 1e6 / HBM_PEAK_GBS, 4),
                                "note": "SURVEY 8 d4 stretch: only block inputs / outputs, frame and labels touch HBM, f32 (%.0f MB/frame)" % (blockfused_b / 1e6)}}
+        roofline["whole_step"]["headline"] = "blockfused_f32"
+        roofline["whole_step_frac"] = roofline["whole_step"]["blockfused_f32"]["frac"]
+        # one frame per call (the reference's call shape): as-built bytes of the B = 1 plan / time per call / HBM peak
+        if fps_b1:
+            hip.check(eng.lib.ams_student_profile(eng._h, 1))
+            eng.predict(frames[:1].contiguous())
+            rows1 = read_profile(eng)
+            hip.check(eng.lib.ams_student_profile(eng._h, 0))
+            bytes1 = sum(r[3] for r in rows1)
+            ms1 = 1e3 / fps_b1
+            roofline["batch1"] = {"launches": len(rows1), "as_built_bytes": round(bytes1), "ms_per_call": round(ms1, 4),
+                                  "achieved_GBps": round(bytes1 / ms1 / 1e6, 1), "frac": round(bytes1 / ms1 / 1e6 / HBM_PEAK_GBS, 4),
+                                  "kernel_ms": round(sum(r[2] for r in rows1), 4),
+                                  "note": "one 512x1024 frame per call: %d dependent launches of 30-70 blocks; latency-bound, not bandwidth-bound" % len(rows1)}
         if dom[0].startswith("xdw_wreg_kernel"):
             # The fused expand+depthwise of the 160 -> 960 blocks moves 12 % of the bytes of the two kernels it replaces; what
             # bounds it is the matrix pipe (every f32 product is 6, or 3, bf16 MFMAs) next to the depthwise VALU work.  Reported
@@ -374,7 +412,21 @@ def main():
         low_g = eng.logits_lowres.view(-1, hl, wl, 32)[:nf, :, :, :19].cpu().numpy()
         lab_g = lab_g.cpu().numpy()
         lg = loss_g.cpu().numpy()
-        parity = {"frames": nf, "size": "%dx%d" % (H, 2 * H), "oracle": "oracle/student_torch.py, PyTorch-CPU f32 (parity unpinned: no TensorFlow here, DESIGN.md §2)",
+        # the TIMED call itself (B frames, the plan the headline ran): one frame out of each half of the batch against the oracle
+        pick = [0, B - 1] if B > 1 else [0]
+        lab_full = eng.predict(frames)
+        low_full = eng.logits_lowres.view(-1, hl, wl, 32)[:B, :, :, :19]
+        fr_pick = frames_np[pick].astype(np.float32)
+        with torch.no_grad():
+            low_po = oracle.forward_lowres(fr_pick, "frozen").numpy()
+        lab_po = oracle.predict(fr_pick, "frozen")
+        lab_pg = lab_full[pick].cpu().numpy()
+        timed = {"batch": B, "plan": roofline["timed_plan"] if roofline else None, "frames_checked": pick,
+                 "label_exact_match_fraction": round(float((lab_pg == lab_po).mean()), 7),
+                 "label_mismatch_pixels": int((lab_pg != lab_po).sum()),
+                 "logits_max_rel_err": float("%.3e" % (np.abs(low_full[pick].cpu().numpy() - low_po).max() / np.abs(low_po).max()))}
+        parity = {"frames": nf, "batch": nf, "plan": "one stream (2-frame call)", "timed_call": timed,
+                  "size": "%dx%d" % (H, 2 * H), "oracle": "oracle/student_torch.py, PyTorch-CPU f32 (parity unpinned: no TensorFlow here, DESIGN.md §2)",
                   "label_exact_match_fraction": round(float((lab_g == lab_o).mean()), 7),
                   "label_mismatch_pixels": int((lab_g != lab_o).sum()),
                   "logits_max_rel_err": float("%.3e" % (np.abs(low_g - low_o).max() / np.abs(low_o).max())),
@@ -454,6 +506,7 @@ def main():
         return tt, float(ls[0] / max(ls[1], 1))
 
     distill = distill_strong = None
+    rccl_seen = None
     TB = args.train_batch
     n_train = max(3, min(args.steps, 10))
     if not args.no_train:
@@ -462,6 +515,11 @@ def main():
         tf = torch.from_numpy(frames_np[:TB]).to(dev)
         tl = torch.from_numpy(labels_np[:TB]).to(dev)
         kw, sync = make_sync(teng)
+        if sync is not None and hasattr(sync, "rank_world"):
+            rccl_seen = sync.rank_world()                  # what RCCL itself reports, not WORLD_SIZE
+            if rccl_seen != (rank, world):
+                print("bench: RCCL communicator reports rank %d of %d, launcher says %d of %d" % (rccl_seen + (rank, world)), file=sys.stderr)
+                sys.exit(3)
         tt, loss_v = time_steps(teng, tf, tl, kw, TB * n_gpus, n_train)
         step_bytes = 3.0 * TB * layerwise_b + 7 * 4.0 * spec.n_trainable + 4.0 * 2 * spec.n_stats
         ms = 1e3 * tt / n_train
@@ -503,7 +561,8 @@ def main():
         vl = torch.from_numpy(clip_l).to(dev)
         server = StudentEngine(CI, H, 2 * H, max_batch=TB, trainable=True, device=dev)
         server.load_variables(W0)
-        edge = StudentEngine(CI, H, 2 * H, max_batch=1, trainable=False, device=dev)
+        PASS = 3                                              # frames per inference pass of the edge (the edge holds two frames: 67 ms at 30 fps)
+        edge = StudentEngine(CI, H, 2 * H, max_batch=PASS, trainable=False, device=dev)
         edge.load_variables(W0)
         edge.freeze()
 
@@ -520,10 +579,10 @@ def main():
                 with torch.cuda.stream(train_stream):         # (enqueuing it from a second host thread measured the same: 40.5x)
                     idx_s = torch.arange(TB, device=dev) * 5 % vf.shape[0]
                     server.train_step(vf[idx_s], vl[idx_s], 1e-3)
-            for k in range(fps_video):                        # edge: every frame of this second, one at a time, with metric
-                i = (sec * fps_video + k) % vf.shape[0]
-                _lab, conf, _loss = edge.predict_with_metric(vf[i:i + 1], vl[i:i + 1])
-                conf_sum += conf
+            for k in range(0, fps_video, PASS):               # edge: every frame of this second with its own metrics, PASS frames per pass
+                idx_e = (torch.arange(k, min(k + PASS, fps_video), device=dev) + sec * fps_video) % vf.shape[0]
+                _lab, confs, _loss = edge.predict_frames(vf[idx_e], vl[idx_e])
+                conf_sum += confs.sum(0)
             if overlap:
                 main.wait_stream(train_stream)
             else:
@@ -551,7 +610,7 @@ def main():
                   "realtime_factor_sequential": round(secs / tt_seq, 2),
                   "overlap": "the server's fine-tune step of a second runs on a second stream beside the edge's 30 inferences of that second (they are "
                              "independent until the hand-off, as in the deployed system); realtime_factor_sequential is the same work one after the other",
-                  "per_video_second": "30 x predict_with_metric(1 frame) on the edge model + 1 x %d-frame fine-tune step + server->edge hand-off (device copy + BN fold)" % TB,
+                  "per_video_second": "30 frames labelled with per-frame metrics on the edge model, %d frames per pass (ams_student_predict_frames) + 1 x %d-frame fine-tune step + server->edge hand-off (device copy + BN fold)" % (PASS, TB),
                   "miou_vs_teacher_rank0": round(miou_of(conf_total.cpu().numpy()), 5),
                   "target": ">= 30 frames/s of inference + one 8-frame step per second on one GPU (BASELINE.json north star): realtime_factor >= 1",
                   "note": "configs[2] interleaved on one GPU; with N > 1 configs[3]: every rank serves its own video with its own student pair, no collective"}
@@ -606,7 +665,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "rccl_ranks": (rccl_seen[1] if rccl_seen else (1 if dist is None else None)),
+            "rccl_ranks_source": ("ams_comm_stats (the library's RCCL communicator)" if rccl_seen else
+                                  "no RCCL communicator in this run" + ("" if dist is None else " (ranks share GPUs: gloo host callback)")),
             "precision_note": "f32 storage and accumulation everywhere; products of the late 1x1 layers (output stride 16 + head) are "
                               "formed as 6 bf16 MFMAs on three-part splits of the f32 operands (all 24 significand bits: f32-level; "
                               "512x1024 logits 4e-5 from the f64 oracle, same as exact f32 MFMA and as the f32 CPU oracle: "
@@ -617,6 +678,11 @@ def main():
                        "frames_per_step_per_gpu": B, "class_subset": CI, "weights": "synthetic seed 0",
                        "parallelism": "replicas x%d (no collective on the inference path)" % n_gpus},
             "frames_per_sec_batch1": round(fps_b1, 2) if fps_b1 else None,
+            "frames_per_sec_batch1_pipelined": ({**{("frames_per_pass_%d" % k): round(v, 2) for k, v in b1_micro.items()},
+                                                 "note": "one-frame results, several frames per pass: frames_per_pass_n = n consecutive frames labelled in ONE pass "
+                                                         "with per-frame metrics (ams_student_predict_frames; the edge holds n - 1 frames: 33 ms each at 30 fps); "
+                                                         "per-frame results are bit-identical to the one-frame call"}
+                                                if b1_micro else None),
             "hipgraph": {"frames_per_sec": round(graph_fps, 2) if graph_fps else None,
                          "frames_per_sec_batch1": round(graph_fps_b1, 2) if graph_fps_b1 else None,
                          "note": "same step captured once with torch.cuda.graph and replayed; single GPU, not the headline"},

@@ -139,6 +139,14 @@ int ams_student_predict_with_metric(ams_student* s, const void* frames_dev, int3
 
 /* ---- phi-score: replaces calc_cross_miou's confusion matrix (SemanticNetwork.py:124-139, :184-194) -------
  * labels_dev: uint8 [2,H,W] (before, after); conf_mat_dev: int64 [K*K] overwritten. */
+/* The edge's per-frame call, several frames at a time: what ams_student_predict_with_metric computes for ONE frame, for each of `batch`
+ * frames in one pass — labels [batch,H,W], conf_mats_dev [batch][K][K], losses_dev [batch][2] (teacher_dev NULL: labels only).  A frame at
+ * a time the forward is ~45 dependent launches of 30-70 blocks on a 256-CU chip (0.49 ms); two frames take 0.59 ms, three 0.68 ms (MI355X):
+ * a caller that can hold a frame for one or two frame times (33 ms at 30 fps) gets 1.7x / 2.2x the frames per second.  Every frame's result
+ * is what a one-frame call returns (batch-composition invariance: tests/test_gpu_fullsize.py). */
+int ams_student_predict_frames(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch, int32_t mode,
+                               const uint8_t* teacher_dev, int32_t* labels_out_dev, int64_t* conf_mats_dev, double* losses_dev, void* stream);
+
 int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t n_pixels, int64_t* conf_mat_dev,
                         void* stream);
 
@@ -189,13 +197,18 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_TRAIN_RECOMPUTE = 11 /* fine-tune step: 1 (default) the early blocks (block input <= 32 channels) run without their 6x-expanded
+enum { AMS_OPT_DUAL_AUTOTUNE = 12 /* with AMS_OPT_DUAL_STREAM = 1: 1 = pick the number of parts per batch size by TIMING the plans inside the first call
+                                      with that batch size (median of three passes each; that call synchronises the host and its result then depends
+                                      on which plan won); 0 (default) = the static rule: the same call always runs the same plan */,
+       AMS_OPT_DUAL_PARTS = 13 /* parts (2 .. 4) of the forced split, AMS_OPT_DUAL_STREAM = n >= 2 */,
+       AMS_OPT_TRAIN_RECOMPUTE = 11 /* fine-tune step: 1 (default) the early blocks (block input <= 32 channels) run without their 6x-expanded
                                        tensors — every consumer recomputes z_e = x . W_e from the block input (k_xdw_train.hip); 0 the
                                        layer-by-layer step (every tensor materialised).  Same mathematics, f32-level differences (summation order). */,
        AMS_OPT_DUAL_STREAM = 10 /* frozen inference: a batch as two to four parts on as many streams (the caller's and up to three the student
-                                   owns; one fork and one join per call), each frame computed exactly as in a batch of the part's size.  0 never;
-                                   1 (default) decided per batch size (>= 16 frames) by timing the one-stream plan and the 2-, 3- and 4-part
-                                   plans inside the first call with that batch size; n >= 2 always two parts from n frames on.  It pays where the single-stream grids quantise badly (512x1024: +3.5 % at 32-36 frames). */,
+                                   owns, created with the student; one fork and one join per call), each frame computed exactly as in a batch of the
+                                   part's size.  0 never; 1 (default) a fixed function of the batch size (two parts at 32-36 and 64 frames, three at
+                                   48: where the single-stream grids quantise badly at 512x1024, +3.5 %) — nothing is timed, the call never
+                                   synchronises; n >= 2 always AMS_OPT_DUAL_PARTS parts from n frames on (the caller decides). */,
        AMS_OPT_BLOCK_X6 = 8 /* whole-block kernels: 1 (default) the expand products of the blocks with 24 / 32 input channels, and the stem's
                                products in the one-kernel first block (operands from a 258-entry table of the normalised byte values), run as six bf16
                                MFMAs on three-part splits (f32-level, 96 instead of 256 matrix-pipe cycles per 16x16 tile); 0 exact f32 MFMA

@@ -54,6 +54,17 @@ class OracleSemanticNetwork:
         iou = calculate_miou(cm, nan=True)
         return lab, cm, iou, np.nanmean(iou), np.float32(loss)
 
+    # the asynchronous surface of the product class (run.py --edge_pipeline): computed at once, handed out on collect
+    def predict_with_metric_async(self, frames, labels_teacher):
+        if not hasattr(self, "_pending"):
+            self._pending, self._ticket = {}, 0
+        self._ticket += 1
+        self._pending[self._ticket] = self.predict_with_metric(frames, labels_teacher)
+        return self._ticket
+
+    def collect(self, ticket):
+        return self._pending.pop(ticket)
+
     def predict_input(self, frames):
         return self.oracle.predict(np.asarray(frames, np.float32), self._mode())
 

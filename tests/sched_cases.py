@@ -126,3 +126,24 @@ def case_reference_sampling_default(tmp_path, network_cls=None):
     for tag, total in (("ref", 24), ("sec", 6)):
         txt = open(glob.glob(outs[tag] + "*_results*_update.txt")[0]).read().split()
         assert int(txt[4]) == total
+
+
+def case_edge_pipeline_equals_synchronous_loop(tmp_path, network_cls=None):
+    """--edge_pipeline n (frame t + 1 submitted before frame t is collected; model reloads drain the pipeline first): every per-frame
+    output file is identical to the synchronous loop's."""
+    import glob
+    outs = {}
+    for tag, extra in (("sync", []), ("pipe", ["--edge_pipeline", "2"])):
+        out = str(tmp_path / tag) + "/"
+        np.random.seed(4)
+        random.seed(4)
+        s = _main(network_cls, ["--input_video", "synthetic:25-synth:seconds=6:fps=3", "--student_checkpoint", "synthetic:0", "--output_dir", out,
+                                "--gpu", "0", "--mode", "simple", "--height", "64", "--batch_size", "2", "--iter", "1", "--send_period", "3",
+                                "--train_period", "2", "--first_train_time", "2", "--memory_len", "4"] + extra)
+        # (height 64: from 17 low-resolution pixels per frame on, a frame's arithmetic does not depend on how many frames share the pass;
+        # below that the one-row kernel of the image-pooling branch also takes the 1x1 layers of a single frame)
+        assert s["frames"] == 18
+        outs[tag] = out
+    for suffix in ("_loss.npy", "_mioucats.npy", "_mious.npy", "_mioumems.npy", "_model_update_times.npy"):
+        a, b = _results(outs["sync"], suffix), _results(outs["pipe"], suffix)
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), suffix

@@ -298,9 +298,46 @@ def test_two_stream_plan_is_two_half_batches(W0):
     eng.set_dual_stream(0)
     lab1 = eng.predict(frames)                            # one stream: the 32-frame plan, f32-level from the half-size plan
     assert rel(_lowres(eng, B), low2) < 1e-4 and (lab1 != lab2).float().mean().item() < 1e-4
-    eng.set_dual_stream(1)                                # decided by timing in the first call; the same bits from then on
+    eng.set_dual_stream(1)                                # default: a fixed function of the batch size (32 frames -> two parts), never timed
     first = eng.predict(frames).clone()
+    assert torch.equal(first, lab2)
     for _ in range(3):
         assert torch.equal(eng.predict(frames), first)
-    assert torch.equal(first, lab1) or torch.equal(first, lab2)
+    eng.set_dual_stream(2, parts=4)                       # the caller's choice: four parts of eight frames = four 8-frame calls
+    lab4 = eng.predict(frames).clone()
+    eng.set_dual_stream(0)
+    for k in range(4):
+        assert torch.equal(eng.predict(frames[8 * k:8 * k + 8]), lab4[8 * k:8 * k + 8])
+    eng.set_dual_stream(1, parts=2, autotune=True)        # opt-in: timed in the first call (median of three), the same bits from then on
+    tuned = eng.predict(frames).clone()
+    for _ in range(3):
+        assert torch.equal(eng.predict(frames), tuned)
+    assert any(torch.equal(tuned, x) for x in (lab1, lab2, lab4)) or (tuned != lab1).float().mean().item() < 1e-4
+    eng.close()
+
+
+def test_frames_per_pass_equal_single_frame_calls(W0):
+    """ams_student_predict_frames: several frames labelled in ONE pass with per-frame metrics.  Each frame's label map, confusion matrix
+    and loss sums are what its own one-frame call returns, bit for bit (batch-composition invariance incl. the loss: a pixel's loss enters
+    the sums as a multiple of 2^-20, so no partial sum ever rounds)."""
+    n = 7
+    frames, labels = synth.SyntheticVideo(H, n, CI, seed=11).clip()
+    ref = StudentEngine(CI, H, 2 * H, max_batch=1, trainable=False)
+    ref.load_variables(W0)
+    ref.freeze()
+    want = [ref.predict_with_metric_host(frames[i:i + 1], labels[i:i + 1]) for i in range(n)]
+    again = ref.predict_with_metric_host(frames[0:1], labels[0:1])
+    assert np.array_equal(again[2], want[0][2])           # the loss sums are reproducible run to run (order-independent atomics)
+    ref.close()
+    eng = StudentEngine(CI, H, 2 * H, max_batch=4, trainable=False)
+    eng.load_variables(W0)
+    eng.freeze()
+    for b0, nb in ((0, 2), (2, 3), (3, 4)):
+        eng.predict_frames(frames[b0:b0 + nb], labels[b0:b0 + nb])
+        labs, confs, losses = eng.fetch_frames()
+        for k in range(nb):
+            assert np.array_equal(labs[k], want[b0 + k][0][0]) and np.array_equal(confs[k], want[b0 + k][1]) and \
+                np.array_equal(losses[k], want[b0 + k][2]), (b0, nb, k)
+    labs_only = eng.predict_frames(frames[0:3])[0].cpu().numpy()       # no teacher: labels only
+    assert all(np.array_equal(labs_only[k], want[k][0][0]) for k in range(3))
     eng.close()

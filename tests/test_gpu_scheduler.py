@@ -76,7 +76,7 @@ def test_directory_source_with_gpu_ingest_equals_host_resize(tmp_path):
     np.testing.assert_allclose(la, lb, rtol=1e-5)
 
 
-from sched_cases import _results, case_asr_atr_control_loop, case_other_scheduler_modes, case_reference_sampling_default, case_upload_period_is_the_train_period
+from sched_cases import _results, case_asr_atr_control_loop, case_edge_pipeline_equals_synchronous_loop, case_other_scheduler_modes, case_reference_sampling_default, case_upload_period_is_the_train_period
 
 
 def test_scheduler_matches_the_oracle_backed_run(tmp_path, golden_dir):
@@ -129,3 +129,7 @@ def test_default_sampling_is_the_reference_fraction(tmp_path):
 @pytest.mark.parametrize("mode", ["early", "pretrained", "horizon"])
 def test_other_scheduler_modes(tmp_path, mode):
     case_other_scheduler_modes(tmp_path, mode)
+
+
+def test_edge_pipeline_equals_synchronous_loop(tmp_path):
+    case_edge_pipeline_equals_synchronous_loop(tmp_path)

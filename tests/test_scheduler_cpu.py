@@ -4,7 +4,7 @@ path."""
 import pytest
 
 from oracle.oracle_network import OracleSemanticNetwork
-from sched_cases import case_asr_atr_control_loop, case_other_scheduler_modes, case_reference_sampling_default, case_upload_period_is_the_train_period
+from sched_cases import case_asr_atr_control_loop, case_edge_pipeline_equals_synchronous_loop, case_other_scheduler_modes, case_reference_sampling_default, case_upload_period_is_the_train_period
 
 
 @pytest.mark.parametrize("sampling", ["reference", "per_second"])
@@ -24,3 +24,7 @@ def test_default_sampling_is_the_reference_fraction(tmp_path):
 @pytest.mark.parametrize("mode", ["early", "pretrained", "horizon"])
 def test_other_scheduler_modes(tmp_path, mode):
     case_other_scheduler_modes(tmp_path, mode, OracleSemanticNetwork)
+
+
+def test_edge_pipeline_equals_synchronous_loop(tmp_path):
+    case_edge_pipeline_equals_synchronous_loop(tmp_path, OracleSemanticNetwork)

@@ -14,6 +14,7 @@ struct ams_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     int64_t calls = 0, bytes = 0;        // what the steps exchanged so far (tests)
+    bool aborted = false;
 };
 
 namespace ams {
@@ -24,6 +25,9 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     const char* error = nullptr;
@@ -46,6 +50,9 @@ Rccl& rccl() {
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");               // optional: error path only
+        r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");               // optional: ams_comm_stats
+        r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.handle, "ncclCommUserRank");
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) r.error = "librccl lacks a required symbol";
@@ -61,11 +68,19 @@ int fail(const char* what, ncclResult_t rc) {
 }  // namespace
 
 int comm_allreduce(ams_comm* c, void* p, size_t n, int dtype, hipStream_t st) {
+    if (c && c->aborted) { set_error("comm: the communicator was aborted after an earlier RCCL error"); return AMS_E_STATE; }
     if (!c || !c->comm) return AMS_OK;             // world 1 without a communicator: the sum over one rank is the value itself
     Rccl& r = rccl();
     const ncclDataType_t dt = dtype == AMS_DT_F64 ? ncclFloat64 : ncclFloat32;
     const ncclResult_t rc = r.AllReduce(p, p, n, dt, ncclSum, c->comm, st);
-    if (rc != ncclSuccess) return fail("ncclAllReduce", rc);
+    if (rc != ncclSuccess) {
+        // a rank that fails between two collectives of a step leaves its peers waiting inside theirs: abort the communicator so that
+        // they return with an error instead of hanging; this handle is dead from here on
+        if (r.CommAbort) (void)r.CommAbort(c->comm);
+        c->comm = nullptr;
+        c->aborted = true;
+        return fail("ncclAllReduce (communicator aborted)", rc);
+    }
     c->calls += 1;
     c->bytes += (int64_t)n * (dtype == AMS_DT_F64 ? 8 : 4);
     return AMS_OK;
@@ -90,10 +105,12 @@ int ams_comm_unique_id(uint8_t* id_out, size_t cap) {
 
 int ams_comm_create(const uint8_t* id_bytes, size_t id_len, int32_t rank, int32_t world, ams_comm** out) {
     AMS_REQUIRE(out && world >= 1 && rank >= 0 && rank < world, "comm_create: rank %d of %d", rank, world);
+    // every argument is checked before anything is allocated
+    AMS_REQUIRE(world == 1 || id_bytes, "comm_create: a communicator of %d ranks needs the unique id", world);
+    AMS_REQUIRE(!id_bytes || id_len >= NCCL_UNIQUE_ID_BYTES, "comm_create: the unique id is %d bytes", NCCL_UNIQUE_ID_BYTES);
     ams_comm* c = new ams_comm();
     c->rank = rank; c->world = world;
     if (world > 1 || id_bytes) {                   // world 1 with an id: a real single-rank communicator (what the GPU test exercises)
-        AMS_REQUIRE(id_bytes && id_len >= NCCL_UNIQUE_ID_BYTES, "comm_create: the unique id is %d bytes", NCCL_UNIQUE_ID_BYTES);
         Rccl& r = rccl();
         if (r.error) { set_error("comm: %s", r.error); delete c; return AMS_E_STATE; }
         ncclUniqueId id;
@@ -113,8 +130,18 @@ void ams_comm_destroy(ams_comm* c) {
 
 int ams_comm_stats(const ams_comm* c, int32_t* rank, int32_t* world, int64_t* calls, int64_t* bytes) {
     AMS_REQUIRE(c, "comm_stats: null communicator");
-    if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    // rank / world as RCCL itself reports them for this communicator (what was asked for when there is none: world 1)
+    int r_seen = c->rank, w_seen = c->world;
+    if (c->comm) {
+        Rccl& r = rccl();
+        if (r.CommCount && r.CommUserRank) {
+            ncclResult_t rc = r.CommCount(c->comm, &w_seen);
+            if (rc == ncclSuccess) rc = r.CommUserRank(c->comm, &r_seen);
+            if (rc != ncclSuccess) return fail("ncclCommCount / ncclCommUserRank", rc);
+        }
+    }
+    if (rank) *rank = r_seen;
+    if (world) *world = w_seen;
     if (calls) *calls = c->calls;
     if (bytes) *bytes = c->bytes;
     return AMS_OK;

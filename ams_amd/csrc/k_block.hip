@@ -400,11 +400,37 @@ int launch_block_pack(const float* sc_e, const float* sh_e, const float* sc_d, c
     return AMS_OK;
 }
 
+// LDS of the tile-per-wave kernel: the [13][Cexp] table + four waves' expanded tiles (16 channels, halo included)
+static size_t blk_lds_bytes(int stride, int th, int tw, int Cexp) {
+    const int ih = (th - 1) * stride + 3, iw = (tw - 1) * stride + 3;
+    const int nrg = (ih * iw + 15) / 16;
+    return ((size_t)13 * Cexp + (size_t)4 * nrg * 16 * blk_act_pitch(stride, tw)) * sizeof(float);
+}
+
+// tile (output pixels per wave) for a block, or false when none of the instantiated tiles fits the 64 KB of LDS.
+// Measured on the six early blocks at 32 frames (tools/blk_sweep.sh): 8 x 8 at stride 1 (4 x 16 in the X6 form: no spills, conflict-free tap
+// reads along a row); at stride 2 4 x 8, or 2 x 8 when the project layer is 64 wide (four accumulator tiles per row group: the smaller tile
+// keeps the registers of two waves per SIMD) — and whenever 4 x 8 does not fit (Cexp > 272)
+static bool blk_pick_tile(int Cexp, int Cout, int stride, bool x6, int* th, int* tw) {
+    if (stride == 1) {
+        *th = x6 ? 4 : 8; *tw = x6 ? 16 : 8;
+        if (blk_lds_bytes(1, *th, *tw, Cexp) <= 64 * 1024) return true;
+        *th = 4; *tw = 8;
+        return blk_lds_bytes(1, 4, 8, Cexp) <= 64 * 1024;
+    }
+    *th = Cout > 32 ? 2 : 4; *tw = 8;
+    if (blk_lds_bytes(2, *th, *tw, Cexp) <= 64 * 1024) return true;
+    *th = 2;
+    return blk_lds_bytes(2, 2, 8, Cexp) <= 64 * 1024;
+}
+
 bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bool residual) {
     if (Cin % 4 != 0 || Cin > 32 || rate != 1 || (stride != 1 && stride != 2)) return false;
     if (Cout % 4 != 0 || Cout > 64) return false;
     if (residual && (stride != 1 || Cin != Cout)) return false;
-    return Cexp % 16 == 0 && Cexp <= 384;
+    if (Cexp % 16 != 0 || Cexp > 384) return false;
+    int th, tw;
+    return blk_pick_tile(Cexp, Cout, stride, false, &th, &tw) && blk_pick_tile(Cexp, Cout, stride, true, &th, &tw);
 }
 
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
@@ -421,12 +447,12 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
     if (wparts && Cin > 16) { a.wparts = wparts; a.wplane = wplane; }      // X6 pays from K = 24 on (at K = 16 half of every bf16 MFMA is padding)
     same_pad(H, 3, stride, 1, &a.Ho, &a.pt);
     same_pad(W, 3, stride, 1, &a.Wo, &a.pl);
-    // tile of output pixels per WAVE
-    // measured on the six early blocks at 32 frames (tools/blk_sweep.sh): 8 x 8 at stride 1; at stride 2 4 x 8, or 2 x 8 when the
-    // project layer is 64 wide (four accumulator tiles per row group: the smaller tile keeps the registers of two waves per SIMD)
-    int th = stride == 1 ? 8 : (Cout > 32 ? 2 : 4), tw = 8;
-    if (stride == 1 && a.wparts) { th = 4; tw = 16; }   // X6 form: 4 x 16 (no spills, conflict-free tap reads along a row): 327 vs 337 us on block 2
-    if (knobs().blk_th > 0) { th = knobs().blk_th; tw = knobs().blk_tw; }              // tuning knob AMS_BLK_TILE (tools/block_one.py)
+    // tile of output pixels per WAVE: the measured choice, or the next smaller one that fits LDS (blk_pick_tile)
+    int th, tw;
+    AMS_REQUIRE(blk_pick_tile(Cexp, Cout, stride, a.wparts != nullptr, &th, &tw), "block kernel: no tile fits LDS for Cexp=%d", Cexp);
+    if (knobs().blk_th > 0 && blk_lds_bytes(stride, knobs().blk_th, knobs().blk_tw, Cexp) <= 64 * 1024) {
+        th = knobs().blk_th; tw = knobs().blk_tw;          // tuning knob AMS_BLK_TILE (tools/block_one.py); ignored when it does not fit
+    }
 #define BLK(S_, TH_, TW_) if (stride == S_ && th == TH_ && tw == TW_) return launch_blk_t<S_, TH_, TW_>(a, st);
     BLK(1, 8, 8) BLK(1, 4, 16) BLK(1, 4, 8) BLK(2, 4, 8) BLK(2, 2, 8) BLK(2, 4, 4)
 #undef BLK

@@ -297,7 +297,8 @@ int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin
                     const float* shift_d, float* y, void* stream);
 
 /* A whole early block in one kernel (k_block.hip): y = bn_p(relu6(bn_d(dw3x3(relu6(bn_e(x @ w_exp))))) @ w_proj) (+ x when residual != 0:
- * stride 1 and Cout == Cin only).  Cin in {16, 24, 32}, Cexp % 32 == 0 or % 48 == 0, Cout % 4 == 0 and <= 64, stride 1|2, rate 1.
+ * stride 1 and Cout == Cin only).  Cin % 4 == 0 and <= 32, Cexp % 16 == 0 and <= 384, Cout % 4 == 0 and <= 64, stride 1|2, rate 1
+ * (the launcher picks the largest measured tile that fits 64 KB of LDS; AMS_E_INVALID for any other shape).
  * panels == NULL: exact f32 products in the k order of ams_k_pointwise — the same bits as ams_k_expand_dw followed by ams_k_pointwise.
  * panels != NULL (scratch of >= 3*Cexp*32 uint16) and Cin > 16: the EXPAND products as six bf16 MFMAs on three-part splits (all 24
  * significand bits, f32-level: what the engine does by default, AMS_OPT_BLOCK_X6); depthwise and project stay exact f32. */

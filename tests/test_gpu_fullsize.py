@@ -58,7 +58,9 @@ def test_frozen_inference_full_size_matches_oracle(W0, clip):
     margin = srt[..., -1] - srt[..., -2]
     bad = got != want
     assert not np.any(bad & (margin > 2e-3 * np.abs(low).max()))
-    assert bad.mean() < 1e-3
+    # measured: 1 pixel of 1 048 576 (a top-2 tie at f32 summation-order level); the bar allows ten
+    print("full-size label mismatches vs the f32 oracle: %d of %d" % (int(bad.sum()), bad.size))
+    assert bad.mean() <= 1e-5
     p, cm, l = o.predict_with_metric(fr, labels[:B], "frozen")
     assert conf.sum().item() == cm.sum()
     ls = loss.cpu().numpy()
@@ -230,6 +232,25 @@ def test_fine_tune_step_config2_batch_against_f64_oracle(W0, clip):
         want = grads_o[name].numpy().reshape(-1)
         e = np.linalg.norm(g[v.offset:v.offset + v.size] - want) / np.linalg.norm(want)
         assert e < 3e-2, (name, e)
+    # every one of the 164 gradient tensors by relative L2.  A shift in front of a training-mode BN has no effect, so the beta / bias
+    # gradients of the layers that feed one are exactly 0 in real arithmetic: for those the error is taken against the typical tensor
+    # norm of the step instead of their own (which is rounding noise in the f64 oracle too).
+    norms = np.array([np.linalg.norm(grads_o[v.name].numpy()) for v in eng.spec.trainable])
+    floor = 1e-3 * np.median(norms)
+    errs, noise = [], []
+    for v in eng.spec.trainable:
+        want = grads_o[v.name].numpy().reshape(-1)
+        d = np.linalg.norm(g[v.offset:v.offset + v.size] - want)
+        (errs if np.linalg.norm(want) >= floor else noise).append((d / max(np.linalg.norm(want), floor), v.name))
+    errs.sort(reverse=True)
+    noise.sort(reverse=True)
+    print("8-frame 512x1024 step, relative L2 of %d gradient tensors vs f64: worst five %s; median %.2e; %d zero-gradient tensors, worst %s" %
+          (len(errs), ["%s %.2e" % (n, e) for e, n in errs[:5]], float(np.median([e for e, _ in errs])), len(noise),
+           ["%s %.2e" % (n, e) for e, n in noise[:2]]))
+    assert len(errs) + len(noise) == 164 and len(errs) >= 120
+    assert errs[0][0] < 3e-2, errs[:5]                     # f32 error class of this graph (the f32 CPU oracle: 1e-2 .. 3e-2 on the same tensors)
+    assert float(np.median([e for e, _ in errs])) < 2e-2
+    assert not noise or noise[0][0] < 0.2, noise[:3]       # against the floor: rounding noise stays well below the smallest real gradients
     # first Adam step: -lr * sign(g) wherever |g| is far above eps; entries whose f64 gradient is significant must move the
     # way the oracle's do
     after = eng.params.cpu().numpy().astype(np.float64)
@@ -292,6 +313,19 @@ def test_two_stream_plan_is_two_half_batches(W0):
     low2 = _lowres(eng, B).copy()
     assert torch.equal(lab2[:16], lab_a) and torch.equal(lab2[16:], lab_b)
     assert np.array_equal(low2[:16], low_a) and np.array_equal(low2[16:], low_b)
+    # the benchmarked plan itself against the oracle: one frame out of each half of the 32-frame two-stream call
+    from oracle.student_torch import StudentOracle
+    o = StudentOracle(W0, CI)
+    pick = [3, 29]
+    fr = frames[pick].astype(np.float32)
+    with torch.no_grad():
+        low_o = o.forward_lowres(fr, "frozen").numpy()
+        full_o = o.reduced_logits(o.logits_full(fr, "frozen")).numpy()
+    assert rel(low2[pick], low_o) < 2e-4
+    bad = lab2[pick].cpu().numpy() != np.argmax(full_o, axis=-1)
+    print("two-stream 32-frame call, frames %s vs the f32 oracle: %d of %d labels differ, logits %.2e" % (pick, int(bad.sum()), bad.size,
+                                                                                                         rel(low2[pick], low_o)))
+    assert bad.mean() <= 1e-5
     lab_m, conf, loss = eng.predict_with_metric(frames, labels)
     assert torch.equal(lab_m, lab2)
     assert conf.sum().item() == int(np.isin(labels, CI).sum())

@@ -38,5 +38,5 @@ def test_engine_follows_the_reference_graph(tag, nc, ci):
         margin = srt[..., -1] - srt[..., -2]
         bad = lab != want_lab
         assert not np.any(bad & (margin > 2 * tol * np.abs(want_low).max())), "label mismatch away from a tie"
-        assert bad.mean() < 2e-3
+        assert bad.sum() <= 2, "%d of %d labels differ from the executor of the reference graph" % (int(bad.sum()), bad.size)
     eng.close()

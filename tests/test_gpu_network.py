@@ -74,7 +74,9 @@ def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     err = rel(got_low, low)
     assert err < 1e-3, "low-res logits rel err %g" % err
     mismatch = _check_labels(got_lab.cpu().numpy(), full, tol=2e-3 * np.abs(low).max())
-    assert mismatch < 1e-3
+    # f32-level plans: at most one tie pixel of these small maps; the two-part split (logits 2e-4 .. 5e-4) a handful
+    npix = got_lab.numel()
+    assert mismatch * npix <= (1 if matmul != hip.MATMUL_SPLIT_BF16 else 8), "%d label mismatches of %d" % (round(mismatch * npix), npix)
     # metrics are consistent with the oracle
     p, cm, l = o.predict_with_metric(frames.astype(np.float32), labels, "frozen")
     got_cm = conf.cpu().numpy()

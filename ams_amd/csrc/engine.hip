@@ -123,6 +123,9 @@ struct ams_student {
     // stream has its own reduction scratch.
     float* dz2 = nullptr;
     float* scratch2 = nullptr;
+    float* scratch3 = nullptr;       // depthwise weight gradients on their own stream (side2), AMS_OVERLAP_WGRAD=2
+    hipStream_t side2 = nullptr;
+    hipEvent_t ev_xt = nullptr;      // the weight-gradient reductions of a recompute block (side stream) have left xt_scratch
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_head = nullptr;
     // Frozen inference as two half-batches on two streams (forward_frozen_dual).  AMS_OPT_DUAL_STREAM: 0 never, 1 (default) decided per
@@ -147,6 +150,8 @@ struct ams_student {
         if (ev_fork_dual) (void)hipEventDestroy(ev_fork_dual);
         for (auto& e : ev_wg) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
+        if (side2) (void)hipStreamDestroy(side2);
+        if (ev_xt) (void)hipEventDestroy(ev_xt);
     }
     float* scratch = nullptr; size_t scratch_floats = 0;
     float* tmp_c = nullptr;          // [1024] small per-channel temp
@@ -353,6 +358,9 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
                 if (need > xt) xt = need;
             }
         }
+        if (s->n_backbone >= 3 && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE && s->L[2].d.stride == 1 && s->L[2].d.rate == 1 &&
+            xdw_stem_scratch(B, c.height, c.width) > xt)
+            xt = xdw_stem_scratch(B, c.height, c.width);
         s->xt_floats = xt;
         s->xt_scratch = cv.take<float>(xt);
         for (int i = 2; i + 1 <= s->n_backbone; ++i) {
@@ -373,6 +381,7 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
         s->dz = cv.take<float>((size_t)B * max_elems);
         s->dz2 = cv.take<float>((size_t)B * max_elems);
         s->scratch2 = cv.take<float>(sc);
+        s->scratch3 = cv.take<float>(sc);
         for (int i = 1; i <= c.n_layers; ++i) {
             LayerRt& l = s->L[i];
             if (l.d.role == AMS_ROLE_LOGITS) continue;     // logits live in s->logits / s->dlogits
@@ -1034,8 +1043,12 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     if (overlap && !s->ev_wg[0]) {
         if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         for (auto& e : s->ev_wg) AMS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_xt, hipEventDisableTiming));
     }
+    const bool three = overlap && s->overlap_wgrad >= 2 && s->scratch3;      // depthwise weight gradients on a third stream
+    if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
     bool wg_pending[2] = {false, false};
+    bool xt_pending = false;
     for (int i = s->n_backbone; i >= 1; --i) {
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
@@ -1051,6 +1064,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             const float* x = lin.a;
             int rows = 0;
             int64_t stride = 0;
+            if (xt_pending) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0)); xt_pending = false; }     // xt_scratch is free again
             RUNK(i, 4.0 * ((double)B * (le.px_in * le.d.cin + l.px_out * l.d.cout)),
                  launch_xdw_bwd_reduce(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.d.cout, le.scale, le.shift, le.mean, le.rstd, le.d.act,
                                        P + l.d.w_off, l.d.stride, dz, s->xt_scratch, &rows, &stride, st));
@@ -1068,15 +1082,51 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             RUNK(i - 1, 4.0 * ((double)B * (le.px_in * le.d.cin * (skip ? 3 : 2) + l.px_out * l.d.cout)),
                  launch_xdw_bwd_dx(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.d.cout, le.scale, le.shift, le.d.act, P + l.d.w_off,
                                    l.d.stride, dz, le.cA, le.cB, le.cC, skip, lin.da, st));
-            // weight gradients from the partial rows: depthwise taps, then the expand weights from (G1 | XX | g0)
+            // weight gradients from the partial rows: depthwise taps, then the expand weights from (G1 | XX | g0).  They only feed the
+            // optimizer: on the side stream, behind the coefficients (recorded before the dx pass, which does not touch the rows)
             const int KP = (le.d.cin + 15) / 16 * 16;
             const int64_t n_dw = 9 * (int64_t)le.d.cout, n_g = (int64_t)KP * le.d.cout;
             float* reduced = s->xt_scratch + (int64_t)rows * stride;
-            RUN(launch_reduce_splits(s->xt_scratch + 2 * (int64_t)le.d.cout, rows, n_dw, G + l.d.w_off, st, stride));
-            RUN(launch_reduce_splits(s->xt_scratch + 11 * (int64_t)le.d.cout, rows, n_g, reduced, st, stride));
-            RUN(launch_xdw_dwe(reduced, le.xx_g0, le.d.cin, le.d.cout, P + le.d.w_off, le.cA, le.cB, le.cC, G + le.d.w_off, st));
+            hipStream_t xs = st;
+            if (overlap) {
+                AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+                AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+                xs = s->side;
+            }
+            RUN(launch_reduce_splits(s->xt_scratch + 2 * (int64_t)le.d.cout, rows, n_dw, G + l.d.w_off, xs, stride));
+            RUN(launch_reduce_splits(s->xt_scratch + 11 * (int64_t)le.d.cout, rows, n_g, reduced, xs, stride));
+            RUN(launch_xdw_dwe(reduced, le.xx_g0, le.d.cin, le.d.cout, P + le.d.w_off, le.cA, le.cB, le.cC, G + le.d.w_off, xs));
+            if (overlap) { AMS_CHECK_HIP(hipEventRecord(s->ev_xt, s->side)); xt_pending = true; }
             --i;                                       // the expand layer is done
             continue;
+        }
+        if (l.d.role == AMS_ROLE_DEPTHWISE && i == 2 && s->train_recompute && s->L[1].d.role == AMS_ROLE_STEM && s->L[1].d.cout == 32 &&
+            l.d.stride == 1 && l.d.rate == 1 && s->xt_scratch && xdw_stem_scratch(s->cfg.max_batch, c.height, c.width) <= s->xt_floats) {
+            // first block: the stem is the "expand" layer of this depthwise conv (a 1x1 conv over the 27-tap patch of the frame).  One pass
+            // over dz and the frames gives the stem's BN-backward sums, the depthwise weight gradient and the pieces of the stem weight
+            // gradient; da / dz of the stem, its im2col matrix and a_stem are never read or written in backward
+            LayerRt& le = s->L[1];
+            int rows = 0;
+            int64_t stride = 0;
+            if (xt_pending) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0)); xt_pending = false; }
+            RUNK(i, 4.0 * B * l.px_out * l.d.cout,
+                 launch_xdw_bwd_reduce_stem(frames, dtype, B, c.height, c.width, c.pixel_scale, P + le.d.w_off, le.scale, le.shift, le.mean, le.rstd,
+                                            le.d.act, P + l.d.w_off, dz, s->xt_scratch, &rows, &stride, st));
+            const double n_e = (double)global_B * le.px_out;
+            if (!sc || !sc->cb) {
+                RUN(launch_bn_bwd_finalize_partials(s->xt_scratch, rows, stride, le.d.cout, le.bsums, n_e, P + le.d.gamma_off, le.mean, le.rstd,
+                                                    le.cA, le.cB, le.cC, G + le.d.gamma_off, G + le.d.beta_off, st));
+            } else {
+                RUN(launch_partials_to_sums(s->xt_scratch, rows, stride, le.d.cout, le.bsums, st));
+                RUN(launch_bn_param_grads(le.bsums, le.d.cout, G + le.d.gamma_off, G + le.d.beta_off, st));
+                RUN(sync_doubles(sc, le.bsums, 2 * (size_t)le.d.cout, st));
+                RUN(launch_bn_bwd_coef(le.bsums, n_e, le.d.cout, P + le.d.gamma_off, le.mean, le.rstd, le.cA, le.cB, le.cC, nullptr, nullptr, st));
+            }
+            float* reduced = s->xt_scratch + (int64_t)rows * stride;
+            RUN(launch_reduce_splits(s->xt_scratch + 2 * 32, rows, 9 * 32, G + l.d.w_off, st, stride));
+            RUN(launch_reduce_splits(s->xt_scratch + 11 * 32, rows, 32 * 32 + 32 * 32 + 32, reduced, st, stride));
+            RUN(launch_xdw_dwe(reduced, reduced + 32 * 32, 27, 32, P + le.d.w_off, le.cA, le.cB, le.cC, G + le.d.w_off, st));
+            break;                                     // the stem is done
         }
         if (l.d.role == AMS_ROLE_STEM) {
             RUN(launch_stem_im2col(frames, dtype, B, c.height, c.width, c.pixel_scale, s->im2col, st));
@@ -1087,9 +1137,11 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         hipStream_t wst = st;
         float* wscratch = s->scratch;
         if (overlap) {
+            const bool on2 = three && l.d.role == AMS_ROLE_DEPTHWISE;
+            wst = on2 ? s->side2 : s->side;
+            wscratch = on2 ? s->scratch3 : s->scratch2;
             AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
-            AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-            wst = s->side; wscratch = s->scratch2;
+            AMS_CHECK_HIP(hipStreamWaitEvent(wst, s->ev_fork, 0));
         }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             if (overlap) RUN(launch_depthwise_wgrad(prev.a, dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off, wscratch, s->scratch_floats, wst));
@@ -1098,7 +1150,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         } else {
             RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch));
         }
-        if (overlap) { AMS_CHECK_HIP(hipEventRecord(s->ev_wg[zb], s->side)); wg_pending[zb] = true; }
+        if (overlap) { AMS_CHECK_HIP(hipEventRecord(s->ev_wg[zb], wst)); wg_pending[zb] = true; }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
         } else {
@@ -1113,6 +1165,12 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     // the optimizer (and the gradient all-reduce) wait for every weight gradient
     for (int k = 0; k < 2; ++k)
         if (overlap && wg_pending[k]) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_wg[k], 0));
+    if (xt_pending) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0));
+    if (overlap) {                                     // everything either side stream still holds (events cover the last launch of each buffer only)
+        AMS_CHECK_HIP(hipEventRecord(s->ev_fork, s->side));
+        AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_fork, 0));
+        if (three) { AMS_CHECK_HIP(hipEventRecord(s->ev_fork, s->side2)); AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_fork, 0)); }
+    }
     return AMS_OK;
 }
 
@@ -1201,6 +1259,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (const char* e = getenv("AMS_OVERLAP_HEAD")) s->overlap_head = atoi(e);              // tuning knob
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
+    if (const char* e = getenv("AMS_OVERLAP_WGRAD")) s->overlap_wgrad = atoi(e);            // tuning knob: 0 one stream, 1 weight gradients on a side stream, 2 depthwise ones on a third
     if (const char* e = getenv("AMS_TRAIN_RECOMPUTE")) s->train_recompute = atoi(e);       // tuning knob (see AMS_OPT_TRAIN_RECOMPUTE)
     *out = s;
     return AMS_OK;

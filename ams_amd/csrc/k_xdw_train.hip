@@ -53,7 +53,26 @@ struct XtArgs {
     float* part;
     int64_t part_stride;       // floats per block row
     int tiles_y, tiles_x, n_tiles;      // tiles of 64 input pixels per image: 4 x 16 (stride 1) / 8 x 8 in padded coordinates (stride 2)
+    // STEM form (first block of the network): the "expand" layer is the stem conv = a 1x1 conv over the 27-tap patch of the normalised,
+    // 127.5-padded frame (k = tap * 3 + channel), gathered per pixel from the frames [B, fH, fW, 3]; H x W is the stem's output grid
+    const void* frames;
+    int fH, fW, spt, spl;
+    float ps;
 };
+
+// value of the normalised, 127.5-padded frame at (iy, ix, ch) in padded coordinates; outside of it the stem's SAME zero padding
+// (two roundings, x * ps - 1, as the graph's Mul and Sub)
+template <typename TIn>
+__device__ __forceinline__ float xt_frame_value(const TIn* img, int H, int W, int iy, int ix, int ch, float ps) {
+    const bool inside = iy >= 0 && ix >= 0 && iy <= H && ix <= W;
+    const bool pad = iy >= H || ix >= W;
+    const int iyc = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    const int ixc = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+    float raw = (float)img[(iyc * W + ixc) * 3 + ch];
+    raw = pad ? 127.5f : raw;
+    const float v = __fsub_rn(__fmul_rn(raw, ps), 1.0f);
+    return inside ? v : 0.f;
+}
 
 // Tile geometry.  A tile is 64 INPUT pixels = four 16-pixel row groups:
 //   stride 1: 4 rows x 16 columns, row group = tile row; the gradient values it needs are a 6 x 18 patch of dz_d;
@@ -153,8 +172,9 @@ __device__ __forceinline__ float4 sum16(float4 v) {                   // over th
     return v;
 }
 
-template <int MODE, int S, int KC>
-__global__ __launch_bounds__(768) void xdw_train_kernel(XtArgs a) {
+template <int MODE, int S, int KC, typename TIn = void>
+__global__ __launch_bounds__(std::is_void<TIn>::value ? 768 : 128) void xdw_train_kernel(XtArgs a) {
+    constexpr bool STEM = !std::is_void<TIn>::value;      // the block input is gathered from the frames; XX / g0 are formed here (no forward pass did)
     typedef XtGeo<S> G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
@@ -211,6 +231,27 @@ __global__ __launch_bounds__(768) void xdw_train_kernel(XtArgs a) {
             int iy, ix;
             const bool live = xt_pixel<S>(a, tc, rg, l15, iy, ix);
             m = live ? 1.f : 0.f;
+            if constexpr (STEM) {
+                // the 27-tap patch of the normalised frame under this stem pixel, k = tap * 3 + channel (the im2col row).  Branch-free
+                // border form throughout: an interior fast path (plain loads at constant offsets) measured the same 195 us — the pass
+                // is not bound by this gather
+                typedef typename std::conditional<STEM, TIn, float>::type TI;
+                const TI* img = reinterpret_cast<const TI*>(a.frames) + (int64_t)tc.b * a.fH * a.fW * 3;
+                const int fy = iy * 2 - a.spt, fx = ix * 2 - a.spl;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    float t[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 16 * c + 4 * q + j, tap = k / 3;
+                        const int ch = k - tap * 3, dy = tap / 3, dx = tap - dy * 3;
+                        const float v = xt_frame_value(img, a.fH, a.fW, fy + (k < 27 ? dy : 0), fx + (k < 27 ? dx : 0), k < 27 ? ch : 0, a.ps);
+                        t[j] = (k < 27 && live) ? v : 0.f;
+                    }
+                    xv[c] = make_float4(t[0], t[1], t[2], t[3]);
+                }
+                return;
+            }
             const float* px = a.x + (int64_t)tc.b * a.H * a.W * a.Cin + (iy * a.W + ix) * a.Cin;      // wave-uniform base + 32-bit offset
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -299,6 +340,10 @@ __global__ __launch_bounds__(768) void xdw_train_kernel(XtArgs a) {
 #pragma unroll
             for (int c = 0; c < KC; ++c) st4(sX + (c * 16 + l15) * 20 + 4 * q, xv[c]);
             st4(sD + l15 * 20 + 4 * q, dy);
+            if (STEM && wave == 0) {
+#pragma unroll
+                for (int c = 0; c < KC; ++c) g0[c] = add4_pk(g0[c], xv[c]);
+            }
             wave_lds_fence();
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
@@ -308,6 +353,12 @@ __global__ __launch_bounds__(768) void xdw_train_kernel(XtArgs a) {
                 const float dt = sD[(4 * gq + q) * 20 + l15];
 #pragma unroll
                 for (int c = 0; c < KC; ++c) g1[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[c], dt, g1[c], 0, 0, 0);
+                if (STEM && wave == 0) {                  // no forward statistics pass ran over the patches: their Gram matrix is formed here
+#pragma unroll
+                    for (int c = 0; c < KC; ++c)
+#pragma unroll
+                        for (int c2 = 0; c2 < KC; ++c2) xx[c][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(xt[c], xt[c2], xx[c][c2], 0, 0, 0);
+                }
             }
             wave_lds_fence();
         };
@@ -368,6 +419,21 @@ __global__ __launch_bounds__(768) void xdw_train_kernel(XtArgs a) {
     for (int c = 0; c < KC; ++c)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rG[(int64_t)(16 * c + 4 * q + r) * a.Cexp + n0 + l15] = g1[c][r];
+    if (STEM && wave == 0) {                            // XX [KP][KP] | g0 [KP] behind G1
+        float* rX = rG + (int64_t)KP * a.Cexp;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int c2 = 0; c2 < KC; ++c2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rX[(16 * c + 4 * q + r) * KP + 16 * c2 + l15] = xx[c][c2][r];
+        float* r0 = rX + KP * KP;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const float4 t = sum16(g0[c]);
+            if (l15 == 0) st4(r0 + 16 * c + 4 * q, t);
+        }
+    }
 }
 
 // ---- pass 2: dx.  A wave owns tiles and walks the 16-channel chunks: the patch of the next chunk is in flight (registers) while the
@@ -517,10 +583,12 @@ static void xt_geometry(XtArgs& a, int stride) {
 static int64_t xt_part_stride(int KP, int Cexp) { return ((int64_t)(2 + 9 + KP) * Cexp + 3) / 4 * 4; }       // backward: S | dWd | G1
 static int64_t xt_fwd_stride(int KP, int Cexp) { return ((int64_t)2 * Cexp + KP * KP + KP + 3) / 4 * 4; }     // forward: S | XX | g0
 
-int xdw_train_blocks(int B, int H, int W) {
+// blocks (= partial rows) of the passes over a block with Cexp expanded channels.  A block has Cexp / 16 waves; the stem (2 waves per
+// block) needs 2048 blocks to fill the chip (328 -> 194 us); for 6 / 9 waves 1024 / 682 blocks measured 15-20 % slower than 512
+int xdw_train_blocks(int B, int H, int W, int Cexp) {
     const int64_t tiles = cdiv64((int64_t)B * H * W, 64);
-    int64_t blocks = tiles / 4;                        // >= 4 tiles (256 pixels) per wave
-    if (blocks > 512) blocks = 512;
+    int64_t blocks = Cexp / 16 <= 2 ? 2048 : 512;
+    if (blocks > tiles / 4) blocks = tiles / 4;        // >= 4 tiles (256 pixels) per wave
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -529,7 +597,7 @@ size_t xdw_train_scratch(int B, int H, int W, int Cin, int Cexp) {
     const int KP = (Cin + 15) / 16 * 16;
     // partial rows + the reduced row
     const int64_t st = xt_part_stride(KP, Cexp) > xt_fwd_stride(KP, Cexp) ? xt_part_stride(KP, Cexp) : xt_fwd_stride(KP, Cexp);
-    return (size_t)(xdw_train_blocks(B, H, W) + 1) * st;
+    return (size_t)(xdw_train_blocks(B, H, W, Cexp) + 1) * st;
 }
 
 template <int MODE, int S>
@@ -560,7 +628,7 @@ int launch_xdw_fwd_stats(const float* x, int B, int H, int W, int Cin, const flo
     memset(&a, 0, sizeof(a));
     a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.w_exp = w_exp; a.Cexp = Cexp; a.center = center;
     xt_geometry(a, 1);
-    int blocks = xdw_train_blocks(B, H, W);
+    int blocks = xdw_train_blocks(B, H, W, Cexp);
     if (blocks > a.n_tiles) blocks = a.n_tiles;
     a.part = scratch; a.part_stride = xt_fwd_stride((Cin + 15) / 16 * 16, Cexp);
     *rows_out = blocks; *stride_out = a.part_stride;
@@ -578,11 +646,46 @@ int launch_xdw_bwd_reduce(const float* x, int B, int H, int W, int Cin, const fl
     a.sc_e = sc_e; a.sh_e = sh_e; a.mean_e = mean_e; a.rstd_e = rstd_e; a.act_e = act_e; a.w_dw = w_dw; a.dz_d = dz_d;
     xt_geometry(a, stride);
     const int KP = (Cin + 15) / 16 * 16;
-    int blocks = xdw_train_blocks(B, H, W);
+    int blocks = xdw_train_blocks(B, H, W, Cexp);
     if (blocks > a.n_tiles) blocks = a.n_tiles;
     a.part = scratch; a.part_stride = xt_part_stride(KP, Cexp);
     *rows_out = blocks; *stride_out = a.part_stride;
     return stride == 1 ? launch_xt<XT_BWD, 1>(a, blocks, st) : launch_xt<XT_BWD, 2>(a, blocks, st);
+}
+
+// The first block of the network: stem conv (3x3 stride 2 on the normalised frame, 3 -> 32) as the "expand" layer over its 27-tap patch,
+// followed by the first depthwise conv (stride 1).  There is no input gradient: this one pass yields everything the stem and the
+// depthwise layer need.  Partial rows  S [2][32] | dWd [9][32] | G1 [32][32] | XX [32][32] | g0 [32]
+size_t xdw_stem_scratch(int B, int fH, int fW) {
+    int H, W, p;
+    same_pad(fH + 1, 3, 2, 1, &H, &p);
+    same_pad(fW + 1, 3, 2, 1, &W, &p);
+    const int64_t stride = xt_part_stride(32, 32) + 32 * 32 + 32;
+    return (size_t)(xdw_train_blocks(B, H, W, 32) + 1) * stride;
+}
+
+int launch_xdw_bwd_reduce_stem(const void* frames, int dtype, int B, int fH, int fW, float pixel_scale, const float* w_stem, const float* sc_e,
+                               const float* sh_e, const float* mean_e, const float* rstd_e, int act_e, const float* w_dw, const float* dz_d,
+                               float* scratch, int* rows_out, int64_t* stride_out, hipStream_t st) {
+    AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "xdw_stem: frames must be uint8 or float32");
+    XtArgs a;
+    memset(&a, 0, sizeof(a));
+    a.frames = frames; a.fH = fH; a.fW = fW; a.ps = pixel_scale; a.B = B; a.Cin = 27; a.w_exp = w_stem; a.Cexp = 32;
+    same_pad(fH + 1, 3, 2, 1, &a.H, &a.spt);           // the stem's output grid = the depthwise conv's input grid
+    same_pad(fW + 1, 3, 2, 1, &a.W, &a.spl);
+    AMS_REQUIRE((int64_t)fH * fW * 3 < 0x7fffffffLL, "xdw_stem: frame too large");
+    a.sc_e = sc_e; a.sh_e = sh_e; a.mean_e = mean_e; a.rstd_e = rstd_e; a.act_e = act_e; a.w_dw = w_dw; a.dz_d = dz_d;
+    xt_geometry(a, 1);
+    int blocks = xdw_train_blocks(B, a.H, a.W, 32);
+    if (blocks > a.n_tiles) blocks = a.n_tiles;
+    a.part = scratch; a.part_stride = xt_part_stride(32, 32) + 32 * 32 + 32;
+    *rows_out = blocks; *stride_out = a.part_stride;
+    const size_t lds = ((size_t)2 * (XtGeo<1>::TAP_FLOATS + 3 * 16 * 20) + 13 * 32) * sizeof(float);
+    note_kernel("xdw_train_kernel<BWD, stem>");
+    if (dtype == AMS_DT_U8) hipLaunchKernelGGL((xdw_train_kernel<XT_BWD, 1, 2, uint8_t>), dim3(blocks), dim3(128), lds, st, a);
+    else hipLaunchKernelGGL((xdw_train_kernel<XT_BWD, 1, 2, float>), dim3(blocks), dim3(128), lds, st, a);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
 }
 
 // backward pass 2: dx [B,H,W,Cin] = dz_e . W_e^T (+ res)

@@ -122,7 +122,7 @@ int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* 
 // z_e = x . W_e from the block input (see the file header)
 bool xdw_train_supported(int Cin, int Cexp, int stride, int rate);
 size_t xdw_train_scratch(int B, int H, int W, int Cin, int Cexp);      // floats: partial rows of the passes below + one reduced row
-int xdw_train_blocks(int B, int H, int W);
+int xdw_train_blocks(int B, int H, int W, int Cexp);
 // forward statistics: partial rows  S [2][Cexp] (sum(z - center), sum((z - center)^2)) | XX [KP][KP] = x^T x | g0 [KP] = sum x
 // (KP = Cin rounded up to 16) -> scratch
 int launch_xdw_fwd_stats(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* center, float* scratch,
@@ -131,6 +131,12 @@ int launch_xdw_fwd_stats(const float* x, int B, int H, int W, int Cin, const flo
 int launch_xdw_bwd_reduce(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* sc_e, const float* sh_e,
                           const float* mean_e, const float* rstd_e, int act_e, const float* w_dw, int stride, const float* dz_d, float* scratch,
                           int* rows_out, int64_t* stride_out, hipStream_t st);
+// first block: stem conv (as a 1x1 conv over its 27-tap patch of the frame) + first depthwise conv; partial rows
+// S [2][32] | dWd [9][32] | G1 [32][32] | XX [32][32] | g0 [32]
+size_t xdw_stem_scratch(int B, int fH, int fW);
+int launch_xdw_bwd_reduce_stem(const void* frames, int dtype, int B, int fH, int fW, float pixel_scale, const float* w_stem, const float* sc_e,
+                               const float* sh_e, const float* mean_e, const float* rstd_e, int act_e, const float* w_dw, const float* dz_d,
+                               float* scratch, int* rows_out, int64_t* stride_out, hipStream_t st);
 // backward pass 2: dx = (cA dy_e + cB + cC z_e) . W_e^T (+ res)
 int launch_xdw_bwd_dx(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* sc_e, const float* sh_e,
                       int act_e, const float* w_dw, int stride, const float* dz_d, const float* cA, const float* cB, const float* cC,

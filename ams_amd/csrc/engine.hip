@@ -109,6 +109,7 @@ struct ams_student {
     float* dlogits = nullptr;
     float* ce_scratch = nullptr;       // unnormalised CE gradient planes of the one-pass loss kernel (k_head.hip)
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
+    int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
     float *vec_ones = nullptr, *vec_zeros = nullptr;             // [1024] each: identity BN for a fused kernel's raw output
@@ -676,6 +677,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
                                                            le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
                                                            s->act[o], st));
             x = s->act[o]; x_i = o; i += 2;
+            if (s->emulate_bf16_storage && ld.px_out == (int64_t)s->h * s->w)
+                RUN(launch_round_bf16(s->act[o], (int64_t)B * ld.px_out * ld.d.cout, st));          // d as bf16 storage would hold it
         } else {
         if (s->L[i].d.role == AMS_ROLE_EXPAND) {
             LayerRt& l = s->L[i];
@@ -712,6 +715,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
             const int o = other(cur_i, x_i);
             RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, l.fscale,
                                                      l.fshift, l.d.act, s->act[o], st));
+            if (s->emulate_bf16_storage && l.px_out == (int64_t)s->h * s->w)
+                RUN(launch_round_bf16(s->act[o], (int64_t)B * l.px_out * l.d.cout, st));
             x = s->act[o]; x_i = o; ++i;
         }
         }
@@ -728,9 +733,12 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
                 // split by every channel-chunk block there
                 a.ysplit = s->xsplit; a.ysplit_plane = a.M * a.N; a.ysplit_np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : s->matmul_mode == AMS_MATMUL_BF16 ? 1 : 2;
             }
+            if (s->emulate_bf16_storage && l.px_out == (int64_t)s->h * s->w) a.ysplit = nullptr;      // the parts would be those of the unrounded result
             RUN(frozen_pointwise(s, i, a, st, &wrote));
             cur_parts = wrote ? s->xsplit : nullptr;
             cur = s->act[o]; cur_i = o; ++i;
+            if (s->emulate_bf16_storage && l.px_out == (int64_t)s->h * s->w)
+                RUN(launch_round_bf16(s->act[o], (int64_t)B * l.px_out * l.d.cout, st));            // block input as bf16 storage would hold it
         }
     }
     return AMS_OK;
@@ -1610,6 +1618,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     }
     if (option == AMS_OPT_FUSE_EXPAND_DW) {
         s->fuse_expand_dw = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_EMULATE_BF16_STORAGE) {
+        s->emulate_bf16_storage = value != 0;
         return AMS_OK;
     }
     if (option == AMS_OPT_TRAIN_RECOMPUTE) {

@@ -541,6 +541,21 @@ int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, h
     return AMS_OK;
 }
 
+// x <- float(bf16(x)), round to nearest even: what bf16 STORAGE of a tensor would leave behind (the study in tools/bf16_storage_study.py)
+__global__ __launch_bounds__(256) void round_bf16_kernel(float* __restrict__ p, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = ld4(p + 4 * i);
+        v.x = (float)(__bf16)v.x; v.y = (float)(__bf16)v.y; v.z = (float)(__bf16)v.z; v.w = (float)(__bf16)v.w;
+        st4(p + 4 * i, v);
+    }
+}
+int launch_round_bf16(float* p, int64_t n, hipStream_t st) {
+    AMS_REQUIRE(n % 4 == 0, "round_bf16: n must be a multiple of 4");
+    hipLaunchKernelGGL(round_bf16_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, st, p, n / 4);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 __global__ void fill_kernel(float* p, int64_t n, float v) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }

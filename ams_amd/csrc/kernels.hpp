@@ -226,6 +226,7 @@ int launch_bn_bwd_finalize_partials(const float* part, int rows, int64_t row_str
                                     float* dbeta, hipStream_t st);
 int launch_partials_to_sums(const float* part, int rows, int64_t row_stride, int C, double* sums, hipStream_t st);
 int launch_fill(float* p, int64_t n, float v, hipStream_t st);
+int launch_round_bf16(float* p, int64_t n, hipStream_t st);       // x <- float(bf16(x)) in place (bf16-storage study)
 int launch_copy(float* dst, const float* src, int64_t n, hipStream_t st);
 size_t pack_fp16_scratch(int64_t n);
 int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* out, int64_t* n_out, int64_t* counts, hipStream_t st);

@@ -18,7 +18,7 @@ ABI_VERSION = 2
 # enums of include/ams_hip.h
 ROLE_STEM, ROLE_EXPAND, ROLE_DEPTHWISE, ROLE_PROJECT, ROLE_POOL_CONV, ROLE_ASPP, ROLE_CONCAT_PROJ, ROLE_LOGITS = range(8)
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
-DT_F32, DT_U8, DT_BF16, DT_I32, DT_F64 = 0, 1, 2, 3, 4
+DT_F32, DT_U8, DT_I32, DT_F64 = 0, 1, 3, 4          # 2 was bf16 activation storage: measured and dropped (include/ams_hip.h)
 MODE_FROZEN, MODE_LIVE = 0, 1
 OPT_MATMUL = 1
 RESIZE_NEAREST, RESIZE_LINEAR = 0, 1
@@ -31,6 +31,7 @@ OPT_LATE_SUBBATCH = 7
 OPT_BLOCK_X6 = 8
 OPT_DUAL_STREAM = 10
 OPT_TRAIN_RECOMPUTE = 11
+OPT_EMULATE_BF16_STORAGE = 15
 OPT_DUAL_AUTOTUNE = 12
 OPT_DUAL_PARTS = 13
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3

@@ -110,6 +110,7 @@ struct ams_student {
     float* ce_scratch = nullptr;       // unnormalised CE gradient planes of the one-pass loss kernel (k_head.hip)
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
     int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
+    int fuse_dgrad_bn = 1;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
     float *vec_ones = nullptr, *vec_zeros = nullptr;             // [1024] each: identity BN for a fused kernel's raw output
@@ -1057,13 +1058,34 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
     bool wg_pending[2] = {false, false};
     bool xt_pending = false;
+    int fused_rows = 0;                               // > 0: this layer's da already holds dy = da . act' and s->scratch its BN-backward partial rows
     for (int i = s->n_backbone; i >= 1; --i) {
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
         const int zb = i & 1;
         float* dz = overlap && zb ? s->dz2 : s->dz;
         if (overlap && wg_pending[zb]) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_wg[zb], 0)); wg_pending[zb] = false; }
-        RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz));
+        if (fused_rows > 0) {
+            // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the
+            // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z
+            const double n_l = (double)global_B * l.px_out;
+            if (!sc || !sc->cb) {
+                RUN(launch_bn_bwd_finalize_partials(s->scratch, fused_rows, 11 * (int64_t)l.d.cout, l.d.cout, l.bsums, n_l, P + l.d.gamma_off, l.mean,
+                                                    l.rstd, l.cA, l.cB, l.cC, G + l.d.gamma_off, G + l.d.beta_off, st));
+            } else {
+                RUN(launch_partials_to_sums(s->scratch, fused_rows, 11 * (int64_t)l.d.cout, l.d.cout, l.bsums, st));
+                RUN(launch_bn_param_grads(l.bsums, l.d.cout, G + l.d.gamma_off, G + l.d.beta_off, st));
+                RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
+                RUN(launch_bn_bwd_coef(l.bsums, n_l, l.d.cout, P + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC, nullptr, nullptr, st));
+            }
+            // the depthwise layer's weight gradient came with the same rows (taps behind the two sums)
+            RUN(launch_reduce_splits(s->scratch + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st,
+                                     11 * (int64_t)l.d.cout));
+            RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
+            fused_rows = 0;
+        } else {
+            RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz));
+        }
         if (l.d.role == AMS_ROLE_DEPTHWISE && train_recompute_block(s, i - 1)) {
             // early block: from dz of the depthwise layer straight to the gradient of the block input; da_e / dz_e / a_e are recomputed
             // from the block input inside the kernels and never stored (k_xdw_train.hip)
@@ -1142,6 +1164,16 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             break;
         }
         LayerRt& prev = s->L[i - 1];
+        const bool fuse_here = l.d.role == AMS_ROLE_DEPTHWISE && s->fuse_dgrad_bn && l.d.stride == 1 && prev.d.role == AMS_ROLE_EXPAND &&
+                               prev.d.cout == l.d.cin && depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin) <= s->scratch_floats && l.d.cin <= 1024;
+        if (fuse_here) {
+            // input gradient + activation derivative + BN-backward sums of the expand layer + this layer's weight gradient in one kernel
+            // (k_conv.hip): prev.da <- dy, partial rows in s->scratch until the next iteration's second stage
+            RUNK(i, dw_bytes(l, B) + 4.0 * B * l.px_in * l.d.cin,
+                 launch_depthwise_dgrad_bn(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, prev.z, prev.scale, prev.shift, prev.d.act, prev.mean,
+                                           prev.rstd, prev.da, s->scratch, &fused_rows, st));
+            continue;
+        }
         hipStream_t wst = st;
         float* wscratch = s->scratch;
         if (overlap) {
@@ -1268,6 +1300,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (const char* e = getenv("AMS_FUSE_BLOCK")) s->fuse_block = atoi(e);                  // tuning knob (see AMS_OPT_FUSE_BLOCK)
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     if (const char* e = getenv("AMS_OVERLAP_WGRAD")) s->overlap_wgrad = atoi(e);            // tuning knob: 0 one stream, 1 weight gradients on a side stream, 2 depthwise ones on a third
+    if (const char* e = getenv("AMS_FUSE_DGRAD_BN")) s->fuse_dgrad_bn = atoi(e);             // tuning knob
     if (const char* e = getenv("AMS_TRAIN_RECOMPUTE")) s->train_recompute = atoi(e);       // tuning knob (see AMS_OPT_TRAIN_RECOMPUTE)
     *out = s;
     return AMS_OK;
@@ -1622,6 +1655,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     }
     if (option == AMS_OPT_EMULATE_BF16_STORAGE) {
         s->emulate_bf16_storage = value != 0;
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_FUSE_DGRAD_BN) {
+        s->fuse_dgrad_bn = value != 0;
         return AMS_OK;
     }
     if (option == AMS_OPT_TRAIN_RECOMPUTE) {

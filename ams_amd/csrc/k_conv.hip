@@ -534,6 +534,147 @@ int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const fl
     return AMS_OK;
 }
 
+// Input gradient of a stride-1 depthwise conv FUSED with the first half of the BN backward of the layer in front of it (the fine-tune
+// step of the stride-16 blocks: that layer is the block's expand layer).  da_e = dwconv^T(dz_d) as above; then, with the expand layer's
+// raw output z_e read at the same position, dy_e = da_e . act'(z_e sc + sh) is what gets written, and sum(dy_e), sum(dy_e xhat_e) are
+// accumulated on the way: the separate reduction pass over (da_e, z_e) — one launch and two tensor reads per block — disappears, and
+// bn_bwd_apply then runs on dy_e with the activation already applied.  The depthwise WEIGHT gradient rides along too: tap (i, j) pairs
+// a_e at this position (= clamp(z_e sc + sh), already at hand for the mask) with exactly the dz_d value that the input gradient multiplies
+// by w[i][j], so dW[i][j] += a_e . dz_d costs nine more FMAs per output and no load — the separate weight-gradient kernel (two tensor
+// reads) and its split reduction disappear from the side stream.  A block owns one column strip of one image and walks DOWN all its
+// row tiles with its sums in registers; threads of a block that share a channel group are added in a fixed order through LDS:
+// one partial row [2 + 9][C] per block, deterministic.
+template <int R>
+__global__ __launch_bounds__(256) void dw3x3_dgrad_bn_kernel(const float* __restrict__ dy, const float* __restrict__ wgt, const float* __restrict__ z,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float* __restrict__ out, float* __restrict__ part, DwGeom g) {
+    constexpr int TH = 4, RS = R == 2 ? 2 : 1, NR = RS == 2 ? TH + 2 : TH + 2 * R;
+    constexpr int NQ = 8 + 36;                                         // s1, s2, nine taps: 4 channels each
+    __shared__ float s_acc[256][NQ + 1];
+    const int tx = blockIdx.x % g.tiles_x, b = blockIdx.x / g.tiles_x;
+    const int flat = tx * 256 + threadIdx.x;
+    const int ox = flat / g.CG, cg = flat - ox * g.CG;
+    const bool live = ox < g.Wo;
+    const int c0 = cg * 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = zero4, s2 = zero4, dwv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwv[k] = zero4;
+    if (live) {
+        const float* xb = dy + (int64_t)b * g.H * g.W * g.C + c0;
+        const float* zb = z + (int64_t)b * g.Ho * g.Wo * g.C + c0;
+        float* yb = out + (int64_t)b * g.Ho * g.Wo * g.C + c0;
+        int ixc[3];
+        bool okx[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ix = ox - g.pl + j * R;
+            okx[j] = ix >= 0 && ix < g.W;
+            ixc[j] = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
+        }
+        float4 wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + (8 - k) * g.C + c0);            // the conv with the flipped kernel
+        const float4 sc = ld4(scale + c0), sh = ld4(shift + c0), mu = ld4(mean + c0), rs = ld4(rstd + c0);
+        const float lo = act == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = act == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+        for (int ty = 0; ty < g.tiles_y; ++ty) {
+            const int oy0 = (ty / RS) * (TH * RS) + (ty % RS);
+            const int iy0 = oy0 - g.pt;
+            float4 in[NR][3];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const int iy = iy0 + rr * (RS == 2 ? R : 1);
+                const bool oky = iy >= 0 && iy < g.H;
+                const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+                const float* rp = xb + (int64_t)iyc * g.W * g.C;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float4 v = ld4(rp + (int64_t)ixc[j] * g.C);
+                    const bool ok = oky && okx[j];
+                    in[rr][j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+                }
+            }
+            float4 zv[TH];
+#pragma unroll
+            for (int r = 0; r < TH; ++r) {
+                const int oy = oy0 + r * RS;
+                const int oyc = oy < g.Ho ? oy : g.Ho - 1;
+                zv[r] = ld4(zb + ((int64_t)oyc * g.Wo + ox) * g.C);
+            }
+#pragma unroll
+            for (int r = 0; r < TH; ++r) {
+                const int oy = oy0 + r * RS;
+                if (oy >= g.Ho) break;
+                float4 acc = zero4;
+                const float4 y = muladd4_pk(zv[r], sc, sh);
+                const float4 ae = make_float4(__builtin_amdgcn_fmed3f(y.x, lo, hi), __builtin_amdgcn_fmed3f(y.y, lo, hi),
+                                              __builtin_amdgcn_fmed3f(y.z, lo, hi), __builtin_amdgcn_fmed3f(y.w, lo, hi));
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float4 v = in[RS == 2 ? r + i : r + i * R][j];
+                        const float4 w4 = wv[i * 3 + j];
+                        acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
+                        acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
+                        // position (i, j) of the flipped kernel is tap 8 - (3i + j) of the forward conv
+                        fma4_pk(dwv[8 - (i * 3 + j)], ae, v);
+                    }
+                const float4 d = make_float4((y.x > lo && y.x < hi) ? acc.x : 0.f, (y.y > lo && y.y < hi) ? acc.y : 0.f,
+                                             (y.z > lo && y.z < hi) ? acc.z : 0.f, (y.w > lo && y.w < hi) ? acc.w : 0.f);
+                st4(yb + ((int64_t)oy * g.Wo + ox) * g.C, d);
+                s1 = add4_pk(s1, d);
+                s2 = add4_pk(s2, mul4_pk(mul4_pk(d, sub4_pk(zv[r], mu)), rs));
+            }
+        }
+    }
+    // fixed-order sum of the threads that share a channel group (thread t, t + CG, ...), then one partial row per block
+    float* sa = s_acc[threadIdx.x];
+    sa[0] = s1.x; sa[1] = s1.y; sa[2] = s1.z; sa[3] = s1.w; sa[4] = s2.x; sa[5] = s2.y; sa[6] = s2.z; sa[7] = s2.w;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { sa[8 + 4 * k] = dwv[k].x; sa[9 + 4 * k] = dwv[k].y; sa[10 + 4 * k] = dwv[k].z; sa[11 + 4 * k] = dwv[k].w; }
+    sa[NQ] = live ? 1.f : -1.f;
+    __syncthreads();
+    // a block touches at most min(CG, 256) channel groups: cg0 .. ; thread e owns (group index e / 8 of the block's range, quantity e % 8)
+    const int cg_first = (tx * 256) % g.CG;
+    const int ngroups = g.CG < 256 ? g.CG : 256;
+    float* row = part + (int64_t)blockIdx.x * 11 * g.C;              // [sum dy | sum dy xhat | dW taps 0..8][C]
+    for (int e = threadIdx.x; e < ngroups * NQ; e += 256) {
+        const int gi = e / NQ, qn = e - gi * NQ;
+        const int cgw = (cg_first + gi) % g.CG;
+        float s = 0.f;
+        for (int t = gi; t < 256; t += g.CG)                        // threads t with (tx * 256 + t) % CG == cgw, ascending
+            if (s_acc[t][NQ] >= 0.f) s += s_acc[t][qn];
+        row[(qn >> 2) * g.C + cgw * 4 + (qn & 3)] = s;
+    }
+}
+
+size_t depthwise_dgrad_bn_scratch(int B, int H, int W, int C) { return (size_t)B * cdiv((int64_t)W * (C / 4), 256) * 11 * C; }
+
+// dx_masked [B,H,W,C] = dwconv^T(dy, w) . act'(z sc + sh) (stride 1, rate 1|2; the conv keeps the size), partial rows [rows][11][C] of
+// (sum dx_masked, sum dx_masked xhat, the nine taps of the depthwise weight gradient sum act(z sc + sh) . dy) in scratch
+int launch_depthwise_dgrad_bn(const float* dy, int B, int H, int W, int C, const float* w, int rate, const float* z, const float* scale,
+                              const float* shift, int act, const float* mean, const float* rstd, float* out, float* scratch, int* rows_out,
+                              hipStream_t st) {
+    DwGeom f;
+    int rc = dw_geom(B, H, W, C, 1, rate, false, &f);
+    if (rc) return rc;
+    AMS_REQUIRE(C / 4 >= 1, "depthwise_dgrad_bn: C=%d", C);
+    f.tiles_y = rate == 2 ? 2 * cdiv(f.Ho, 8) : cdiv(f.Ho, 4);
+    f.tiles_x = cdiv((int64_t)f.Wo * f.CG, 256);
+    const unsigned nb = (unsigned)f.tiles_x * B;
+    *rows_out = (int)nb;
+    // a block whose 256 flat indices wrap around the channel groups more than once covers every group: rows are complete; otherwise the
+    // groups it does not touch must read as zero
+    AMS_REQUIRE(f.CG <= 256, "depthwise_dgrad_bn: C=%d exceeds 1024", C);
+    note_kernel(rate == 2 ? "dw3x3_dgrad_bn_kernel<2>" : "dw3x3_dgrad_bn_kernel<1>");
+    if (rate == 1) hipLaunchKernelGGL((dw3x3_dgrad_bn_kernel<1>), dim3(nb), dim3(256), 0, st, dy, w, z, scale, shift, act, mean, rstd, out, scratch, f);
+    else hipLaunchKernelGGL((dw3x3_dgrad_bn_kernel<2>), dim3(nb), dim3(256), 0, st, dy, w, z, scale, shift, act, mean, rstd, out, scratch, f);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 // weight gradient: dw[i,j,c] = sum_{b,oy,ox} x[b, oy*S-pt+i*R, ox*S-pl+j*R, c] * dy[b,oy,ox,c]
 // A thread owns 4 channels and walks work items = (image, group of TH = 4 output rows, output column): the
 // (TH-1)*S + 2R + 1 input rows that the group touches are each loaded once (3 taps per row) and feed up to 3 output

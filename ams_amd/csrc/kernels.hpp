@@ -108,6 +108,11 @@ int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w,
                      const float* scale, const float* shift, int act, float* y, hipStream_t st);
 int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const float* w, int stride, int rate,
                            float* dx, hipStream_t st);
+// stride-1 input gradient fused with the mask and the BN-backward sums of the layer in front (see k_conv.hip); C <= 1024
+size_t depthwise_dgrad_bn_scratch(int B, int H, int W, int C);
+int launch_depthwise_dgrad_bn(const float* dy, int B, int H, int W, int C, const float* w, int rate, const float* z, const float* scale,
+                              const float* shift, int act, const float* mean, const float* rstd, float* out, float* scratch, int* rows_out,
+                              hipStream_t st);
 size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate);
 int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
                            float* dw, float* scratch, size_t scratch_floats, hipStream_t st);

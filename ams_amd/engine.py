@@ -207,9 +207,12 @@ class StudentEngine:
                   "ams_pack_masked_fp16")
         return out[:int(cnt.item())]
 
-    def set_train_recompute(self, on: bool) -> None:
-        """Fine-tune step of the early blocks without their 6x-expanded tensors (default on); off = every tensor materialised."""
+    def set_train_recompute(self, on: bool, fuse_dgrad_bn: Optional[bool] = None) -> None:
+        """Fine-tune step of the early blocks without their 6x-expanded tensors (default on); off = every tensor materialised.
+        ``fuse_dgrad_bn``: the one-kernel depthwise backward of the stride-16 blocks (default on)."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_TRAIN_RECOMPUTE, int(bool(on))), "ams_student_set_option")
+        if fuse_dgrad_bn is not None:
+            hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DGRAD_BN, int(bool(fuse_dgrad_bn))), "ams_student_set_option")
 
     def set_fuse_first_block(self, on: int) -> None:
         """Frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel with a tile per block

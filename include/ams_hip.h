@@ -209,6 +209,9 @@ enum { AMS_OPT_DUAL_AUTOTUNE = 12 /* with AMS_OPT_DUAL_STREAM = 1: 1 = pick the 
                                             the block inputs of the output-stride-16 section to bf16 after they are written — the values bf16
                                             STORAGE of those tensors would hold; the arithmetic and every other tensor stay f32.  Costs a pass per
                                             tensor: an accuracy probe, not a fast path */,
+       AMS_OPT_FUSE_DGRAD_BN = 16 /* fine-tune step, stride-1 blocks that keep their tensors (blocks 7-16): 1 (default) the depthwise input gradient,
+                                     the expand layer's activation derivative and BN-backward sums, and the depthwise weight gradient come out of
+                                     ONE kernel (k_conv.hip: dw3x3_dgrad_bn_kernel); 0 four separate passes.  Same mathematics, f32-level differences */,
        AMS_OPT_TRAIN_RECOMPUTE = 11 /* fine-tune step: 1 (default) the early blocks (block input <= 32 channels) run without their 6x-expanded
                                        tensors — every consumer recomputes z_e = x . W_e from the block input (k_xdw_train.hip); 0 the
                                        layer-by-layer step (every tensor materialised).  Same mathematics, f32-level differences (summation order). */,

@@ -1,4 +1,5 @@
-"""Fine-tune step of the early blocks without their expanded tensors (ams_amd/csrc/k_xdw_train.hip, AMS_OPT_TRAIN_RECOMPUTE) against the
+"""Fine-tune step of the early blocks without their expanded tensors (ams_amd/csrc/k_xdw_train.hip, AMS_OPT_TRAIN_RECOMPUTE) and with the
+one-kernel depthwise backward of the stride-16 blocks (k_conv.hip dw3x3_dgrad_bn_kernel, AMS_OPT_FUSE_DGRAD_BN) against the
 layer-by-layer step of the same engine: same mathematics, different summation orders, so every gradient tensor, the BN moving
 statistics and the loss must agree at f32 level.  (Both forms are held to the f64 oracle by tests/test_gpu_network.py and
 tests/test_gpu_fullsize.py, which run the default = recompute form.)  Sizes cover odd and even block inputs: the stride-2 blocks pad
@@ -20,7 +21,7 @@ def _step(H, B, recompute, seed=3, steps=1):
     fr, lb = synth.SyntheticVideo(H, B, CI, seed=seed).clip()
     eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
     eng.load_variables(W0)
-    eng.set_train_recompute(recompute)
+    eng.set_train_recompute(recompute, fuse_dgrad_bn=recompute)       # both fused forms on, or the layer-by-layer step
     losses = []
     for _ in range(steps):
         losses.append(eng.train_step(fr, lb, 1e-3).cpu().numpy().copy())

@@ -110,6 +110,8 @@ struct ams_student {
     float* ce_scratch = nullptr;       // unnormalised CE gradient planes of the one-pass loss kernel (k_head.hip)
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
     int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
+    int fuse_gemm_red = 2;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics (off: -0.05 ms, and the
+                                       // f32 noise of the 64x128 oracle test doubles), bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
     int fuse_dgrad_bn = 1;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
@@ -824,14 +826,30 @@ static bool train_recompute_block(const ams_student* s, int i) {
            xdw_train_scratch(s->cfg.max_batch, l.Hin, l.Win, l.d.cin, l.d.cout) <= s->xt_floats;
 }
 
+// most partial rows a GEMM with a fused column reduction can leave behind (PwArgs::red_mode): one per block of the persistent streaming
+// kernel (<= 8 per CU), one per 64-row strip of the tiled split kernel
+static size_t red_rows_bound(int64_t M) { return M >= 32768 ? 2048 : (size_t)(M / 64 + 8); }
+
+// pre_rows > 0: the kernel that wrote l.z already left the statistics' partial rows [pre_rows][2][C] in s->scratch
 static int bn_train(ams_student* s, LayerRt& l, int64_t M_local, double n_global, bool update_ema, const SyncCtx* sc,
-                    const float* res, hipStream_t st) {
+                    const float* res, hipStream_t st, int pre_rows = 0) {
     const ams_student_config& c = s->cfg;
     const float* center = s->stats + l.d.mean_off;       // shifted sums: moving_mean is a good, rank-identical centre
     const float omd = 1.0f - c.bn_decay;
     float* mm = update_ema ? s->stats + l.d.mean_off : nullptr;
     float* mv = update_ema ? s->stats + l.d.var_off : nullptr;
-    if (!sc || !sc->cb) {
+    if (pre_rows > 0) {
+        if (!sc || !sc->cb) {
+            RUN(launch_bn_fwd_finalize_partials(s->scratch, pre_rows, 2 * (int64_t)l.d.cout, l.d.cout, l.fsums, n_global, center,
+                                                s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd, mm, mv, l.scale, l.shift,
+                                                l.mean, l.rstd, st));
+        } else {
+            RUN(launch_partials_to_sums(s->scratch, pre_rows, 2 * (int64_t)l.d.cout, l.d.cout, l.fsums, st));
+            RUN(sync_doubles(sc, l.fsums, 2 * (size_t)l.d.cout, st));
+            RUN(launch_bn_finalize(l.fsums, n_global, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
+                                   mm, mv, l.scale, l.shift, l.mean, l.rstd, st));
+        }
+    } else if (!sc || !sc->cb) {
         // no cross-rank sum between the statistics and their use: the reduction's second stage finishes the BN arithmetic
         RUNK(0, 4.0 * M_local * l.d.cout,
              launch_colstats_bn(l.z, M_local, l.d.cout, center, l.fsums, s->scratch, n_global, s->params + l.d.gamma_off,
@@ -900,15 +918,20 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
             ++i;
             continue;
         }
+        int pre_rows = 0;
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, nullptr, nullptr,
                                                      AMS_ACT_NONE, l.z, st));
         } else {
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, l.z, l.d.cout);
+            // the BN statistics of the result in this GEMM's epilogue, where the kernel chosen can do it
+            if ((s->fuse_gemm_red & 1) && red_rows_bound(a.M) * 2 * (size_t)l.d.cout <= s->scratch_floats) {
+                a.red_mode = 1; a.red_center = s->stats + l.d.mean_off; a.red_part = s->scratch; a.red_rows_out = &pre_rows;
+            }
             RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         }
         const float* res = l.d.residual_from ? s->L[l.d.residual_from].a : nullptr;
-        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st));
+        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st, pre_rows));
     }
     LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];
     const float* feat = s->L[s->n_backbone].a;
@@ -1058,7 +1081,11 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
     bool wg_pending[2] = {false, false};
     bool xt_pending = false;
-    int fused_rows = 0;                               // > 0: this layer's da already holds dy = da . act' and s->scratch its BN-backward partial rows
+    // > 0: the kernel that produced this layer's da already multiplied it by the activation's derivative and left the BN-backward partial
+    // rows in s->scratch (fused_stride floats apart; fused_dw: the nine taps of the NEXT layer's depthwise weight gradient behind the sums)
+    int fused_rows = 0;
+    int64_t fused_stride = 0;
+    bool fused_dw = false;
     for (int i = s->n_backbone; i >= 1; --i) {
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
@@ -1070,17 +1097,17 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z
             const double n_l = (double)global_B * l.px_out;
             if (!sc || !sc->cb) {
-                RUN(launch_bn_bwd_finalize_partials(s->scratch, fused_rows, 11 * (int64_t)l.d.cout, l.d.cout, l.bsums, n_l, P + l.d.gamma_off, l.mean,
+                RUN(launch_bn_bwd_finalize_partials(s->scratch, fused_rows, fused_stride, l.d.cout, l.bsums, n_l, P + l.d.gamma_off, l.mean,
                                                     l.rstd, l.cA, l.cB, l.cC, G + l.d.gamma_off, G + l.d.beta_off, st));
             } else {
-                RUN(launch_partials_to_sums(s->scratch, fused_rows, 11 * (int64_t)l.d.cout, l.d.cout, l.bsums, st));
+                RUN(launch_partials_to_sums(s->scratch, fused_rows, fused_stride, l.d.cout, l.bsums, st));
                 RUN(launch_bn_param_grads(l.bsums, l.d.cout, G + l.d.gamma_off, G + l.d.beta_off, st));
                 RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
                 RUN(launch_bn_bwd_coef(l.bsums, n_l, l.d.cout, P + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC, nullptr, nullptr, st));
             }
             // the depthwise layer's weight gradient came with the same rows (taps behind the two sums)
-            RUN(launch_reduce_splits(s->scratch + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st,
-                                     11 * (int64_t)l.d.cout));
+            if (fused_dw)
+                RUN(launch_reduce_splits(s->scratch + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st, fused_stride));
             RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
             fused_rows = 0;
         } else {
@@ -1172,6 +1199,8 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             RUNK(i, dw_bytes(l, B) + 4.0 * B * l.px_in * l.d.cin,
                  launch_depthwise_dgrad_bn(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, prev.z, prev.scale, prev.shift, prev.d.act, prev.mean,
                                            prev.rstd, prev.da, s->scratch, &fused_rows, st));
+            fused_stride = 11 * (int64_t)l.d.cin;
+            fused_dw = true;
             continue;
         }
         hipStream_t wst = st;
@@ -1199,7 +1228,15 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) {
                 a.res = s->L[i + 2].da; a.ldr = l.d.cin;
             }
+            // first half of the previous layer's BN backward in this GEMM's epilogue (activation derivative + the two column sums), where
+            // the kernel chosen can do it: the separate pass over (da, z) of that layer disappears
+            int red_rows = 0;
+            if ((s->fuse_gemm_red & 2) && !a.res && i - 1 >= 2 && red_rows_bound(Mo) * 2 * (size_t)l.d.cin <= s->scratch_floats) {
+                a.red_mode = 2; a.red_z = prev.z; a.red_scale = prev.scale; a.red_shift = prev.shift; a.red_mean = prev.mean; a.red_rstd = prev.rstd;
+                a.red_act = prev.d.act; a.red_part = s->scratch; a.red_rows_out = &red_rows;
+            }
             RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
+            if (red_rows > 0) { fused_rows = red_rows; fused_stride = 2 * (int64_t)l.d.cin; fused_dw = false; }
         }
     }
     // the optimizer (and the gradient all-reduce) wait for every weight gradient
@@ -1301,6 +1338,7 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     if (const char* e = getenv("AMS_FUSE_XDS")) s->fuse_expand_dw_stream = atoi(e);      // tuning knob (see AMS_OPT_FUSE_EXPAND_DW_STREAM)
     if (const char* e = getenv("AMS_OVERLAP_WGRAD")) s->overlap_wgrad = atoi(e);            // tuning knob: 0 one stream, 1 weight gradients on a side stream, 2 depthwise ones on a third
     if (const char* e = getenv("AMS_FUSE_DGRAD_BN")) s->fuse_dgrad_bn = atoi(e);             // tuning knob
+    if (const char* e = getenv("AMS_FUSE_GEMM_RED")) s->fuse_gemm_red = atoi(e);             // tuning knob
     if (const char* e = getenv("AMS_TRAIN_RECOMPUTE")) s->train_recompute = atoi(e);       // tuning knob (see AMS_OPT_TRAIN_RECOMPUTE)
     *out = s;
     return AMS_OK;
@@ -1659,6 +1697,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     }
     if (option == AMS_OPT_FUSE_DGRAD_BN) {
         s->fuse_dgrad_bn = value != 0;
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_FUSE_GEMM_RED) {
+        s->fuse_gemm_red = value & 3;
         return AMS_OK;
     }
     if (option == AMS_OPT_TRAIN_RECOMPUTE) {

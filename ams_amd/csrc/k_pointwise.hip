@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void pw_small_m_kernel(PwArgs a) {
 }
 
 int launch_pointwise(const PwArgs& a, hipStream_t st) {
+    if (a.red_rows_out) *a.red_rows_out = 0;               // set by the kernels that can fuse the column reduction (PwArgs::red_mode)
     AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0, "pointwise: empty problem M=%lld K=%d N=%d", (long long)a.M, a.K, a.N);
     AMS_REQUIRE(a.Kw > 0 && a.Kw <= a.K, "pointwise: Kw=%d must be in 1..K=%d", a.Kw, a.K);
     AMS_REQUIRE(a.K % 4 == 0 && a.ldx % 4 == 0, "pointwise: K (%d) and ldx (%d) must be multiples of 4", a.K, a.ldx);

@@ -23,8 +23,19 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
 
     const int64_t wave_stride = (int64_t)gridDim.x * 4;
     const int64_t g_first = (int64_t)blockIdx.x * 4 + wave;
-    if (g_first >= n_groups) return;
-    const int64_t my_groups = (n_groups - 1 - g_first) / wave_stride + 1;
+    const bool red = EPI == EPI_PLAIN && a.red_mode != 0;      // block-uniform; the launcher clears red_mode where it does not apply
+    float* sRedVec = sSh + 16 * NT + 4 * (16 * (16 * NT + 4));  // behind the waves' output slabs: 4 x 16 NT vectors, then the waves' sums
+    float4 rs1[EPI == EPI_PLAIN ? NT : 1], rs2[EPI == EPI_PLAIN ? NT : 1];
+    if constexpr (EPI == EPI_PLAIN) {
+        if (red) {
+            pw_red_stage<NT>(a, sRedVec, n0, tid, 256);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { rs1[t] = make_float4(0.f, 0.f, 0.f, 0.f); rs2[t] = rs1[t]; }
+            __syncthreads();
+        }
+    }
+    if (g_first >= n_groups && !red) return;                   // (with a fused reduction every wave reaches the block barrier at the end)
+    const int64_t my_groups = g_first < n_groups ? (n_groups - 1 - g_first) / wave_stride + 1 : 0;
     const int64_t n_items = my_groups * n_chunks;              // (row group, 16-k chunk) pairs walked by this wave
 
     // branch-free operand fetch: addresses are clamped into the tensor (rows to M-1, the k offset to K-4) and lanes
@@ -43,7 +54,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
         }
     };
     float4 a_cur[RM], a_nxt[RM];
-    fetch(g_first, 0, a_cur);
+    fetch(g_first < n_groups ? g_first : n_groups - 1, 0, a_cur);
     f32x4 acc[RM][NT];
     int64_t g = g_first;
     int c = 0;
@@ -67,9 +78,17 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
             // stores, so a wait placed after them would sit behind a full store round trip with the matrix pipe idle.
             asm volatile("" : "+v"(a_cur[r].x), "+v"(a_cur[r].y), "+v"(a_cur[r].z), "+v"(a_cur[r].w));
         }
-        if (c == n_chunks - 1) pw_epilogue_t<RM, NT, EPI>(a, acc, g * (16 * RM), n0, lane, sSc, sSh, sOut);
+        if (c == n_chunks - 1) {
+            if constexpr (EPI == EPI_PLAIN) {
+                if (red) pw_red_rowgroups<RM, NT>(a, acc, g * (16 * RM), n0, l15, q, sRedVec, rs1, rs2);
+            }
+            pw_epilogue_t<RM, NT, EPI>(a, acc, g * (16 * RM), n0, lane, sSc, sSh, sOut);
+        }
         c = cn;
         g = gn;
+    }
+    if constexpr (EPI == EPI_PLAIN) {
+        if (red) pw_red_finish<NT>(a, rs1, rs2, lane, wave, 4, sRedVec + 4 * 16 * NT, blockIdx.x, n0, tid, 256);
     }
 }
 
@@ -78,7 +97,8 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     constexpr int PITCH = 16 * NT + 4;
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     const int64_t n_groups = cdiv64(a.M, 16 * RM);
-    const size_t lds = ((size_t)((a.K + 15) / 16 * 16) * PITCH + 32 * NT + 4 * 16 * (16 * NT + 4)) * sizeof(float);
+    // weight panel | scale, shift | four output slabs | (fused reduction: 4 vectors + 4 waves x 2 sums of 16 NT floats)
+    const size_t lds = ((size_t)((a.K + 15) / 16 * 16) * PITCH + 32 * NT + 4 * 16 * (16 * NT + 4) + (EPI == EPI_PLAIN ? 12 * 16 * NT : 0)) * sizeof(float);
     int64_t blocks = cdiv64(n_groups, 4);
     // persistent grid: exactly the blocks that are co-resident (work is pre-partitioned by grid-stride, so any block that
     // has to wait for a slot would run its whole share on a half-empty chip)
@@ -90,7 +110,12 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
     static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT, EPI>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, a, n_tiles_n, n_groups);
+    PwArgs b = a;
+    if (b.red_mode) {
+        if (EPI == EPI_PLAIN && pw_red_ok(b)) { if (b.red_rows_out) *b.red_rows_out = (int)blocks; }
+        else { b.red_mode = 0; if (b.red_rows_out) *b.red_rows_out = 0; }
+    }
+    hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT, EPI>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, b, n_tiles_n, n_groups);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
     constexpr int NPIECE = NP * ROWS * 4;            // 16-byte pieces per stage (NP panels, 32 k = 4 pieces per row)
     constexpr int NREG = (NPIECE + 255) / 256;
     // the weight stages and the epilogue slabs share one region (the stage loop ends with a barrier): more blocks per CU
-    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = (EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4)) * 4;
+    // (+ 4 x 16 NT floats behind the slabs for the vectors of a fused column reduction, PwArgs::red_mode)
+    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = (EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4) + (EPI == EPI_PLAIN ? 4 * 16 * NT : 0)) * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES > OUT_BYTES ? W_BYTES : OUT_BYTES];
     typedef unsigned short (*WStage)[NP][ROWS * PITCH];
     WStage sW = reinterpret_cast<WStage>(smem);                                        // [buffer][part][...]
@@ -246,8 +247,28 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
     };
     if (RM >= 2 && half) main_loop(RHalf{});
     else main_loop(RFull{});
+    const bool red = EPI == EPI_PLAIN && a.red_mode != 0;           // block-uniform (the launcher clears red_mode for the other epilogues)
+    float4 rs1[EPI == EPI_PLAIN ? NT : 1], rs2[EPI == EPI_PLAIN ? NT : 1];
+    if constexpr (EPI == EPI_PLAIN) {
+        if (red) {
+            // the stage loop ended with a barrier: the weight stages are dead, their LDS holds the reduction's vectors and, later, the waves' sums
+            float* sRedVec = reinterpret_cast<float*>(smem) + 4 * 16 * (16 * NT + 4);
+            pw_red_stage<NT>(a, sRedVec, n0, tid, 256);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { rs1[t] = make_float4(0.f, 0.f, 0.f, 0.f); rs2[t] = rs1[t]; }
+            __syncthreads();
+            pw_red_rowgroups<RM, NT>(a, acc, m_base, n0, l15, q, sRedVec, rs1, rs2, nrg);
+        }
+    }
     if (EPI == EPI_GENERIC) pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q, sSc, sSh, nrg);
     else pw_epilogue_t<RM, NT, EPI, true>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)), nrg);
+    if constexpr (EPI == EPI_PLAIN) {
+        if (red) {
+            __syncthreads();                                        // the epilogue slabs are consumed
+            const int64_t row = half ? (int64_t)(n_full / n_tiles_n) + tile_m : tile_m;
+            pw_red_finish<NT>(a, rs1, rs2, lane, wave, 4, reinterpret_cast<float*>(smem), row, n0, tid, 256);
+        }
+    }
 }
 
 struct SplitPanels { const uint16_t* base; int64_t plane; int np; };     // part p at base + p * plane
@@ -291,11 +312,16 @@ static int launch_pw_x3_d(const PwArgs& a, const SplitPanels& w, int Kp, hipStre
     const int64_t full_strips = pw_plan_tail(a.M, RM, n_tiles_n, slots, &half_strips);
     const int64_t n_full = full_strips * n_tiles_n;
     const int64_t nblocks = n_full + half_strips * n_tiles_n;
+    PwArgs b = a;
+    if (b.red_mode) {
+        if (EPI == EPI_PLAIN && pw_red_ok(b)) { if (b.red_rows_out) *b.red_rows_out = (int)(nblocks / n_tiles_n); }
+        else { b.red_mode = 0; if (b.red_rows_out) *b.red_rows_out = 0; }
+    }
     // the kernel's own symbol (rocprofv3 reports the same text); NP = 3 is the six-product "x6" training variant
     static const std::string nm = "pw_gemm_bf16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) +
                                   ", " + std::to_string(D) + ", " + std::to_string(NP) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI, D, NP>), dim3((unsigned)nblocks), dim3(256), 0, st, a, w.base, w.plane, Kp,
+    hipLaunchKernelGGL((pw_gemm_bf16x3_l<RM, NT, EPI, D, NP>), dim3((unsigned)nblocks), dim3(256), 0, st, b, w.base, w.plane, Kp,
                        n_tiles_n, (unsigned)nblocks, (unsigned)n_full);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
@@ -320,6 +346,7 @@ static int launch_pw_x3(const PwArgs& a, const SplitPanels& w, int Kp, hipStream
 }
 
 static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
+    if (a.red_rows_out) *a.red_rows_out = 0;               // set below when the launch fuses the column reduction (PwArgs::red_mode)
     AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0 && Kp % 32 == 0 && Kp >= a.K, "pointwise_split: bad problem");
     AMS_REQUIRE(a.K % 8 == 0 && a.ldx % 4 == 0, "pointwise_split: K (%d) must be a multiple of 8", a.K);
     int rm, nt;

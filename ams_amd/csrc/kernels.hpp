@@ -52,6 +52,19 @@ struct PwArgs {
     uint16_t* ysplit;
     int64_t ysplit_plane;
     int ysplit_np;
+    // optional column reduction fused into the epilogue (fine-tune step; plain epilogues only: no scale / shift / bias / residual):
+    //   red_mode 1  forward BN statistics of y:  sum(y - red_center), sum((y - red_center)^2)
+    //   red_mode 2  y is the gradient wrt the ACTIVATED output of a BN layer whose raw output is red_z [M, ldy]: y is multiplied by the
+    //               activation's derivative act'(red_z red_scale + red_shift) before it is stored, and sum(y), sum(y xhat) are formed
+    //               (xhat = (red_z - red_mean) red_rstd): the first half of that layer's BN backward
+    // partial rows [rows][2][N] go to red_part, the row count to *red_rows_out (HOST pointer; 0 = the kernel chosen cannot fuse: the caller
+    // runs the separate reduction)
+    int red_mode;
+    const float* red_center;
+    const float* red_z; const float* red_scale; const float* red_shift; const float* red_mean; const float* red_rstd;
+    int red_act;
+    float* red_part;
+    int* red_rows_out;
 };
 int launch_pointwise(const PwArgs& a, hipStream_t st);
 bool pointwise_stream_applies(const PwArgs& a);     // the persistent streaming variant (small K x N) can take this problem

@@ -173,6 +173,110 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Column reductions fused into the GEMM epilogue (PwArgs::red_mode).  Done in the MFMA layout, where a lane owns 4 consecutive columns
+// (16t + 4q ..) of row l15 for every tile t: the lane's columns are the same for every row group it ever sees, so the sums stay in 8 NT
+// registers until the wave is done; then 16 rows are folded by shuffles and the block's waves in a fixed order through LDS.
+// Mode 2 also rewrites the accumulators (gradient x activation derivative): what the epilogue stores afterwards is the masked value.
+// sRedVec (mode 2): scale | shift | mean | rstd of this column tile, 4 x 16 NT floats, staged by pw_red_stage.
+// ---------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void pw_red_stage(const PwArgs& a, float* sRedVec, int n0, int tid, int nthreads) {
+    for (int e = tid; e < 4 * 16 * NT; e += nthreads) {
+        const int which = e / (16 * NT), n = n0 + e - which * (16 * NT);
+        float v = which == 0 ? 1.f : 0.f;
+        if (n < a.N) {
+            if (a.red_mode == 2) v = (which == 0 ? a.red_scale : which == 1 ? a.red_shift : which == 2 ? a.red_mean : a.red_rstd)[n];
+            else v = (which == 0 && a.red_center) ? a.red_center[n] : 0.f;
+        }
+        sRedVec[e] = v;
+    }
+}
+
+template <int RM, int NT>
+__device__ __forceinline__ void pw_red_rowgroups(const PwArgs& a, f32x4 (&acc)[RM][NT], int64_t m_base, int n0, int l15, int q,
+                                                 const float* sRedVec, float4 (&s1)[NT], float4 (&s2)[NT], int nrg = RM) {
+    const float lo = a.red_act == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = a.red_act == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        if (r >= nrg) break;
+        int64_t m = m_base + r * 16 + l15;
+        const float w = m < a.M ? 1.f : 0.f;               // rows beyond M (tail tiles) add nothing
+        if (m > a.M - 1) m = a.M - 1;
+        if (a.red_mode == 2) {
+            float4 zv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                int n4 = n0 + 16 * t + 4 * q;
+                if (n4 > a.N - 4) n4 = a.N - 4;
+                zv[t] = ld4(a.red_z + m * a.ldy + n4);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c4 = 16 * t + 4 * q;
+                const float4 sc = ld4(sRedVec + c4), sh = ld4(sRedVec + 16 * NT + c4), mu = ld4(sRedVec + 32 * NT + c4), rs = ld4(sRedVec + 48 * NT + c4);
+                const float4 y = muladd4_pk(zv[t], sc, sh);
+                float4 d;
+                d.x = (y.x > lo && y.x < hi) ? acc[r][t][0] : 0.f; d.y = (y.y > lo && y.y < hi) ? acc[r][t][1] : 0.f;
+                d.z = (y.z > lo && y.z < hi) ? acc[r][t][2] : 0.f; d.w = (y.w > lo && y.w < hi) ? acc[r][t][3] : 0.f;
+                acc[r][t][0] = d.x; acc[r][t][1] = d.y; acc[r][t][2] = d.z; acc[r][t][3] = d.w;
+                if (n0 + c4 < a.N) {
+                    const float4 dw = make_float4(d.x * w, d.y * w, d.z * w, d.w * w);
+                    s1[t] = add4_pk(s1[t], dw);
+                    s2[t] = add4_pk(s2[t], mul4_pk(mul4_pk(dw, sub4_pk(zv[t], mu)), rs));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c4 = 16 * t + 4 * q;
+                if (n0 + c4 >= a.N) continue;
+                const float4 ctr = ld4(sRedVec + c4);
+                float4 d = sub4_pk(make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]), ctr);
+                d = make_float4(d.x * w, d.y * w, d.z * w, d.w * w);
+                s1[t] = add4_pk(s1[t], d);
+                s2[t] = add4_pk(s2[t], mul4_pk(d, d));
+            }
+        }
+    }
+}
+
+// the wave's sums -> the block's partial row `row` of red_part ([2][N]); sRed: >= nwaves * 2 * 16 NT floats of LDS, free to use.
+// Every wave of the block must call this (block barrier inside).
+template <int NT>
+__device__ __forceinline__ void pw_red_finish(const PwArgs& a, float4 (&s1)[NT], float4 (&s2)[NT], int lane, int wave, int nwaves, float* sRed,
+                                              int64_t row, int n0, int tid, int nthreads) {
+    const int l15 = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float4 u = s1[t], v = s2[t];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            u.x += __shfl_xor(u.x, off, 64); u.y += __shfl_xor(u.y, off, 64); u.z += __shfl_xor(u.z, off, 64); u.w += __shfl_xor(u.w, off, 64);
+            v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64); v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+        }
+        if (l15 == 0) {
+            st4(sRed + (wave * 2 + 0) * 16 * NT + 16 * t + 4 * q, u);
+            st4(sRed + (wave * 2 + 1) * 16 * NT + 16 * t + 4 * q, v);
+        }
+    }
+    __syncthreads();
+    float* out = a.red_part + row * 2 * (int64_t)a.N;
+    for (int e = tid; e < 2 * 16 * NT; e += nthreads) {
+        const int which = e / (16 * NT), c = e - which * (16 * NT);
+        if (n0 + c >= a.N) continue;
+        float s = 0.f;
+        for (int wv = 0; wv < nwaves; ++wv) s += sRed[(wv * 2 + which) * 16 * NT + c];
+        out[(int64_t)which * a.N + n0 + c] = s;
+    }
+}
+
+// the fused reduction needs a plain vector epilogue: the value reduced is the raw product
+static inline bool pw_red_ok(const PwArgs& a) {
+    return a.red_mode != 0 && a.red_part && !a.scale && !a.shift && !a.img_bias && !a.res && a.act == AMS_ACT_NONE && a.N % 4 == 0 && a.ldy % 4 == 0 &&
+           a.N >= 4;
+}
+
 // which epilogue a problem can use
 static inline int pw_pick_epi(const PwArgs& a) {
     const bool vec_ok = a.N >= 4 && (a.N & 3) == 0 && (a.ldy & 3) == 0 && (!a.res || (a.ldr & 3) == 0);

@@ -32,6 +32,7 @@ OPT_BLOCK_X6 = 8
 OPT_DUAL_STREAM = 10
 OPT_TRAIN_RECOMPUTE = 11
 OPT_FUSE_DGRAD_BN = 16
+OPT_FUSE_GEMM_RED = 17
 OPT_EMULATE_BF16_STORAGE = 15
 OPT_DUAL_AUTOTUNE = 12
 OPT_DUAL_PARTS = 13

@@ -176,7 +176,11 @@ def test_train_step_matches_oracle(W0, clip64):
             e_f32 = np.linalg.norm(grads_32[v.name].numpy().reshape(-1).astype(np.float64) - want) / floor
             errs_gpu.append(e_gpu)
             errs_f32.append(e_f32)
-            assert e_gpu <= max(3e-2, 4 * e_f32), "gradient of %s: HIP %.2e vs f32 CPU %.2e" % (v.name, e_gpu, e_f32)
+        order = np.argsort(errs_gpu)[::-1][:4]
+        print("step %d worst gradient tensors vs f64 (HIP, f32 CPU):" % step,
+              [(eng.spec.trainable[k].name, "%.2e" % errs_gpu[k], "%.2e" % errs_f32[k]) for k in order])
+        for k, v in enumerate(eng.spec.trainable):
+            assert errs_gpu[k] <= max(3e-2, 4 * errs_f32[k]), "gradient of %s: HIP %.2e vs f32 CPU %.2e" % (v.name, errs_gpu[k], errs_f32[k])
         assert np.median(errs_gpu) <= 3 * np.median(errs_f32) + 5e-3, (np.median(errs_gpu), np.median(errs_f32))
         o.train_step(fr.astype(np.float32), lb, lr)
         _compare_train_state(eng, o, before, lr, 1, "after step %d" % (step + 1), grads_o)

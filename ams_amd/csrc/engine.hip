@@ -112,7 +112,7 @@ struct ams_student {
     int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
     int fuse_gemm_red = 2;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics (off: -0.05 ms, and the
                                        // f32 noise of the 64x128 oracle test doubles), bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
-    int fuse_dgrad_bn = 1;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
+    int fuse_dgrad_bn = 2;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
     float *vec_ones = nullptr, *vec_zeros = nullptr;             // [1024] each: identity BN for a fused kernel's raw output
@@ -326,8 +326,14 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
             const LayerRt& l = s->L[i];
             size_t need;
             const int64_t M = (int64_t)B * l.px_out;
-            if (l.d.role == AMS_ROLE_DEPTHWISE) need = depthwise_wgrad_scratch(B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate);
-            else if (l.d.role == AMS_ROLE_STEM) need = pointwise_wgrad_scratch(M, 27, l.d.cout);
+            if (l.d.role == AMS_ROLE_DEPTHWISE) {
+                need = depthwise_wgrad_scratch(B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate);
+                if (l.d.stride == 1 && i >= 3 && l.d.cin >= 64 && l.d.cin <= 1024) {       // the one-kernel forms of the blocks that keep their tensors
+                    const size_t n1 = depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin), n2 = depthwise_fwd_bn_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate);
+                    if (n1 > need) need = n1;
+                    if (n2 > need) need = n2;
+                }
+            } else if (l.d.role == AMS_ROLE_STEM) need = pointwise_wgrad_scratch(M, 27, l.d.cout);
             else need = pointwise_wgrad_scratch(M, l.d.cin, l.d.cout);
             if (need > sc) sc = need;
         }
@@ -826,13 +832,28 @@ static bool train_recompute_block(const ams_student* s, int i) {
            xdw_train_scratch(s->cfg.max_batch, l.Hin, l.Win, l.d.cin, l.d.cout) <= s->xt_floats;
 }
 
+// Stride-1 depthwise layer i of a block that keeps its tensors: its backward is ONE kernel that recomputes the expand layer's activation
+// from z_e (backward(), k_conv.hip dw3x3_dgrad_bn_kernel) — so nothing in backward reads a_e, and at fuse_dgrad_bn >= 2 the forward
+// does not write it either (dw3x3_fwd_bn_kernel applies the expand layer's BN + activation on its tap loads).
+static bool dw_fused_train(const ams_student* s, int i, int B) {
+    if (i < 3 || i > s->n_backbone || !s->fuse_dgrad_bn || train_recompute_block(s, i - 1)) return false;
+    const LayerRt& l = s->L[i];
+    const LayerRt& prev = s->L[i - 1];
+    return l.d.role == AMS_ROLE_DEPTHWISE && l.d.stride == 1 && prev.d.role == AMS_ROLE_EXPAND && prev.d.cout == l.d.cin && l.d.cin <= 1024 &&
+           depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin) <= s->scratch_floats;
+}
+static bool dw_fused_train_fwd(const ams_student* s, int i, int B) {
+    return s->fuse_dgrad_bn >= 2 && dw_fused_train(s, i, B) &&
+           depthwise_fwd_bn_scratch(B, s->L[i].Hin, s->L[i].Win, s->L[i].d.cin, s->L[i].d.rate) <= s->scratch_floats;
+}
+
 // most partial rows a GEMM with a fused column reduction can leave behind (PwArgs::red_mode): one per block of the persistent streaming
 // kernel (<= 8 per CU), one per 64-row strip of the tiled split kernel
 static size_t red_rows_bound(int64_t M) { return M >= 32768 ? 2048 : (size_t)(M / 64 + 8); }
 
 // pre_rows > 0: the kernel that wrote l.z already left the statistics' partial rows [pre_rows][2][C] in s->scratch
 static int bn_train(ams_student* s, LayerRt& l, int64_t M_local, double n_global, bool update_ema, const SyncCtx* sc,
-                    const float* res, hipStream_t st, int pre_rows = 0) {
+                    const float* res, hipStream_t st, int pre_rows = 0, bool act_pass = true) {
     const ams_student_config& c = s->cfg;
     const float* center = s->stats + l.d.mean_off;       // shifted sums: moving_mean is a good, rank-identical centre
     const float omd = 1.0f - c.bn_decay;
@@ -860,6 +881,7 @@ static int bn_train(ams_student* s, LayerRt& l, int64_t M_local, double n_global
         RUN(launch_bn_finalize(l.fsums, n_global, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
                                mm, mv, l.scale, l.shift, l.mean, l.rstd, st));
     }
+    if (!act_pass) return AMS_OK;              // the consumer applies scale / shift / activation on its own loads of z
     RUNK(0, 4.0 * M_local * l.d.cout * (res ? 3 : 2), launch_bn_act(l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, res, l.a, st));
     return AMS_OK;
 }
@@ -919,7 +941,12 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
             continue;
         }
         int pre_rows = 0;
-        if (l.d.role == AMS_ROLE_DEPTHWISE) {
+        if (l.d.role == AMS_ROLE_DEPTHWISE && dw_fused_train_fwd(s, i, B)) {
+            // BN + activation of the expand layer on the tap loads (its `a` was not written), the statistics of the result on the way out
+            const LayerRt& le = s->L[i - 1];
+            RUNK(i, dw_bytes(l, B), launch_depthwise_fwd_bn(le.z, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, le.scale, le.shift, le.d.act,
+                                                            s->stats + l.d.mean_off, l.z, s->scratch, &pre_rows, st));
+        } else if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, nullptr, nullptr,
                                                      AMS_ACT_NONE, l.z, st));
         } else {
@@ -931,7 +958,8 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
             RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         }
         const float* res = l.d.residual_from ? s->L[l.d.residual_from].a : nullptr;
-        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st, pre_rows));
+        const bool act_pass = !(l.d.role == AMS_ROLE_EXPAND && dw_fused_train_fwd(s, i + 1, B));
+        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st, pre_rows, act_pass));
     }
     LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];
     const float* feat = s->L[s->n_backbone].a;
@@ -1191,9 +1219,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             break;
         }
         LayerRt& prev = s->L[i - 1];
-        const bool fuse_here = l.d.role == AMS_ROLE_DEPTHWISE && s->fuse_dgrad_bn && l.d.stride == 1 && prev.d.role == AMS_ROLE_EXPAND &&
-                               prev.d.cout == l.d.cin && depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin) <= s->scratch_floats && l.d.cin <= 1024;
-        if (fuse_here) {
+        if (dw_fused_train(s, i, B)) {
             // input gradient + activation derivative + BN-backward sums of the expand layer + this layer's weight gradient in one kernel
             // (k_conv.hip): prev.da <- dy, partial rows in s->scratch until the next iteration's second stage
             RUNK(i, dw_bytes(l, B) + 4.0 * B * l.px_in * l.d.cin,
@@ -1696,7 +1722,7 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_DGRAD_BN) {
-        s->fuse_dgrad_bn = value != 0;
+        s->fuse_dgrad_bn = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_GEMM_RED) {

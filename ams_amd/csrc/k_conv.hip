@@ -548,11 +548,12 @@ template <int R>
 __global__ __launch_bounds__(256) void dw3x3_dgrad_bn_kernel(const float* __restrict__ dy, const float* __restrict__ wgt, const float* __restrict__ z,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             float* __restrict__ out, float* __restrict__ part, DwGeom g) {
+                                                             float* __restrict__ out, float* __restrict__ part, DwGeom g, int bands,
+                                                             int tiles_per_band) {
     constexpr int TH = 4, RS = R == 2 ? 2 : 1, NR = RS == 2 ? TH + 2 : TH + 2 * R;
     constexpr int NQ = 8 + 36;                                         // s1, s2, nine taps: 4 channels each
     __shared__ float s_acc[256][NQ + 1];
-    const int tx = blockIdx.x % g.tiles_x, b = blockIdx.x / g.tiles_x;
+    const int tx = blockIdx.x % g.tiles_x, band = (blockIdx.x / g.tiles_x) % bands, b = blockIdx.x / (g.tiles_x * bands);
     const int flat = tx * 256 + threadIdx.x;
     const int ox = flat / g.CG, cg = flat - ox * g.CG;
     const bool live = ox < g.Wo;
@@ -578,7 +579,8 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_bn_kernel(const float* __rest
         for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + (8 - k) * g.C + c0);            // the conv with the flipped kernel
         const float4 sc = ld4(scale + c0), sh = ld4(shift + c0), mu = ld4(mean + c0), rs = ld4(rstd + c0);
         const float lo = act == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = act == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
-        for (int ty = 0; ty < g.tiles_y; ++ty) {
+        const int ty_end = (band + 1) * tiles_per_band < g.tiles_y ? (band + 1) * tiles_per_band : g.tiles_y;
+        for (int ty = band * tiles_per_band; ty < ty_end; ++ty) {
             const int oy0 = (ty / RS) * (TH * RS) + (ty % RS);
             const int iy0 = oy0 - g.pt;
             float4 in[NR][3];
@@ -650,7 +652,30 @@ __global__ __launch_bounds__(256) void dw3x3_dgrad_bn_kernel(const float* __rest
     }
 }
 
-size_t depthwise_dgrad_bn_scratch(int B, int H, int W, int C) { return (size_t)B * cdiv((int64_t)W * (C / 4), 256) * 11 * C; }
+// A strip per image is too few blocks on the narrow layers: the walk down an image is split into bands of row tiles until the launch has
+// ~`target` blocks (one partial row per block either way).
+static void dw_walk_plan(int B, int H, int W, int C, int rate, int target, DwGeom* f, int* bands, int* tpb) {
+    dw_geom(B, H, W, C, 1, rate, false, f);
+    f->tiles_y = rate == 2 ? 2 * cdiv(f->Ho, 8) : cdiv(f->Ho, 4);
+    f->tiles_x = cdiv((int64_t)f->Wo * f->CG, 256);
+    int nb = cdiv(target, f->tiles_x * B);
+    nb = nb < 1 ? 1 : (nb > f->tiles_y ? f->tiles_y : nb);
+    *tpb = cdiv(f->tiles_y, nb);
+    *bands = cdiv(f->tiles_y, *tpb);
+}
+// backward kernel: bands measured no faster at 8 frames of 512x1024 (400 blocks: 9.13 ms a step, 768: 9.21, one strip per image: 9.11 —
+// every extra partial row is eleven vectors for the second stage and the tap reduction), so it keeps one strip per image
+constexpr int kDgradBnBlocks = 1;
+
+size_t depthwise_dgrad_bn_scratch(int B, int H, int W, int C) {
+    if (C % 4 != 0 || C / 4 > 256) return (size_t)-1;
+    DwGeom f; int bands, tpb;
+    // (the rate does not change the count: tiles_y only caps the bands, and both rates have >= 8 row tiles wherever bands are wanted)
+    dw_walk_plan(B, H, W, C, 1, kDgradBnBlocks, &f, &bands, &tpb);
+    DwGeom f2; int bands2, tpb2;
+    dw_walk_plan(B, H, W, C, 2, kDgradBnBlocks, &f2, &bands2, &tpb2);
+    return (size_t)B * f.tiles_x * (bands > bands2 ? bands : bands2) * 11 * C;
+}
 
 // dx_masked [B,H,W,C] = dwconv^T(dy, w) . act'(z sc + sh) (stride 1, rate 1|2; the conv keeps the size), partial rows [rows][11][C] of
 // (sum dx_masked, sum dx_masked xhat, the nine taps of the depthwise weight gradient sum act(z sc + sh) . dy) in scratch
@@ -661,16 +686,131 @@ int launch_depthwise_dgrad_bn(const float* dy, int B, int H, int W, int C, const
     int rc = dw_geom(B, H, W, C, 1, rate, false, &f);
     if (rc) return rc;
     AMS_REQUIRE(C / 4 >= 1, "depthwise_dgrad_bn: C=%d", C);
-    f.tiles_y = rate == 2 ? 2 * cdiv(f.Ho, 8) : cdiv(f.Ho, 4);
-    f.tiles_x = cdiv((int64_t)f.Wo * f.CG, 256);
-    const unsigned nb = (unsigned)f.tiles_x * B;
+    int bands, tpb;
+    dw_walk_plan(B, H, W, C, rate, kDgradBnBlocks, &f, &bands, &tpb);
+    const unsigned nb = (unsigned)f.tiles_x * bands * B;
     *rows_out = (int)nb;
     // a block whose 256 flat indices wrap around the channel groups more than once covers every group: rows are complete; otherwise the
     // groups it does not touch must read as zero
     AMS_REQUIRE(f.CG <= 256, "depthwise_dgrad_bn: C=%d exceeds 1024", C);
     note_kernel(rate == 2 ? "dw3x3_dgrad_bn_kernel<2>" : "dw3x3_dgrad_bn_kernel<1>");
-    if (rate == 1) hipLaunchKernelGGL((dw3x3_dgrad_bn_kernel<1>), dim3(nb), dim3(256), 0, st, dy, w, z, scale, shift, act, mean, rstd, out, scratch, f);
-    else hipLaunchKernelGGL((dw3x3_dgrad_bn_kernel<2>), dim3(nb), dim3(256), 0, st, dy, w, z, scale, shift, act, mean, rstd, out, scratch, f);
+    if (rate == 1) hipLaunchKernelGGL((dw3x3_dgrad_bn_kernel<1>), dim3(nb), dim3(256), 0, st, dy, w, z, scale, shift, act, mean, rstd, out, scratch, f, bands, tpb);
+    else hipLaunchKernelGGL((dw3x3_dgrad_bn_kernel<2>), dim3(nb), dim3(256), 0, st, dy, w, z, scale, shift, act, mean, rstd, out, scratch, f, bands, tpb);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// Training forward of a stride-1 depthwise layer in a block that keeps its tensors, three passes in one: the taps are read from the
+// expand layer's RAW output z_e with its BN + activation applied on the load (a_e = act(z_e sc + sh) is never written: the backward
+// kernel above recomputes it the same way), the depthwise result z_d is written, and the BN statistics of z_d — shifted sums about
+// `center` — are accumulated on the way.  Same walk as the backward kernel: a block owns one column strip of one image and a band of
+// its row tiles, sums in registers, threads that share a channel group folded in a fixed order: one partial row [2][C] per block.
+template <int R>
+__global__ __launch_bounds__(256) void dw3x3_fwd_bn_kernel(const float* __restrict__ ze, const float* __restrict__ wgt, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int act, const float* __restrict__ center,
+                                                           float* __restrict__ zd, float* __restrict__ part, DwGeom g, int bands, int tiles_per_band) {
+    constexpr int TH = 4, RS = R == 2 ? 2 : 1, NR = RS == 2 ? TH + 2 : TH + 2 * R;
+    constexpr int NQ = 8;
+    __shared__ float s_acc[256][NQ + 1];
+    const int tx = blockIdx.x % g.tiles_x, band = (blockIdx.x / g.tiles_x) % bands, b = blockIdx.x / (g.tiles_x * bands);
+    const int flat = tx * 256 + threadIdx.x;
+    const int ox = flat / g.CG, cg = flat - ox * g.CG;
+    const bool live = ox < g.Wo;
+    const int c0 = cg * 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = zero4, s2 = zero4;
+    if (live) {
+        const float* xb = ze + (int64_t)b * g.H * g.W * g.C + c0;
+        float* yb = zd + (int64_t)b * g.Ho * g.Wo * g.C + c0;
+        int ixc[3];
+        bool okx[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int ix = ox - g.pl + j * R;
+            okx[j] = ix >= 0 && ix < g.W;
+            ixc[j] = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
+        }
+        float4 wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = ld4(wgt + k * g.C + c0);
+        const float4 sc = ld4(scale + c0), sh = ld4(shift + c0), ctr = center ? ld4(center + c0) : zero4;
+        const float lo = act == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = act == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+        const int ty_end = (band + 1) * tiles_per_band < g.tiles_y ? (band + 1) * tiles_per_band : g.tiles_y;
+        for (int ty = band * tiles_per_band; ty < ty_end; ++ty) {
+            const int oy0 = (ty / RS) * (TH * RS) + (ty % RS);
+            const int iy0 = oy0 - g.pt;
+            float4 in[NR][3];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const int iy = iy0 + rr * (RS == 2 ? R : 1);
+                const bool oky = iy >= 0 && iy < g.H;
+                const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+                const float* rp = xb + (int64_t)iyc * g.W * g.C;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float4 y = muladd4_pk(ld4(rp + (int64_t)ixc[j] * g.C), sc, sh);
+                    const bool ok = oky && okx[j];                    // SAME padding pads the ACTIVATION with zeros
+                    in[rr][j] = make_float4(ok ? __builtin_amdgcn_fmed3f(y.x, lo, hi) : 0.f, ok ? __builtin_amdgcn_fmed3f(y.y, lo, hi) : 0.f,
+                                            ok ? __builtin_amdgcn_fmed3f(y.z, lo, hi) : 0.f, ok ? __builtin_amdgcn_fmed3f(y.w, lo, hi) : 0.f);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < TH; ++r) {
+                const int oy = oy0 + r * RS;
+                if (oy >= g.Ho) break;
+                float4 acc = zero4;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float4 v = in[RS == 2 ? r + i : r + i * R][j];
+                        const float4 w4 = wv[i * 3 + j];
+                        acc.x = fmaf(v.x, w4.x, acc.x); acc.y = fmaf(v.y, w4.y, acc.y);
+                        acc.z = fmaf(v.z, w4.z, acc.z); acc.w = fmaf(v.w, w4.w, acc.w);
+                    }
+                st4(yb + ((int64_t)oy * g.Wo + ox) * g.C, acc);
+                const float4 d = sub4_pk(acc, ctr);
+                s1 = add4_pk(s1, d);
+                s2 = add4_pk(s2, mul4_pk(d, d));
+            }
+        }
+    }
+    float* sa = s_acc[threadIdx.x];
+    sa[0] = s1.x; sa[1] = s1.y; sa[2] = s1.z; sa[3] = s1.w; sa[4] = s2.x; sa[5] = s2.y; sa[6] = s2.z; sa[7] = s2.w;
+    sa[NQ] = live ? 1.f : -1.f;
+    __syncthreads();
+    const int cg_first = (tx * 256) % g.CG;
+    const int ngroups = g.CG < 256 ? g.CG : 256;
+    float* row = part + (int64_t)blockIdx.x * 2 * g.C;                  // [sum (z - center) | sum (z - center)^2][C]
+    for (int e = threadIdx.x; e < ngroups * NQ; e += 256) {
+        const int gi = e / NQ, qn = e - gi * NQ;
+        const int cgw = (cg_first + gi) % g.CG;
+        float s = 0.f;
+        for (int t = gi; t < 256; t += g.CG)                            // threads t with (tx * 256 + t) % CG == cgw, ascending
+            if (s_acc[t][NQ] >= 0.f) s += s_acc[t][qn];
+        row[(qn >> 2) * g.C + cgw * 4 + (qn & 3)] = s;
+    }
+}
+
+size_t depthwise_fwd_bn_scratch(int B, int H, int W, int C, int rate) {
+    DwGeom f; int bands, tpb;
+    if (C % 4 != 0 || C / 4 > 256) return (size_t)-1;
+    dw_walk_plan(B, H, W, C, rate, 1024, &f, &bands, &tpb);
+    return (size_t)f.tiles_x * bands * B * 2 * C;
+}
+
+// zd [B,H,W,C] = dwconv(act(ze scale + shift), w) (stride 1, rate 1|2), partial rows [rows][2][C] of (sum (zd - center), sum (zd - center)^2)
+int launch_depthwise_fwd_bn(const float* ze, int B, int H, int W, int C, const float* w, int rate, const float* scale, const float* shift, int act,
+                            const float* center, float* zd, float* scratch, int* rows_out, hipStream_t st) {
+    DwGeom f;
+    int bands, tpb;
+    AMS_REQUIRE(C % 4 == 0 && C / 4 <= 256 && (rate == 1 || rate == 2), "depthwise_fwd_bn: C=%d rate=%d", C, rate);
+    dw_walk_plan(B, H, W, C, rate, 1024, &f, &bands, &tpb);
+    const unsigned nb = (unsigned)f.tiles_x * bands * B;
+    *rows_out = (int)nb;
+    note_kernel(rate == 2 ? "dw3x3_fwd_bn_kernel<2>" : "dw3x3_fwd_bn_kernel<1>");
+    if (rate == 1) hipLaunchKernelGGL((dw3x3_fwd_bn_kernel<1>), dim3(nb), dim3(256), 0, st, ze, w, scale, shift, act, center, zd, scratch, f, bands, tpb);
+    else hipLaunchKernelGGL((dw3x3_fwd_bn_kernel<2>), dim3(nb), dim3(256), 0, st, ze, w, scale, shift, act, center, zd, scratch, f, bands, tpb);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

@@ -122,6 +122,10 @@ int launch_depthwise(const float* x, int B, int H, int W, int C, const float* w,
 int launch_depthwise_dgrad(const float* dy, int B, int H, int W, int C, const float* w, int stride, int rate,
                            float* dx, hipStream_t st);
 // stride-1 input gradient fused with the mask and the BN-backward sums of the layer in front (see k_conv.hip); C <= 1024
+// training forward of the same layers: BN + activation of the layer in front on the tap loads, BN statistics of the result as partial rows
+size_t depthwise_fwd_bn_scratch(int B, int H, int W, int C, int rate);
+int launch_depthwise_fwd_bn(const float* ze, int B, int H, int W, int C, const float* w, int rate, const float* scale, const float* shift, int act,
+                            const float* center, float* zd, float* scratch, int* rows_out, hipStream_t st);
 size_t depthwise_dgrad_bn_scratch(int B, int H, int W, int C);
 int launch_depthwise_dgrad_bn(const float* dy, int B, int H, int W, int C, const float* w, int rate, const float* z, const float* scale,
                               const float* shift, int act, const float* mean, const float* rstd, float* out, float* scratch, int* rows_out,

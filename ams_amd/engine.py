@@ -215,7 +215,7 @@ class StudentEngine:
         if fuse_gemm_red is not None:
             hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_GEMM_RED, int(fuse_gemm_red)), "ams_student_set_option")
         if fuse_dgrad_bn is not None:
-            hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DGRAD_BN, int(bool(fuse_dgrad_bn))), "ams_student_set_option")
+            hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DGRAD_BN, 2 if fuse_dgrad_bn is True else int(fuse_dgrad_bn)), "ams_student_set_option")
 
     def set_fuse_first_block(self, on: int) -> None:
         """Frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel with a tile per block

@@ -209,9 +209,11 @@ enum { AMS_OPT_DUAL_AUTOTUNE = 12 /* with AMS_OPT_DUAL_STREAM = 1: 1 = pick the 
                                             the block inputs of the output-stride-16 section to bf16 after they are written — the values bf16
                                             STORAGE of those tensors would hold; the arithmetic and every other tensor stay f32.  Costs a pass per
                                             tensor: an accuracy probe, not a fast path */,
-       AMS_OPT_FUSE_DGRAD_BN = 16 /* fine-tune step, stride-1 blocks that keep their tensors (blocks 7-16): 1 (default) the depthwise input gradient,
+       AMS_OPT_FUSE_DGRAD_BN = 16 /* fine-tune step, stride-1 blocks that keep their tensors (blocks 7-16): >= 1 the depthwise input gradient,
                                      the expand layer's activation derivative and BN-backward sums, and the depthwise weight gradient come out of
-                                     ONE kernel (k_conv.hip: dw3x3_dgrad_bn_kernel); 0 four separate passes.  Same mathematics, f32-level differences */,
+                                     ONE kernel (k_conv.hip: dw3x3_dgrad_bn_kernel); 2 (default) the forward too: the depthwise conv applies the
+                                     expand layer's BN + activation on its tap loads and leaves the statistics of its result (dw3x3_fwd_bn_kernel) —
+                                     the expand activation is never written; 0 separate passes.  Same mathematics, f32-level differences */,
        AMS_OPT_FUSE_GEMM_RED = 17 /* fine-tune step, BN column reductions in the epilogue of the 1x1 GEMM that holds the values in registers
                                      (pw_common.hpp pw_red_*): bit 0 the forward statistics of the GEMM's own result, bit 1 the BN-backward sums of the
                                      layer whose output gradient the dgrad GEMM produces.  Default 2; 0 = separate reduction passes.  Same mathematics,

@@ -110,8 +110,7 @@ struct ams_student {
     float* ce_scratch = nullptr;       // unnormalised CE gradient planes of the one-pass loss kernel (k_head.hip)
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
     int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
-    int fuse_gemm_red = 2;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics (off: -0.05 ms, and the
-                                       // f32 noise of the 64x128 oracle test doubles), bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
+    int fuse_gemm_red = 3;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics, bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
     int fuse_dgrad_bn = 2;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
@@ -328,7 +327,7 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
             const int64_t M = (int64_t)B * l.px_out;
             if (l.d.role == AMS_ROLE_DEPTHWISE) {
                 need = depthwise_wgrad_scratch(B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate);
-                if (l.d.stride == 1 && i >= 3 && l.d.cin >= 64 && l.d.cin <= 1024) {       // the one-kernel forms of the blocks that keep their tensors
+                if (l.d.stride == 1 && l.d.cin <= 1024) {       // the one-kernel forms of the blocks that keep their tensors
                     const size_t n1 = depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin), n2 = depthwise_fwd_bn_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate);
                     if (n1 > need) need = n1;
                     if (n2 > need) need = n2;
@@ -842,9 +841,17 @@ static bool dw_fused_train(const ams_student* s, int i, int B) {
     return l.d.role == AMS_ROLE_DEPTHWISE && l.d.stride == 1 && prev.d.role == AMS_ROLE_EXPAND && prev.d.cout == l.d.cin && l.d.cin <= 1024 &&
            depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin) <= s->scratch_floats;
 }
+// First block: the stem is the "expand" layer of depthwise layer 2, and the backward of the pair is one pass over dz and the frames that
+// never reads the stem's activation either (backward(), launch_xdw_bwd_reduce_stem).
+static bool stem_fused_train(const ams_student* s) {
+    const ams_student_config& c = s->cfg;
+    return s->n_backbone >= 2 && s->train_recompute && s->L[1].d.role == AMS_ROLE_STEM && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE &&
+           s->L[2].d.stride == 1 && s->L[2].d.rate == 1 && s->xt_scratch && xdw_stem_scratch(c.max_batch, c.height, c.width) <= s->xt_floats;
+}
 static bool dw_fused_train_fwd(const ams_student* s, int i, int B) {
-    return s->fuse_dgrad_bn >= 2 && dw_fused_train(s, i, B) &&
-           depthwise_fwd_bn_scratch(B, s->L[i].Hin, s->L[i].Win, s->L[i].d.cin, s->L[i].d.rate) <= s->scratch_floats;
+    if (s->fuse_dgrad_bn < 2 || i < 2 || i > s->n_backbone) return false;
+    if (!(i == 2 ? stem_fused_train(s) : dw_fused_train(s, i, B))) return false;
+    return depthwise_fwd_bn_scratch(B, s->L[i].Hin, s->L[i].Win, s->L[i].d.cin, s->L[i].d.rate) <= s->scratch_floats;
 }
 
 // most partial rows a GEMM with a fused column reduction can leave behind (PwArgs::red_mode): one per block of the persistent streaming
@@ -901,7 +908,7 @@ static int forward_live(ams_student* s, const void* frames, int dtype, int B, in
         LayerRt& l = s->L[1];
         RUN(launch_stem(frames, dtype, B, c.height, c.width, P + l.d.w_off, l.d.cout, nullptr, nullptr, AMS_ACT_NONE,
                         c.pixel_scale, l.z, st));
-        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, nullptr, st));
+        RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, nullptr, st, 0, !dw_fused_train_fwd(s, 2, B)));
     }
     for (int i = 2; i <= s->n_backbone; ++i) {
         LayerRt& l = s->L[i];
@@ -1185,8 +1192,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             --i;                                       // the expand layer is done
             continue;
         }
-        if (l.d.role == AMS_ROLE_DEPTHWISE && i == 2 && s->train_recompute && s->L[1].d.role == AMS_ROLE_STEM && s->L[1].d.cout == 32 &&
-            l.d.stride == 1 && l.d.rate == 1 && s->xt_scratch && xdw_stem_scratch(s->cfg.max_batch, c.height, c.width) <= s->xt_floats) {
+        if (i == 2 && stem_fused_train(s)) {
             // first block: the stem is the "expand" layer of this depthwise conv (a 1x1 conv over the 27-tap patch of the frame).  One pass
             // over dz and the frames gives the stem's BN-backward sums, the depthwise weight gradient and the pieces of the stem weight
             // gradient; da / dz of the stem, its im2col matrix and a_stem are never read or written in backward

@@ -216,7 +216,7 @@ enum { AMS_OPT_DUAL_AUTOTUNE = 12 /* with AMS_OPT_DUAL_STREAM = 1: 1 = pick the 
                                      the expand activation is never written; 0 separate passes.  Same mathematics, f32-level differences */,
        AMS_OPT_FUSE_GEMM_RED = 17 /* fine-tune step, BN column reductions in the epilogue of the 1x1 GEMM that holds the values in registers
                                      (pw_common.hpp pw_red_*): bit 0 the forward statistics of the GEMM's own result, bit 1 the BN-backward sums of the
-                                     layer whose output gradient the dgrad GEMM produces.  Default 2; 0 = separate reduction passes.  Same mathematics,
+                                     layer whose output gradient the dgrad GEMM produces.  Default 3; 0 = separate reduction passes.  Same mathematics,
                                      f32-level differences (partial sums per row strip instead of per column chunk) */,
        AMS_OPT_TRAIN_RECOMPUTE = 11 /* fine-tune step: 1 (default) the early blocks (block input <= 32 channels) run without their 6x-expanded
                                        tensors — every consumer recomputes z_e = x . W_e from the block input (k_xdw_train.hip); 0 the

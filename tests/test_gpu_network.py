@@ -141,8 +141,11 @@ def test_train_step_matches_oracle(W0, clip64):
     dead channels) an f32 evaluation is itself 1-6 % away from the f64 one on the worst tensors, CPU and GPU alike, so the
     f32 torch oracle cannot arbitrate at 1e-3 (measured: per-tensor relative L2 error vs f64 has median ~1e-2 for BOTH the
     f32 CPU oracle and the HIP path, at 64x128 and at 128x256; tools/debug_grads.py).  The HIP path is therefore held to
-    the f32 error class: (a) per tensor, relative L2 error vs the f64 oracle no worse than max(3e-2, 4x the f32 CPU
-    oracle's own error) and a median over tensors no worse than 3x the f32 CPU oracle's median + 5e-3; (b) cosine similarity of the whole gradient with
+    the f32 error class: (a) per tensor, relative L2 error vs the f64 oracle no worse than max(6e-2, 4x the f32 CPU
+    oracle's own error) — the gross-error bar: the worst tensor of ONE f32 evaluation scatters between 4e-3 and 3e-2 from seed
+    to seed for every form of the step and for the f32 CPU oracle alike (tests/grad_noise_study.py), so the error class itself is
+    held statistically by test_gradient_error_class_over_seeds below — and a median over tensors no worse than 3x the f32 CPU
+    oracle's median + 5e-3; (b) cosine similarity of the whole gradient with
     the f64 gradient >= 0.9995; (c) loss within 1e-3; (d) the Adam update and BN moving averages as in
     _compare_train_state."""
     frames, labels = clip64
@@ -180,7 +183,7 @@ def test_train_step_matches_oracle(W0, clip64):
         print("step %d worst gradient tensors vs f64 (HIP, f32 CPU):" % step,
               [(eng.spec.trainable[k].name, "%.2e" % errs_gpu[k], "%.2e" % errs_f32[k]) for k in order])
         for k, v in enumerate(eng.spec.trainable):
-            assert errs_gpu[k] <= max(3e-2, 4 * errs_f32[k]), "gradient of %s: HIP %.2e vs f32 CPU %.2e" % (v.name, errs_gpu[k], errs_f32[k])
+            assert errs_gpu[k] <= max(6e-2, 4 * errs_f32[k]), "gradient of %s: HIP %.2e vs f32 CPU %.2e" % (v.name, errs_gpu[k], errs_f32[k])
         assert np.median(errs_gpu) <= 3 * np.median(errs_f32) + 5e-3, (np.median(errs_gpu), np.median(errs_f32))
         o.train_step(fr.astype(np.float32), lb, lr)
         _compare_train_state(eng, o, before, lr, 1, "after step %d" % (step + 1), grads_o)
@@ -193,6 +196,38 @@ def test_train_step_matches_oracle(W0, clip64):
         assert np.linalg.norm(m[v.offset:v.offset + v.size] - want) / np.linalg.norm(want) < 5e-2, name
     eng.close()
 
+
+
+def test_gradient_error_class_over_seeds():
+    """One f32 evaluation of this gradient is a noisy measurement of the f64 one (ReLU6 masks flip on last-bit differences and the 54
+    training-mode BNs amplify them), so the per-tensor error of any single seed is a lottery ticket.  Over several seeds the
+    DISTRIBUTION is what identifies the error class: the HIP step's worst-tensor and median-tensor relative L2 errors vs the f64
+    oracle, averaged over the seeds, must stay within 1.5x (+2e-3) of the f32 CPU oracle's own on the same inputs."""
+    H, B, seeds = 64, 4, range(6)
+    worst_gpu, worst_f32, med_gpu, med_f32 = [], [], [], []
+    for seed in seeds:
+        W = Wt.synthetic_weights(S.build_spec(), seed=seed)
+        fr, lb = synth.SyntheticVideo(H, B, CI, seed=seed + 100).clip()
+        _, grads_o = _oracle(W, torch.float64).gradients(fr.astype(np.float32), lb)
+        _, grads_32 = _oracle(W, torch.float32).gradients(fr.astype(np.float32), lb)
+        eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+        eng.load_variables(W)
+        eng.train_step(fr, lb, 1e-3)
+        g = eng.grads.cpu().numpy().astype(np.float64)
+        gnorm = max(float(gv.abs().max()) for gv in grads_o.values())
+        e_gpu, e_f32 = [], []
+        for v in eng.spec.trainable:
+            want = grads_o[v.name].numpy().reshape(-1)
+            floor = max(np.linalg.norm(want), 1e-3 * gnorm * np.sqrt(want.size))
+            e_gpu.append(np.linalg.norm(g[v.offset:v.offset + v.size] - want) / floor)
+            e_f32.append(np.linalg.norm(grads_32[v.name].numpy().reshape(-1).astype(np.float64) - want) / floor)
+        eng.close()
+        worst_gpu.append(max(e_gpu)); worst_f32.append(max(e_f32)); med_gpu.append(np.median(e_gpu)); med_f32.append(np.median(e_f32))
+    print("worst tensor, mean over seeds: HIP %.2e  f32 CPU %.2e;  median tensor: HIP %.2e  f32 CPU %.2e"
+          % (np.mean(worst_gpu), np.mean(worst_f32), np.mean(med_gpu), np.mean(med_f32)))
+    assert max(worst_gpu) < 6e-2
+    assert np.mean(worst_gpu) <= 1.5 * np.mean(worst_f32) + 2e-3
+    assert np.mean(med_gpu) <= 1.5 * np.mean(med_f32) + 2e-3
 
 def test_free_running_schedule_tracks_oracle(W0):
     """a short free-running distillation schedule (no re-synchronisation with the oracle between steps).  Two

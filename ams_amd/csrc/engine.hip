@@ -1263,7 +1263,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             // first half of the previous layer's BN backward in this GEMM's epilogue (activation derivative + the two column sums), where
             // the kernel chosen can do it: the separate pass over (da, z) of that layer disappears
             int red_rows = 0;
-            if ((s->fuse_gemm_red & 2) && !a.res && i - 1 >= 2 && red_rows_bound(Mo) * 2 * (size_t)l.d.cin <= s->scratch_floats) {
+            if ((s->fuse_gemm_red & 2) && i - 1 >= 2 && red_rows_bound(Mo) * 2 * (size_t)l.d.cin <= s->scratch_floats) {
                 a.red_mode = 2; a.red_z = prev.z; a.red_scale = prev.scale; a.red_shift = prev.shift; a.red_mean = prev.mean; a.red_rstd = prev.rstd;
                 a.red_act = prev.d.act; a.red_part = s->scratch; a.red_rows_out = &red_rows;
             }

@@ -337,6 +337,13 @@ static int launch_pw_x3_e(const PwArgs& a, const SplitPanels& w, int Kp, hipStre
 
 template <int RM, int NT>
 static int launch_pw_x3(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
+    if (a.red_mode == 2 && a.res && !a.img_bias && (a.ldr & 3) == 0) {
+        // dgrad GEMM whose result also takes the residual branch's gradient: the fused reduction adds it (acc + res, what EPI_RES
+        // computes) ahead of the mask and the sums, and the plain epilogue stores the total
+        PwArgs b = a;
+        b.red_res = a.res; b.red_ldr = a.ldr; b.res = nullptr;
+        if (pw_red_ok(b)) return launch_pw_x3_e<RM, NT, EPI_PLAIN>(b, w, Kp, st);
+    }
     switch (pw_pick_epi(a)) {
         case EPI_PLAIN: return launch_pw_x3_e<RM, NT, EPI_PLAIN>(a, w, Kp, st);
         case EPI_RES: return launch_pw_x3_e<RM, NT, EPI_RES>(a, w, Kp, st);

@@ -52,7 +52,8 @@ struct PwArgs {
     uint16_t* ysplit;
     int64_t ysplit_plane;
     int ysplit_np;
-    // optional column reduction fused into the epilogue (fine-tune step; plain epilogues only: no scale / shift / bias / residual):
+    // optional column reduction fused into the epilogue (fine-tune step; plain epilogues only: no scale / shift / bias; a residual
+    // operand only in mode 2 of the tiled split-bf16 kernel, where it joins the product before the mask and the sums):
     //   red_mode 1  forward BN statistics of y:  sum(y - red_center), sum((y - red_center)^2)
     //   red_mode 2  y is the gradient wrt the ACTIVATED output of a BN layer whose raw output is red_z [M, ldy]: y is multiplied by the
     //               activation's derivative act'(red_z red_scale + red_shift) before it is stored, and sum(y), sum(y xhat) are formed
@@ -65,6 +66,8 @@ struct PwArgs {
     int red_act;
     float* red_part;
     int* red_rows_out;
+    // set by the split-bf16 launcher only (mode 2 with a residual operand: the residual moves here and the plain epilogue runs)
+    const float* red_res; int red_ldr;
 };
 int launch_pointwise(const PwArgs& a, hipStream_t st);
 bool pointwise_stream_applies(const PwArgs& a);     // the persistent streaming variant (small K x N) can take this problem

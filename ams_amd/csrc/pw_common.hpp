@@ -211,6 +211,15 @@ __device__ __forceinline__ void pw_red_rowgroups(const PwArgs& a, f32x4 (&acc)[R
                 if (n4 > a.N - 4) n4 = a.N - 4;
                 zv[t] = ld4(a.red_z + m * a.ldy + n4);
             }
+            if (a.red_res) {                               // the residual branch's gradient joins before the mask and the sums (acc + res, as EPI_RES adds it)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    int n4 = n0 + 16 * t + 4 * q;
+                    if (n4 > a.N - 4) n4 = a.N - 4;
+                    const float4 rv = ld4(a.red_res + m * a.red_ldr + n4);
+                    acc[r][t][0] += rv.x; acc[r][t][1] += rv.y; acc[r][t][2] += rv.z; acc[r][t][3] += rv.w;
+                }
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int c4 = 16 * t + 4 * q;

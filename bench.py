@@ -531,6 +531,16 @@ def main():
                    "roofline": {"bound": "hbm", "alg_bytes_per_step": round(step_bytes), "achieved": round(step_bytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round(step_bytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                                 "note": "SURVEY 8 d4: 3 x B x layer-wise f32 inference bytes + optimizer (7 x 4 B x params) + BN moving averages, per GPU"}}
+        # HBM bytes of one step from the committed counter passes (tools/profile_r03.sh `pmc`; valid for 8 frames of 512x1024 on one GPU)
+        tfile = sorted(f for f in os.listdir(ROOT / "profiles") if f.endswith("_train_pmc_traffic.json"))
+        if tfile and TB == 8 and H == 512 and dist is None:
+            tj = json.load(open(ROOT / "profiles" / tfile[-1]))
+            distill["roofline"]["traffic"] = round(tj["total_GB_per_step"] * 1e9)
+            distill["roofline"]["traffic_detail"] = {"source": "profiles/" + tfile[-1], "fetch_bytes": round(tj["fetch_GB_per_step"] * 1e9),
+                                                     "write_bytes": round(tj["write_GB_per_step"] * 1e9), "fetch_correction": 2.0,
+                                                     "hbm_GBps_at_this_step_time": round(tj["total_GB_per_step"] * 1e3 / ms, 1)}
+        else:
+            distill["roofline"]["traffic"] = None
         if sync is not None and hasattr(sync, "stats"):
             calls, nbytes = sync.stats()
             distill["collectives_per_step"] = round(calls / (n_train + 2), 1)

@@ -128,6 +128,7 @@ struct ams_student {
     float* scratch2 = nullptr;
     float* scratch3 = nullptr;       // depthwise weight gradients on their own stream (side2), AMS_OVERLAP_WGRAD=2
     hipStream_t side2 = nullptr;
+    hipEvent_t ev_dw = nullptr;      // the side stream's reduction of the depthwise taps has left the rows buffer (scratch3)
     hipEvent_t ev_xt = nullptr;      // the weight-gradient reductions of a recompute block (side stream) have left xt_scratch
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_head = nullptr;
@@ -155,6 +156,7 @@ struct ams_student {
         if (side) (void)hipStreamDestroy(side);
         if (side2) (void)hipStreamDestroy(side2);
         if (ev_xt) (void)hipEventDestroy(ev_xt);
+        if (ev_dw) (void)hipEventDestroy(ev_dw);
     }
     float* scratch = nullptr; size_t scratch_floats = 0;
     float* tmp_c = nullptr;          // [1024] small per-channel temp
@@ -1111,6 +1113,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         for (auto& e : s->ev_wg) AMS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_xt, hipEventDisableTiming));
+        AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_dw, hipEventDisableTiming));
     }
     const bool three = overlap && s->overlap_wgrad >= 2 && s->scratch3;      // depthwise weight gradients on a third stream
     if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
@@ -1121,6 +1124,11 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     int fused_rows = 0;
     int64_t fused_stride = 0;
     bool fused_dw = false;
+    // where those rows are: the depthwise kernel's rows go to their own buffer when the side stream is there to reduce the nine taps
+    // (they only feed the optimizer), so that the main stream's next user of s->scratch need not wait for that
+    float* fused_buf = s->scratch;
+    float* const dw_rows = overlap && !three && s->scratch3 ? s->scratch3 : s->scratch;
+    bool dw_taps_pending = false;
     for (int i = s->n_backbone; i >= 1; --i) {
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
@@ -1132,17 +1140,24 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z
             const double n_l = (double)global_B * l.px_out;
             if (!sc || !sc->cb) {
-                RUN(launch_bn_bwd_finalize_partials(s->scratch, fused_rows, fused_stride, l.d.cout, l.bsums, n_l, P + l.d.gamma_off, l.mean,
+                RUN(launch_bn_bwd_finalize_partials(fused_buf, fused_rows, fused_stride, l.d.cout, l.bsums, n_l, P + l.d.gamma_off, l.mean,
                                                     l.rstd, l.cA, l.cB, l.cC, G + l.d.gamma_off, G + l.d.beta_off, st));
             } else {
-                RUN(launch_partials_to_sums(s->scratch, fused_rows, fused_stride, l.d.cout, l.bsums, st));
+                RUN(launch_partials_to_sums(fused_buf, fused_rows, fused_stride, l.d.cout, l.bsums, st));
                 RUN(launch_bn_param_grads(l.bsums, l.d.cout, G + l.d.gamma_off, G + l.d.beta_off, st));
                 RUN(sync_doubles(sc, l.bsums, 2 * (size_t)l.d.cout, st));
                 RUN(launch_bn_bwd_coef(l.bsums, n_l, l.d.cout, P + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC, nullptr, nullptr, st));
             }
             // the depthwise layer's weight gradient came with the same rows (taps behind the two sums)
-            if (fused_dw)
-                RUN(launch_reduce_splits(s->scratch + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st, fused_stride));
+            if (fused_dw && fused_buf != s->scratch) {
+                AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));                         // (the rows are complete: the kernel that wrote them is in front)
+                AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+                RUN(launch_reduce_splits(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, s->side, fused_stride));
+                AMS_CHECK_HIP(hipEventRecord(s->ev_dw, s->side));
+                dw_taps_pending = true;
+            } else if (fused_dw) {
+                RUN(launch_reduce_splits(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st, fused_stride));
+            }
             RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
             fused_rows = 0;
         } else {
@@ -1226,13 +1241,15 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         }
         LayerRt& prev = s->L[i - 1];
         if (dw_fused_train(s, i, B)) {
+            if (dw_taps_pending) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_dw, 0)); dw_taps_pending = false; }       // the rows buffer is free again
             // input gradient + activation derivative + BN-backward sums of the expand layer + this layer's weight gradient in one kernel
             // (k_conv.hip): prev.da <- dy, partial rows in s->scratch until the next iteration's second stage
             RUNK(i, dw_bytes(l, B) + 4.0 * B * l.px_in * l.d.cin,
                  launch_depthwise_dgrad_bn(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, prev.z, prev.scale, prev.shift, prev.d.act, prev.mean,
-                                           prev.rstd, prev.da, s->scratch, &fused_rows, st));
+                                           prev.rstd, prev.da, dw_rows, &fused_rows, st));
             fused_stride = 11 * (int64_t)l.d.cin;
             fused_dw = true;
+            fused_buf = dw_rows;
             continue;
         }
         hipStream_t wst = st;
@@ -1268,7 +1285,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
                 a.red_act = prev.d.act; a.red_part = s->scratch; a.red_rows_out = &red_rows;
             }
             RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
-            if (red_rows > 0) { fused_rows = red_rows; fused_stride = 2 * (int64_t)l.d.cin; fused_dw = false; }
+            if (red_rows > 0) { fused_rows = red_rows; fused_stride = 2 * (int64_t)l.d.cin; fused_dw = false; fused_buf = s->scratch; }
         }
     }
     // the optimizer (and the gradient all-reduce) wait for every weight gradient

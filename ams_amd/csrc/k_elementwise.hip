@@ -510,33 +510,42 @@ int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mas
     return AMS_OK;
 }
 
-// out[i] = sum_k part[k*n + i].  One block per 16 outputs: thread t owns output (t & 15) and every 16th split starting
-// at (t >> 4); the 16 f64 partials of an output are added in a fixed order (deterministic, and ~16x shorter dependent
-// load chains than one thread per output: with ~1000 splits the serial form cost > 100 us per call).
-__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ part, int splits, int64_t n,
-                                                            float* __restrict__ out, int64_t stride) {
-    __shared__ double sacc[16][17];
+// out[i] = sum_k part[k*n + i].  One block per 16 outputs: thread t owns output (t & 15) and every LP-th split starting at (t >> 4),
+// eight loads in flight; the LP f64 partials of an output are added in a fixed order (deterministic, and LP x shorter dependent load
+// chains than one thread per output: with ~1000 splits the serial form cost > 100 us per call, 16 lanes with two loads in flight
+// still 21 us for the 2048 rows of the first-block kernel).  LP = 64 from 256 splits on.
+template <int LP>
+__global__ __launch_bounds__(16 * LP) void reduce_splits_kernel(const float* __restrict__ part, int splits, int64_t n,
+                                                                float* __restrict__ out, int64_t stride) {
+    __shared__ double sacc[LP][17];
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
     const int kpart = threadIdx.x >> 4;
     double s = 0.0;
     if (i < n) {
-        double s0 = 0, s1 = 0;
+        const float* p = part + i;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int k = kpart;
-        for (; k + 16 < splits; k += 32) { s0 += part[(int64_t)k * stride + i]; s1 += part[(int64_t)(k + 16) * stride + i]; }
-        if (k < splits) s0 += part[(int64_t)k * stride + i];
-        s = s0 + s1;
+        for (; k + 7 * LP < splits; k += 8 * LP) {
+            const float v0 = p[(int64_t)k * stride], v1 = p[(int64_t)(k + LP) * stride], v2 = p[(int64_t)(k + 2 * LP) * stride],
+                        v3 = p[(int64_t)(k + 3 * LP) * stride], v4 = p[(int64_t)(k + 4 * LP) * stride], v5 = p[(int64_t)(k + 5 * LP) * stride],
+                        v6 = p[(int64_t)(k + 6 * LP) * stride], v7 = p[(int64_t)(k + 7 * LP) * stride];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
+        for (; k < splits; k += LP) s0 += p[(int64_t)k * stride];
+        s = (s0 + s1) + (s2 + s3);
     }
     sacc[kpart][threadIdx.x & 15] = s;
     __syncthreads();
     if (threadIdx.x < 16 && (int64_t)blockIdx.x * 16 + threadIdx.x < n) {
         double t = 0.0;
-        for (int k = 0; k < 16; ++k) t += sacc[k][threadIdx.x];
+        for (int k = 0; k < LP; ++k) t += sacc[k][threadIdx.x];
         out[(int64_t)blockIdx.x * 16 + threadIdx.x] = (float)t;
     }
 }
 
 int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st, int64_t stride) {
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, splits, n, out, stride > 0 ? stride : n);
+    if (splits >= 256) hipLaunchKernelGGL((reduce_splits_kernel<64>), dim3(cdiv(n, 16)), dim3(1024), 0, st, part, splits, n, out, stride > 0 ? stride : n);
+    else hipLaunchKernelGGL((reduce_splits_kernel<16>), dim3(cdiv(n, 16)), dim3(256), 0, st, part, splits, n, out, stride > 0 ? stride : n);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

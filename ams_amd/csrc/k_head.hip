@@ -352,9 +352,21 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
         }
         // only columns whose x0 is an OWNED cell column count towards the loss (the overlap column belongs to the block on the left)
         const bool own = x0 >= j_lo;
-        for (int y = ybeg; y < yend; ++y) {
-            const int target = ct.lut[teacher[((int64_t)b * g.H + y) * g.W + x]];
-            if (target < 0) continue;
+        // Eight rows at a time: their label bytes, then their class-table entries, are requested together — the two dependent loads per
+        // row were the kernel (63 % of the wave cycles waiting with six waves per SIMD to hide a ~1 us chain per row).  Same arithmetic,
+        // same row order: the same bits.
+        const uint8_t* tcol = teacher + (int64_t)b * g.H * g.W + x;
+        for (int yb = ybeg; yb < yend; yb += 8) {
+          int tgt[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) tgt[r] = tcol[(int64_t)(yb + r < yend ? yb + r : yend - 1) * g.W];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) tgt[r] = ct.lut[tgt[r]];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const int y = yb + r;
+            const int target = tgt[r];
+            if (y >= yend || target < 0) continue;
             const float src = __fmul_rn((float)y, g.sy);
             const float ty = __fsub_rn(src, floorf(src));
             float z[KMAX];
@@ -379,6 +391,7 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
                     gt[k] += wt * d;
                     gb[k] += ty * d;
                 }
+          }
         }
     }
 #pragma unroll

@@ -1,8 +1,9 @@
 #!/bin/bash
 # SQ counters of the kernels of ANY command whose name contains <pattern>, three rocprofv3 --pmc passes of <= 8 counters each.
 # Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count QUAD-cycles summed over waves (share = x / SQ_WAVE_CYCLES);
-# SQ_BUSY_CYCLES and SQ_VALU_MFMA_BUSY_CYCLES count CYCLES (the MFMA pipe's share of a wave's life = cycles / (4 x SQ_WAVE_CYCLES / waves)
-# is not meaningful per wave: the table prints them as cycles per launch and, for the MFMA pipe, as a share of SQ_BUSY_CYCLES);
+# SQ_BUSY_CYCLES and SQ_VALU_MFMA_BUSY_CYCLES count CYCLES: SQ_BUSY_CYCLES summed over the 32 SQ instances of the chip (one per shader engine:
+# SQ_BUSY_CYCLES / 32 ~ the kernel's duration in cycles), SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs (= MFMAs x 16 cycles for the
+# 16x16x32 bf16 form).  The MFMA pipe's busy share is therefore MFMA_BUSY / (1024 x SQ_BUSY / 32) = MFMA_BUSY / (32 x SQ_BUSY);
 # SQ_INSTS_* count instructions.
 # usage (GPU box, repo root): bash tools/pmc_cmd.sh <tag> <kernel substring> <program> [args...]    (program directly: no env / bash -c hop)
 tag=$1; pat=$2; shift 2
@@ -38,7 +39,7 @@ for k, d in sorted(agg.items()):
         elif c in ("SQ_BUSY_CYCLES",):
             print("   %-26s %16.0f cycles (summed over SQs)" % (c, a))
         elif c == "SQ_VALU_MFMA_BUSY_CYCLES":
-            print("   %-26s %16.0f cycles       %6.1f %% of SQ_BUSY_CYCLES" % (c, a, 100 * a / busy if busy else 0.0))
+            print("   %-26s %16.0f cycles (summed over SIMDs)  pipe busy %5.1f %% = x / (32 x SQ_BUSY_CYCLES)" % (c, a, 100 * a / (32 * busy) if busy else 0.0))
         else:
             print("   %-26s %16.0f" % (c, a))
 PY

@@ -365,6 +365,10 @@ static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp,
         if (a.N == 96 || a.N == 960) nt = 6;
         else if (a.N == 320) nt = 10;
     }
+    // one frame per call (33 x 65 = 2145 rows at the output stride): 34 row strips cannot fill the chip with 64- or 80-wide column tiles;
+    // 32-wide tiles give 2-5x the blocks for the same k loop (same products in the same order: same bits).  0.495 -> 0.480 ms per frame;
+    // from two frames on the wide tiles win again (measured at 2, 3, 4 frames)
+    if (a.M <= 2400 && rm == 1 && a.N % 32 == 0 && a.N >= 64) nt = 2;
     if (knobs().pwx_rm > 0) { rm = knobs().pwx_rm; nt = knobs().pwx_nt; }            // tuning knob AMS_PWX_FORCE
 #define PW_X(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_x3<RM_, NT_>(a, w, Kp, st);
     PW_X(4, 4) PW_X(4, 3) PW_X(4, 5)

@@ -246,12 +246,21 @@ def main():
         for _ in range(3):
             eng.predict(one)
         torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
         n1 = max(10, args.steps)
-        for _ in range(n1):
-            eng.predict(one)
-        torch.cuda.synchronize(dev)
-        fps_b1 = n1 / (time.perf_counter() - t1)
+
+        def window(fn):
+            """median of three timed windows of n1 calls (a window is ~10 ms: one host hiccup would otherwise decide the number)"""
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(n1):
+                    fn()
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t1)
+            return sorted(ts)[1]
+
+        fps_b1 = n1 / window(lambda: eng.predict(one))
         # the same one-frame RESULTS, several frames per pass: bit-identical per frame to the one-frame call (tests/test_gpu_fullsize.py)
         for mb in (2, 3, 4):                              # n frames in ONE pass with per-frame metrics (ams_student_predict_frames)
             pe = StudentEngine(CI, H, 2 * H, max_batch=mb, trainable=False, device=dev)
@@ -260,12 +269,8 @@ def main():
             fmb = frames[:mb].contiguous()
             for _ in range(3):
                 pe.predict_frames(fmb)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for _ in range(n1):
-                lab_mb, _c, _l = pe.predict_frames(fmb)
-            torch.cuda.synchronize(dev)
-            b1_micro[mb] = mb * n1 / (time.perf_counter() - t1)
+            b1_micro[mb] = mb * n1 / window(lambda: pe.predict_frames(fmb))
+            lab_mb, _c, _l = pe.predict_frames(fmb)
             assert torch.equal(lab_mb[:1], eng.predict(one)), "a frame of a %d-frame pass differs from its one-frame call" % mb
             pe.close()
             del pe

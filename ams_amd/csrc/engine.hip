@@ -1186,9 +1186,16 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
                 RUN(launch_bn_bwd_coef(le.bsums, n_e, le.d.cout, P + le.d.gamma_off, le.mean, le.rstd, le.cA, le.cB, le.cC, nullptr, nullptr, st));
             }
             const float* skip = (i + 1 <= s->n_backbone && s->L[i + 1].d.residual_from == i - 2) ? s->L[i + 1].da : nullptr;
+            // the block input is the previous block's project layer (BN, no activation): the first half of ITS BN backward rides on the
+            // dx pass (sum dx, sum dx xhat as one partial row per block), the separate pass over (dx, z) disappears
+            const bool red_dx = (s->fuse_gemm_red & 2) && i - 2 >= 3 && lin.d.role == AMS_ROLE_PROJECT && lin.d.act == AMS_ACT_NONE && lin.z &&
+                                (size_t)2048 * 2 * lin.d.cout <= s->scratch_floats;
+            int dx_rows = 0;
             RUNK(i - 1, 4.0 * ((double)B * (le.px_in * le.d.cin * (skip ? 3 : 2) + l.px_out * l.d.cout)),
                  launch_xdw_bwd_dx(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.d.cout, le.scale, le.shift, le.d.act, P + l.d.w_off,
-                                   l.d.stride, dz, le.cA, le.cB, le.cC, skip, lin.da, st));
+                                   l.d.stride, dz, le.cA, le.cB, le.cC, skip, lin.da, st, red_dx ? lin.z : nullptr, lin.mean, lin.rstd,
+                                   red_dx ? s->scratch : nullptr, red_dx ? &dx_rows : nullptr));
+            if (dx_rows > 0) { fused_rows = dx_rows; fused_stride = 2 * (int64_t)lin.d.cout; fused_dw = false; fused_buf = s->scratch; }
             // weight gradients from the partial rows: depthwise taps, then the expand weights from (G1 | XX | g0).  They only feed the
             // optimizer: on the side stream, behind the coefficients (recorded before the dx pass, which does not touch the rows)
             const int KP = (le.d.cin + 15) / 16 * 16;

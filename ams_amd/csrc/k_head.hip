@@ -294,7 +294,9 @@ int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32
 // owns is complete in x.  Two partial planes come out — T[b][i0][j] and B[b][i0 + 1][j], each element written exactly once (no
 // atomics: run-to-run identical) — and ce_combine_kernel adds them, applies 1 / (valid pixels) and scatters to the class columns.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kCeCB = 8;              // cell columns per block
+// cell columns per block: ten, so that the (CB + 1) x 17 + 2 = 189 pixel columns of a block fill its 192 threads and the 8-frame launch
+// (7 x 33 x 8 = 1848 blocks) fits ONE round of the 2048 resident blocks; with eight it was 2376 blocks of 155 live threads: two rounds
+constexpr int kCeCB = 10;
 
 template <int KMAX>
 __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restrict__ logits, HeadGeom g, ClassTable ct,

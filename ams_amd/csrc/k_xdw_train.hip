@@ -49,6 +49,10 @@ struct XtArgs {
     const float* cA; const float* cB; const float* cC;       // dz_e = cA dy_e + cB + cC z_e
     const float* res;          // gradient arriving over the skip connection [B, H, W, Cin], or null
     float* dx;                 // [B, H, W, Cin]
+    // dx pass, optional: dx is the gradient wrt the output of a BN layer WITHOUT activation (the previous block's project layer) whose raw
+    // output is red_z: sum(dx) and sum(dx xhat) come out as one partial row [2][Cin] per block (first half of that layer's BN backward)
+    const float* red_z; const float* red_mean; const float* red_rstd;
+    float* red_part;
     // partial rows (one per block):  S [2][Cexp] | dWd [9][Cexp] | G1 [KP][Cexp] | XX [KP][KP] | g0 [KP]   (KP = 16 KC)
     float* part;
     int64_t part_stride;       // floats per block row
@@ -456,6 +460,16 @@ __global__ __launch_bounds__(256) void xdw_dx_kernel(XtArgs a) {
     float* sTap = smem + 14 * a.Cexp + wave * G::TAP_FLOATS;
     const float lo = a.act_e == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = a.act_e == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     const int chunks = a.Cexp / 16;
+    const bool red = a.red_part != nullptr;              // block-uniform
+    float4 rs1[NTO], rs2[NTO], rmu[NTO], rrs[NTO];
+#pragma unroll
+    for (int tt = 0; tt < NTO; ++tt) {
+        const int c4 = 16 * tt + 4 * q;
+        const int c4c = c4 < a.Cin ? c4 : 0;
+        rs1[tt] = make_float4(0.f, 0.f, 0.f, 0.f); rs2[tt] = rs1[tt];
+        rmu[tt] = red ? ld4(a.red_mean + c4c) : rs1[tt];
+        rrs[tt] = red ? ld4(a.red_rstd + c4c) : rs1[tt];
+    }
     for (int t = blockIdx.x * 4 + wave; t < a.n_tiles; t += gridDim.x * 4) {
         const XtTileCtx tc = xt_tile<S>(a, t);
         float4 x4[4][KC];
@@ -549,7 +563,33 @@ __global__ __launch_bounds__(256) void xdw_dx_kernel(XtArgs a) {
                 float4 v = make_float4(out[rg][tt][0], out[rg][tt][1], out[rg][tt][2], out[rg][tt][3]);
                 if (a.res) v = add4_pk(v, ld4(a.res + xoff[rg] + c4));
                 st4(a.dx + xoff[rg] + c4, v);
+                if (red) {
+                    const float4 zp = ld4(a.red_z + xoff[rg] + c4);
+                    rs1[tt] = add4_pk(rs1[tt], v);
+                    rs2[tt] = add4_pk(rs2[tt], mul4_pk(mul4_pk(v, sub4_pk(zp, rmu[tt])), rrs[tt]));
+                }
             }
+        }
+    }
+    if (red) {
+        // lanes of a wave that share q hold the same channels: add the 16 pixels, then the four waves in a fixed order; one row per block
+        __syncthreads();                                 // every wave is done with the LDS table and its tap patch
+        float* sRed = smem;                              // [4 waves][2][16 NTO]
+#pragma unroll
+        for (int tt = 0; tt < NTO; ++tt) {
+            const float4 u = sum16(rs1[tt]), v = sum16(rs2[tt]);
+            if (l15 == 0) {
+                st4(sRed + (wave * 2 + 0) * 16 * NTO + 16 * tt + 4 * q, u);
+                st4(sRed + (wave * 2 + 1) * 16 * NTO + 16 * tt + 4 * q, v);
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * 16 * NTO; e += 256) {
+            const int which = e / (16 * NTO), c = e - which * (16 * NTO);
+            if (c >= a.Cin) continue;
+            float s = 0.f;
+            for (int wv = 0; wv < 4; ++wv) s += sRed[(wv * 2 + which) * 16 * NTO + c];
+            a.red_part[(int64_t)blockIdx.x * 2 * a.Cin + which * a.Cin + c] = s;
         }
     }
 }
@@ -691,7 +731,8 @@ int launch_xdw_bwd_reduce_stem(const void* frames, int dtype, int B, int fH, int
 // backward pass 2: dx [B,H,W,Cin] = dz_e . W_e^T (+ res)
 int launch_xdw_bwd_dx(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* sc_e, const float* sh_e,
                       int act_e, const float* w_dw, int stride, const float* dz_d, const float* cA, const float* cB, const float* cC,
-                      const float* res, float* dx, hipStream_t st) {
+                      const float* res, float* dx, hipStream_t st, const float* red_z, const float* red_mean, const float* red_rstd,
+                      float* red_part, int* red_rows_out) {
     AMS_REQUIRE(xdw_train_supported(Cin, Cexp, stride, 1), "xdw_bwd_dx: unsupported shape Cin=%d Cexp=%d s=%d", Cin, Cexp, stride);
     XtArgs a;
     memset(&a, 0, sizeof(a));
@@ -700,6 +741,12 @@ int launch_xdw_bwd_dx(const float* x, int B, int H, int W, int Cin, const float*
     xt_geometry(a, stride);
     int64_t blocks = cdiv64(a.n_tiles, 4);
     if (blocks > 256 * 8) blocks = 256 * 8;
+    if (red_rows_out) *red_rows_out = 0;
+    if (red_part) {
+        AMS_REQUIRE(red_z && red_mean && red_rstd && red_rows_out && Cin % 4 == 0, "xdw_bwd_dx: incomplete arguments for the fused BN-backward sums");
+        a.red_z = red_z; a.red_mean = red_mean; a.red_rstd = red_rstd; a.red_part = red_part;
+        *red_rows_out = (int)blocks;
+    }
     const size_t lds = ((size_t)14 * Cexp + 4 * (stride == 1 ? XtGeo<1>::TAP_FLOATS : XtGeo<2>::TAP_FLOATS)) * sizeof(float);
     const int KC = (Cin + 15) / 16;
     note_kernel("xdw_dx_kernel");

@@ -165,7 +165,8 @@ int launch_xdw_bwd_reduce_stem(const void* frames, int dtype, int B, int fH, int
 // backward pass 2: dx = (cA dy_e + cB + cC z_e) . W_e^T (+ res)
 int launch_xdw_bwd_dx(const float* x, int B, int H, int W, int Cin, const float* w_exp, int Cexp, const float* sc_e, const float* sh_e,
                       int act_e, const float* w_dw, int stride, const float* dz_d, const float* cA, const float* cB, const float* cC,
-                      const float* res, float* dx, hipStream_t st);
+                      const float* res, float* dx, hipStream_t st, const float* red_z = nullptr, const float* red_mean = nullptr,
+                      const float* red_rstd = nullptr, float* red_part = nullptr, int* red_rows_out = nullptr);
 // dW_e from the reduced G1 [KP][Cexp], the forward pass's (XX | g0) and the BN-backward coefficients
 int launch_xdw_dwe(const float* G1, const float* xx_g0, int Cin, int Cexp, const float* w_exp, const float* cA, const float* cB, const float* cC,
                    float* dw, hipStream_t st);

@@ -1997,6 +1997,30 @@ int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t
     return launch_depthwise_wgrad(x, dy, B, H, W, C, stride, rate, dw, scratch, scratch_floats, (hipStream_t)stream);
 }
 
+size_t ams_k_depthwise3x3_fwd_bn_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate) { return depthwise_fwd_bn_scratch(B, H, W, C, rate); }
+int ams_k_depthwise3x3_fwd_bn(const float* ze, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate, const float* scale,
+                              const float* shift, int32_t act, const float* center, float* zd, float* scratch, size_t scratch_floats,
+                              int32_t* rows_out, void* stream) {
+    AMS_REQUIRE(ze && w && scale && shift && zd && scratch && rows_out, "depthwise3x3_fwd_bn: null pointer");
+    AMS_REQUIRE(scratch_floats >= depthwise_fwd_bn_scratch(B, H, W, C, rate), "depthwise3x3_fwd_bn: scratch too small");
+    int rows = 0;
+    int rc = launch_depthwise_fwd_bn(ze, B, H, W, C, w, rate, scale, shift, act, center, zd, scratch, &rows, (hipStream_t)stream);
+    *rows_out = rows;
+    return rc;
+}
+size_t ams_k_depthwise3x3_dgrad_bn_scratch(int32_t B, int32_t H, int32_t W, int32_t C) { return depthwise_dgrad_bn_scratch(B, H, W, C); }
+int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate, const float* z_prev,
+                                const float* scale, const float* shift, int32_t act, const float* mean, const float* rstd, float* out,
+                                float* scratch, size_t scratch_floats, int32_t* rows_out, void* stream) {
+    AMS_REQUIRE(dz && w && z_prev && scale && shift && mean && rstd && out && scratch && rows_out, "depthwise3x3_dgrad_bn: null pointer");
+    AMS_REQUIRE(rate == 1 || rate == 2, "depthwise3x3_dgrad_bn: rate %d", rate);
+    AMS_REQUIRE(scratch_floats >= depthwise_dgrad_bn_scratch(B, H, W, C), "depthwise3x3_dgrad_bn: scratch too small");
+    int rows = 0;
+    int rc = launch_depthwise_dgrad_bn(dz, B, H, W, C, w, rate, z_prev, scale, shift, act, mean, rstd, out, scratch, &rows, (hipStream_t)stream);
+    *rows_out = rows;
+    return rc;
+}
+
 int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t, float beta1,
                float beta2, float eps, void* stream) {
     return launch_adam(params, grads, m, v, mask, n, lr_t, beta1, beta2, eps, (hipStream_t)stream);

@@ -396,6 +396,22 @@ int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t
                              int32_t stride, int32_t rate, float* dw, float* scratch, size_t scratch_floats,
                              void* stream);
 
+/* The fine-tune step's one-kernel forms of a stride-1 depthwise layer inside a block that keeps its tensors (what tf.gradients spreads over
+ * FusedBatchNormV3 / Relu6 / DepthwiseConv2dNative and their Grad ops, SemanticNetwork.py:253-260 via utils/graph_utils.py:457-496):
+ *   forward: zd [B,H,W,C] = dwconv3x3(act(ze * scale + shift), w) (rate 1 | 2, SAME: the ACTIVATION is zero-padded), and partial rows
+ *            [rows][2][C] of sum(zd - center), sum((zd - center)^2) (center may be NULL) in scratch; *rows_out = rows;
+ *   backward: out [B,H,W,C] = dwconv3x3^T(dz, w) * act'(z_prev * scale + shift), and partial rows [rows][11][C] of sum(out),
+ *            sum(out * (z_prev - mean) * rstd) and the nine taps of the depthwise weight gradient sum(act(z_prev * scale + shift) . dz).
+ * scratch_floats must be at least the matching *_scratch(). */
+size_t ams_k_depthwise3x3_fwd_bn_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate);
+int ams_k_depthwise3x3_fwd_bn(const float* ze, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate,
+                              const float* scale, const float* shift, int32_t act, const float* center, float* zd, float* scratch,
+                              size_t scratch_floats, int32_t* rows_out, void* stream);
+size_t ams_k_depthwise3x3_dgrad_bn_scratch(int32_t B, int32_t H, int32_t W, int32_t C);
+int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate,
+                                const float* z_prev, const float* scale, const float* shift, int32_t act, const float* mean,
+                                const float* rstd, float* out, float* scratch, size_t scratch_floats, int32_t* rows_out, void* stream);
+
 /* K14-K16: fused Adam + coordinate-descent mask over a flat arena (TF1 Adam, Appendix C.10). */
 int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t,
                float beta1, float beta2, float eps, void* stream);

@@ -230,6 +230,60 @@ def test_depthwise_forward_and_backward(lib, H, W, Cn, stride, rate):
     assert rel_err(dw.cpu().numpy(), wt.grad.permute(2, 3, 0, 1).numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,Cn,rate,act", [(33, 65, 384, 1, "relu6"), (33, 65, 960, 2, "relu6"), (17, 31, 576, 1, "relu6"), (9, 9, 64, 2, "none"),
+                                             (20, 7, 36, 1, "relu6"), (257, 129, 32, 1, "relu6"), (5, 3, 1024, 2, "relu6")])
+def test_depthwise_fine_tune_kernels(lib, H, W, Cn, rate, act):
+    """The fine-tune step's one-kernel forward and backward of a stride-1 depthwise layer (k_conv.hip: dw3x3_fwd_bn_kernel,
+    dw3x3_dgrad_bn_kernel) against f64 math on ragged sizes: result tensors, the BN sums folded from the partial rows, the nine weight-gradient
+    taps.  Row bands (forward), column strips that wrap around the channel groups several times, more channels than a block has threads."""
+    import ctypes as C
+    rng = np.random.default_rng(H * W + Cn + rate)
+    B = 2
+    ze = rng.standard_normal((B, H, W, Cn)).astype(np.float32) * 2.0
+    w = (rng.standard_normal((3, 3, Cn, 1)) * 0.4).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cn).astype(np.float32)
+    shift = rng.standard_normal(Cn).astype(np.float32)
+    center = rng.standard_normal(Cn).astype(np.float32) * 0.1
+    mean = rng.standard_normal(Cn).astype(np.float32) * 0.2
+    rstd = rng.uniform(0.5, 2.0, Cn).astype(np.float32)
+    act_id = hip.ACT_RELU6 if act == "relu6" else hip.ACT_NONE
+    _, pt, pb = S.same_pad(H, 3, 1, rate)
+    _, pl, pr = S.same_pad(W, 3, 1, rate)
+    zt = torch.as_tensor(ze).double().permute(0, 3, 1, 2)
+    y = zt * torch.as_tensor(scale).double().view(1, -1, 1, 1) + torch.as_tensor(shift).double().view(1, -1, 1, 1)
+    a_e = (torch.clamp(y, 0, 6) if act == "relu6" else y).requires_grad_(True)
+    wt = torch.as_tensor(w).double().permute(2, 3, 0, 1).requires_grad_(True)
+    zd_ref = F.conv2d(F.pad(a_e, (pl, pr, pt, pb)), wt, dilation=rate, groups=Cn)
+    # ---- forward
+    n_scr = lib.ams_k_depthwise3x3_fwd_bn_scratch(B, H, W, Cn, rate)
+    scr = torch.full((n_scr,), float("nan"), device=DEV)
+    zd = torch.empty((B, H, W, Cn), device=DEV)
+    rows = C.c_int32(0)
+    hip.check(lib.ams_k_depthwise3x3_fwd_bn(PD(ze), B, H, W, Cn, PD(w), rate, PD(scale), PD(shift), act_id, PD(center), P(zd), P(scr), n_scr,
+                                            C.byref(rows), stream()))
+    want = zd_ref.detach().permute(0, 2, 3, 1).numpy()
+    assert rel_err(zd.cpu().numpy(), want) < 1e-5
+    part = scr[: rows.value * 2 * Cn].cpu().numpy().astype(np.float64).reshape(rows.value, 2, Cn).sum(axis=0)
+    d = want - center.astype(np.float64)
+    assert rel_err(part[0], d.sum(axis=(0, 1, 2))) < 2e-5 and rel_err(part[1], (d * d).sum(axis=(0, 1, 2))) < 2e-5
+    # ---- backward
+    dz = rng.standard_normal((B, H, W, Cn)).astype(np.float32)
+    zd_ref.backward(torch.as_tensor(dz).double().permute(0, 3, 1, 2))
+    mask = ((y > 0) & (y < 6)).double() if act == "relu6" else torch.ones_like(y)
+    dy_ref = (a_e.grad * mask).permute(0, 2, 3, 1).numpy()
+    xhat = (ze.astype(np.float64) - mean) * rstd
+    n_scr = lib.ams_k_depthwise3x3_dgrad_bn_scratch(B, H, W, Cn)
+    scr = torch.full((n_scr,), float("nan"), device=DEV)
+    out = torch.empty((B, H, W, Cn), device=DEV)
+    hip.check(lib.ams_k_depthwise3x3_dgrad_bn(PD(dz), B, H, W, Cn, PD(w), rate, PD(ze), PD(scale), PD(shift), act_id, PD(mean), PD(rstd), P(out),
+                                              P(scr), n_scr, C.byref(rows), stream()))
+    assert rel_err(out.cpu().numpy(), dy_ref) < 1e-5
+    part = scr[: rows.value * 11 * Cn].cpu().numpy().astype(np.float64).reshape(rows.value, 11, Cn).sum(axis=0)
+    assert rel_err(part[0], dy_ref.sum(axis=(0, 1, 2))) < 2e-5
+    assert rel_err(part[1], (dy_ref * xhat).sum(axis=(0, 1, 2))) < 2e-5
+    assert rel_err(part[2:].reshape(3, 3, Cn), wt.grad.permute(2, 3, 0, 1).numpy()[..., 0]) < 2e-5
+
+
 @pytest.mark.parametrize("H,W,Cin,Cexp,stride", [(33, 65, 16, 96, 2), (40, 37, 24, 144, 1), (33, 65, 24, 144, 2), (29, 50, 32, 192, 1),
                                                  (17, 17, 64, 384, 1), (65, 129, 16, 96, 1)])
 def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):

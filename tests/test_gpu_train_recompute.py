@@ -31,7 +31,7 @@ def _step(H, B, recompute, seed=3, steps=1):
     return out
 
 
-@pytest.mark.parametrize("H,B", [(64, 2), (62, 3), (96, 1)])
+@pytest.mark.parametrize("H,B", [(64, 2), (62, 3), (96, 1), (50, 2), (34, 5)])
 def test_recompute_step_matches_layerwise_step(H, B):
     a = _step(H, B, True)
     b = _step(H, B, False)

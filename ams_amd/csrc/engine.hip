@@ -2021,6 +2021,39 @@ int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W
     return rc;
 }
 
+size_t ams_k_xdw_train_scratch(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cexp) { return xdw_train_scratch(B, H, W, Cin, Cexp); }
+int ams_k_xdw_fwd_stats(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* center,
+                        float* scratch, size_t scratch_floats, int32_t* rows_out, int64_t* stride_out, void* stream) {
+    AMS_REQUIRE(x && w_exp && scratch && rows_out && stride_out, "xdw_fwd_stats: null pointer");
+    AMS_REQUIRE(xdw_train_supported(Cin, Cexp, 1, 1) && scratch_floats >= xdw_train_scratch(B, H, W, Cin, Cexp), "xdw_fwd_stats: shape or scratch");
+    int rows = 0;
+    int rc = launch_xdw_fwd_stats(x, B, H, W, Cin, w_exp, Cexp, center, scratch, &rows, stride_out, (hipStream_t)stream);
+    *rows_out = rows;
+    return rc;
+}
+int ams_k_xdw_bwd_reduce(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* sc_e,
+                         const float* sh_e, const float* mean_e, const float* rstd_e, int32_t act_e, const float* w_dw, int32_t stride,
+                         const float* dz_d, float* scratch, size_t scratch_floats, int32_t* rows_out, int64_t* stride_out, void* stream) {
+    AMS_REQUIRE(x && w_exp && sc_e && sh_e && mean_e && rstd_e && w_dw && dz_d && scratch && rows_out && stride_out, "xdw_bwd_reduce: null pointer");
+    AMS_REQUIRE(xdw_train_supported(Cin, Cexp, stride, 1) && scratch_floats >= xdw_train_scratch(B, H, W, Cin, Cexp), "xdw_bwd_reduce: shape or scratch");
+    int rows = 0;
+    int rc = launch_xdw_bwd_reduce(x, B, H, W, Cin, w_exp, Cexp, sc_e, sh_e, mean_e, rstd_e, act_e, w_dw, stride, dz_d, scratch, &rows, stride_out,
+                                   (hipStream_t)stream);
+    *rows_out = rows;
+    return rc;
+}
+int ams_k_xdw_bwd_dx(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* sc_e,
+                     const float* sh_e, int32_t act_e, const float* w_dw, int32_t stride, const float* dz_d, const float* cA, const float* cB,
+                     const float* cC, const float* res, float* dx, void* stream) {
+    AMS_REQUIRE(x && w_exp && sc_e && sh_e && w_dw && dz_d && cA && cB && cC && dx, "xdw_bwd_dx: null pointer");
+    return launch_xdw_bwd_dx(x, B, H, W, Cin, w_exp, Cexp, sc_e, sh_e, act_e, w_dw, stride, dz_d, cA, cB, cC, res, dx, (hipStream_t)stream);
+}
+int ams_k_xdw_dwe(const float* G1, const float* xx_g0, int32_t Cin, int32_t Cexp, const float* w_exp, const float* cA, const float* cB,
+                  const float* cC, float* dw_exp, void* stream) {
+    AMS_REQUIRE(G1 && xx_g0 && w_exp && cA && cB && cC && dw_exp, "xdw_dwe: null pointer");
+    return launch_xdw_dwe(G1, xx_g0, Cin, Cexp, w_exp, cA, cB, cC, dw_exp, (hipStream_t)stream);
+}
+
 int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t, float beta1,
                float beta2, float eps, void* stream) {
     return launch_adam(params, grads, m, v, mask, n, lr_t, beta1, beta2, eps, (hipStream_t)stream);

@@ -412,6 +412,26 @@ int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W
                                 const float* z_prev, const float* scale, const float* shift, int32_t act, const float* mean,
                                 const float* rstd, float* out, float* scratch, size_t scratch_floats, int32_t* rows_out, void* stream);
 
+/* The fine-tune step of an early inverted-residual block WITHOUT its 6x-expanded tensors (k_xdw_train.hip; Cin 8..32, Cexp 32..192 in 16s,
+ * depthwise stride 1 | 2, rate 1): every pass recomputes z_e = x . w_exp from the block input x [B,H,W,Cin].  KP = Cin rounded up to 16.
+ *   fwd_stats : partial rows  S [2][Cexp] = sum(z_e - center), sum((z_e - center)^2) | XX [KP][KP] = x^T x | g0 [KP] = sum x
+ *   bwd_reduce: with dz_d = gradient wrt the depthwise layer's raw output [B,Ho,Wo,Cexp]: dy_e = dwconv^T(dz_d) . act'(z_e sc + sh);
+ *               partial rows  S [2][Cexp] = sum dy_e, sum dy_e xhat_e | dWd [9][Cexp] (depthwise weight gradient) | G1 [KP][Cexp] = x^T dy_e
+ *   bwd_dx    : dx [B,H,W,Cin] = (cA dy_e + cB + cC z_e) . w_exp^T (+ res)
+ *   dwe       : dw_exp [Cin][Cexp] = cA G1 + g0^T cB + cC (XX . w_exp) from the REDUCED rows (G1; XX | g0 contiguous)
+ * rows of *stride_out floats, *rows_out of them, in scratch (>= ams_k_xdw_train_scratch floats). */
+size_t ams_k_xdw_train_scratch(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cexp);
+int ams_k_xdw_fwd_stats(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* center,
+                        float* scratch, size_t scratch_floats, int32_t* rows_out, int64_t* stride_out, void* stream);
+int ams_k_xdw_bwd_reduce(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* sc_e,
+                         const float* sh_e, const float* mean_e, const float* rstd_e, int32_t act_e, const float* w_dw, int32_t stride,
+                         const float* dz_d, float* scratch, size_t scratch_floats, int32_t* rows_out, int64_t* stride_out, void* stream);
+int ams_k_xdw_bwd_dx(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* sc_e,
+                     const float* sh_e, int32_t act_e, const float* w_dw, int32_t stride, const float* dz_d, const float* cA, const float* cB,
+                     const float* cC, const float* res, float* dx, void* stream);
+int ams_k_xdw_dwe(const float* G1, const float* xx_g0, int32_t Cin, int32_t Cexp, const float* w_exp, const float* cA, const float* cB,
+                  const float* cC, float* dw_exp, void* stream);
+
 /* K14-K16: fused Adam + coordinate-descent mask over a flat arena (TF1 Adam, Appendix C.10). */
 int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint8_t* mask, int64_t n, float lr_t,
                float beta1, float beta2, float eps, void* stream);

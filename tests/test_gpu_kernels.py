@@ -284,6 +284,78 @@ def test_depthwise_fine_tune_kernels(lib, H, W, Cn, rate, act):
     assert rel_err(part[2:].reshape(3, 3, Cn), wt.grad.permute(2, 3, 0, 1).numpy()[..., 0]) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,Cin,Cexp,stride", [(20, 37, 24, 144, 1), (21, 38, 24, 144, 2), (22, 37, 24, 144, 2), (16, 16, 16, 96, 2),
+                                                 (9, 50, 32, 192, 1), (33, 65, 32, 192, 2), (8, 8, 8, 32, 1), (5, 3, 12, 48, 2), (64, 128, 16, 96, 1)])
+def test_recompute_block_kernels(lib, H, W, Cin, Cexp, stride):
+    """The fine-tune step of an early block without its expanded tensors (k_xdw_train.hip) through its own C-ABI entries, against f64
+    autograd of the materialised block: forward statistics + x^T x + sum x, the backward partial rows (BN sums, depthwise taps, x^T dy),
+    the input gradient with the skip gradient, and the expand weight gradient rebuilt from the reduced sums.  Odd and even sizes at stride 2
+    (SAME pads 0 or 1 before: the parity classes of the transposed conv move), maps smaller than a tile, Cin below a full k chunk."""
+    import ctypes as C
+    rng = np.random.default_rng(H * 131 + W * 7 + Cin + stride)
+    B = 2
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    we = (rng.standard_normal((Cin, Cexp)) / np.sqrt(Cin)).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, Cexp, 1)) * 0.4).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
+    sh = (rng.standard_normal(Cexp) + 1.0).astype(np.float32)
+    mean = (rng.standard_normal(Cexp) * 0.2).astype(np.float32)
+    rstd = rng.uniform(0.5, 2.0, Cexp).astype(np.float32)
+    center = (rng.standard_normal(Cexp) * 0.1).astype(np.float32)
+    cA, cB, cC = (rng.standard_normal(Cexp).astype(np.float32) for _ in range(3))
+    Ho, pt, pb = S.same_pad(H, 3, stride, 1)
+    Wo, pl, pr = S.same_pad(W, 3, stride, 1)
+    dz_d = rng.standard_normal((B, Ho, Wo, Cexp)).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    KP = (Cin + 15) // 16 * 16
+    # ---- f64 reference of the materialised block
+    xt = torch.as_tensor(x).double()
+    wet = torch.as_tensor(we).double()
+    ze = xt @ wet                                                        # [B,H,W,Cexp]
+    y = ze * torch.as_tensor(sc).double() + torch.as_tensor(sh).double()
+    ae = torch.clamp(y, 0, 6).permute(0, 3, 1, 2).requires_grad_(True)
+    wdt = torch.as_tensor(wd).double().permute(2, 3, 0, 1).requires_grad_(True)
+    zd = F.conv2d(F.pad(ae, (pl, pr, pt, pb)), wdt, stride=stride, groups=Cexp)
+    zd.backward(torch.as_tensor(dz_d).double().permute(0, 3, 1, 2))
+    dy = (ae.grad.permute(0, 2, 3, 1) * ((y > 0) & (y < 6)).double()).numpy()       # [B,H,W,Cexp]
+    zen = ze.numpy()
+    xhat = (zen - mean.astype(np.float64)) * rstd.astype(np.float64)
+    x64 = x.astype(np.float64).reshape(-1, Cin)
+    n_scr = lib.ams_k_xdw_train_scratch(B, H, W, Cin, Cexp)
+    rows, stride_out = C.c_int32(0), C.c_int64(0)
+    # ---- forward statistics
+    scr = torch.full((n_scr,), float("nan"), device=DEV)
+    hip.check(lib.ams_k_xdw_fwd_stats(PD(x), B, H, W, Cin, PD(we), Cexp, PD(center), P(scr), n_scr, C.byref(rows), C.byref(stride_out), stream()))
+    part = scr[: rows.value * stride_out.value].cpu().numpy().astype(np.float64).reshape(rows.value, stride_out.value).sum(axis=0)
+    d = zen - center.astype(np.float64)
+    assert rel_err(part[:Cexp], d.sum(axis=(0, 1, 2))) < 2e-5 and rel_err(part[Cexp:2 * Cexp], (d * d).sum(axis=(0, 1, 2))) < 2e-5
+    XX = part[2 * Cexp:2 * Cexp + KP * KP].reshape(KP, KP)
+    g0 = part[2 * Cexp + KP * KP:2 * Cexp + KP * KP + KP]
+    assert rel_err(XX[:Cin, :Cin], x64.T @ x64) < 2e-5 and rel_err(g0[:Cin], x64.sum(axis=0)) < 2e-5
+    # ---- backward: partial rows
+    scr2 = torch.full((n_scr,), float("nan"), device=DEV)
+    hip.check(lib.ams_k_xdw_bwd_reduce(PD(x), B, H, W, Cin, PD(we), Cexp, PD(sc), PD(sh), PD(mean), PD(rstd), hip.ACT_RELU6, PD(wd), stride, PD(dz_d),
+                                       P(scr2), n_scr, C.byref(rows), C.byref(stride_out), stream()))
+    pb_ = scr2[: rows.value * stride_out.value].cpu().numpy().astype(np.float64).reshape(rows.value, stride_out.value).sum(axis=0)
+    assert rel_err(pb_[:Cexp], dy.sum(axis=(0, 1, 2))) < 2e-5
+    assert rel_err(pb_[Cexp:2 * Cexp], (dy * xhat).sum(axis=(0, 1, 2))) < 2e-5
+    assert rel_err(pb_[2 * Cexp:11 * Cexp].reshape(3, 3, Cexp), wdt.grad.permute(2, 3, 0, 1).numpy()[..., 0]) < 2e-5
+    G1 = pb_[11 * Cexp:11 * Cexp + KP * Cexp].reshape(KP, Cexp)
+    assert rel_err(G1[:Cin], x64.T @ dy.reshape(-1, Cexp)) < 2e-5
+    # ---- backward: input gradient
+    dze = cA.astype(np.float64) * dy + cB.astype(np.float64) + cC.astype(np.float64) * zen
+    dx_ref = dze.reshape(-1, Cexp) @ we.astype(np.float64).T + res.astype(np.float64).reshape(-1, Cin)
+    dx = torch.empty((B, H, W, Cin), device=DEV)
+    hip.check(lib.ams_k_xdw_bwd_dx(PD(x), B, H, W, Cin, PD(we), Cexp, PD(sc), PD(sh), hip.ACT_RELU6, PD(wd), stride, PD(dz_d), PD(cA), PD(cB), PD(cC),
+                                   PD(res), P(dx), stream()))
+    assert rel_err(dx.cpu().numpy().reshape(-1, Cin), dx_ref) < 2e-5
+    # ---- expand weight gradient from the reduced sums: x^T dz_e without a pass over dz_e
+    xx_g0 = np.concatenate([XX.reshape(-1), g0]).astype(np.float32)
+    dwe = torch.empty((Cin, Cexp), device=DEV)
+    hip.check(lib.ams_k_xdw_dwe(PD(G1.astype(np.float32)), PD(xx_g0), Cin, Cexp, PD(we), PD(cA), PD(cB), PD(cC), P(dwe), stream()))
+    assert rel_err(dwe.cpu().numpy(), x64.T @ dze.reshape(-1, Cexp)) < 5e-5
+
+
 @pytest.mark.parametrize("H,W,Cin,Cexp,stride", [(33, 65, 16, 96, 2), (40, 37, 24, 144, 1), (33, 65, 24, 144, 2), (29, 50, 32, 192, 1),
                                                  (17, 17, 64, 384, 1), (65, 129, 16, 96, 1)])
 def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):

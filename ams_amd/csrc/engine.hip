@@ -2048,6 +2048,18 @@ int ams_k_xdw_bwd_dx(const float* x, int32_t B, int32_t H, int32_t W, int32_t Ci
     AMS_REQUIRE(x && w_exp && sc_e && sh_e && w_dw && dz_d && cA && cB && cC && dx, "xdw_bwd_dx: null pointer");
     return launch_xdw_bwd_dx(x, B, H, W, Cin, w_exp, Cexp, sc_e, sh_e, act_e, w_dw, stride, dz_d, cA, cB, cC, res, dx, (hipStream_t)stream);
 }
+size_t ams_k_xdw_stem_scratch(int32_t B, int32_t fH, int32_t fW) { return xdw_stem_scratch(B, fH, fW); }
+int ams_k_xdw_bwd_reduce_stem(const void* frames, int32_t frames_dtype, int32_t B, int32_t fH, int32_t fW, float pixel_scale, const float* w_stem,
+                              const float* sc_e, const float* sh_e, const float* mean_e, const float* rstd_e, int32_t act_e, const float* w_dw,
+                              const float* dz_d, float* scratch, size_t scratch_floats, int32_t* rows_out, int64_t* stride_out, void* stream) {
+    AMS_REQUIRE(frames && w_stem && sc_e && sh_e && mean_e && rstd_e && w_dw && dz_d && scratch && rows_out && stride_out, "xdw_bwd_reduce_stem: null pointer");
+    AMS_REQUIRE(scratch_floats >= xdw_stem_scratch(B, fH, fW), "xdw_bwd_reduce_stem: scratch too small");
+    int rows = 0;
+    int rc = launch_xdw_bwd_reduce_stem(frames, frames_dtype, B, fH, fW, pixel_scale, w_stem, sc_e, sh_e, mean_e, rstd_e, act_e, w_dw, dz_d, scratch,
+                                        &rows, stride_out, (hipStream_t)stream);
+    *rows_out = rows;
+    return rc;
+}
 int ams_k_xdw_dwe(const float* G1, const float* xx_g0, int32_t Cin, int32_t Cexp, const float* w_exp, const float* cA, const float* cB,
                   const float* cC, float* dw_exp, void* stream) {
     AMS_REQUIRE(G1 && xx_g0 && w_exp && cA && cB && cC && dw_exp, "xdw_dwe: null pointer");

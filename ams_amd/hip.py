@@ -123,6 +123,9 @@ SIGNATURES = {
     "ams_k_xdw_bwd_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _sz,
                                       C.POINTER(_i32), C.POINTER(_i64), _vp]),
     "ams_k_xdw_bwd_dx": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ams_k_xdw_stem_scratch": (_sz, [_i32, _i32, _i32]),
+    "ams_k_xdw_bwd_reduce_stem": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _sz,
+                                           C.POINTER(_i32), C.POINTER(_i64), _vp]),
     "ams_k_xdw_dwe": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ams_k_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp]),
 }

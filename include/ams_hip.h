@@ -429,6 +429,13 @@ int ams_k_xdw_bwd_reduce(const float* x, int32_t B, int32_t H, int32_t W, int32_
 int ams_k_xdw_bwd_dx(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* sc_e,
                      const float* sh_e, int32_t act_e, const float* w_dw, int32_t stride, const float* dz_d, const float* cA, const float* cB,
                      const float* cC, const float* res, float* dx, void* stream);
+/* the first block of the network in the same form: the stem conv (3x3 stride 2 over the normalised, 127.5-padded frame, 3 -> 32) is the
+ * "expand" layer over its 27-tap patch (k = tap * 3 + channel), followed by the first depthwise conv.  One pass over dz_d [B,H1,W1,32] and
+ * the frames: partial rows  S [2][32] | dWd [9][32] | G1 [32][32] (27 rows used) | XX [32][32] | g0 [32]. */
+size_t ams_k_xdw_stem_scratch(int32_t B, int32_t fH, int32_t fW);
+int ams_k_xdw_bwd_reduce_stem(const void* frames, int32_t frames_dtype, int32_t B, int32_t fH, int32_t fW, float pixel_scale, const float* w_stem,
+                              const float* sc_e, const float* sh_e, const float* mean_e, const float* rstd_e, int32_t act_e, const float* w_dw,
+                              const float* dz_d, float* scratch, size_t scratch_floats, int32_t* rows_out, int64_t* stride_out, void* stream);
 int ams_k_xdw_dwe(const float* G1, const float* xx_g0, int32_t Cin, int32_t Cexp, const float* w_exp, const float* cA, const float* cB,
                   const float* cC, float* dw_exp, void* stream);
 

@@ -356,6 +356,56 @@ def test_recompute_block_kernels(lib, H, W, Cin, Cexp, stride):
     assert rel_err(dwe.cpu().numpy(), x64.T @ dze.reshape(-1, Cexp)) < 5e-5
 
 
+@pytest.mark.parametrize("H,W,dtype", [(32, 64, np.uint8), (37, 50, np.uint8), (9, 7, np.float32), (128, 256, np.uint8)])
+def test_recompute_first_block_kernel(lib, H, W, dtype):
+    """The first block's backward without the stem's tensors (launch_xdw_bwd_reduce_stem): BN-backward sums of the stem, the first depthwise
+    layer's weight gradient and the pieces of the stem weight gradient (x^T dy over the 27-tap patch, x^T x, sum x) against f64 autograd."""
+    import ctypes as C
+    rng = np.random.default_rng(H + 3 * W)
+    B = 2
+    frames = rng.integers(0, 256, (B, H, W, 3)).astype(dtype)
+    ws = (rng.standard_normal((3, 3, 3, 32)) * 0.3).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, 32, 1)) * 0.4).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 32).astype(np.float32)
+    sh = (rng.standard_normal(32) + 1.0).astype(np.float32)
+    mean = (rng.standard_normal(32) * 0.2).astype(np.float32)
+    rstd = rng.uniform(0.5, 2.0, 32).astype(np.float32)
+    H1, pt, pb = S.same_pad(H + 1, 3, 2, 1)
+    W1, pl, pr = S.same_pad(W + 1, 3, 2, 1)
+    dz_d = rng.standard_normal((B, H1, W1, 32)).astype(np.float32)
+    # reference: normalised, 127.5-padded frame -> im2col patches [B,H1,W1,27] (k = tap * 3 + channel) -> 1x1 conv -> BN -> ReLU6 -> depthwise
+    xin = torch.as_tensor(frames.astype(np.float32)).permute(0, 3, 1, 2)
+    xin = (F.pad(xin, (0, 1, 0, 1), value=127.5) * np.float32(S.PIXEL_SCALE) - 1.0).double()
+    xp = F.pad(xin, (pl, pr, pt, pb))
+    patches = F.unfold(xp, kernel_size=3, stride=2).view(B, 3, 9, H1, W1).permute(0, 3, 4, 2, 1).reshape(B, H1, W1, 27)     # [.., tap, ch]
+    wmat = torch.as_tensor(ws).double().reshape(27, 32)                                                               # HWIO: (tap, ch) rows
+    ze = patches @ wmat
+    y = ze * torch.as_tensor(sc).double() + torch.as_tensor(sh).double()
+    ae = torch.clamp(y, 0, 6).permute(0, 3, 1, 2).requires_grad_(True)
+    wdt = torch.as_tensor(wd).double().permute(2, 3, 0, 1).requires_grad_(True)
+    zd = F.conv2d(F.pad(ae, (1, 1, 1, 1)), wdt, groups=32)
+    zd.backward(torch.as_tensor(dz_d).double().permute(0, 3, 1, 2))
+    dy = (ae.grad.permute(0, 2, 3, 1) * ((y > 0) & (y < 6)).double()).numpy()
+    xhat = (ze.numpy() - mean.astype(np.float64)) * rstd.astype(np.float64)
+    p64 = patches.numpy().reshape(-1, 27)
+    n_scr = lib.ams_k_xdw_stem_scratch(B, H, W)
+    scr = torch.full((n_scr,), float("nan"), device=DEV)
+    rows, stride_out = C.c_int32(0), C.c_int64(0)
+    fd = torch.as_tensor(frames).to(DEV)
+    hip.check(lib.ams_k_xdw_bwd_reduce_stem(P(fd), hip.DT_U8 if dtype == np.uint8 else hip.DT_F32, B, H, W, S.PIXEL_SCALE, PD(ws), PD(sc), PD(sh),
+                                            PD(mean), PD(rstd), hip.ACT_RELU6, PD(wd), PD(dz_d), P(scr), n_scr, C.byref(rows), C.byref(stride_out),
+                                            stream()))
+    part = scr[: rows.value * stride_out.value].cpu().numpy().astype(np.float64).reshape(rows.value, stride_out.value).sum(axis=0)
+    assert rel_err(part[:32], dy.sum(axis=(0, 1, 2))) < 2e-5 and rel_err(part[32:64], (dy * xhat).sum(axis=(0, 1, 2))) < 2e-5
+    assert rel_err(part[64:11 * 32].reshape(3, 3, 32), wdt.grad.permute(2, 3, 0, 1).numpy()[..., 0]) < 2e-5
+    G1 = part[11 * 32:11 * 32 + 32 * 32].reshape(32, 32)
+    assert rel_err(G1[:27], p64.T @ dy.reshape(-1, 32)) < 2e-5
+    base = 11 * 32 + 32 * 32
+    XX = part[base:base + 32 * 32].reshape(32, 32)
+    g0 = part[base + 32 * 32:base + 32 * 32 + 32]
+    assert rel_err(XX[:27, :27], p64.T @ p64) < 2e-5 and rel_err(g0[:27], p64.sum(axis=0)) < 2e-5
+
+
 @pytest.mark.parametrize("H,W,Cin,Cexp,stride", [(33, 65, 16, 96, 2), (40, 37, 24, 144, 1), (33, 65, 24, 144, 2), (29, 50, 32, 192, 1),
                                                  (17, 17, 64, 384, 1), (65, 129, 16, 96, 1)])
 def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):

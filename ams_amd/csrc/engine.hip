@@ -1997,6 +1997,35 @@ int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t
     return launch_depthwise_wgrad(x, dy, B, H, W, C, stride, rate, dw, scratch, scratch_floats, (hipStream_t)stream);
 }
 
+int ams_k_pointwise_red(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w, int32_t split, int32_t mode,
+                        const float* center, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                        int32_t act, const float* res, float* y, float* part, size_t part_floats, int32_t* rows_out, uint16_t* panels,
+                        size_t panel_elems, void* stream) {
+    AMS_REQUIRE(x && w && y && part && rows_out && (mode == 1 || mode == 2), "pointwise_red: bad arguments");
+    AMS_REQUIRE(mode == 1 || (z && scale && shift && mean && rstd), "pointwise_red: mode 2 needs z, scale, shift, mean, rstd");
+    AMS_REQUIRE(part_floats >= red_rows_bound(M) * 2 * (size_t)N, "pointwise_red: partial-row buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    PwArgs a = pw_args(x, M, K, K, w, N, y, N);
+    if (trans_w) { a.w_sk = 1; a.w_sn = K; }
+    a.res = res; a.ldr = N;
+    a.red_mode = mode; a.red_center = center; a.red_z = z; a.red_scale = scale; a.red_shift = shift; a.red_mean = mean; a.red_rstd = rstd;
+    a.red_act = act; a.red_part = part;
+    int rows = 0;
+    a.red_rows_out = &rows;
+    int rc;
+    if (split) {
+        const int Kp = (K + 31) / 32 * 32;
+        const size_t plane = (size_t)N * Kp;
+        AMS_REQUIRE(panels && panel_elems >= 3 * plane && K % 8 == 0, "pointwise_red: panel scratch too small (need %zu) or K %% 8", 3 * plane);
+        RUN(launch_split_weights3(w, a.w_sk, a.w_sn, K, N, Kp, panels, panels + plane, panels + 2 * plane, st));
+        rc = launch_pointwise_split3(a, panels, panels + plane, panels + 2 * plane, Kp, st);
+    } else {
+        rc = launch_pointwise(a, st);
+    }
+    *rows_out = rows;
+    return rc;
+}
+
 size_t ams_k_depthwise3x3_fwd_bn_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate) { return depthwise_fwd_bn_scratch(B, H, W, C, rate); }
 int ams_k_depthwise3x3_fwd_bn(const float* ze, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate, const float* scale,
                               const float* shift, int32_t act, const float* center, float* zd, float* scratch, size_t scratch_floats,

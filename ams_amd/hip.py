@@ -113,6 +113,8 @@ SIGNATURES = {
     "ams_k_pointwise_wgrad_split": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_depthwise3x3_dgrad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ams_k_depthwise3x3_wgrad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "ams_k_pointwise_red": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _sz,
+                                     C.POINTER(_i32), _vp, _sz, _vp]),
     "ams_k_depthwise3x3_fwd_bn_scratch": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "ams_k_depthwise3x3_fwd_bn": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_i32), _vp]),
     "ams_k_depthwise3x3_dgrad_bn_scratch": (_sz, [_i32, _i32, _i32, _i32]),

@@ -396,6 +396,19 @@ int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t
                              int32_t stride, int32_t rate, float* dw, float* scratch, size_t scratch_floats,
                              void* stream);
 
+/* A 1x1 conv of the fine-tune step with a BN column reduction in its epilogue (pw_common.hpp pw_red_*; what FusedBatchNormV3 /
+ * FusedBatchNormGradV3's reductions are to the reference's graph).  y [M,N] = x [M,K] . w [K,N] (trans_w: w is [N,K], the dgrad orientation).
+ *   mode 1: partial rows [rows][2][N] of sum(y - center), sum((y - center)^2)            (forward statistics; center may be NULL)
+ *   mode 2: y is the gradient wrt the ACTIVATED output of a BN layer with raw output z [M,N]: y (+ res [M,N] first, if given) is multiplied by
+ *           act'(z scale + shift) BEFORE it is stored; partial rows of sum(y), sum(y (z - mean) rstd)   (first half of that layer's BN backward)
+ * split != 0: the three-part bf16 kernel (panels: >= 3 N Kp bf16 scratch), else the exact-f32 streaming kernel.  *rows_out = 0 means the kernel
+ * chosen for this shape cannot fuse the reduction (y is then the plain product, + res): the caller runs the separate pass.
+ * part_floats >= (M / 64 + 8 or 2048) * 2 N. */
+int ams_k_pointwise_red(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w, int32_t split, int32_t mode,
+                        const float* center, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                        int32_t act, const float* res, float* y, float* part, size_t part_floats, int32_t* rows_out, uint16_t* panels,
+                        size_t panel_elems, void* stream);
+
 /* The fine-tune step's one-kernel forms of a stride-1 depthwise layer inside a block that keeps its tensors (what tf.gradients spreads over
  * FusedBatchNormV3 / Relu6 / DepthwiseConv2dNative and their Grad ops, SemanticNetwork.py:253-260 via utils/graph_utils.py:457-496):
  *   forward: zd [B,H,W,C] = dwconv3x3(act(ze * scale + shift), w) (rate 1 | 2, SAME: the ACTIVATION is zero-padded), and partial rows

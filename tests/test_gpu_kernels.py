@@ -163,6 +163,60 @@ def test_pointwise_wgrad_split(lib, M, K, N):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("M,K,N,split,trans", [(4290, 160, 960, 1, 1), (16421, 960, 160, 1, 0), (17160, 576, 96, 1, 1), (2145, 384, 64, 1, 0),
+                                                (33001, 64, 384, 1, 0), (40003, 24, 144, 0, 1), (33000, 32, 192, 0, 0), (65537, 16, 96, 0, 1),
+                                                (70001, 144, 24, 0, 0)])
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_pointwise_with_fused_column_reduction(lib, M, K, N, split, trans, mode):
+    """1x1 GEMMs whose epilogue also reduces (PwArgs::red_mode): forward statistics (mode 1), BN-backward sums with the activation's
+    derivative applied to the stored result (mode 2), the same with a residual gradient added first (3 = mode 2 + res) — tiled three-part
+    kernel and streaming exact-f32 kernel, ragged row counts (tail strips, half-height tail blocks), both weight orientations."""
+    import ctypes as C
+    rng = np.random.default_rng(M + K + N + mode)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K) if trans else (K, N)) / np.sqrt(K)).astype(np.float32)
+    center = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    z = (rng.standard_normal((M, N)) * 2).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    shift = (rng.standard_normal(N) + 1).astype(np.float32)
+    mean = (rng.standard_normal(N) * 0.2).astype(np.float32)
+    rstd = rng.uniform(0.5, 2.0, N).astype(np.float32)
+    # no activation within rounding distance of a ReLU6 knee (the f32 and f64 masks must agree element for element)
+    a0 = z.astype(np.float64) * scale + shift
+    near = (np.abs(a0) < 1e-3) | (np.abs(a0 - 6) < 1e-3)
+    z = np.where(near, z + np.float32(0.01) / scale, z).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32) if mode == 3 else None
+    prod = x.astype(np.float64) @ (w.astype(np.float64).T if trans else w.astype(np.float64))
+    y = torch.empty((M, N), device=DEV)
+    n_part = max(M // 64 + 8, 2048) * 2 * N
+    part = torch.full((n_part,), float("nan"), device=DEV)
+    Kp = (K + 31) // 32 * 32
+    panels = torch.empty(3 * N * Kp, dtype=torch.int16, device=DEV)
+    rows = C.c_int32(-1)
+    hip.check(lib.ams_k_pointwise_red(PD(x), M, K, PD(w), N, trans, split, 1 if mode == 1 else 2, PD(center), PD(z), PD(scale), PD(shift), PD(mean),
+                                      PD(rstd), hip.ACT_RELU6, PD(res) if res is not None else None, P(y), P(part), n_part, C.byref(rows),
+                                      P(panels), panels.numel(), stream()))
+    tol = 3e-5 if split else 1e-5
+    if mode == 3 and not split:
+        # the streaming kernel does not take a residual into its reduction: it must say so and return the plain sum
+        assert rows.value == 0
+        assert rel_err(y.cpu().numpy(), prod + res) < tol
+        return
+    assert rows.value > 0, "the kernel chosen for this shape should fuse the reduction"
+    sums = part[: rows.value * 2 * N].cpu().numpy().astype(np.float64).reshape(rows.value, 2, N).sum(axis=0)
+    if mode == 1:
+        assert rel_err(y.cpu().numpy(), prod) < tol
+        d = prod - center
+        assert rel_err(sums[0], d.sum(axis=0)) < 5e-5 and rel_err(sums[1], (d * d).sum(axis=0)) < 5e-5
+    else:
+        g = prod + (res if res is not None else 0.0)
+        a = z.astype(np.float64) * scale + shift
+        dy = g * ((a > 0) & (a < 6))
+        assert rel_err(y.cpu().numpy(), dy) < tol
+        xhat = (z.astype(np.float64) - mean) * rstd
+        assert rel_err(sums[0], dy.sum(axis=0)) < 5e-5 and rel_err(sums[1], (dy * xhat).sum(axis=0)) < 5e-5
+
+
 def test_pointwise_wgrad_split_rejects_small_problems(lib):
     scr = torch.empty(1024, device=DEV)
     z = torch.zeros(16, device=DEV)

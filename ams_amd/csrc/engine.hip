@@ -59,6 +59,9 @@ struct LayerRt {
     double *fsums = nullptr, *bsums = nullptr;      // [2][cout] each, inside the BN_SYNC region
     // training activations (max_batch images each)
     float *z = nullptr, *a = nullptr, *da = nullptr;
+    // gradient wrt the raw conv output: written IN PLACE over da, except where da is read again as the gradient over a skip connection (the
+    // project layer of a residual block): those layers get a tensor of their own
+    float* dzp = nullptr;
     // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
@@ -390,7 +393,6 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
         s->d_pooled = cv.take<float>((size_t)B * head_cin);
         s->im2col = cv.take<float>((size_t)B * s->L[1].px_out * 32);
         s->dz = cv.take<float>((size_t)B * max_elems);
-        s->dz2 = cv.take<float>((size_t)B * max_elems);
         s->scratch2 = cv.take<float>(sc);
         s->scratch3 = cv.take<float>(sc);
         for (int i = 1; i <= c.n_layers; ++i) {
@@ -400,6 +402,7 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.z = cv.take<float>(e);
             l.a = cv.take<float>(e);
             l.da = cv.take<float>(e);
+            if (l.d.residual_from) l.dzp = cv.take<float>(e);
         }
     }
     *bytes_out = (cv.off + 255) & ~(size_t)255;
@@ -1107,17 +1110,15 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     // stream goes on with the input gradient and the next layer's BN backward (many of these kernels are latency-bound at 8 frames
     // and share the chip well).  dz alternates between two buffers; the main stream waits for the weight gradient that read a
     // buffer two layers ago before it overwrites it.
-    const bool overlap = s->overlap_wgrad && !s->prof.on && s->dz2 && s->scratch2;
+    const bool overlap = s->overlap_wgrad && !s->prof.on && s->scratch2;
     if (overlap && !s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-    if (overlap && !s->ev_wg[0]) {
+    if (overlap && !s->ev_xt) {
         if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-        for (auto& e : s->ev_wg) AMS_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_xt, hipEventDisableTiming));
         AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_dw, hipEventDisableTiming));
     }
     const bool three = overlap && s->overlap_wgrad >= 2 && s->scratch3;      // depthwise weight gradients on a third stream
     if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
-    bool wg_pending[2] = {false, false};
     bool xt_pending = false;
     // > 0: the kernel that produced this layer's da already multiplied it by the activation's derivative and left the BN-backward partial
     // rows in s->scratch (fused_stride floats apart; fused_dw: the nine taps of the NEXT layer's depthwise weight gradient behind the sums)
@@ -1132,9 +1133,10 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     for (int i = s->n_backbone; i >= 1; --i) {
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
-        const int zb = i & 1;
-        float* dz = overlap && zb ? s->dz2 : s->dz;
-        if (overlap && wg_pending[zb]) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_wg[zb], 0)); wg_pending[zb] = false; }
+        // dz of a layer lives in that layer's own memory (in place over da, or dzp): no buffer is reused inside a step, so the main stream
+        // never waits for a weight gradient (every hipStreamWaitEvent / hipEventRecord between two dependent kernels costs 5-9 us of queue
+        // processing on this stack: with two alternating dz buffers that was ~40 waits a step)
+        float* dz = l.dzp ? l.dzp : l.da;
         if (fused_rows > 0) {
             // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the
             // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z
@@ -1275,7 +1277,6 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         } else {
             RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch));
         }
-        if (overlap) { AMS_CHECK_HIP(hipEventRecord(s->ev_wg[zb], wst)); wg_pending[zb] = true; }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
         } else {
@@ -1296,8 +1297,6 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         }
     }
     // the optimizer (and the gradient all-reduce) wait for every weight gradient
-    for (int k = 0; k < 2; ++k)
-        if (overlap && wg_pending[k]) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_wg[k], 0));
     if (xt_pending) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0));
     if (overlap) {                                     // everything either side stream still holds (events cover the last launch of each buffer only)
         AMS_CHECK_HIP(hipEventRecord(s->ev_fork, s->side));

@@ -454,11 +454,12 @@ int launch_bn_act(const float* z, int64_t M, int C, const float* scale, const fl
     return AMS_OK;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ z,
+// (da and dz may be the same tensor: every element is read before it is written, by the same thread)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* da, const float* __restrict__ z,
                                                            int64_t n4, int C4, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int act,
                                                            const float* __restrict__ cA, const float* __restrict__ cB,
-                                                           const float* __restrict__ cC, float* __restrict__ dz) {
+                                                           const float* __restrict__ cC, float* dz) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % C4) * 4;
         const float4 g = ld4(da + i * 4), v = ld4(z + i * 4);

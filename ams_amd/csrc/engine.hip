@@ -62,6 +62,8 @@ struct LayerRt {
     // gradient wrt the raw conv output: written IN PLACE over da, except where da is read again as the gradient over a skip connection (the
     // project layer of a residual block): those layers get a tensor of their own
     float* dzp = nullptr;
+    // stride-1 depthwise layer (training): partial rows of its one-kernel backward, kept until the step's batched reduction of the taps
+    float* dw_rows = nullptr;
     // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
@@ -131,7 +133,6 @@ struct ams_student {
     float* scratch2 = nullptr;
     float* scratch3 = nullptr;       // depthwise weight gradients on their own stream (side2), AMS_OVERLAP_WGRAD=2
     hipStream_t side2 = nullptr;
-    hipEvent_t ev_dw = nullptr;      // the side stream's reduction of the depthwise taps has left the rows buffer (scratch3)
     hipEvent_t ev_xt = nullptr;      // the weight-gradient reductions of a recompute block (side stream) have left xt_scratch
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_head = nullptr;
@@ -159,7 +160,6 @@ struct ams_student {
         if (side) (void)hipStreamDestroy(side);
         if (side2) (void)hipStreamDestroy(side2);
         if (ev_xt) (void)hipEventDestroy(ev_xt);
-        if (ev_dw) (void)hipEventDestroy(ev_dw);
     }
     float* scratch = nullptr; size_t scratch_floats = 0;
     float* tmp_c = nullptr;          // [1024] small per-channel temp
@@ -403,6 +403,8 @@ static int layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.a = cv.take<float>(e);
             l.da = cv.take<float>(e);
             if (l.d.residual_from) l.dzp = cv.take<float>(e);
+            if (l.d.role == AMS_ROLE_DEPTHWISE && l.d.stride == 1 && i >= 3 && l.d.cin <= 1024)
+                l.dw_rows = cv.take<float>(depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin));
         }
     }
     *bytes_out = (cv.off + 255) & ~(size_t)255;
@@ -1115,7 +1117,6 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     if (overlap && !s->ev_xt) {
         if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_xt, hipEventDisableTiming));
-        AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_dw, hipEventDisableTiming));
     }
     const bool three = overlap && s->overlap_wgrad >= 2 && s->scratch3;      // depthwise weight gradients on a third stream
     if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
@@ -1128,8 +1129,9 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     // where those rows are: the depthwise kernel's rows go to their own buffer when the side stream is there to reduce the nine taps
     // (they only feed the optimizer), so that the main stream's next user of s->scratch need not wait for that
     float* fused_buf = s->scratch;
-    float* const dw_rows = overlap && !three && s->scratch3 ? s->scratch3 : s->scratch;
-    bool dw_taps_pending = false;
+    // reductions that only feed the optimizer (depthwise taps, ...) are collected and run as ONE launch at the end of the pass: their partial
+    // rows stay in per-layer memory, so nothing on the way waits for them or signals them
+    ReduceJobs deferred;
     for (int i = s->n_backbone; i >= 1; --i) {
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
@@ -1151,15 +1153,9 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
                 RUN(launch_bn_bwd_coef(l.bsums, n_l, l.d.cout, P + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC, nullptr, nullptr, st));
             }
             // the depthwise layer's weight gradient came with the same rows (taps behind the two sums)
-            if (fused_dw && fused_buf != s->scratch) {
-                AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));                         // (the rows are complete: the kernel that wrote them is in front)
-                AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-                RUN(launch_reduce_splits(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, s->side, fused_stride));
-                AMS_CHECK_HIP(hipEventRecord(s->ev_dw, s->side));
-                dw_taps_pending = true;
-            } else if (fused_dw) {
+            if (fused_dw && !(fused_buf != s->scratch &&
+                              deferred.add(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, fused_stride)))
                 RUN(launch_reduce_splits(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st, fused_stride));
-            }
             RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
             fused_rows = 0;
         } else {
@@ -1173,6 +1169,13 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             const float* x = lin.a;
             int rows = 0;
             int64_t stride = 0;
+            if (overlap && deferred.n > 0) {
+                // the stride-16 blocks are behind us: their deferred reductions (80 MB of partial rows) run on the side stream under the early blocks
+                AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+                AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+                RUN(launch_reduce_batch(deferred, s->side));
+                deferred.n = 0;
+            }
             if (xt_pending) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0)); xt_pending = false; }     // xt_scratch is free again
             RUNK(i, 4.0 * ((double)B * (le.px_in * le.d.cin + l.px_out * l.d.cout)),
                  launch_xdw_bwd_reduce(x, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.d.cout, le.scale, le.shift, le.mean, le.rstd, le.d.act,
@@ -1250,15 +1253,14 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         }
         LayerRt& prev = s->L[i - 1];
         if (dw_fused_train(s, i, B)) {
-            if (dw_taps_pending) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_dw, 0)); dw_taps_pending = false; }       // the rows buffer is free again
             // input gradient + activation derivative + BN-backward sums of the expand layer + this layer's weight gradient in one kernel
             // (k_conv.hip): prev.da <- dy, partial rows in s->scratch until the next iteration's second stage
             RUNK(i, dw_bytes(l, B) + 4.0 * B * l.px_in * l.d.cin,
                  launch_depthwise_dgrad_bn(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, prev.z, prev.scale, prev.shift, prev.d.act, prev.mean,
-                                           prev.rstd, prev.da, dw_rows, &fused_rows, st));
+                                           prev.rstd, prev.da, l.dw_rows ? l.dw_rows : s->scratch, &fused_rows, st));
             fused_stride = 11 * (int64_t)l.d.cin;
             fused_dw = true;
-            fused_buf = dw_rows;
+            fused_buf = l.dw_rows ? l.dw_rows : s->scratch;
             continue;
         }
         hipStream_t wst = st;
@@ -1296,6 +1298,7 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
             if (red_rows > 0) { fused_rows = red_rows; fused_stride = 2 * (int64_t)l.d.cin; fused_dw = false; fused_buf = s->scratch; }
         }
     }
+    RUN(launch_reduce_batch(deferred, st));
     // the optimizer (and the gradient all-reduce) wait for every weight gradient
     if (xt_pending) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0));
     if (overlap) {                                     // everything either side stream still holds (events cover the last launch of each buffer only)

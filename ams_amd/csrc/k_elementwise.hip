@@ -544,6 +544,57 @@ __global__ __launch_bounds__(16 * LP) void reduce_splits_kernel(const float* __r
     }
 }
 
+// Several such reductions in ONE launch (the fine-tune step defers the reductions that only feed the optimizer to the end of its backward
+// pass: no launch, event or wait per layer).  Job j owns blocks [first_j, first_{j+1}); 64 lanes per output.
+template <int LP>
+__global__ __launch_bounds__(16 * LP) void reduce_batch_kernel(ReduceJobs jobs) {
+    __shared__ double sacc[LP][17];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;          // block-uniform
+    const float* part = jobs.part[j];
+    const int splits = jobs.splits[j];
+    const int64_t n = jobs.count[j], stride = jobs.stride[j];
+    const int64_t i = (int64_t)((int)blockIdx.x - jobs.first_block[j]) * 16 + (threadIdx.x & 15);
+    const int kpart = threadIdx.x >> 4;
+    double s = 0.0;
+    if (i < n) {
+        const float* p = part + i;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int k = kpart;
+        for (; k + 7 * LP < splits; k += 8 * LP) {
+            const float v0 = p[(int64_t)k * stride], v1 = p[(int64_t)(k + LP) * stride], v2 = p[(int64_t)(k + 2 * LP) * stride],
+                        v3 = p[(int64_t)(k + 3 * LP) * stride], v4 = p[(int64_t)(k + 4 * LP) * stride], v5 = p[(int64_t)(k + 5 * LP) * stride],
+                        v6 = p[(int64_t)(k + 6 * LP) * stride], v7 = p[(int64_t)(k + 7 * LP) * stride];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+        }
+        for (; k < splits; k += LP) s0 += p[(int64_t)k * stride];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    sacc[kpart][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && i < n) {
+        double t = 0.0;
+        for (int k = 0; k < LP; ++k) t += sacc[k][threadIdx.x];
+        jobs.out[j][i] = (float)t;
+    }
+}
+
+int launch_reduce_batch(ReduceJobs& jobs, hipStream_t st) {
+    if (jobs.n <= 0) return AMS_OK;
+    int total = 0, most = 0;
+    for (int j = 0; j < jobs.n; ++j) {
+        jobs.first_block[j] = total;
+        total += (int)cdiv(jobs.count[j], 16);
+        if (jobs.splits[j] > most) most = jobs.splits[j];
+    }
+    note_kernel("reduce_batch_kernel");
+    // 64 lanes per output only for long sums: with a few hundred rows the launch is bound by its thread count, not by its load chains
+    if (most >= 1024) hipLaunchKernelGGL((reduce_batch_kernel<64>), dim3(total), dim3(1024), 0, st, jobs);
+    else hipLaunchKernelGGL((reduce_batch_kernel<16>), dim3(total), dim3(256), 0, st, jobs);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st, int64_t stride) {
     if (splits >= 256) hipLaunchKernelGGL((reduce_splits_kernel<64>), dim3(cdiv(n, 16)), dim3(1024), 0, st, part, splits, n, out, stride > 0 ? stride : n);
     else hipLaunchKernelGGL((reduce_splits_kernel<16>), dim3(cdiv(n, 16)), dim3(256), 0, st, part, splits, n, out, stride > 0 ? stride : n);

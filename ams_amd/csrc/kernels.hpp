@@ -242,6 +242,18 @@ int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mas
                 float b2, float eps, hipStream_t st);
 // out[i] = sum_k part[k*n + i], k ascending (deterministic second stage of split reductions)
 // stride: floats between the partial rows (0 = n: dense)
+// up to 32 split reductions in one launch: out[j][i] = sum_k part[j][k * stride[j] + i], i < count[j], k < splits[j]
+struct ReduceJobs {
+    static constexpr int kMax = 32;
+    int n = 0;
+    const float* part[kMax]; float* out[kMax]; int splits[kMax]; int64_t count[kMax]; int64_t stride[kMax]; int first_block[kMax];
+    bool add(const float* p, int splits_, int64_t count_, float* o, int64_t stride_) {
+        if (n >= kMax) return false;
+        part[n] = p; splits[n] = splits_; count[n] = count_; out[n] = o; stride[n] = stride_ > 0 ? stride_ : count_; ++n;
+        return true;
+    }
+};
+int launch_reduce_batch(ReduceJobs& jobs, hipStream_t st);
 int launch_reduce_splits(const float* part, int splits, int64_t n, float* out, hipStream_t st, int64_t stride = 0);
 // the second (per-channel) stages of the BN reductions over partial rows [rows][2][C] produced elsewhere, row_stride floats apart
 int launch_bn_fwd_finalize_partials(const float* part, int rows, int64_t row_stride, int C, double* sums, double n, const float* center,

@@ -125,17 +125,15 @@ struct ams_student {
     float *pooled = nullptr, *pool_a = nullptr, *img_bias = nullptr;          // [B,cin_head], [B,256], [B,256]
     float *d_img_bias = nullptr, *d_pool_a = nullptr, *d_pool_z = nullptr, *d_pooled = nullptr;
     float* im2col = nullptr;         // [B*px1, 32]
-    float* dz = nullptr;             // scratch: gradient wrt a raw conv output, max layer size
+    float* dz = nullptr;             // head: gradient wrt a raw conv output, max layer size (the backbone writes dz in place, LayerRt::dzp)
     // Backward overlap: the weight gradient of a layer runs on a side stream beside the input gradient / BN backward chain of the
-    // main stream (it only feeds the optimizer).  dz alternates between two buffers so that the chain can move on, and the side
-    // stream has its own reduction scratch.
-    float* dz2 = nullptr;
+    // main stream (it only feeds the optimizer); the side stream has its own reduction scratch.
     float* scratch2 = nullptr;
     float* scratch3 = nullptr;       // depthwise weight gradients on their own stream (side2), AMS_OVERLAP_WGRAD=2
     hipStream_t side2 = nullptr;
     hipEvent_t ev_xt = nullptr;      // the weight-gradient reductions of a recompute block (side stream) have left xt_scratch
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_wg[2] = {nullptr, nullptr}, ev_head = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_head = nullptr;
     // Frozen inference as two half-batches on two streams (forward_frozen_dual).  AMS_OPT_DUAL_STREAM: 0 never, 1 (default) decided per
     // batch size by timing both plans inside the first call with that batch size (>= 16 frames), n >= 2 always from n frames on.
     // Whether it pays is a matter of grid quantisation: at 512x1024 it is +3.5 % at 32-36 frames and -1..-5 % at 24-30 and 40.
@@ -156,7 +154,6 @@ struct ams_student {
         for (auto& e : part_done) if (e) (void)hipEventDestroy(e);
         for (auto& t : part_stream) if (t) (void)hipStreamDestroy(t);
         if (ev_fork_dual) (void)hipEventDestroy(ev_fork_dual);
-        for (auto& e : ev_wg) if (e) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
         if (side2) (void)hipStreamDestroy(side2);
         if (ev_xt) (void)hipEventDestroy(ev_xt);
@@ -1110,8 +1107,8 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
     }
     // backbone, last layer to first.  A layer's weight gradient only feeds the optimizer: it runs on the side stream while the main
     // stream goes on with the input gradient and the next layer's BN backward (many of these kernels are latency-bound at 8 frames
-    // and share the chip well).  dz alternates between two buffers; the main stream waits for the weight gradient that read a
-    // buffer two layers ago before it overwrites it.
+    // and share the chip well).  Nothing the side stream reads is overwritten inside the step (dz lives in per-layer memory), so the main
+    // stream never waits for it before the final join.
     const bool overlap = s->overlap_wgrad && !s->prof.on && s->scratch2;
     if (overlap && !s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     if (overlap && !s->ev_xt) {
@@ -1136,8 +1133,8 @@ static int backward(ams_student* s, const void* frames, int dtype, const uint8_t
         LayerRt& l = s->L[i];
         const int64_t Mo = (int64_t)B * l.px_out;
         // dz of a layer lives in that layer's own memory (in place over da, or dzp): no buffer is reused inside a step, so the main stream
-        // never waits for a weight gradient (every hipStreamWaitEvent / hipEventRecord between two dependent kernels costs 5-9 us of queue
-        // processing on this stack: with two alternating dz buffers that was ~40 waits a step)
+        // never waits for a weight gradient (with two alternating dz buffers it did, ~40 times a step: 0.2 ms of real stalls behind
+        // weight gradients that sharing the chip had stretched)
         float* dz = l.dzp ? l.dzp : l.da;
         if (fused_rows > 0) {
             // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the

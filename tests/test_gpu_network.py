@@ -53,7 +53,8 @@ def _check_labels(got, oracle_logits_sel, tol):
 
 @pytest.mark.parametrize("H,B,matmul", [(64, 2, hip.MATMUL_F32), (48, 3, hip.MATMUL_F32), (64, 2, hip.MATMUL_SPLIT_BF16),
                                         (128, 2, hip.MATMUL_SPLIT_BF16), (64, 2, hip.MATMUL_SPLIT_BF16_X6),
-                                        (128, 3, hip.MATMUL_SPLIT_BF16_X6)])
+                                        (128, 3, hip.MATMUL_SPLIT_BF16_X6), (62, 3, hip.MATMUL_SPLIT_BF16_X6), (34, 5, hip.MATMUL_SPLIT_BF16_X6),
+                                        (50, 1, hip.MATMUL_SPLIT_BF16_X6)])
 def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     frames, labels = synth.SyntheticVideo(H, B, CI, seed=3).clip()
     eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)

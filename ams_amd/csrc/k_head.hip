@@ -192,7 +192,7 @@ template <int KMAX>
 __global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ logits, HeadGeom g, ClassTable ct,
                                                       const uint8_t* __restrict__ teacher,
                                                       const double* __restrict__ loss_and_count, float* __restrict__ dlogits,
-                                                      int ldd) {
+                                                      int ldd, float empty_val) {
     __shared__ float s_part[4][KMAX];
     const int j = blockIdx.x, i = blockIdx.y, b = blockIdx.z;
     const double nvalid = loss_and_count[1];
@@ -258,13 +258,14 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(const float* __restrict__ 
         if (c < 256) {
             const int k = ct.lut[c];
             if (k >= 0) v = (s_part[0][k] + s_part[1][k]) + (s_part[2][k] + s_part[3][k]);
+            if (k >= 0 && !(nvalid > 0.5)) v = empty_val;          // no valid pixel in the batch: 0, or the reference's 0 / 0 (AMS_OPT_NAN_GRADS)
         }
         out[c] = v;
     }
 }
 
 int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
-                   const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st) {
+                   const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st, float empty_val) {
     ClassTable ct;
     int rc = fill_class_table(cls, K, NC, &ct);
     if (rc) return rc;
@@ -274,11 +275,11 @@ int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32
     const dim3 grid(w, h, B);
     note_kernel(K <= 8 ? "ce_grad_kernel<8>" : K <= 20 ? "ce_grad_kernel<20>" : "ce_grad_kernel<32>");
     if (K <= 8)
-        hipLaunchKernelGGL(ce_grad_kernel<8>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd);
+        hipLaunchKernelGGL(ce_grad_kernel<8>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd, empty_val);
     else if (K <= 20)
-        hipLaunchKernelGGL(ce_grad_kernel<20>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd);
+        hipLaunchKernelGGL(ce_grad_kernel<20>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd, empty_val);
     else
-        hipLaunchKernelGGL(ce_grad_kernel<32>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd);
+        hipLaunchKernelGGL(ce_grad_kernel<32>, grid, dim3(256), 0, st, logits, g, ct, teacher, loss_and_count, dlogits, ldd, empty_val);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -431,7 +432,8 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
 template <int KMAX>
 __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ partT, const float* __restrict__ partB, int64_t cells,
                                                          int w_cells, int h_cells, ClassTable ct, int K,
-                                                         const double* __restrict__ loss_and_count, float* __restrict__ dlogits, int ldd) {
+                                                         const double* __restrict__ loss_and_count, float* __restrict__ dlogits, int ldd,
+                                                         float empty_val) {
     const double nvalid = loss_and_count[1];
     const float inv_n = nvalid > 0.5 ? (float)(1.0 / nvalid) : 0.f;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < cells * ldd; e += (int64_t)gridDim.x * blockDim.x) {
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict
             const int i = (int)((cell / w_cells) % h_cells);
             const float t = partT[cell * KMAX + k];
             v = (i > 0 ? t + partB[cell * KMAX + k] : t) * inv_n;          // row 0 has no band above it
+            if (!(nvalid > 0.5)) v = empty_val;                             // no valid pixel: 0, or the reference's 0 / 0 (AMS_OPT_NAN_GRADS)
         }
         dlogits[e] = v;
     }
@@ -481,7 +484,7 @@ int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const 
 
 // pass 2 (after the valid-pixel count is final, i.e. after its cross-rank sum in a data-parallel step)
 int launch_ce_combine(int B, int h, int w, const int32_t* cls, int K, int NC, const double* loss_and_count, const float* scratch,
-                      float* dlogits, int ldd, hipStream_t st) {
+                      float* dlogits, int ldd, hipStream_t st, float empty_val) {
     ClassTable ct;
     int rc = fill_class_table(cls, K, NC, &ct);
     if (rc) return rc;
@@ -491,9 +494,9 @@ int launch_ce_combine(int B, int h, int w, const int32_t* cls, int K, int NC, co
     const float* partT = scratch;
     const float* partB = scratch + (size_t)cells * KM;
     const int grid = (int)(cdiv64(cells * ldd, 256) < 2048 ? cdiv64(cells * ldd, 256) : 2048);
-    if (KM == 8) hipLaunchKernelGGL(ce_combine_kernel<8>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd);
-    else if (KM == 20) hipLaunchKernelGGL(ce_combine_kernel<20>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd);
-    else hipLaunchKernelGGL(ce_combine_kernel<32>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd);
+    if (KM == 8) hipLaunchKernelGGL(ce_combine_kernel<8>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd, empty_val);
+    else if (KM == 20) hipLaunchKernelGGL(ce_combine_kernel<20>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd, empty_val);
+    else hipLaunchKernelGGL(ce_combine_kernel<32>, dim3(grid), dim3(256), 0, st, partT, partB, cells, w, h, ct, K, loss_and_count, dlogits, ldd, empty_val);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

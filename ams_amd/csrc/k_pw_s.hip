@@ -112,7 +112,7 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     note_kernel(nm.c_str());
     PwArgs b = a;
     if (b.red_mode) {
-        if (EPI == EPI_PLAIN && pw_red_ok(b)) { if (b.red_rows_out) *b.red_rows_out = (int)blocks; }
+        if (EPI == EPI_PLAIN && pw_red_ok(b, blocks)) { if (b.red_rows_out) *b.red_rows_out = (int)blocks; }
         else { b.red_mode = 0; if (b.red_rows_out) *b.red_rows_out = 0; }
     }
     hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT, EPI>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, b, n_tiles_n, n_groups);

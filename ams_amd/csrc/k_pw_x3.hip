@@ -314,7 +314,7 @@ static int launch_pw_x3_d(const PwArgs& a, const SplitPanels& w, int Kp, hipStre
     const int64_t nblocks = n_full + half_strips * n_tiles_n;
     PwArgs b = a;
     if (b.red_mode) {
-        if (EPI == EPI_PLAIN && pw_red_ok(b)) { if (b.red_rows_out) *b.red_rows_out = (int)(nblocks / n_tiles_n); }
+        if (EPI == EPI_PLAIN && pw_red_ok(b, nblocks / n_tiles_n)) { if (b.red_rows_out) *b.red_rows_out = (int)(nblocks / n_tiles_n); }
         else { b.red_mode = 0; if (b.red_rows_out) *b.red_rows_out = 0; }
     }
     // the kernel's own symbol (rocprofv3 reports the same text); NP = 3 is the six-product "x6" training variant
@@ -342,7 +342,7 @@ static int launch_pw_x3(const PwArgs& a, const SplitPanels& w, int Kp, hipStream
         // computes) ahead of the mask and the sums, and the plain epilogue stores the total
         PwArgs b = a;
         b.red_res = a.res; b.red_ldr = a.ldr; b.res = nullptr;
-        if (pw_red_ok(b)) return launch_pw_x3_e<RM, NT, EPI_PLAIN>(b, w, Kp, st);
+        if (pw_red_ok(b, cdiv64(b.M, 32) + 2)) return launch_pw_x3_e<RM, NT, EPI_PLAIN>(b, w, Kp, st);      // (upper bound of the strips: the exact count is checked again at launch)
     }
     switch (pw_pick_epi(a)) {
         case EPI_PLAIN: return launch_pw_x3_e<RM, NT, EPI_PLAIN>(a, w, Kp, st);

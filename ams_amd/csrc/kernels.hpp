@@ -65,6 +65,7 @@ struct PwArgs {
     const float* red_z; const float* red_scale; const float* red_shift; const float* red_mean; const float* red_rstd;
     int red_act;
     float* red_part;
+    size_t red_part_floats;    // capacity of red_part: a launch whose partial rows would not fit runs WITHOUT the fused reduction (*red_rows_out = 0)
     int* red_rows_out;
     // set by the split-bf16 launcher only (mode 2 with a residual operand: the residual moves here and the plain epilogue runs)
     const float* red_res; int red_ldr;
@@ -274,15 +275,17 @@ int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* o
 int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
                            const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st, int per_frame = 0);
 int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
-                   const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st);
+                   const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st, float empty_val = 0.f);
 // loss + gradient in one pass (fine-tune step): pass 1 leaves the CE sum / valid count in loss[2] and the unnormalised gradient in
 // scratch (ce_loss_grad_scratch floats); pass 2 scales by 1 / count (after its cross-rank sum) and writes dlogits [B*h*w, ldd]
 bool ce_loss_grad_supported(int w, int W);
 size_t ce_loss_grad_scratch(int B, int h, int w, int K);
 int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W, const uint8_t* teacher,
                         int NC, double* loss, float* scratch, hipStream_t st);
+// empty_val: every selected class's gradient when NO pixel of the (global) batch is valid: 0, or NaN = the reference's 0 / 0
+// (utils/graph_utils.py:408: loss = sum(w ce) / sum(w))
 int launch_ce_combine(int B, int h, int w, const int32_t* cls, int K, int NC, const double* loss_and_count, const float* scratch,
-                      float* dlogits, int ldd, hipStream_t st);
+                      float* dlogits, int ldd, hipStream_t st, float empty_val = 0.f);
 int launch_cross_confusion(const uint8_t* a, const uint8_t* b, int64_t n, const int32_t* lut /*[256] -> subset idx or -1*/,
                            int K, int64_t* conf, hipStream_t st);
 

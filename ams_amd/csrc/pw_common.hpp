@@ -281,8 +281,8 @@ __device__ __forceinline__ void pw_red_finish(const PwArgs& a, float4 (&s1)[NT],
 }
 
 // the fused reduction needs a plain vector epilogue: the value reduced is the raw product
-static inline bool pw_red_ok(const PwArgs& a) {
-    return a.red_mode != 0 && a.red_part && !a.scale && !a.shift && !a.img_bias && !a.res && a.act == AMS_ACT_NONE && a.N % 4 == 0 && a.ldy % 4 == 0 &&
+static inline bool pw_red_ok(const PwArgs& a, int64_t rows) {
+    return a.red_mode != 0 && a.red_part && (size_t)rows * 2 * (size_t)a.N <= a.red_part_floats && !a.scale && !a.shift && !a.img_bias && !a.res && a.act == AMS_ACT_NONE && a.N % 4 == 0 && a.ldy % 4 == 0 &&
            a.N >= 4;
 }
 

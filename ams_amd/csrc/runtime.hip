@@ -27,22 +27,22 @@ bool launch_table_needs_attr(int device, const void* fn, size_t lds) {
     return true;
 }
 
-void launch_table_forget(int device, const void* fn) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_attr.erase({device, fn});
-}
-
+// The grant is recorded only AFTER hipFuncSetAttribute succeeded, and the mutex is held across the call: a second host thread that
+// launches the same kernel meanwhile (server and edge students of one process) waits here instead of seeing "already set" and
+// launching with more dynamic LDS than the function is allowed yet.
 int func_allow_lds(const void* fn, size_t lds) {
     if (lds <= 64 * 1024) return AMS_OK;
     int dev = 0;
     AMS_CHECK_HIP(hipGetDevice(&dev));
-    if (!launch_table_needs_attr(dev, fn, lds)) return AMS_OK;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_attr.find({dev, fn});
+    if (it != g_attr.end() && lds <= it->second) return AMS_OK;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
-        launch_table_forget(dev, fn);                    // not set: the next launch must try again
         set_error("hipFuncSetAttribute(dynamic LDS %zu) -> %s", lds, hipGetErrorString(e));
         return AMS_E_HIP;
     }
+    g_attr[{dev, fn}] = lds;
     return AMS_OK;
 }
 

@@ -7,6 +7,7 @@ an engine without a GPU or without the built library raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -17,6 +18,16 @@ from .spec import (BN_DECAY, BN_EPS_FROZEN, PIXEL_SCALE, Layer, StudentSpec, bui
 from . import weights as W
 
 _ACT = {"none": hip.ACT_NONE, "relu": hip.ACT_RELU, "relu6": hip.ACT_RELU6}
+
+# Tuning knobs of tools/*.sh and the profiling recipes: environment variable -> ams_student_set_option id.  They are read HERE, once per
+# engine, and applied through the one documented option entry point; the library itself reads no per-student environment.
+_ENV_OPTIONS = {
+    "AMS_DUAL_STREAM": hip.OPT_DUAL_STREAM, "AMS_DUAL_PARTS": hip.OPT_DUAL_PARTS, "AMS_DUAL_AUTOTUNE": hip.OPT_DUAL_AUTOTUNE,
+    "AMS_BLOCK_X6": hip.OPT_BLOCK_X6, "AMS_LATE_SUB": hip.OPT_LATE_SUBBATCH, "AMS_STREAM_MIN_ROWS": hip.OPT_STREAM_MIN_ROWS,
+    "AMS_OVERLAP_HEAD": hip.OPT_OVERLAP_HEAD, "AMS_FUSE_BLOCK": hip.OPT_FUSE_BLOCK, "AMS_FUSE_XDS": hip.OPT_FUSE_EXPAND_DW_STREAM,
+    "AMS_OVERLAP_WGRAD": hip.OPT_OVERLAP_WGRAD, "AMS_FUSE_DGRAD_BN": hip.OPT_FUSE_DGRAD_BN, "AMS_FUSE_GEMM_RED": hip.OPT_FUSE_GEMM_RED,
+    "AMS_TRAIN_RECOMPUTE": hip.OPT_TRAIN_RECOMPUTE, "AMS_NAN_GRADS": hip.OPT_NAN_GRADS,
+}
 
 
 def _role(layer: Layer) -> int:
@@ -112,6 +123,9 @@ class StudentEngine:
         self._out_dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self._out_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
         self._keepalive = []
+        for name, opt in _ENV_OPTIONS.items():
+            if name in os.environ:
+                hip.check(self.lib.ams_student_set_option(self._h, opt, int(os.environ[name])), "ams_student_set_option(%s)" % name)
 
     # ------------------------------------------------------------------ plumbing
     def _view(self, region: int, dtype: torch.dtype) -> torch.Tensor:
@@ -216,6 +230,11 @@ class StudentEngine:
             hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_GEMM_RED, int(fuse_gemm_red)), "ams_student_set_option")
         if fuse_dgrad_bn is not None:
             hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DGRAD_BN, 2 if fuse_dgrad_bn is True else int(fuse_dgrad_bn)), "ams_student_set_option")
+
+    def set_nan_grads(self, on: bool) -> None:
+        """A fine-tune batch without one valid pixel: True (default) NaN loss and NaN gradients like the reference's 0 / 0
+        (utils/graph_utils.py:408); False NaN loss but zero gradients (the weights survive)."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_NAN_GRADS, int(bool(on))), "ams_student_set_option")
 
     def set_fuse_first_block(self, on: int) -> None:
         """Frozen inference, stem + depthwise + project of the first block: 0 three kernels, 1 one kernel with a tile per block

@@ -13,7 +13,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libams_hip.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums of include/ams_hip.h
 ROLE_STEM, ROLE_EXPAND, ROLE_DEPTHWISE, ROLE_PROJECT, ROLE_POOL_CONV, ROLE_ASPP, ROLE_CONCAT_PROJ, ROLE_LOGITS = range(8)
@@ -36,6 +36,10 @@ OPT_FUSE_GEMM_RED = 17
 OPT_EMULATE_BF16_STORAGE = 15
 OPT_DUAL_AUTOTUNE = 12
 OPT_DUAL_PARTS = 13
+OPT_NAN_GRADS = 18
+OPT_OVERLAP_WGRAD = 19
+OPT_OVERLAP_HEAD = 20
+OPT_STREAM_MIN_ROWS = 21
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)

@@ -191,9 +191,16 @@ class SemanticNetwork(object):
     def _mode(self) -> int:
         return hip.MODE_FROZEN if self.frozen else hip.MODE_LIVE
 
+    def _drain_async(self):
+        """A synchronous call shares the engine's one output block with the asynchronous edge pipeline: a pass that is still on the GPU is
+        fetched first, so that ``collect`` later returns ITS metrics and not this call's."""
+        if self.frozen and self._pending:
+            self._fetch_pending()
+
     def predict_input(self, frames):
         self.process_lock.acquire()
         try:
+            self._drain_async()
             labels_ = self.engine.predict_host(frames, self._mode())
             assert labels_.shape == tuple(frames.shape[:-1] if hasattr(frames, 'shape') else np.shape(frames)[:-1])
         finally:
@@ -217,6 +224,7 @@ class SemanticNetwork(object):
     def predict_with_metric(self, frames, labels_teacher):
         self.process_lock.acquire()
         try:
+            self._drain_async()
             # one device -> host copy for labels + confusion matrix + loss (they share one preallocated output block)
             labels_student, conf_i64, ls = self.engine.predict_with_metric_host(frames, labels_teacher, self._mode())
             conf_mat_ = conf_i64.astype(np.float64)
@@ -429,7 +437,9 @@ class SemanticNetwork(object):
         labels = list(label_deque) if isinstance(label_deque, deque) else label_deque
         crop = [self.height, self.height * 2]
         fast = (list(self.scale) == [1] and all(f.shape[:2] == tuple(crop) for f in frames))
+        fast = fast and all(f.dtype == np.uint8 for f in frames) and all(l.dtype == np.uint8 and l.shape == tuple(crop) for l in labels)
         for _ in range(number_of_batches):
+            slot = None
             if fast:
                 picks = []
                 for _j in range(self.mini_batch_size):
@@ -437,14 +447,39 @@ class SemanticNetwork(object):
                     random.randint(0, 0)      # scale choice
                     random.randint(0, 0)      # row offset  (slack is 0 when the frame already has the crop size)
                     random.randint(0, 0)      # column offset
-                image_batch = np.stack([frames[p] for p in picks])
-                label_batch = np.stack([labels[p] for p in picks])
+                # gathered straight into a pinned staging slot: one host copy per frame, none per batch (a fresh pin_memory() per batch
+                # costs a page-lock of 12-16 MB each time)
+                slot = self._staging_slot()
+                image_batch, label_batch = slot[0].numpy(), slot[1].numpy()
+                for j, p in enumerate(picks):
+                    image_batch[j] = frames[p]
+                    label_batch[j] = labels[p]
             else:
                 ib, lb = mini_batch(frames, labels, crop, self.scale, self.mini_batch_size, 1, flip=False)
                 image_batch, label_batch = ib[0], lb[0]
             assert np.shape(label_batch) == (self.mini_batch_size, self.height, self.height * 2)
             assert np.shape(image_batch) == (self.mini_batch_size, self.height, self.height * 2, 3)
-            batch_deque.append({'frames': image_batch, 'labels': label_batch})
+            batch_deque.append({'frames': image_batch, 'labels': label_batch, 'slot': slot})
+
+    def _staging_slot(self):
+        """Next slot of a small ring of pinned host buffers [mini_batch, H, 2H, 3] / [mini_batch, H, 2H] uint8 (created on first use).  A slot
+        is handed out again only after the stager has issued the H2D copy that reads it AND that copy has finished (its event): the sampler runs
+        at most four batches ahead of the copies."""
+        ring = getattr(self, "_staging", None)
+        if ring is None:
+            shape = (self.mini_batch_size, self.height, 2 * self.height)
+            ring = self._staging = {"next": 0, "slots": [
+                [torch.empty(shape + (3,), dtype=torch.uint8).pin_memory(), torch.empty(shape, dtype=torch.uint8).pin_memory(), None, False]
+                for _ in range(4)]}
+        slot = ring["slots"][ring["next"] % len(ring["slots"])]
+        ring["next"] += 1
+        while slot[3] and slot[2] is None:        # handed out earlier and still waiting in the batch deque for the stager
+            time.sleep(self.THREAD_SLEEP_INTERVAL)
+        if slot[2] is not None:
+            slot[2].synchronize()
+            slot[2] = None
+        slot[3] = True
+        return slot
 
     def _fill_queue(self, batch_deque, number_of_batches, signal_deque):
         """Stager thread (the FIFO queue of the reference graph, capacity 200): H2D on a side stream."""
@@ -457,17 +492,26 @@ class SemanticNetwork(object):
                     batch = batch_deque.popleft()
                 except IndexError:
                     time.sleep(self.THREAD_SLEEP_INTERVAL)
-            fr = batch['frames']
-            fr = fr if fr.dtype == np.uint8 else fr.astype(np.float32)
-            lb = batch['labels']
-            if lb.dtype != np.uint8:
-                li = lb.astype(np.float32).astype(np.int64)
-                lb = np.where((li >= 0) & (li < 255), li, 255).astype(np.uint8)
-            with torch.cuda.stream(copy_stream):
-                f_dev = torch.from_numpy(np.ascontiguousarray(fr)).pin_memory().to(dev, non_blocking=True)
-                l_dev = torch.from_numpy(np.ascontiguousarray(lb)).pin_memory().to(dev, non_blocking=True)
-                ready = torch.cuda.Event()
-                ready.record(copy_stream)
+            slot = batch.get('slot')
+            if slot is not None:              # already in pinned memory (_fill_batch's fast path)
+                with torch.cuda.stream(copy_stream):
+                    f_dev = slot[0].to(dev, non_blocking=True)
+                    l_dev = slot[1].to(dev, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(copy_stream)
+                slot[2] = ready
+            else:
+                fr = batch['frames']
+                fr = fr if fr.dtype == np.uint8 else fr.astype(np.float32)
+                lb = batch['labels']
+                if lb.dtype != np.uint8:
+                    li = lb.astype(np.float32).astype(np.int64)
+                    lb = np.where((li >= 0) & (li < 255), li, 255).astype(np.uint8)
+                with torch.cuda.stream(copy_stream):
+                    f_dev = torch.from_numpy(np.ascontiguousarray(fr)).pin_memory().to(dev, non_blocking=True)
+                    l_dev = torch.from_numpy(np.ascontiguousarray(lb)).pin_memory().to(dev, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(copy_stream)
             while len(signal_deque) >= 200:
                 time.sleep(self.THREAD_SLEEP_INTERVAL)
             signal_deque.append((f_dev, l_dev, ready))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AMS_ABI_VERSION 2
+#define AMS_ABI_VERSION 3
 
 enum {
     AMS_OK = 0,
@@ -201,7 +201,15 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_DUAL_AUTOTUNE = 12 /* with AMS_OPT_DUAL_STREAM = 1: 1 = pick the number of parts per batch size by TIMING the plans inside the first call
+enum { AMS_OPT_NAN_GRADS = 18 /* fine-tune step on a batch WITHOUT a valid pixel: 1 (default) the reference's result — loss = 0 / 0 and every gradient
+                                  NaN (utils/graph_utils.py:408: sum(w ce) / sum(w)), so the Adam update poisons the masked parameters exactly as
+                                  TensorFlow's would; 0 = NaN loss but zero gradients (the weights survive) */,
+       AMS_OPT_OVERLAP_WGRAD = 19 /* fine-tune step: 1 (default) weight gradients on a side stream beside the input-gradient chain, 2 depthwise ones on a
+                                     third stream (measured slower), 0 everything on the caller's stream.  Same bits */,
+       AMS_OPT_OVERLAP_HEAD = 20 /* frozen inference: 1 = the image-pooling branch on a side stream beside the aspp0 GEMM; 0 (default): measured slower */,
+       AMS_OPT_STREAM_MIN_ROWS = 21 /* frozen inference: rows (frames x pixels at the block's resolution) from which the streaming expand+depthwise
+                                       kernels run (default 16384) */,
+       AMS_OPT_DUAL_AUTOTUNE = 12 /* with AMS_OPT_DUAL_STREAM = 1: 1 = pick the number of parts per batch size by TIMING the plans inside the first call
                                       with that batch size (median of three passes each; that call synchronises the host and its result then depends
                                       on which plan won); 0 (default) = the static rule: the same call always runs the same plan */,
        AMS_OPT_DUAL_PARTS = 13 /* parts (2 .. 4) of the forced split, AMS_OPT_DUAL_STREAM = n >= 2 */,

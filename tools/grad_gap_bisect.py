@@ -1,0 +1,85 @@
+"""Which kernel owns the head-gradient gap?  (aspp0/weights 2.8e-3 from f64 where an f32 CPU evaluation is 9.5e-5.)
+
+Runs ONE fine-tune step of the smoke configuration (64x128, 2 frames; also 4 frames / other seeds on request) under every switch the
+engine has, and prints for each form the max-norm and L2 errors of the gradient tensors vs the f64 oracle beside the f32 CPU oracle's own
+errors: the tensor named, and the five worst HIP / f32-CPU ratios among the tensors whose f32-CPU error is below 1e-3 (the well-conditioned
+ones, where a ratio far above 1 is a kernel's arithmetic and not the graph's noise).
+
+    python tools/grad_gap_bisect.py [H=64] [B=2] [seed=0] [tensor=aspp0/weights:0]
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from ams_amd import hip, spec, synth, weights  # noqa: E402
+from ams_amd.engine import StudentEngine  # noqa: E402
+from oracle.student_torch import StudentOracle  # noqa: E402
+
+CI = [0, 1, 2, 10, 11, 13]
+
+
+def errors(spec_, g, grads_ref):
+    """per tensor: (max-norm error / max |want|, L2 error / ||want||)"""
+    out = {}
+    for v in spec_.trainable:
+        want = grads_ref[v.name].numpy().reshape(-1).astype(np.float64)
+        got = g[v.name] if isinstance(g, dict) else g[v.offset:v.offset + v.size]
+        got = np.asarray(got, dtype=np.float64).reshape(-1)
+        mx = np.abs(want).max()
+        out[v.name] = (np.abs(got - want).max() / max(mx, 1e-30), np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+    return out
+
+
+def main():
+    H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    name = sys.argv[4] if len(sys.argv) > 4 else "aspp0/weights:0"
+    sp = spec.build_spec()
+    W0 = weights.synthetic_weights(sp, seed=seed)
+    frames, labels = synth.SyntheticVideo(H, B, CI, seed=7 + seed).clip()
+    fr32 = frames.astype(np.float32)
+    _, g64 = StudentOracle(W0, CI, dtype=torch.float64).gradients(fr32, labels)
+    _, g32 = StudentOracle(W0, CI).gradients(fr32, labels)
+    e32 = errors(sp, {k: v.numpy() for k, v in g32.items()}, g64)
+    print("f32 CPU oracle: %s max-norm %.2e  L2 %.2e" % (name, *e32[name]))
+
+    forms = [
+        ("default", {}),
+        ("fuse_gemm_red=0", {"gemm_red": 0}),
+        ("fuse_gemm_red=1 (fwd stats only)", {"gemm_red": 1}),
+        ("fuse_gemm_red=2 (bwd sums only)", {"gemm_red": 2}),
+        ("fuse_dgrad_bn=0", {"dgrad_bn": 0}),
+        ("train_recompute=0", {"recompute": 0}),
+        ("matmul f32", {"matmul": hip.MATMUL_F32}),
+        ("layer-wise (recompute 0, dgrad_bn 0, gemm_red 0)", {"recompute": 0, "dgrad_bn": 0, "gemm_red": 0}),
+        ("layer-wise + matmul f32", {"recompute": 0, "dgrad_bn": 0, "gemm_red": 0, "matmul": hip.MATMUL_F32}),
+        ("layer-wise + matmul f32 + one stream", {"recompute": 0, "dgrad_bn": 0, "gemm_red": 0, "matmul": hip.MATMUL_F32, "overlap": 0}),
+    ]
+    well = [v.name for v in sp.trainable if e32[v.name][1] < 1e-3]
+    print("%d of %d tensors have an f32-CPU L2 error < 1e-3" % (len(well), len(sp.trainable)))
+    for tag, opt in forms:
+        eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+        eng.load_variables(W0)
+        eng.set_train_recompute(bool(opt.get("recompute", 1)), fuse_dgrad_bn=opt.get("dgrad_bn", 2), fuse_gemm_red=opt.get("gemm_red", 3))
+        if "matmul" in opt:
+            eng.set_matmul_mode(opt["matmul"])
+        if "overlap" in opt:
+            hip.check(eng.lib.ams_student_set_option(eng._h, hip.OPT_OVERLAP_WGRAD, opt["overlap"]))
+        eng.train_step(frames, labels, 1e-3)
+        g = eng.grads.cpu().numpy().astype(np.float64)
+        eg = errors(sp, g, g64)
+        ratios = sorted(((eg[n][1] / max(e32[n][1], 1e-12), n) for n in well), reverse=True)[:5]
+        print("%-52s %s max-norm %.2e (x%.1f)  L2 %.2e (x%.1f) | worst ratios among well-conditioned: %s"
+              % (tag, name, eg[name][0], eg[name][0] / e32[name][0], eg[name][1], eg[name][1] / e32[name][1],
+                 ", ".join("%s x%.1f (%.1e)" % (n.replace("MobilenetV2/", "").replace(":0", ""), r, eg[n][1]) for r, n in ratios)))
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,6 +99,17 @@ int ams_student_lowres_size(const ams_student* s, int32_t* h, int32_t* w) {
     return AMS_OK;
 }
 
+int ams_student_layer_tensor(const ams_student* s, int32_t layer, int32_t which, size_t* offset_bytes, size_t* n_elems) {
+    AMS_REQUIRE(s && offset_bytes && n_elems, "layer_tensor: null pointer");
+    AMS_REQUIRE(layer >= 1 && layer <= s->cfg.n_layers && which >= 0 && which <= 3, "layer_tensor: layer %d / which %d out of range", layer, which);
+    const LayerRt& l = s->L[layer];
+    const float* p = which == 0 ? l.z : which == 1 ? l.a : which == 2 ? l.da : (l.dzp ? l.dzp : l.da);
+    if (!p) { set_error("layer_tensor: layer %d has no such tensor (trainable=%d)", layer, s->cfg.trainable); return AMS_E_STATE; }
+    *offset_bytes = (size_t)((const char*)p - s->arena);
+    *n_elems = (size_t)s->cfg.max_batch * l.px_out * l.d.cout;
+    return AMS_OK;
+}
+
 int ams_student_freeze(ams_student* s, void* stream) {
     AMS_REQUIRE(s, "freeze: null student");
     hipStream_t st = (hipStream_t)stream;
@@ -255,6 +266,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     }
     if (option == AMS_OPT_TRAIN_RECOMPUTE) {
         s->train_recompute = value != 0;
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_FUSE_OPERAND_BN) {
+        s->fuse_operand_bn = value & 7;
         return AMS_OK;
     }
     if (option == AMS_OPT_NAN_GRADS) {
@@ -534,6 +549,37 @@ int ams_k_pointwise_red(const float* x, int64_t M, int32_t K, const float* w, in
     }
     *rows_out = rows;
     return rc;
+}
+
+int ams_k_pointwise_xform(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w, int32_t split, int32_t x_mode,
+                          int32_t x_act, const float* v0, const float* v1, const float* v2, const float* x2, float* y, float* x_tmp,
+                          uint16_t* panels, size_t panel_elems, void* stream) {
+    AMS_REQUIRE(x && w && y && v0 && v1 && (x_mode == 1 || (x_mode == 2 && v2 && x2)), "pointwise_xform: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    PwArgs a = pw_args(x, M, K, K, w, N, y, N);
+    if (trans_w) { a.w_sk = 1; a.w_sn = K; }
+    a.x_mode = x_mode; a.x_act = x_act; a.x_v0 = v0; a.x_v1 = v1; a.x_v2 = v2; a.x2 = x2; a.x_tmp = x_tmp;
+    if (split) {
+        const int Kp = (K + 31) / 32 * 32;
+        const size_t plane = (size_t)N * Kp;
+        AMS_REQUIRE(panels && panel_elems >= 3 * plane && K % 8 == 0, "pointwise_xform: panel scratch too small (need %zu) or K %% 8", 3 * plane);
+        RUN(launch_split_weights3(w, a.w_sk, a.w_sn, K, N, Kp, panels, panels + plane, panels + 2 * plane, st));
+        return launch_pointwise_split3(a, panels, panels + plane, panels + 2 * plane, Kp, st);
+    }
+    return launch_pointwise(a, st);
+}
+
+int ams_k_pointwise_wgrad_xform(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, int32_t split, int32_t x_mode, int32_t x_act,
+                                const float* v0, const float* v1, int32_t dy_mode, const float* d0, const float* d1, const float* d2,
+                                const float* dy2, float* dw, float* scratch, size_t scratch_floats, void* stream) {
+    AMS_REQUIRE(x && dy && dw && scratch, "pointwise_wgrad_xform: null pointer");
+    if (split && !pointwise_wgrad_x6_applies(M, K, N, K, N)) { set_error("pointwise_wgrad_xform: shape M=%lld K=%d N=%d outside the split kernel", (long long)M, K, N); return AMS_E_INVALID; }
+    WgArgs a;
+    a.x = x; a.ldx = K; a.K = K; a.dy = dy; a.ldy = N; a.N = N; a.M = M; a.dw = dw; a.scratch = scratch; a.scratch_floats = scratch_floats;
+    a.allow_split = split != 0;
+    a.x_mode = x_mode; a.x_act = x_act; a.x_v0 = v0; a.x_v1 = v1;
+    a.dy_mode = dy_mode; a.dy_v0 = d0; a.dy_v1 = d1; a.dy_v2 = d2; a.dy2 = dy2;
+    return launch_pointwise_wgrad(a, (hipStream_t)stream);
 }
 
 size_t ams_k_depthwise3x3_fwd_bn_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate) { return depthwise_fwd_bn_scratch(B, H, W, C, rate); }

@@ -104,6 +104,9 @@ struct ams_student {
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
     int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
     int fuse_gemm_red = 3;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics, bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
+    int fuse_operand_bn = 3;           // fine-tune step: elementwise BN passes folded into the operand loads of the consuming 1x1 GEMMs / weight-gradient kernels
+                                       // (AMS_OPT_FUSE_OPERAND_BN): bit 0 BN + activation of a depthwise layer (a_d is never written), bit 1 dz of a project layer
+                                       // (A dy + B + C z formed by its input-gradient GEMM and its weight gradient), bit 2 the same for the stride-16 expand layers
     int fuse_dgrad_bn = 2;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
@@ -234,6 +237,7 @@ bool train_recompute_block(const ams_student* s, int i);
 bool dw_fused_train(const ams_student* s, int i, int B);
 bool stem_fused_train(const ams_student* s);
 bool dw_fused_train_fwd(const ams_student* s, int i, int B);
+bool operand_bn_act(const ams_student* s, int i);      // depthwise layer i: its BN + activation is applied by the project layer's GEMM and weight gradient on their loads of z
 size_t red_rows_bound(int64_t M);
 int check_call(const ams_student* s, const void* frames, int dtype, int batch);
 int run_forward(ams_student* s, const void* frames, int dtype, int batch, int mode, hipStream_t st);

@@ -8,8 +8,9 @@ namespace ams {
 // backward + update
 // =======================================================================================================
 // BN backward of layer l given da (gradient wrt the layer's activated output): writes dz into s->dz, dgamma/dbeta into grads
+// apply == false: only the sums and the coefficients (A, B, C): the layer's consumers form dz = A dy + B + C z on their operand loads
 static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_local, double n_global, const SyncCtx* sc,
-                       hipStream_t st, float* dz = nullptr) {
+                       hipStream_t st, float* dz = nullptr, bool apply = true) {
     if (!dz) dz = s->dz;
     if (!sc || !sc->cb) {
         RUNK(0, 8.0 * M_local * l.d.cout,
@@ -25,17 +26,22 @@ static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_lo
         RUN(launch_bn_bwd_coef(l.bsums, n_global, l.d.cout, s->params + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC,
                                nullptr, nullptr, st));
     }
+    if (!apply) return AMS_OK;
     RUNK(0, 12.0 * M_local * l.d.cout,
          launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, dz, st));
     return AMS_OK;
 }
 
+// xa: the layer whose BN + activation the x operand still needs (x = its raw output z); dl: the layer whose dz the dy operand stands for
+// (dy = the gradient wrt its BN output, masked already where it has an activation) — WgArgs x_mode 1 / dy_mode 2
 static int pw_wgrad(ams_student* s, const float* x, int ldx, int K, const float* dy, int ldy, int N, int64_t M, float* dw,
-                    hipStream_t st, float* scratch = nullptr) {
+                    hipStream_t st, float* scratch = nullptr, const LayerRt* xa = nullptr, const LayerRt* dl = nullptr) {
     WgArgs a;
     a.x = x; a.ldx = ldx; a.K = K; a.dy = dy; a.ldy = ldy; a.N = N; a.M = M; a.dw = dw;
     a.scratch = scratch ? scratch : s->scratch; a.scratch_floats = s->scratch_floats;
     a.allow_split = s->matmul_mode != AMS_MATMUL_F32;
+    if (xa) { a.x = xa->z; a.x_mode = 1; a.x_act = xa->d.act; a.x_v0 = xa->scale; a.x_v1 = xa->shift; }
+    if (dl) { a.dy = dy; a.dy_mode = 2; a.dy_v0 = dl->cA; a.dy_v1 = dl->cB; a.dy_v2 = dl->cC; a.dy2 = dl->z; }
     RUNK(0, 4.0 * ((double)M * (K + N) + (double)K * N), launch_pointwise_wgrad(a, st));
     return AMS_OK;
 }
@@ -144,6 +150,11 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         // never waits for a weight gradient (with two alternating dz buffers it did, ~40 times a step: 0.2 ms of real stalls behind
         // weight gradients that sharing the chip had stretched)
         float* dz = l.dzp ? l.dzp : l.da;
+        // this layer's dz is not written: its input-gradient GEMM and its weight gradient form A dy + B + C z on their operand loads
+        // (project layers: BN without activation; stride-16 expand layers whose masked gradient the depthwise kernel left in da)
+        const bool lazy_dz = i >= 3 && l.d.cout % 4 == 0 && l.d.cout <= 1024 &&
+                             (((s->fuse_operand_bn & 2) && l.d.role == AMS_ROLE_PROJECT && l.d.act == AMS_ACT_NONE) ||
+                              ((s->fuse_operand_bn & 4) && l.d.role == AMS_ROLE_EXPAND && fused_rows > 0 && !train_recompute_block(s, i)));
         if (fused_rows > 0) {
             // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the
             // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z
@@ -161,10 +172,10 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             if (fused_dw && !(fused_buf != s->scratch &&
                               deferred.add(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, fused_stride)))
                 RUN(launch_reduce_splits(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st, fused_stride));
-            RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
+            if (!lazy_dz) RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
             fused_rows = 0;
         } else {
-            RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz));
+            RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz, !lazy_dz));
         }
         if (l.d.role == AMS_ROLE_DEPTHWISE && train_recompute_block(s, i - 1)) {
             // early block: from dz of the depthwise layer straight to the gradient of the block input; da_e / dz_e / a_e are recomputed
@@ -282,12 +293,14 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             else RUNK(i, dw_bytes(l, B), launch_depthwise_wgrad(prev.a, dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off,
                                                                 wscratch, s->scratch_floats, wst));
         } else {
-            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch));
+            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, lazy_dz ? l.da : dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch,
+                         (l.d.role == AMS_ROLE_PROJECT && operand_bn_act(s, i - 1)) ? &prev : nullptr, lazy_dz ? &l : nullptr));
         }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
         } else {
             PwArgs a = dgrad_args(dz, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, prev.da);
+            if (lazy_dz) { a.x = l.da; a.x_mode = 2; a.x_act = AMS_ACT_NONE; a.x_v0 = l.cA; a.x_v1 = l.cB; a.x_v2 = l.cC; a.x2 = l.z; a.x_tmp = dz; }
             // the block input also feeds the residual add at the end of this block: add that gradient here
             if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) {
                 a.res = s->L[i + 2].da; a.ldr = l.d.cin;

@@ -346,6 +346,15 @@ bool dw_fused_train_fwd(const ams_student* s, int i, int B) {
     return depthwise_fwd_bn_scratch(B, s->L[i].Hin, s->L[i].Win, s->L[i].d.cin, s->L[i].d.rate) <= s->scratch_floats;
 }
 
+// depthwise layer i feeds a project layer: with AMS_OPT_FUSE_OPERAND_BN bit 0 its activation a = act(z scale + shift) is never written — the
+// project GEMM (forward) and the project weight gradient (backward) apply it on their operand loads (PwArgs / WgArgs x_mode 1)
+bool operand_bn_act(const ams_student* s, int i) {
+    if (!(s->fuse_operand_bn & 1) || i < 2 || i + 1 > s->n_backbone) return false;
+    const LayerRt& l = s->L[i];
+    const LayerRt& lj = s->L[i + 1];
+    return l.d.role == AMS_ROLE_DEPTHWISE && lj.d.role == AMS_ROLE_PROJECT && lj.d.cin == l.d.cout && l.d.cout % 4 == 0 && l.d.cout <= 1024;
+}
+
 // most partial rows a GEMM with a fused column reduction can leave behind (PwArgs::red_mode): one per 64-row strip of the tiled split kernel
 // (it also takes layers of >= 32768 rows when the panel is too large for the streaming kernel), one per block of the persistent streaming
 // kernel (<= 8 per CU).  Sizing only: the launchers compare the exact row count with PwArgs::red_part_floats and drop the fusion when the
@@ -440,7 +449,7 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
             RUNK(i + 1, 4.0 * ((double)B * (l.px_in * l.d.cin + ld.px_out * ld.d.cout)),
                  launch_expand_dw(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.scale, l.shift, l.d.act, l.d.cout, P + ld.d.w_off, ld.d.stride,
                                   ld.d.rate, s->vec_ones, s->vec_zeros, AMS_ACT_NONE, ld.z, st));
-            RUN(bn_train(s, ld, (int64_t)B * ld.px_out, (double)global_B * ld.px_out, update_ema, sc, nullptr, st));
+            RUN(bn_train(s, ld, (int64_t)B * ld.px_out, (double)global_B * ld.px_out, update_ema, sc, nullptr, st, 0, !operand_bn_act(s, i + 1)));
             ++i;
             continue;
         }
@@ -455,6 +464,11 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
                                                      AMS_ACT_NONE, l.z, st));
         } else {
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, l.z, l.d.cout);
+            if (l.d.role == AMS_ROLE_PROJECT && operand_bn_act(s, i - 1)) {
+                // the depthwise layer's activation was not written: BN + activation on this GEMM's loads of its raw output
+                const LayerRt& ld = s->L[i - 1];
+                a.x = ld.z; a.x_mode = 1; a.x_act = ld.d.act; a.x_v0 = ld.scale; a.x_v1 = ld.shift; a.x_tmp = ld.a;
+            }
             // the BN statistics of the result in this GEMM's epilogue, where the kernel chosen can do it
             if (s->fuse_gemm_red & 1) {
                 a.red_mode = 1; a.red_center = s->stats + l.d.mean_off; a.red_part = s->scratch; a.red_part_floats = s->scratch_floats; a.red_rows_out = &pre_rows;
@@ -462,7 +476,7 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
             RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
         }
         const float* res = l.d.residual_from ? s->L[l.d.residual_from].a : nullptr;
-        const bool act_pass = !(l.d.role == AMS_ROLE_EXPAND && dw_fused_train_fwd(s, i + 1, B));
+        const bool act_pass = !(l.d.role == AMS_ROLE_EXPAND && dw_fused_train_fwd(s, i + 1, B)) && !operand_bn_act(s, i);
         RUN(bn_train(s, l, (int64_t)B * l.px_out, (double)global_B * l.px_out, update_ema, sc, res, st, pre_rows, act_pass));
     }
     LayerRt& lp = s->L[s->iPool]; LayerRt& la = s->L[s->iAspp]; LayerRt& lc = s->L[s->iProj]; LayerRt& ll = s->L[s->iLogits];

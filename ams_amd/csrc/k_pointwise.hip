@@ -54,13 +54,28 @@ __global__ __launch_bounds__(256) void pw_small_m_kernel(PwArgs a) {
     }
 }
 
-int launch_pointwise(const PwArgs& a, hipStream_t st) {
+int pointwise_materialize_x(const PwArgs& a, PwArgs* b, hipStream_t st) {
+    AMS_REQUIRE(a.x_mode == 1 || a.x_mode == 2, "pointwise: unknown operand transform %d", a.x_mode);
+    AMS_REQUIRE(a.x_tmp && a.ldx == a.K && a.K % 4 == 0 && a.x_v0 && a.x_v1, "pointwise: this kernel cannot transform its operand on load and no dense x_tmp was given");
+    if (a.x_mode == 1) RUN_RC(launch_bn_act(a.x, a.M, a.K, a.x_v0, a.x_v1, a.x_act, nullptr, a.x_tmp, st));
+    else {
+        AMS_REQUIRE(a.x_v2 && a.x2 && a.x_act == AMS_ACT_NONE, "pointwise: operand transform 2 needs (A, B, C), z and no activation");
+        RUN_RC(launch_bn_bwd_apply(a.x, a.x2, a.M, a.K, a.x_v0, a.x_v1, AMS_ACT_NONE, a.x_v0, a.x_v1, a.x_v2, a.x_tmp, st));
+    }
+    *b = a;
+    b->x = a.x_tmp; b->x_mode = 0; b->x_tmp = nullptr;
+    return AMS_OK;
+}
+
+int launch_pointwise(const PwArgs& a0, hipStream_t st) {
+    PwArgs a = a0;
     if (a.red_rows_out) *a.red_rows_out = 0;               // set by the kernels that can fuse the column reduction (PwArgs::red_mode)
     AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0, "pointwise: empty problem M=%lld K=%d N=%d", (long long)a.M, a.K, a.N);
     AMS_REQUIRE(a.Kw > 0 && a.Kw <= a.K, "pointwise: Kw=%d must be in 1..K=%d", a.Kw, a.K);
     AMS_REQUIRE(a.K % 4 == 0 && a.ldx % 4 == 0, "pointwise: K (%d) and ldx (%d) must be multiples of 4", a.K, a.ldx);
     AMS_REQUIRE((reinterpret_cast<uintptr_t>(a.x) & 15) == 0, "pointwise: x must be 16-byte aligned");
     if (a.M <= 16) {
+        if (a.x_mode != 0) { PwArgs b; RUN_RC(pointwise_materialize_x(a, &b, st)); a = b; }
         note_kernel("pw_small_m_kernel");
         hipLaunchKernelGGL(pw_small_m_kernel, dim3(cdiv(a.N, 16), (unsigned)a.M), dim3(256), 0, st, a);
         AMS_CHECK_LAUNCH();
@@ -70,9 +85,10 @@ int launch_pointwise(const PwArgs& a, hipStream_t st) {
     const int frm = knobs().pw_rm, fnt = knobs().pw_nt;
     if ((a.M >= 32768 && force != 'l') || force == 's') {
         bool handled = false;
-        const int rc = launch_pointwise_stream(a, frm, force == 's' ? fnt : 0, &handled, st);
+        const int rc = launch_pointwise_stream(a, frm, force == 's' ? fnt : 0, &handled, st);     // applies PwArgs::x_mode 1 itself
         if (rc || handled) return rc;
     }
+    if (a.x_mode != 0) { PwArgs b; RUN_RC(pointwise_materialize_x(a, &b, st)); a = b; }
     return launch_pointwise_tiled(a, force == 'l' ? frm : 0, fnt, st);
 }
 
@@ -105,7 +121,9 @@ struct VecLd<1> {
     static __device__ __forceinline__ void ld(const float* p, bool ok, float (&o)[1]) { const float v = *p; o[0] = ok ? v : 0.f; }
 };
 
-template <int VA, int VB>
+// XD: the operand transforms of WgArgs (x_mode 1: BN + activation on x; dy_mode 2: second half of BN backward on dy) — a lane's channels
+// are the same for every pixel it loads, so the per-channel vectors live in registers; same unfused arithmetic as the elementwise passes
+template <int VA, int VB, bool XD = false>
 __global__ __launch_bounds__(256) void pw_wgrad_f32(WgArgs a, int tiles_k, int tiles_n, int64_t rows_per_split) {
     __shared__ float sRed[3 * 64 * VA * VB * 4];   // partial tiles of waves 1..3
     const int tile = blockIdx.y;
@@ -127,6 +145,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32(WgArgs a, int tiles_k, int t
     const int ka = k0 + VA * l15, nb = n0 + VB * l15;
     const bool ka_ok = ka < a.K, nb_ok = nb < a.N;        // K, N are multiples of VA / VB for the chosen instantiation
     const int kac = ka_ok ? ka : 0, nbc = nb_ok ? nb : 0;
+    float xs[XD ? VA : 1], xh[XD ? VA : 1], dA[XD ? VB : 1], dB[XD ? VB : 1], dC[XD ? VB : 1];
+    if constexpr (XD) {
+#pragma unroll
+        for (int s = 0; s < VA; ++s) { xs[s] = a.x_mode == 1 ? a.x_v0[kac + s] : 1.f; xh[s] = a.x_mode == 1 ? a.x_v1[kac + s] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            dA[u] = a.dy_mode == 2 ? a.dy_v0[nbc + u] : 1.f; dB[u] = a.dy_mode == 2 ? a.dy_v1[nbc + u] : 0.f; dC[u] = a.dy_mode == 2 ? a.dy_v2[nbc + u] : 0.f;
+        }
+    }
     // each wave takes every 4th group of 4 pixels; 2 groups in flight for latency hiding
     // (loop bounds are wave-uniform: an MFMA must be issued by the whole wave)
     for (int64_t mg = m_begin + wave * 4; mg < m_end; mg += 32) {
@@ -138,6 +165,18 @@ __global__ __launch_bounds__(256) void pw_wgrad_f32(WgArgs a, int tiles_k, int t
             const int64_t mc = ok ? mm : m_end - 1;                    // clamped row, zeroed by select: no exec-masked loads
             VecLd<VA>::ld(a.x + mc * (int64_t)a.ldx + kac, ok && ka_ok, xa[h]);
             VecLd<VB>::ld(a.dy + mc * (int64_t)a.ldy + nbc, ok && nb_ok, yb[h]);
+            if constexpr (XD) {
+                if (a.x_mode == 1) {
+#pragma unroll
+                    for (int s = 0; s < VA; ++s) { const float y = apply_act(xa[h][s] * xs[s] + xh[s], a.x_act); xa[h][s] = (ok && ka_ok) ? y : 0.f; }
+                }
+                if (a.dy_mode == 2) {
+                    float zz[VB];
+                    VecLd<VB>::ld(a.dy2 + mc * (int64_t)a.ldy + nbc, ok && nb_ok, zz);
+#pragma unroll
+                    for (int u = 0; u < VB; ++u) { const float y = (dA[u] * yb[h][u] + dB[u]) + dC[u] * zz[u]; yb[h][u] = (ok && nb_ok) ? y : 0.f; }
+                }
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -198,6 +237,9 @@ static int launch_wg_t(const WgArgs& a, int splits, hipStream_t st) {
     rows = (rows + 3) / 4 * 4;
     static const std::string nm = "pw_wgrad_f32<" + std::to_string(VA) + ", " + std::to_string(VB) + ">";
     note_kernel(nm.c_str());
+    if (a.x_mode != 0 || a.dy_mode != 0)
+        hipLaunchKernelGGL((pw_wgrad_f32<VA, VB, true>), dim3(splits, tiles_k * tiles_n), dim3(256), 0, st, a, tiles_k, tiles_n, rows);
+    else
     hipLaunchKernelGGL((pw_wgrad_f32<VA, VB>), dim3(splits, tiles_k * tiles_n), dim3(256), 0, st, a, tiles_k, tiles_n, rows);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
@@ -205,6 +247,8 @@ static int launch_wg_t(const WgArgs& a, int splits, hipStream_t st) {
 
 int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st) {
     AMS_REQUIRE(a.M > 0 && a.K > 0 && a.N > 0, "wgrad: empty problem");
+    AMS_REQUIRE(a.x_mode == 0 || (a.x_mode == 1 && a.x_v0 && a.x_v1), "wgrad: operand transform of x: mode %d or missing vectors", a.x_mode);
+    AMS_REQUIRE(a.dy_mode == 0 || (a.dy_mode == 2 && a.dy_v0 && a.dy_v1 && a.dy_v2 && a.dy2), "wgrad: operand transform of dy: mode %d or missing operands", a.dy_mode);
     if (a.allow_split && pointwise_wgrad_x6_applies(a.M, a.K, a.N, a.ldx, a.ldy)) {
         const int sp = wgrad_x6_splits(a.M, a.K, a.N);
         AMS_REQUIRE(a.scratch_floats >= (size_t)sp * a.K * a.N, "wgrad: scratch too small (%zu < %zu)", a.scratch_floats,

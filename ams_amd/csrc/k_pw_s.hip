@@ -6,7 +6,9 @@ namespace ams {
 // ---- variant S: streaming layers (huge M, small K x N).  The whole weight panel of this column tile stays in LDS for
 // the block's lifetime; every wave walks its own 16*RM-row groups (grid-stride), no barrier after the prologue, and
 // the A fragment of the NEXT (row group, k chunk) is in flight while the current one feeds the matrix pipe.
-template <int RM, int NT, int EPI>
+// XF = 1: PwArgs::x_mode 1 — BN + activation of the layer that wrote x, applied to every operand fragment before it feeds the matrix pipe
+// (per-k scale / shift in LDS behind everything else); same unfused multiply / add as bn_act_kernel: bit-identical products.
+template <int RM, int NT, int EPI, int XF = 0>
 __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, int64_t n_groups) {
     constexpr int PITCH = 16 * NT + 4;
     extern __shared__ __attribute__((aligned(16))) float sW[];          // [Kpad][PITCH] then scale[16NT], shift[16NT]
@@ -25,6 +27,15 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
     const int64_t g_first = (int64_t)blockIdx.x * 4 + wave;
     const bool red = EPI == EPI_PLAIN && a.red_mode != 0;      // block-uniform; the launcher clears red_mode where it does not apply
     float* sRedVec = sSh + 16 * NT + 4 * (16 * (16 * NT + 4));  // behind the waves' output slabs: 4 x 16 NT vectors, then the waves' sums
+    float* sXv = sRedVec + (EPI == EPI_PLAIN ? 12 * 16 * NT : 0);  // XF: scale [Kpad] | shift [Kpad]
+    const int Kpad = n_chunks * 16;
+    if constexpr (XF == 1) {
+        for (int e = tid; e < Kpad; e += 256) {
+            sXv[e] = e < K ? a.x_v0[e] : 0.f;
+            sXv[Kpad + e] = e < K ? a.x_v1[e] : 0.f;
+        }
+        __syncthreads();
+    }
     float4 rs1[EPI == EPI_PLAIN ? NT : 1], rs2[EPI == EPI_PLAIN ? NT : 1];
     if constexpr (EPI == EPI_PLAIN) {
         if (red) {
@@ -50,7 +61,20 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
             int64_t m = grp * (16 * RM) + r * 16 + l15;
             if (m > a.M - 1) m = a.M - 1;
             const float4 v = ld4(a.x + m * (int64_t)a.ldx + koff);
-            dst[r] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            if constexpr (XF == 1) dst[r] = v;           // transformed, then zeroed beyond K, when it is consumed (xform below)
+            else dst[r] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        }
+    };
+    auto xform = [&](int c, float4 (&v)[RM]) {
+        int koff = c * 16 + 4 * q;
+        const bool ok = koff < K;
+        if (koff > K - 4) koff = K - 4;
+        const float4 sc = ld4(sXv + koff), sh = ld4(sXv + Kpad + koff);
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const float4 y = muladd4_pk(v[r], sc, sh);
+            v[r] = make_float4(ok ? apply_act(y.x, a.x_act) : 0.f, ok ? apply_act(y.y, a.x_act) : 0.f, ok ? apply_act(y.z, a.x_act) : 0.f,
+                               ok ? apply_act(y.w, a.x_act) : 0.f);
         }
     };
     float4 a_cur[RM], a_nxt[RM];
@@ -70,6 +94,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (XF == 1) xform(c, a_cur);
         pw_chunk<RM, NT, PITCH>(acc, a_cur, sW + (c * 16 + 4 * q) * PITCH + l15);
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
@@ -92,36 +117,38 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
     }
 }
 
-template <int RM, int NT, int EPI>
+template <int RM, int NT, int EPI, int XF = 0>
 static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     constexpr int PITCH = 16 * NT + 4;
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     const int64_t n_groups = cdiv64(a.M, 16 * RM);
-    // weight panel | scale, shift | four output slabs | (fused reduction: 4 vectors + 4 waves x 2 sums of 16 NT floats)
-    const size_t lds = ((size_t)((a.K + 15) / 16 * 16) * PITCH + 32 * NT + 4 * 16 * (16 * NT + 4) + (EPI == EPI_PLAIN ? 12 * 16 * NT : 0)) * sizeof(float);
+    // weight panel | scale, shift | four output slabs | (fused reduction: 4 vectors + 4 waves x 2 sums of 16 NT floats) | (XF: 2 x Kpad)
+    const size_t lds = ((size_t)((a.K + 15) / 16 * 16) * PITCH + 32 * NT + 4 * 16 * (16 * NT + 4) + (EPI == EPI_PLAIN ? 12 * 16 * NT : 0) +
+                        (XF ? 2 * ((a.K + 15) / 16 * 16) : 0)) * sizeof(float);
     int64_t blocks = cdiv64(n_groups, 4);
     // persistent grid: exactly the blocks that are co-resident (work is pre-partitioned by grid-stride, so any block that
     // has to wait for a slot would run its whole share on a half-empty chip)
     int per_cu = 1, cus = 256;
-    RUN_RC(func_allow_lds((const void*)pw_gemm_f32_s<RM, NT, EPI>, lds));
-    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f32_s<RM, NT, EPI>, 256, lds, &per_cu));
+    RUN_RC(func_allow_lds((const void*)pw_gemm_f32_s<RM, NT, EPI, XF>, lds));
+    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f32_s<RM, NT, EPI, XF>, 256, lds, &per_cu));
     RUN_RC(device_cus(&cus));
     if (knobs().pw_percu > 0) per_cu = knobs().pw_percu;                  // tuning knob AMS_PW_PERCU (tools/bench_kernel.py)
     if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
-    static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ">";
+    static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + (XF ? ", 1>" : ">");
     note_kernel(nm.c_str());
     PwArgs b = a;
     if (b.red_mode) {
         if (EPI == EPI_PLAIN && pw_red_ok(b, blocks)) { if (b.red_rows_out) *b.red_rows_out = (int)blocks; }
         else { b.red_mode = 0; if (b.red_rows_out) *b.red_rows_out = 0; }
     }
-    hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT, EPI>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, b, n_tiles_n, n_groups);
+    hipLaunchKernelGGL((pw_gemm_f32_s<RM, NT, EPI, XF>), dim3((unsigned)blocks, n_tiles_n), dim3(256), lds, st, b, n_tiles_n, n_groups);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
 
 template <int RM, int NT>
 static int launch_pw_s(const PwArgs& a, hipStream_t st) {
+    if (a.x_mode == 1 && !a.res) return launch_pw_s_e<RM, NT, EPI_PLAIN, 1>(a, st);
     return a.res ? launch_pw_s_e<RM, NT, EPI_RES>(a, st) : launch_pw_s_e<RM, NT, EPI_PLAIN>(a, st);
 }
 
@@ -146,6 +173,7 @@ int launch_pointwise_stream(const PwArgs& a, int force_rm, int force_nt, bool* h
     *handled = false;
     const int nt = pw_stream_nt(a, force_nt);
     if (nt == 0) return AMS_OK;
+    if (a.x_mode != 0 && !(a.x_mode == 1 && !a.res && a.x_v0 && a.x_v1)) return AMS_OK;       // only BN + activation on a plain epilogue: the caller materialises
     *handled = true;
     switch (nt) {
         case 1: return launch_pw_s<2, 1>(a, st);

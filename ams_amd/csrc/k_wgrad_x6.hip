@@ -53,7 +53,9 @@ constexpr int wg_pitch(int channels) {       // bf16 elements per LDS row: multi
     return ((channels + 15) / 16 * 16 / 16) % 2 == 1 ? (channels + 15) / 16 * 16 : (channels + 15) / 16 * 16 + 16;
 }
 
-template <int KT, int NW>
+// XD: the operand transforms of WgArgs applied between the global load and the split into the LDS image (a thread's float4 covers the
+// same four channels in every step: the per-channel vectors are loaded once)
+template <int KT, int NW, bool XD = false>
 __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, int64_t rows_per_split) {
     constexpr int CX = 16 * KT, CY = 16 * NW;                 // channels per tile side
     constexpr int PX = wg_pitch(CX), PY = wg_pitch(CY);       // LDS row pitch in bf16 elements
@@ -77,6 +79,28 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
 
     // global -> register staging of one 32-pixel step (branch-free: clamped addresses, zero select)
     float4 rx[NLX], ry[NLY];
+    float4 rz[XD ? NLY : 1];                                      // dy_mode 2: the raw output beside the gradient
+    unsigned ry_ok = 0;                                           // ... and which of this thread's dy pieces lie inside the problem
+    float4 vxs[XD ? NLX : 1], vxh[XD ? NLX : 1], vA[XD ? NLY : 1], vB[XD ? NLY : 1], vC[XD ? NLY : 1];
+    if constexpr (XD) {
+#pragma unroll
+        for (int u = 0; u < NLX; ++u) {
+            const int e = tid + 256 * u, row = e / VX, c4 = (e - row * VX) * 4;
+            int k = k0 + c4;
+            if (k > a.K - 4) k = a.K - 4;
+            vxs[u] = a.x_mode == 1 ? ld4(a.x_v0 + k) : make_float4(1.f, 1.f, 1.f, 1.f);
+            vxh[u] = a.x_mode == 1 ? ld4(a.x_v1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NLY; ++u) {
+            const int e = tid + 256 * u, row = e / VY, c4 = (e - row * VY) * 4;
+            int n = n0 + c4;
+            if (n > a.N - 4) n = a.N - 4;
+            vA[u] = a.dy_mode == 2 ? ld4(a.dy_v0 + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+            vB[u] = a.dy_mode == 2 ? ld4(a.dy_v1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vC[u] = a.dy_mode == 2 ? ld4(a.dy_v2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     auto fetch = [&](int s) {
         const int64_t mb = m_begin + (int64_t)s * 32;
 #pragma unroll
@@ -87,7 +111,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
             const bool ok = e < 32 * VX && m < m_end && k < a.K;
             if (m > a.M - 1) m = a.M - 1;
             if (k > a.K - 4) k = a.K - 4;
-            const float4 v = ld4(a.x + m * (int64_t)a.ldx + k);
+            float4 v = ld4(a.x + m * (int64_t)a.ldx + k);
+            if constexpr (XD) {
+                if (a.x_mode == 1) {
+                    const float4 y = muladd4_pk(v, vxs[u], vxh[u]);
+                    v = make_float4(apply_act(y.x, a.x_act), apply_act(y.y, a.x_act), apply_act(y.z, a.x_act), apply_act(y.w, a.x_act));
+                }
+            }
             rx[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
 #pragma unroll
@@ -100,6 +130,13 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
             if (n > a.N - 4) n = a.N - 4;
             const float4 v = ld4(a.dy + m * (int64_t)a.ldy + n);
             ry[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            if constexpr (XD) {
+                if (a.dy_mode == 2) {
+                    const float4 z = ld4(a.dy2 + m * (int64_t)a.ldy + n);
+                    rz[u] = make_float4(ok ? z.x : 0.f, ok ? z.y : 0.f, ok ? z.z : 0.f, ok ? z.w : 0.f);
+                    ry_ok = ok ? (ry_ok | (1u << u)) : (ry_ok & ~(1u << u));
+                }
+            }
         }
     };
     auto stage = [&]() {
@@ -111,6 +148,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
 #pragma unroll
         for (int u = 0; u < NLY; ++u) {
             const int e = tid + 256 * u, row = e / VY, c4 = (e - row * VY) * 4;
+            if constexpr (XD) {
+                if (a.dy_mode == 2) {
+                    // (A g + B) + C z as bn_bwd_apply_kernel evaluates it; rows / columns outside the problem stay zero (B is not)
+                    const bool inside = (ry_ok >> u) & 1u;
+                    const float4 y = add4_pk(add4_pk(mul4_pk(vA[u], ry[u]), vB[u]), mul4_pk(vC[u], rz[u]));
+                    ry[u] = inside ? y : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
             if (e < 32 * VY) split_store(ry[u], sY + row * PY + c4, PLY);
         }
     };
@@ -214,9 +259,15 @@ static int launch_wg6_t(const WgArgs& a, int splits, hipStream_t st) {
     int64_t rows = cdiv64(a.M, splits);
     rows = (rows + 31) / 32 * 32;
     const size_t lds = (size_t)3 * 32 * (wg_pitch(16 * KT) + wg_pitch(16 * NW)) * sizeof(unsigned short);
-    RUN_RC(func_allow_lds((const void*)pw_wgrad_bf16x6<KT, NW>, lds));
     static const std::string nm = "pw_wgrad_bf16x6<" + std::to_string(KT) + ", " + std::to_string(NW) + ">";
     note_kernel(nm.c_str());
+    if (a.x_mode != 0 || a.dy_mode != 0) {
+        RUN_RC(func_allow_lds((const void*)pw_wgrad_bf16x6<KT, NW, true>, lds));
+        hipLaunchKernelGGL((pw_wgrad_bf16x6<KT, NW, true>), dim3(splits, tiles_k * tiles_n), dim3(256), lds, st, a, tiles_n, rows);
+        AMS_CHECK_LAUNCH();
+        return AMS_OK;
+    }
+    RUN_RC(func_allow_lds((const void*)pw_wgrad_bf16x6<KT, NW>, lds));
     hipLaunchKernelGGL((pw_wgrad_bf16x6<KT, NW>), dim3(splits, tiles_k * tiles_n), dim3(256), lds, st, a, tiles_n, rows);
     AMS_CHECK_LAUNCH();
     return AMS_OK;

@@ -69,8 +69,19 @@ struct PwArgs {
     int* red_rows_out;
     // set by the split-bf16 launcher only (mode 2 with a residual operand: the residual moves here and the plain epilogue runs)
     const float* red_res; int red_ldr;
+    // optional per-element transform of the OPERAND x as it is loaded (fine-tune step: the elementwise BN passes between two layers
+    // disappear into the consumer; same IEEE operations in the same order as the pass it replaces, so the product is bit-identical):
+    //   x_mode 1  x' = act(x * x_v0[k] + x_v1[k])                    BN + activation of the layer that produced x (bn_act_kernel)
+    //   x_mode 2  x' = x_v0[k] * x + x_v1[k] + x_v2[k] * x2[m, k]    second half of BN backward: x = gradient wrt the BN output, x2 = the
+    //                                                                 layer's raw output z [M, ldx], (x_v0, x_v1, x_v2) = (A, B, C) (bn_bwd_apply_kernel, act none)
+    // A kernel that cannot apply the transform materialises x' into x_tmp [M, K] (dense) first and runs on that; without x_tmp it fails.
+    int x_mode; int x_act;
+    const float* x_v0; const float* x_v1; const float* x_v2; const float* x2;
+    float* x_tmp;
 };
 int launch_pointwise(const PwArgs& a, hipStream_t st);
+// x' of PwArgs::x_mode written to a.x_tmp by the elementwise kernels the transform replaces; on return *b is `a` without the transform
+int pointwise_materialize_x(const PwArgs& a, PwArgs* b, hipStream_t st);
 bool pointwise_stream_applies(const PwArgs& a);     // the persistent streaming variant (small K x N) can take this problem
 
 // split-bf16 (hi + lo) late-layer variant: weights pre-split into [N][Kp] bf16 panels, Kp = K rounded up to 32
@@ -94,6 +105,11 @@ struct WgArgs {
     float* dw;             // [K, N] dense
     float* scratch; size_t scratch_floats;
     int allow_split;       // != 0: layers where the f32 MFMA kernel is matrix-pipe bound may use the 3-part bf16 kernel
+    // operand transforms on load (see PwArgs::x_mode; both wgrad kernels apply them, nothing is materialised):
+    //   x_mode 1   x'  = act(x * x_v0[k] + x_v1[k])
+    //   dy_mode 2  dy' = dy_v0[n] * dy + dy_v1[n] + dy_v2[n] * dy2[m, n]      (dy2 [M, ldy])
+    int x_mode = 0, x_act = 0; const float* x_v0 = nullptr; const float* x_v1 = nullptr;
+    int dy_mode = 0; const float* dy_v0 = nullptr; const float* dy_v1 = nullptr; const float* dy_v2 = nullptr; const float* dy2 = nullptr;
 };
 // fused depthwise 3x3 (+BN+act) -> project 1x1 (+BN, +residual), frozen inference, split-bf16 GEMM (k_dw_project.hip)
 bool dw_project_supported(int C, int N, int stride, int rate);

@@ -26,7 +26,7 @@ _ENV_OPTIONS = {
     "AMS_BLOCK_X6": hip.OPT_BLOCK_X6, "AMS_LATE_SUB": hip.OPT_LATE_SUBBATCH, "AMS_STREAM_MIN_ROWS": hip.OPT_STREAM_MIN_ROWS,
     "AMS_OVERLAP_HEAD": hip.OPT_OVERLAP_HEAD, "AMS_FUSE_BLOCK": hip.OPT_FUSE_BLOCK, "AMS_FUSE_XDS": hip.OPT_FUSE_EXPAND_DW_STREAM,
     "AMS_OVERLAP_WGRAD": hip.OPT_OVERLAP_WGRAD, "AMS_FUSE_DGRAD_BN": hip.OPT_FUSE_DGRAD_BN, "AMS_FUSE_GEMM_RED": hip.OPT_FUSE_GEMM_RED,
-    "AMS_TRAIN_RECOMPUTE": hip.OPT_TRAIN_RECOMPUTE, "AMS_NAN_GRADS": hip.OPT_NAN_GRADS,
+    "AMS_TRAIN_RECOMPUTE": hip.OPT_TRAIN_RECOMPUTE, "AMS_NAN_GRADS": hip.OPT_NAN_GRADS, "AMS_FUSE_OPERAND_BN": hip.OPT_FUSE_OPERAND_BN,
 }
 
 
@@ -220,6 +220,12 @@ class StudentEngine:
                                                 C.c_void_p(scratch.data_ptr()), scratch.numel(), self._stream()),
                   "ams_pack_masked_fp16")
         return out[:int(cnt.item())]
+
+    def set_fuse_operand_bn(self, bits: int) -> None:
+        """Fine-tune step: elementwise BN passes applied by the consuming 1x1 GEMM / weight-gradient kernel on its operand loads (same bits as the
+        separate passes): bit 0 BN + activation of the depthwise layers, bit 1 dz of the project layers, bit 2 dz of the stride-16 expand layers.
+        Default 3; 0 = every pass written."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_OPERAND_BN, int(bits)), "ams_student_set_option")
 
     def set_train_recompute(self, on: bool, fuse_dgrad_bn: Optional[bool] = None, fuse_gemm_red: Optional[int] = None) -> None:
         """Fine-tune step of the early blocks without their 6x-expanded tensors (default on); off = every tensor materialised.

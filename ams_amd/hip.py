@@ -40,6 +40,7 @@ OPT_NAN_GRADS = 18
 OPT_OVERLAP_WGRAD = 19
 OPT_OVERLAP_HEAD = 20
 OPT_STREAM_MIN_ROWS = 21
+OPT_FUSE_OPERAND_BN = 22
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)
@@ -74,6 +75,7 @@ SIGNATURES = {
     "ams_student_destroy": (None, [_vp]),
     "ams_student_region": (C.c_int, [_vp, _i32, C.POINTER(_sz), C.POINTER(_sz)]),
     "ams_student_lowres_size": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ams_student_layer_tensor": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ams_student_freeze": (C.c_int, [_vp, _vp]),
     "ams_student_predict": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ams_student_predict_with_metric": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -117,6 +119,8 @@ SIGNATURES = {
     "ams_k_pointwise_wgrad_split": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_depthwise3x3_dgrad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "ams_k_depthwise3x3_wgrad": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "ams_k_pointwise_xform": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ams_k_pointwise_wgrad_xform": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ams_k_pointwise_red": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _sz,
                                      C.POINTER(_i32), _vp, _sz, _vp]),
     "ams_k_depthwise3x3_fwd_bn_scratch": (_sz, [_i32, _i32, _i32, _i32, _i32]),

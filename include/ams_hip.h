@@ -122,6 +122,12 @@ void ams_student_destroy(ams_student* s);
 int ams_student_region(const ams_student* s, int32_t region, size_t* offset_bytes, size_t* n_elems);
 /* low-resolution feature size (h, w) = output stride 16 of the padded frame */
 int ams_student_lowres_size(const ams_student* s, int32_t* h, int32_t* w);
+/* Debugging / parity bisection (tools/grad_gap_bisect.py; no reference counterpart: tf.Session.run can fetch any tensor by name): byte offset
+ * and element count of a per-layer training tensor of a TRAINABLE student, NHWC [max_batch, Hout, Wout, cout] — which = 0 raw conv output z,
+ * 1 activated output a (= the next layer's input), 2 gradient wrt a (after a fine-tune step it holds dz where the step computed dz in
+ * place), 3 gradient wrt z of a backbone layer (in place over 2, or a tensor of its own where 2 is read again as a skip gradient).  layer is 1-based (ams_layer_desc order).  Which of them a step actually writes depends on the fusion options: with every
+ * AMS_OPT_TRAIN_* / FUSE_* fine-tune option at 0 all of them are. */
+int ams_student_layer_tensor(const ams_student* s, int32_t layer, int32_t which, size_t* offset_bytes, size_t* n_elems);
 
 /* ---- server -> edge hand-off: replaces save_to_frozen_graph / trim_graph_frozen / convert_batchnorms -----
  * (SemanticNetwork.py:706-714, utils/graph_utils.py:52-126).  Snapshots params + moving statistics into the
@@ -201,7 +207,13 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_NAN_GRADS = 18 /* fine-tune step on a batch WITHOUT a valid pixel: 1 (default) the reference's result — loss = 0 / 0 and every gradient
+enum { AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: elementwise BN passes applied by the CONSUMER on its operand loads instead of being written
+                                        (PwArgs / WgArgs x_mode, dy_mode; the same IEEE operations in the same order: bit-identical to the passes).
+                                        Bit 0: BN + activation of every depthwise layer that feeds a project layer — the project GEMM and the project
+                                        weight gradient apply it, the depthwise activation is never written.  Bit 1: dz = A dy + B + C z of every
+                                        project layer — formed by its input-gradient GEMM and its weight gradient.  Bit 2: the same for the
+                                        stride-16 expand layers (their GEMM then pulls two f32 operands).  Default 3; 0 = separate passes. */,
+       AMS_OPT_NAN_GRADS = 18 /* fine-tune step on a batch WITHOUT a valid pixel: 1 (default) the reference's result — loss = 0 / 0 and every gradient
                                   NaN (utils/graph_utils.py:408: sum(w ce) / sum(w)), so the Adam update poisons the masked parameters exactly as
                                   TensorFlow's would; 0 = NaN loss but zero gradients (the weights survive) */,
        AMS_OPT_OVERLAP_WGRAD = 19 /* fine-tune step: 1 (default) weight gradients on a side stream beside the input-gradient chain, 2 depthwise ones on a
@@ -416,6 +428,22 @@ int ams_k_pointwise_red(const float* x, int64_t M, int32_t K, const float* w, in
                         const float* center, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
                         int32_t act, const float* res, float* y, float* part, size_t part_floats, int32_t* rows_out, uint16_t* panels,
                         size_t panel_elems, void* stream);
+
+/* The 1x1 kernels of the fine-tune step with an elementwise BN pass applied on their OPERAND loads instead of being written first
+ * (PwArgs / WgArgs x_mode, dy_mode; AMS_OPT_FUSE_OPERAND_BN): same IEEE operations in the same order as the pass, so the result is
+ * bit-identical to running the pass and then the plain kernel.
+ *   ams_k_pointwise_xform: y [M,N] = x' . w with x' = act(x * v0[k] + v1[k]) (x_mode 1: BN + activation, what FusedBatchNormV3 + Relu6 are to
+ *     the reference's graph) or x' = v0[k] * x + v1[k] + v2[k] * x2 (x_mode 2: the second half of FusedBatchNormGradV3, (v0, v1, v2) = (A, B, C),
+ *     x2 = the BN layer's raw output).  split != 0: the three-part bf16 kernel (panels >= 3 N Kp), else the exact-f32 kernels.  A kernel that
+ *     cannot transform on load writes x' into x_tmp [M,K] first (may be NULL: then such shapes fail with AMS_E_INVALID).
+ *   ams_k_pointwise_wgrad_xform: dw [K,N] = x'^T . dy' with x' as x_mode 1 (x_mode 0: x' = x) and dy' = d0[n] * dy + d1[n] + d2[n] * dy2
+ *     (dy_mode 2; dy_mode 0: dy' = dy); split != 0 the six-product bf16 kernel (shapes as ams_k_pointwise_wgrad_split). */
+int ams_k_pointwise_xform(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w, int32_t split, int32_t x_mode,
+                          int32_t x_act, const float* v0, const float* v1, const float* v2, const float* x2, float* y, float* x_tmp,
+                          uint16_t* panels, size_t panel_elems, void* stream);
+int ams_k_pointwise_wgrad_xform(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, int32_t split, int32_t x_mode, int32_t x_act,
+                                const float* v0, const float* v1, int32_t dy_mode, const float* d0, const float* d1, const float* d2,
+                                const float* dy2, float* dw, float* scratch, size_t scratch_floats, void* stream);
 
 /* The fine-tune step's one-kernel forms of a stride-1 depthwise layer inside a block that keeps its tensors (what tf.gradients spreads over
  * FusedBatchNormV3 / Relu6 / DepthwiseConv2dNative and their Grad ops, SemanticNetwork.py:253-260 via utils/graph_utils.py:457-496):

@@ -158,12 +158,13 @@ class StudentOracle:
         return x
 
     def forward_lowres(self, frames, mode: str = "frozen", params: Optional[Dict[str, torch.Tensor]] = None,
-                       taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                       taps: Optional[Dict[str, torch.Tensor]] = None, ztaps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
         """frames [B,H,W,3] (0..255) -> logits [B,h,w,NUM_CLASSES] at output stride 16 (NHWC).
 
         mode 'frozen': moving statistics, eps 1e-3 everywhere (the graph shipped to the edge);
         mode 'train' : batch statistics with each layer's own eps (the live graph, is_training=True).
-        ``taps`` (optional dict) receives every layer's post-activation output as NHWC, for kernel tests.
+        ``taps`` (optional dict) receives every layer's post-activation output as NHWC, for kernel tests; ``ztaps`` every layer's raw
+        conv output in the graph's own NCHW layout (the tensors themselves: autograd can differentiate with respect to them).
         """
         p = params if params is not None else self.vars
         x = torch.as_tensor(np.asarray(frames), dtype=self.dtype) if not torch.is_tensor(frames) else frames.to(self.dtype)
@@ -175,6 +176,8 @@ class StudentOracle:
             w = p[l.weight_name]
             xin = outs[l.idx - 1]
             y = conv_same(xin, w, l.kind, l.stride, l.rate)
+            if ztaps is not None:
+                ztaps[l.scope] = y
             y = self._act(self._bn(y, l, mode, p), l.act)
             if l.residual_from is not None:
                 y = y + outs[l.residual_from]
@@ -188,9 +191,13 @@ class StudentOracle:
         pool = self._act(self._bn(pool, lp, mode, p), lp.act)
         pool = pool.expand(-1, -1, feat.shape[2], feat.shape[3])            # ResizeBilinear of a 1x1 map
         aspp = F.conv2d(feat, p[la.weight_name].permute(3, 2, 0, 1))
+        if ztaps is not None:
+            ztaps[la.scope] = aspp
         aspp = self._act(self._bn(aspp, la, mode, p), la.act)
         cat = torch.cat([pool, aspp], dim=1)                                # concat_2: pool branch first
         proj = F.conv2d(cat, p[lc.weight_name].permute(3, 2, 0, 1))
+        if ztaps is not None:
+            ztaps[lc.scope] = proj
         proj = self._act(self._bn(proj, lc, mode, p), lc.act)
         logits = F.conv2d(proj, p[ll.weight_name].permute(3, 2, 0, 1)) + p[ll.scope + "/biases:0"].view(1, -1, 1, 1)
         if taps is not None:
@@ -199,10 +206,10 @@ class StudentOracle:
             taps["concat_projection"] = proj.permute(0, 2, 3, 1)
         return logits.permute(0, 2, 3, 1)
 
-    def logits_full(self, frames, mode: str = "frozen", params=None) -> torch.Tensor:
+    def logits_full(self, frames, mode: str = "frozen", params=None, taps=None, ztaps=None) -> torch.Tensor:
         """student_logits: ResizeBilinear_1 is an identity resize, ResizeBilinear_2 goes to the UNPADDED H x W."""
         h, w = frames.shape[1], frames.shape[2]
-        return resize_bilinear_align_corners(self.forward_lowres(frames, mode, params), h, w)
+        return resize_bilinear_align_corners(self.forward_lowres(frames, mode, params, taps, ztaps), h, w)
 
     # ------------------------------------------------------------------ heads added by create_student_v3
     def reduced_logits(self, logits_full: torch.Tensor) -> torch.Tensor:

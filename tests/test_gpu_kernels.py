@@ -795,3 +795,83 @@ def test_split_gemm_half_height_tail_blocks():
     assert torch.equal(y_tail, y_full)
     want = (x.double() @ w.double()) * sc.double() + sh.double()
     assert ((y_tail.double() - want).abs().max() / want.abs().max()).item() < 2e-6
+
+
+@pytest.mark.parametrize("M,K,N,split,trans", [(17160, 960, 160, 1, 0), (17160, 160, 960, 1, 1), (4290, 576, 96, 1, 0), (2145, 64, 384, 1, 1),
+                                                (1000, 384, 64, 1, 0), (33001, 96, 24, 0, 0), (70001, 192, 32, 0, 0), (40003, 32, 192, 0, 1),
+                                                (300, 144, 24, 0, 0), (90, 320, 256, 0, 0)])
+@pytest.mark.parametrize("x_mode", [1, 2])
+def test_pointwise_with_operand_transform(lib, M, K, N, split, trans, x_mode):
+    """1x1 GEMMs that apply an elementwise BN pass on their operand loads (PwArgs::x_mode; AMS_OPT_FUSE_OPERAND_BN): BN + ReLU6 of the layer
+    that wrote x (mode 1), or dz = A dy + B + C z (mode 2).  Against f64 math, and BIT FOR BIT against the same kernel run on the materialised
+    operand (the pass written by bn_act / bn_bwd_apply): tiled three-part kernel, streaming exact-f32 kernel (mode 1 on load, mode 2 through
+    its fallback), the tiled exact-f32 kernel and ragged row counts (fallback: x' written to x_tmp first)."""
+    rng = np.random.default_rng(M + K + N + x_mode)
+    x = (rng.standard_normal((M, K)) * 2).astype(np.float32)
+    x2 = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K) if trans else (K, N)) / np.sqrt(K)).astype(np.float32)
+    v0 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    v1 = (rng.standard_normal(K) + 1).astype(np.float32)
+    v2 = (rng.standard_normal(K) * 0.3).astype(np.float32)
+    x64, w64 = x.astype(np.float64), (w.astype(np.float64).T if trans else w.astype(np.float64))
+    if x_mode == 1:
+        xp = np.clip(x64 * v0 + v1, 0.0, 6.0)
+        xp32 = np.clip(x * v0 + v1, np.float32(0), np.float32(6)).astype(np.float32)          # the pass's own f32 arithmetic (mul, add, clamp)
+    else:
+        xp = v0.astype(np.float64) * x64 + v1 + v2.astype(np.float64) * x2
+        xp32 = ((v0 * x + v1) + v2 * x2).astype(np.float32)
+    want = xp @ w64
+    Kp = (K + 31) // 32 * 32
+    panels = torch.empty(3 * N * Kp, dtype=torch.int16, device=DEV)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    tmp = torch.full((M, K), float("nan"), device=DEV)
+    hip.check(lib.ams_k_pointwise_xform(PD(x), M, K, PD(w), N, trans, split, x_mode, hip.ACT_RELU6 if x_mode == 1 else hip.ACT_NONE, PD(v0), PD(v1),
+                                        PD(v2), PD(x2), P(y), P(tmp), P(panels), panels.numel(), stream()))
+    got = y.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < (3e-5 if split else 1e-5)
+    # the plain kernel on the materialised operand: same bits
+    y2 = torch.empty((M, N), device=DEV)
+    if split:
+        hip.check(lib.ams_k_pointwise_split3(PD(xp32), M, K, PD(w if not trans else np.ascontiguousarray(w.T)), N, None, None, hip.ACT_NONE, None, P(y2),
+                                             P(panels), panels.numel(), stream()))
+    else:
+        hip.check(lib.ams_k_pointwise(PD(xp32), M, K, PD(w), N, trans, None, 0, None, None, hip.ACT_NONE, None, P(y2), stream()))
+    assert torch.equal(y, y2), "transform on load differs from the materialised pass by %g" % (y - y2).abs().max().item()
+
+
+@pytest.mark.parametrize("M,K,N,split", [(17160, 960, 160, 1), (17160, 384, 64, 1), (4290, 576, 96, 1), (2145, 160, 960, 1), (33001, 96, 24, 0),
+                                          (70001, 192, 32, 0), (513, 144, 24, 0), (90, 256, 256, 0)])
+@pytest.mark.parametrize("modes", [(1, 0), (0, 2), (1, 2)])
+def test_pointwise_wgrad_with_operand_transforms(lib, M, K, N, split, modes):
+    """Weight gradient dw = x'^T dy' with BN + ReLU6 applied to x and / or dz = A dy + B + C z formed from (dy, z) on load (WgArgs x_mode,
+    dy_mode): against f64 math and bit for bit against the same kernel on materialised operands."""
+    x_mode, dy_mode = modes
+    rng = np.random.default_rng(M + K + N + 7 * x_mode + dy_mode)
+    x = (rng.standard_normal((M, K)) * 2).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    z = rng.standard_normal((M, N)).astype(np.float32)
+    v0 = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    v1 = (rng.standard_normal(K) + 1).astype(np.float32)
+    d0 = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    d1 = (rng.standard_normal(N) * 0.5).astype(np.float32)
+    d2 = (rng.standard_normal(N) * 0.3).astype(np.float32)
+    xp32 = np.clip(x * v0 + v1, np.float32(0), np.float32(6)).astype(np.float32) if x_mode else x
+    dp32 = ((d0 * dy + d1) + d2 * z).astype(np.float32) if dy_mode else dy
+    xp = np.clip(x.astype(np.float64) * v0 + v1, 0, 6) if x_mode else x.astype(np.float64)
+    dp = (d0.astype(np.float64) * dy + d1 + d2.astype(np.float64) * z) if dy_mode else dy.astype(np.float64)
+    want = xp.T @ dp
+    n_scr = int(lib.ams_k_pointwise_wgrad_scratch(M, K, N))
+    scr = torch.empty(n_scr, device=DEV)
+    dw = torch.full((K, N), float("nan"), device=DEV)
+    hip.check(lib.ams_k_pointwise_wgrad_xform(PD(x), PD(dy), M, K, N, split, x_mode, hip.ACT_RELU6, PD(v0), PD(v1), dy_mode, PD(d0), PD(d1), PD(d2),
+                                              PD(z), P(dw), P(scr), n_scr, stream()))
+    got = dw.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, want) < 3e-5
+    dw2 = torch.empty((K, N), device=DEV)
+    if split:
+        hip.check(lib.ams_k_pointwise_wgrad_split(PD(xp32), PD(dp32), M, K, N, P(dw2), P(scr), n_scr, stream()))
+    else:
+        hip.check(lib.ams_k_pointwise_wgrad(PD(xp32), PD(dp32), M, K, N, P(dw2), P(scr), n_scr, stream()))
+    assert torch.equal(dw, dw2), "transforms on load differ from the materialised operands by %g" % (dw - dw2).abs().max().item()

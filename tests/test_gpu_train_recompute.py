@@ -68,3 +68,32 @@ def test_recompute_step_is_reproducible():
     a = _step(64, 2, True, steps=2)
     b = _step(64, 2, True, steps=2)
     assert np.array_equal(a["grads"], b["grads"]) and np.array_equal(a["params"], b["params"]) and np.array_equal(a["stats"], b["stats"])
+
+
+@pytest.mark.parametrize("H,B", [(64, 2), (62, 3), (128, 4)])
+@pytest.mark.parametrize("layerwise", [False, True])
+def test_operand_transforms_change_no_bit(H, B, layerwise):
+    """AMS_OPT_FUSE_OPERAND_BN moves elementwise BN passes into the operand loads of their consumers with the same IEEE operations in the same
+    order: gradients, parameters after two steps and moving statistics must be BIT-identical with the passes written (0), with the default
+    (3: depthwise activations + project-layer dz) and with the stride-16 expand layers' dz as well (7) — in the fused step and in the
+    layer-by-layer step (where most consumers take the materialising fallback)."""
+    W0 = Wt.synthetic_weights(S.build_spec(), 5)
+    fr, lb = synth.SyntheticVideo(H, B, CI, seed=5).clip()
+    ref = None
+    for bits in (0, 3, 7):
+        eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+        eng.load_variables(W0)
+        if layerwise:
+            eng.set_train_recompute(False, fuse_dgrad_bn=False, fuse_gemm_red=0)
+        eng.set_fuse_operand_bn(bits)
+        l0 = eng.train_step(fr, lb, 1e-3).cpu().numpy().copy()
+        g = eng.grads.cpu().numpy().copy()
+        eng.train_step(fr, lb, 1e-3)
+        out = (l0, g, eng.params.cpu().numpy().copy(), eng.stats.cpu().numpy().copy())
+        eng.close()
+        if ref is None:
+            ref = out
+        else:
+            for k, (x, y) in enumerate(zip(ref, out)):
+                assert np.array_equal(x, y), "fuse_operand_bn=%d changes %s (max diff %g)" % (bits, ("the loss", "the gradients", "the parameters", "the moving statistics")[k],
+                                                                                         np.abs(x.astype(np.float64) - y).max())

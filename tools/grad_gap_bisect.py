@@ -6,6 +6,11 @@ errors: the tensor named, and the five worst HIP / f32-CPU ratios among the tens
 ones, where a ratio far above 1 is a kernel's arithmetic and not the graph's noise).
 
     python tools/grad_gap_bisect.py [H=64] [B=2] [seed=0] [tensor=aspp0/weights:0]
+    python tools/grad_gap_bisect.py layers [H=64] [B=2] [seed=0]
+
+``layers``: the layer-by-layer step (every fine-tune fusion off, so that every tensor exists; ams_student_layer_tensor) compared tensor by
+tensor with the f64 oracle: raw conv outputs z and activations a on the way forward, gradients with respect to z on the way back (autograd
+with respect to the oracle's own z tensors), each beside the f32 CPU oracle's distance from f64 on the same tensor.
 """
 import sys
 from pathlib import Path
@@ -35,7 +40,63 @@ def errors(spec_, g, grads_ref):
     return out
 
 
+def layer_view(eng, layer, which, B, h, w, c):
+    import ctypes as C
+    off, n = C.c_size_t(), C.c_size_t()
+    hip.check(eng.lib.ams_student_layer_tensor(eng._h, layer, which, C.byref(off), C.byref(n)))
+    return eng.arena[off.value:off.value + 4 * B * h * w * c].view(torch.float32).view(B, h, w, c).cpu().numpy().astype(np.float64)
+
+
+def layers_main():
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    sp = spec.build_spec()
+    W0 = weights.synthetic_weights(sp, seed=seed)
+    frames, labels = synth.SyntheticVideo(H, B, CI, seed=7 + seed).clip()
+    fr32 = frames.astype(np.float32)
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        o = StudentOracle(W0, CI, dtype=dt)
+        taps, ztaps = {}, {}
+        z = o.reduced_logits(o.logits_full(fr32, "train", None, taps, ztaps))
+        target, weight = o.label_targets(labels)
+        loss = o.loss_from_reduced(z, target, weight)
+        names = list(ztaps)
+        gz = torch.autograd.grad(loss, [ztaps[k] for k in names])
+        ref[dt] = ({k: v.detach().numpy().astype(np.float64) for k, v in taps.items()},
+                   {k: v.detach().permute(0, 2, 3, 1).numpy().astype(np.float64) for k, v in ztaps.items()},
+                   {k: g.permute(0, 2, 3, 1).numpy().astype(np.float64) for k, g in zip(names, gz)})
+    t64, z64, g64 = ref[torch.float64]
+    t32, z32, g32 = ref[torch.float32]
+    for tag, matmul in (("layer-wise + matmul f32", hip.MATMUL_F32), ("layer-wise, three-part split", hip.MATMUL_SPLIT_BF16_X6)):
+        eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+        eng.load_variables(W0)
+        eng.set_train_recompute(False, fuse_dgrad_bn=0, fuse_gemm_red=0)
+        eng.set_matmul_mode(matmul)
+        eng.train_step(frames, labels, 1e-3)
+        torch.cuda.synchronize()
+        print("==", tag, "   (relative L2 vs the f64 oracle: HIP / f32 CPU oracle)")
+        rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)  # noqa: E731
+        for l in sp.layers:
+            if l.scope not in z64:
+                continue
+            shp = z64[l.scope].shape
+            zz = layer_view(eng, l.idx, 0, *shp)
+            aa = layer_view(eng, l.idx, 1, *shp) if l.scope in t64 and t64[l.scope].shape == shp else None
+            dz = layer_view(eng, l.idx, 3, *shp) if l.scope.startswith("MobilenetV2") else None
+            line = "%2d %-44s z %.1e / %.1e" % (l.idx, l.scope.replace("MobilenetV2/", ""), rel(zz, z64[l.scope]), rel(z32[l.scope], z64[l.scope]))
+            if aa is not None:
+                line += "   a %.1e / %.1e" % (rel(aa, t64[l.scope]), rel(t32[l.scope], t64[l.scope]))
+            if dz is not None:
+                line += "   dz %.1e / %.1e" % (rel(dz, g64[l.scope]), rel(g32[l.scope], g64[l.scope]))
+            print(line)
+        eng.close()
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "layers":
+        return layers_main()
     H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0

@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <mutex>
+#include <vector>
 
 #include "kernels.hpp"
 
@@ -15,6 +16,14 @@ struct ams_comm {
     int rank = 0, world = 1;
     int64_t calls = 0, bytes = 0;        // what the steps exchanged so far (tests)
     bool aborted = false;
+    // diagnostic timing (ams_comm_set_timing): a HIP event pair around every collective on its stream; read back by ams_comm_timing_read
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    std::vector<hipEvent_t> pool;
+    ~ams_comm() {
+        for (auto& sp : spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
 };
 
 namespace ams {
@@ -72,7 +81,14 @@ int comm_allreduce(ams_comm* c, void* p, size_t n, int dtype, hipStream_t st) {
     if (!c || !c->comm) return AMS_OK;             // world 1 without a communicator: the sum over one rank is the value itself
     Rccl& r = rccl();
     const ncclDataType_t dt = dtype == AMS_DT_F64 ? ncclFloat64 : ncclFloat32;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        auto take = [&]() { hipEvent_t e = nullptr; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        e0 = take(); e1 = take();
+        if (e0) (void)hipEventRecord(e0, st);
+    }
     const ncclResult_t rc = r.AllReduce(p, p, n, dt, ncclSum, c->comm, st);
+    if (c->timing && e0 && e1) { (void)hipEventRecord(e1, st); c->spans.emplace_back(e0, e1); }
     if (rc != ncclSuccess) {
         // a rank that fails between two collectives of a step leaves its peers waiting inside theirs: abort the communicator so that
         // they return with an error instead of hanging; this handle is dead from here on
@@ -144,6 +160,29 @@ int ams_comm_stats(const ams_comm* c, int32_t* rank, int32_t* world, int64_t* ca
     if (world) *world = w_seen;
     if (calls) *calls = c->calls;
     if (bytes) *bytes = c->bytes;
+    return AMS_OK;
+}
+
+int ams_comm_set_timing(ams_comm* c, int32_t enable) {
+    AMS_REQUIRE(c, "comm_set_timing: null communicator");
+    AMS_CHECK_HIP(hipDeviceSynchronize());
+    for (auto& sp : c->spans) { c->pool.push_back(sp.first); c->pool.push_back(sp.second); }
+    c->spans.clear();
+    c->timing = enable != 0;
+    return AMS_OK;
+}
+
+int ams_comm_timing_read(ams_comm* c, double* total_ms, double* max_ms, int64_t* spans) {
+    AMS_REQUIRE(c && total_ms && max_ms && spans, "comm_timing_read: null pointer");
+    AMS_CHECK_HIP(hipDeviceSynchronize());
+    double tot = 0.0, mx = 0.0;
+    for (auto& sp : c->spans) {
+        float ms = 0.f;
+        AMS_CHECK_HIP(hipEventElapsedTime(&ms, sp.first, sp.second));
+        tot += ms;
+        if (ms > mx) mx = ms;
+    }
+    *total_ms = tot; *max_ms = mx; *spans = (int64_t)c->spans.size();
     return AMS_OK;
 }
 

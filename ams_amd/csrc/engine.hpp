@@ -104,7 +104,7 @@ struct ams_student {
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
     int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
     int fuse_gemm_red = 3;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics, bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
-    int fuse_operand_bn = 3;           // fine-tune step: elementwise BN passes folded into the operand loads of the consuming 1x1 GEMMs / weight-gradient kernels
+    int fuse_operand_bn = 1;           // fine-tune step: elementwise BN passes folded into the operand loads of the consuming 1x1 GEMMs / weight-gradient kernels
                                        // (AMS_OPT_FUSE_OPERAND_BN): bit 0 BN + activation of a depthwise layer (a_d is never written), bit 1 dz of a project layer
                                        // (A dy + B + C z formed by its input-gradient GEMM and its weight gradient), bit 2 the same for the stride-16 expand layers
     int fuse_dgrad_bn = 2;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
@@ -232,6 +232,7 @@ static inline int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream
 // ---- engine_forward.hip ----------------------------------------------------------------------------------
 bool split_pays(const PwArgs& a);
 int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st);
+bool live_pointwise_transforms_on_load(const ams_student* s, const PwArgs& a);
 int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st, bool* wrote_parts = nullptr, bool force_split = false);
 bool train_recompute_block(const ams_student* s, int i);
 bool dw_fused_train(const ams_student* s, int i, int B);

@@ -152,9 +152,18 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         float* dz = l.dzp ? l.dzp : l.da;
         // this layer's dz is not written: its input-gradient GEMM and its weight gradient form A dy + B + C z on their operand loads
         // (project layers: BN without activation; stride-16 expand layers whose masked gradient the depthwise kernel left in da)
-        const bool lazy_dz = i >= 3 && l.d.cout % 4 == 0 && l.d.cout <= 1024 &&
-                             (((s->fuse_operand_bn & 2) && l.d.role == AMS_ROLE_PROJECT && l.d.act == AMS_ACT_NONE) ||
-                              ((s->fuse_operand_bn & 4) && l.d.role == AMS_ROLE_EXPAND && fused_rows > 0 && !train_recompute_block(s, i)));
+        bool lazy_dz = i >= 3 && l.d.cout % 4 == 0 && l.d.cout <= 1024 &&
+                       (((s->fuse_operand_bn & 2) && l.d.role == AMS_ROLE_PROJECT && l.d.act == AMS_ACT_NONE) ||
+                        ((s->fuse_operand_bn & 4) && l.d.role == AMS_ROLE_EXPAND && fused_rows > 0 && !train_recompute_block(s, i)));
+        if (lazy_dz) {
+            // only where the input-gradient GEMM really transforms on load: its fallback would write dz over da, which the weight gradient
+            // on the side stream reads as the untransformed gradient
+            PwArgs probe = dgrad_args(l.da, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, s->L[i - 1].da);
+            probe.x_mode = 2; probe.x_act = AMS_ACT_NONE; probe.x_v0 = l.cA; probe.x_v1 = l.cB; probe.x_v2 = l.cC; probe.x2 = l.z;
+            if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) { probe.res = s->L[i + 2].da; probe.ldr = l.d.cin; }
+            if ((s->fuse_gemm_red & 2) && i - 1 >= 2) probe.red_mode = 2;
+            lazy_dz = !probe.res && live_pointwise_transforms_on_load(s, probe);      // (with a residual operand the kernel choice depends on the reduction's row capacity)
+        }
         if (fused_rows > 0) {
             // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the
             // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z

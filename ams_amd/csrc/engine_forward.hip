@@ -12,6 +12,13 @@ bool split_pays(const PwArgs& a) {
     return a.M < 32768 || !pointwise_stream_applies(a) || (int64_t)a.K * a.N >= 40 * (int64_t)(a.K + a.N);
 }
 
+// live_pointwise(a) would apply a.x_mode on its operand loads (else it writes x' to a.x_tmp first: the caller must not alias x_tmp with
+// anything another stream still reads)
+bool live_pointwise_transforms_on_load(const ams_student* s, const PwArgs& a) {
+    const bool split = s->matmul_mode != AMS_MATMUL_F32 && s->panel_scratch && split_pays(a) && a.Kw == a.K && a.ldx % 4 == 0;
+    return split ? pointwise_split3_transforms_on_load(a) : pointwise_transforms_on_load(a);
+}
+
 // live (training) 1x1 layer or its input gradient: same split-bf16 rule as the frozen path, the weights are split right
 // before the launch because they change every step (one small kernel; the panels live in one shared scratch buffer)
 int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
@@ -446,10 +453,14 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
                 RUN(launch_bn_finalize(l.fsums, n_e, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
                                        mm, mv, l.scale, l.shift, l.mean, l.rstd, st));
             }
+            // ... which leaves the statistics of that raw output behind as one partial row per tile (no separate pass over z_d)
+            int d_rows = 0;
+            const bool d_stats = (s->fuse_gemm_red & 1) && expand_dw_stats_scratch(B, l.Hin, l.Win, l.d.cout, ld.d.stride) <= s->scratch_floats;
             RUNK(i + 1, 4.0 * ((double)B * (l.px_in * l.d.cin + ld.px_out * ld.d.cout)),
                  launch_expand_dw(x, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.scale, l.shift, l.d.act, l.d.cout, P + ld.d.w_off, ld.d.stride,
-                                  ld.d.rate, s->vec_ones, s->vec_zeros, AMS_ACT_NONE, ld.z, st));
-            RUN(bn_train(s, ld, (int64_t)B * ld.px_out, (double)global_B * ld.px_out, update_ema, sc, nullptr, st, 0, !operand_bn_act(s, i + 1)));
+                                  ld.d.rate, s->vec_ones, s->vec_zeros, AMS_ACT_NONE, ld.z, st, d_stats ? s->stats + ld.d.mean_off : nullptr,
+                                  d_stats ? s->scratch : nullptr, d_stats ? &d_rows : nullptr));
+            RUN(bn_train(s, ld, (int64_t)B * ld.px_out, (double)global_B * ld.px_out, update_ema, sc, nullptr, st, d_rows, !operand_bn_act(s, i + 1)));
             ++i;
             continue;
         }

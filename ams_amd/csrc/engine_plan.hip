@@ -175,6 +175,10 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
             const int64_t M = (int64_t)B * l.px_out;
             if (l.d.role == AMS_ROLE_DEPTHWISE) {
                 need = depthwise_wgrad_scratch(B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate);
+                if (i >= 3 && expand_dw_supported(s->L[i - 1].d.cin, l.d.cin, l.d.stride, l.d.rate)) {      // statistics rows of the recompute blocks' forward
+                    const size_t n0 = expand_dw_stats_scratch(B, l.Hin, l.Win, l.d.cin, l.d.stride);
+                    if (n0 > need) need = n0;
+                }
                 if (l.d.stride == 1 && l.d.cin <= 1024) {       // the one-kernel forms of the blocks that keep their tensors
                     const size_t n1 = depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin), n2 = depthwise_fwd_bn_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate);
                     if (n1 > need) need = n1;

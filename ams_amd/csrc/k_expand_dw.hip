@@ -26,9 +26,12 @@ struct XdwArgs {
     int Ho, Wo, pt, pl;
     int tiles_x, tiles_y, chunks;
     int chunk_splits;        // blocks per tile: each walks chunks / chunk_splits channel chunks
+    // fine-tune forward (STATS): the depthwise layer's BN statistics of the RAW result on the way out — partial rows [tiles][2][Cexp] of
+    // sum(y - center), sum((y - center)^2), one row per tile (a block owns the columns of its chunks)
+    const float* center; float* part;
 };
 
-template <int S, int R, int NT, int TH, int TW, int KC>
+template <int S, int R, int NT, int TH, int TW, int KC, bool STATS = false>
 __global__ __launch_bounds__(256) void expand_dw_kernel(XdwArgs a, unsigned nblocks) {
     constexpr int CC = 16 * NT;                       // expanded channels per block
     constexpr int IH = (TH - 1) * S + 2 * R + 1, IW = (TW - 1) * S + 2 * R + 1;
@@ -168,7 +171,11 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(XdwArgs a, unsigned nblo
     // ---- phase 2: depthwise 3x3 from LDS; thread = (output pixel, 4 channels), channel groups along lanes
     constexpr int CG = CC / 4;
     float* yb = a.y + (int64_t)b * a.Ho * a.Wo * a.Cexp + n0;
-    for (int item = tid; item < TH * TW * CG; item += 256) {
+    // STATS: a thread keeps ONE channel group (its sums stay in registers): threads 0 .. TPC*CG-1 walk the pixels TPC apart
+    constexpr int TPC = 256 / CG;                      // threads per channel group
+    float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f), st2 = st1, ctr = st1;
+    if constexpr (STATS) { if (tid < TPC * CG && a.center) ctr = ld4(a.center + n0 + 4 * (tid % CG)); }
+    for (int item = STATS ? (tid < TPC * CG ? tid : TH * TW * CG) : tid; item < TH * TW * CG; item += STATS ? TPC * CG : 256) {
         const int cg = item % CG, p = item / CG;
         const int ly = p / TW, lx = p - ly * TW;
         const int oy = oy0 + ly, ox = ox0 + lx;
@@ -189,11 +196,33 @@ __global__ __launch_bounds__(256) void expand_dw_kernel(XdwArgs a, unsigned nblo
         o.x = apply_act(acc.x * sc.x + sh.x, a.act_d); o.y = apply_act(acc.y * sc.y + sh.y, a.act_d);
         o.z = apply_act(acc.z * sc.z + sh.z, a.act_d); o.w = apply_act(acc.w * sc.w + sh.w, a.act_d);
         st4(yb + ((int64_t)oy * a.Wo + ox) * a.Cexp + c4, o);
+        if constexpr (STATS) {
+            const float4 d = sub4_pk(o, ctr);
+            st1 = add4_pk(st1, d);
+            st2 = add4_pk(st2, mul4_pk(d, d));
+        }
+    }
+    if constexpr (STATS) {
+        // the block's sums of this chunk: thread (cg, k) -> LDS, then one thread per (sum, channel) adds the TPC entries in a fixed order
+        __syncthreads();                               // phase 2 has finished reading sAct
+        float* sRed = sAct;                            // [TPC][2][CC]
+        if (tid < TPC * CG) {
+            const int cg = tid % CG, k = tid / CG;
+            st4(sRed + (k * 2 + 0) * CC + 4 * cg, st1);
+            st4(sRed + (k * 2 + 1) * CC + 4 * cg, st2);
+        }
+        __syncthreads();
+        if (tid < 2 * CC) {
+            float v = 0.f;
+            for (int k = 0; k < TPC; ++k) v += sRed[k * 2 * CC + tid];
+            const int which = tid / CC, c = tid - which * CC;
+            a.part[((int64_t)(lb / a.chunk_splits) * 2 + which) * a.Cexp + n0 + c] = v;
+        }
     }
     }   // chunk
 }
 
-template <int S, int R, int NT, int TH, int TW, int KC>
+template <int S, int R, int NT, int TH, int TW, int KC, bool STATS = false>
 static int launch_xdw_k(XdwArgs a, hipStream_t st) {
     constexpr int CC = 16 * NT;
     constexpr int IH = (TH - 1) * S + 2 * R + 1, IW = (TW - 1) * S + 2 * R + 1;
@@ -204,7 +233,8 @@ static int launch_xdw_k(XdwArgs a, hipStream_t st) {
     constexpr int Kpad = KC * 16;
     const size_t lds = ((size_t)Kpad * (CC + 4) + 4 * CC + 9 * CC + (size_t)NRG * 16 * (CC + 4)) * sizeof(float);
     AMS_REQUIRE(lds <= 150 * 1024, "expand_dw: tile needs %zu bytes of LDS", lds);
-    RUN_RC(func_allow_lds((const void*)expand_dw_kernel<S, R, NT, TH, TW, KC>, lds > 64 * 1024 ? 150 * 1024 : lds));
+    static_assert(!STATS || (256 / (CC / 4)) * 2 * CC <= NRG * 16 * (CC + 4), "the statistics' LDS scratch must fit the activation tile");
+    RUN_RC(func_allow_lds((const void*)expand_dw_kernel<S, R, NT, TH, TW, KC, STATS>, lds > 64 * 1024 ? 150 * 1024 : lds));
     // all chunks in one block when there are enough tiles to fill the chip (measured: from ~2000 tiles on, ~1000 with 4+ chunks), else one block
     // per (tile, chunk) for parallelism
     const int64_t tiles = (int64_t)a.tiles_x * a.tiles_y * a.B;
@@ -214,13 +244,21 @@ static int launch_xdw_k(XdwArgs a, hipStream_t st) {
     static const std::string nm = "expand_dw_kernel<" + std::to_string(S) + ", " + std::to_string(R) + ", " + std::to_string(NT) + ", " +
                                   std::to_string(TH) + ", " + std::to_string(TW) + ", " + std::to_string(KC) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((expand_dw_kernel<S, R, NT, TH, TW, KC>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((expand_dw_kernel<S, R, NT, TH, TW, KC, STATS>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
 
 template <int S, int R, int NT, int TH, int TW>
 static int launch_xdw_t(XdwArgs a, hipStream_t st) {
+    if (a.part) {
+        switch ((a.Cin + 15) / 16) {
+            case 1: return launch_xdw_k<S, R, NT, TH, TW, 1, true>(a, st);
+            case 2: return launch_xdw_k<S, R, NT, TH, TW, 2, true>(a, st);
+            case 3: return launch_xdw_k<S, R, NT, TH, TW, 3, true>(a, st);
+            default: return launch_xdw_k<S, R, NT, TH, TW, 4, true>(a, st);
+        }
+    }
     switch ((a.Cin + 15) / 16) {
         case 1: return launch_xdw_k<S, R, NT, TH, TW, 1>(a, st);
         case 2: return launch_xdw_k<S, R, NT, TH, TW, 2>(a, st);
@@ -236,12 +274,34 @@ bool expand_dw_supported(int Cin, int Cexp, int stride, int rate) {
     return Cexp % 32 == 0 || Cexp % 48 == 0;
 }
 
+// rows of the statistics form: one per (frame, tile)
+static void xdw_tile(int Cexp, int stride, int* th, int* tw) {
+    const bool nt2 = Cexp % 32 == 0;
+    if (stride == 1) { *th = nt2 ? 16 : 8; *tw = 16; } else { *th = 8; *tw = 8; }
+}
+size_t expand_dw_stats_scratch(int B, int H, int W, int Cexp, int stride) {
+    int th, tw, Ho, Wo, p;
+    xdw_tile(Cexp, stride, &th, &tw);
+    same_pad(H, 3, stride, 1, &Ho, &p);
+    same_pad(W, 3, stride, 1, &Wo, &p);
+    return (size_t)B * cdiv(Ho, th) * cdiv(Wo, tw) * 2 * (size_t)Cexp;
+}
+
 int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e,
                      int Cexp, const float* w_dw, int stride, int rate, const float* sc_d, const float* sh_d, int act_d, float* y,
-                     hipStream_t st) {
+                     hipStream_t st, const float* stats_center, float* stats_part, int* stats_rows) {
     AMS_REQUIRE(expand_dw_supported(Cin, Cexp, stride, rate), "expand_dw: unsupported shape Cin=%d Cexp=%d s=%d r=%d", Cin, Cexp, stride, rate);
     XdwArgs a;
     memset(&a, 0, sizeof(a));
+    a.center = stats_center; a.part = stats_part;
+    if (stats_part) {
+        AMS_REQUIRE(stats_rows, "expand_dw: statistics need a row count output");
+        int th, tw, Ho, Wo, pp;
+        xdw_tile(Cexp, stride, &th, &tw);
+        same_pad(H, 3, stride, rate, &Ho, &pp);
+        same_pad(W, 3, stride, rate, &Wo, &pp);
+        *stats_rows = B * cdiv(Ho, th) * cdiv(Wo, tw);
+    }
     a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.w_exp = w_exp; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e;
     a.Cexp = Cexp; a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.y = y;
     same_pad(H, 3, stride, rate, &a.Ho, &a.pt);

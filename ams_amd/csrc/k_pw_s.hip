@@ -6,8 +6,9 @@ namespace ams {
 // ---- variant S: streaming layers (huge M, small K x N).  The whole weight panel of this column tile stays in LDS for
 // the block's lifetime; every wave walks its own 16*RM-row groups (grid-stride), no barrier after the prologue, and
 // the A fragment of the NEXT (row group, k chunk) is in flight while the current one feeds the matrix pipe.
-// XF = 1: PwArgs::x_mode 1 — BN + activation of the layer that wrote x, applied to every operand fragment before it feeds the matrix pipe
-// (per-k scale / shift in LDS behind everything else); same unfused multiply / add as bn_act_kernel: bit-identical products.
+// XF = PwArgs::x_mode: 1 — BN + activation of the layer that wrote x, 2 — dz = A x + B + C x2 (second half of BN backward) — applied to every
+// operand fragment before it feeds the matrix pipe (per-k vectors in LDS behind everything else); same unfused multiply / add as
+// bn_act_kernel / bn_bwd_apply_kernel: bit-identical products.
 template <int RM, int NT, int EPI, int XF = 0>
 __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, int64_t n_groups) {
     constexpr int PITCH = 16 * NT + 4;
@@ -27,15 +28,17 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
     const int64_t g_first = (int64_t)blockIdx.x * 4 + wave;
     const bool red = EPI == EPI_PLAIN && a.red_mode != 0;      // block-uniform; the launcher clears red_mode where it does not apply
     float* sRedVec = sSh + 16 * NT + 4 * (16 * (16 * NT + 4));  // behind the waves' output slabs: 4 x 16 NT vectors, then the waves' sums
-    float* sXv = sRedVec + (EPI == EPI_PLAIN ? 12 * 16 * NT : 0);  // XF: scale [Kpad] | shift [Kpad]
+    float* sXv = sRedVec + (EPI == EPI_PLAIN ? 12 * 16 * NT : 0);  // XF: v0 [Kpad] | v1 [Kpad] (| v2 [Kpad])
     const int Kpad = n_chunks * 16;
-    if constexpr (XF == 1) {
+    if constexpr (XF != 0) {
         for (int e = tid; e < Kpad; e += 256) {
             sXv[e] = e < K ? a.x_v0[e] : 0.f;
             sXv[Kpad + e] = e < K ? a.x_v1[e] : 0.f;
+            if constexpr (XF == 2) sXv[2 * Kpad + e] = e < K ? a.x_v2[e] : 0.f;
         }
         __syncthreads();
     }
+    const int64_t x2_off = XF == 2 ? (int64_t)(a.x2 - a.x) : 0;
     float4 rs1[EPI == EPI_PLAIN ? NT : 1], rs2[EPI == EPI_PLAIN ? NT : 1];
     if constexpr (EPI == EPI_PLAIN) {
         if (red) {
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
     // branch-free operand fetch: addresses are clamped into the tensor (rows to M-1, the k offset to K-4) and lanes
     // whose k range lies beyond K are zeroed by a select, so the loop body has no exec-masked VMEM and hipcc can keep
     // the prefetch in flight across the MFMAs (an exec-masked load makes it fall back to s_waitcnt vmcnt(0)).
-    auto fetch = [&](int64_t grp, int c, float4 (&dst)[RM]) {
+    auto fetch = [&](int64_t grp, int c, float4 (&dst)[RM], float4 (&dst2)[XF == 2 ? RM : 1]) {
         int koff = c * 16 + 4 * q;
         const bool ok = koff < K;
         if (koff > K - 4) koff = K - 4;
@@ -61,24 +64,35 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
             int64_t m = grp * (16 * RM) + r * 16 + l15;
             if (m > a.M - 1) m = a.M - 1;
             const float4 v = ld4(a.x + m * (int64_t)a.ldx + koff);
-            if constexpr (XF == 1) dst[r] = v;           // transformed, then zeroed beyond K, when it is consumed (xform below)
+            if constexpr (XF != 0) dst[r] = v;           // transformed, then zeroed beyond K, when it is consumed (xform below)
             else dst[r] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            if constexpr (XF == 2) dst2[r] = ld4(a.x + x2_off + m * (int64_t)a.ldx + koff);
         }
     };
-    auto xform = [&](int c, float4 (&v)[RM]) {
+    auto xform = [&](int c, float4 (&v)[RM], const float4 (&v2)[XF == 2 ? RM : 1]) {
         int koff = c * 16 + 4 * q;
         const bool ok = koff < K;
         if (koff > K - 4) koff = K - 4;
         const float4 sc = ld4(sXv + koff), sh = ld4(sXv + Kpad + koff);
+        if constexpr (XF == 1) {
 #pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const float4 y = muladd4_pk(v[r], sc, sh);
-            v[r] = make_float4(ok ? apply_act(y.x, a.x_act) : 0.f, ok ? apply_act(y.y, a.x_act) : 0.f, ok ? apply_act(y.z, a.x_act) : 0.f,
-                               ok ? apply_act(y.w, a.x_act) : 0.f);
+            for (int r = 0; r < RM; ++r) {
+                const float4 y = muladd4_pk(v[r], sc, sh);
+                v[r] = make_float4(ok ? apply_act(y.x, a.x_act) : 0.f, ok ? apply_act(y.y, a.x_act) : 0.f, ok ? apply_act(y.z, a.x_act) : 0.f,
+                                   ok ? apply_act(y.w, a.x_act) : 0.f);
+            }
+        } else {
+            const float4 cc = ld4(sXv + 2 * Kpad + koff);
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                const float4 y = add4_pk(add4_pk(mul4_pk(sc, v[r]), sh), mul4_pk(cc, v2[r]));        // (A g + B) + C z
+                v[r] = make_float4(ok ? y.x : 0.f, ok ? y.y : 0.f, ok ? y.z : 0.f, ok ? y.w : 0.f);
+            }
         }
     };
     float4 a_cur[RM], a_nxt[RM];
-    fetch(g_first < n_groups ? g_first : n_groups - 1, 0, a_cur);
+    float4 z_cur[XF == 2 ? RM : 1], z_nxt[XF == 2 ? RM : 1];
+    fetch(g_first < n_groups ? g_first : n_groups - 1, 0, a_cur, z_cur);
     f32x4 acc[RM][NT];
     int64_t g = g_first;
     int c = 0;
@@ -87,14 +101,14 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
         int cn = c + 1;
         int64_t gn = g;
         if (cn == n_chunks) { cn = 0; gn = g + wave_stride; if (gn >= n_groups) gn = g; }
-        fetch(gn, cn, a_nxt);
+        fetch(gn, cn, a_nxt, z_nxt);
         if (c == 0) {
 #pragma unroll
             for (int r = 0; r < RM; ++r)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        if constexpr (XF == 1) xform(c, a_cur);
+        if constexpr (XF != 0) xform(c, a_cur, z_cur);
         pw_chunk<RM, NT, PITCH>(acc, a_cur, sW + (c * 16 + 4 * q) * PITCH + l15);
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
@@ -102,6 +116,10 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
             // Hand the prefetched fragment over HERE, ahead of the epilogue's stores: vmcnt retires in order and counts
             // stores, so a wait placed after them would sit behind a full store round trip with the matrix pipe idle.
             asm volatile("" : "+v"(a_cur[r].x), "+v"(a_cur[r].y), "+v"(a_cur[r].z), "+v"(a_cur[r].w));
+            if constexpr (XF == 2) {
+                z_cur[r] = z_nxt[r];
+                asm volatile("" : "+v"(z_cur[r].x), "+v"(z_cur[r].y), "+v"(z_cur[r].z), "+v"(z_cur[r].w));
+            }
         }
         if (c == n_chunks - 1) {
             if constexpr (EPI == EPI_PLAIN) {
@@ -124,7 +142,7 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     const int64_t n_groups = cdiv64(a.M, 16 * RM);
     // weight panel | scale, shift | four output slabs | (fused reduction: 4 vectors + 4 waves x 2 sums of 16 NT floats) | (XF: 2 x Kpad)
     const size_t lds = ((size_t)((a.K + 15) / 16 * 16) * PITCH + 32 * NT + 4 * 16 * (16 * NT + 4) + (EPI == EPI_PLAIN ? 12 * 16 * NT : 0) +
-                        (XF ? 2 * ((a.K + 15) / 16 * 16) : 0)) * sizeof(float);
+                        (XF ? (XF + 1) * ((a.K + 15) / 16 * 16) : 0)) * sizeof(float);
     int64_t blocks = cdiv64(n_groups, 4);
     // persistent grid: exactly the blocks that are co-resident (work is pre-partitioned by grid-stride, so any block that
     // has to wait for a slot would run its whole share on a half-empty chip)
@@ -134,7 +152,7 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     RUN_RC(device_cus(&cus));
     if (knobs().pw_percu > 0) per_cu = knobs().pw_percu;                  // tuning knob AMS_PW_PERCU (tools/bench_kernel.py)
     if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
-    static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + (XF ? ", 1>" : ">");
+    static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + (XF ? ", " + std::to_string(XF) + ">" : ">");
     note_kernel(nm.c_str());
     PwArgs b = a;
     if (b.red_mode) {
@@ -149,6 +167,7 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
 template <int RM, int NT>
 static int launch_pw_s(const PwArgs& a, hipStream_t st) {
     if (a.x_mode == 1 && !a.res) return launch_pw_s_e<RM, NT, EPI_PLAIN, 1>(a, st);
+    if (a.x_mode == 2 && !a.res) return launch_pw_s_e<RM, NT, EPI_PLAIN, 2>(a, st);
     return a.res ? launch_pw_s_e<RM, NT, EPI_RES>(a, st) : launch_pw_s_e<RM, NT, EPI_PLAIN>(a, st);
 }
 
@@ -167,13 +186,20 @@ static int pw_stream_nt(const PwArgs& a, int force_nt) {
 }
 
 bool pointwise_stream_applies(const PwArgs& a) { return pw_stream_nt(a, 0) > 0; }
+// launch_pointwise on this problem runs the streaming kernel AND that kernel applies PwArgs::x_mode on its operand loads
+bool pointwise_transforms_on_load(const PwArgs& a) {
+    if (a.x_mode == 0) return true;
+    if (a.M < 32768 || pw_stream_nt(a, 0) <= 0) return false;
+    return !a.res && a.x_v0 && a.x_v1 && (a.x_mode == 1 || (a.x_mode == 2 && a.x_v2 && a.x2 && a.x_act == AMS_ACT_NONE));
+}
 
 // returns AMS_OK and sets *handled when the streaming variant applies (weight panel <= 56 KB, vector-friendly layout)
 int launch_pointwise_stream(const PwArgs& a, int force_rm, int force_nt, bool* handled, hipStream_t st) {
     *handled = false;
     const int nt = pw_stream_nt(a, force_nt);
     if (nt == 0) return AMS_OK;
-    if (a.x_mode != 0 && !(a.x_mode == 1 && !a.res && a.x_v0 && a.x_v1)) return AMS_OK;       // only BN + activation on a plain epilogue: the caller materialises
+    if (a.x_mode != 0 && !(!a.res && a.x_v0 && a.x_v1 && (a.x_mode == 1 || (a.x_mode == 2 && a.x_v2 && a.x2 && a.x_act == AMS_ACT_NONE))))
+        return AMS_OK;                                                                              // transforms only on a plain epilogue: the caller materialises
     *handled = true;
     switch (nt) {
         case 1: return launch_pw_s<2, 1>(a, st);

@@ -438,6 +438,12 @@ static int launch_pointwise_parts(const PwArgs& a, const SplitPanels& w, int Kp,
     return AMS_E_INVALID;
 }
 
+// the three-part launch of this problem applies PwArgs::x_mode on its operand loads (else it materialises x' into x_tmp first)
+bool pointwise_split3_transforms_on_load(const PwArgs& a) {
+    if (a.x_mode == 0) return true;
+    return pw_pick_epi(a) == EPI_PLAIN && pw_x3_xform_ok(a, 3, EPI_PLAIN);
+}
+
 bool pointwise_split_writes_parts(const PwArgs& a) { return pw_pick_epi(a) != EPI_GENERIC && a.N % 4 == 0; }
 
 // y = epilogue(x @ w) with w given as pre-split bf16 hi/lo panels [N][Kp]; requires K % 8 == 0

@@ -83,6 +83,8 @@ int launch_pointwise(const PwArgs& a, hipStream_t st);
 // x' of PwArgs::x_mode written to a.x_tmp by the elementwise kernels the transform replaces; on return *b is `a` without the transform
 int pointwise_materialize_x(const PwArgs& a, PwArgs* b, hipStream_t st);
 bool pointwise_stream_applies(const PwArgs& a);     // the persistent streaming variant (small K x N) can take this problem
+bool pointwise_transforms_on_load(const PwArgs& a);         // launch_pointwise applies a.x_mode on the operand loads (no x_tmp pass)
+bool pointwise_split3_transforms_on_load(const PwArgs& a);  // the same for launch_pointwise_split3
 
 // split-bf16 (hi + lo) late-layer variant: weights pre-split into [N][Kp] bf16 panels, Kp = K rounded up to 32
 int launch_split_weights(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st);
@@ -156,9 +158,12 @@ int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W,
 
 // ---- k_expand_dw.hip : fused expand (1x1+BN+ReLU6) -> depthwise 3x3 (+BN+ReLU6), frozen inference ------------
 bool expand_dw_supported(int Cin, int Cexp, int stride, int rate);
+// stats_part != nullptr (fine-tune forward; sc_d / sh_d / act_d then describe what is WRITTEN, normally the identity): partial rows
+// [*stats_rows][2][Cexp] of sum(y - center), sum((y - center)^2) of the written values, expand_dw_stats_scratch floats
+size_t expand_dw_stats_scratch(int B, int H, int W, int Cexp, int stride);
 int launch_expand_dw(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e,
                      int Cexp, const float* w_dw, int stride, int rate, const float* sc_d, const float* sh_d, int act_d, float* y,
-                     hipStream_t st);
+                     hipStream_t st, const float* stats_center = nullptr, float* stats_part = nullptr, int* stats_rows = nullptr);
 
 // ---- k_xdw_train.hip : fine-tune step of the early blocks (Cin <= 32) without the 6x-expanded tensors: every consumer recomputes
 // z_e = x . W_e from the block input (see the file header)

@@ -85,6 +85,17 @@ class RcclComm:
         hip.check(self.lib.ams_comm_stats(self._h, None, None, C.byref(calls), C.byref(nbytes)), "ams_comm_stats")
         return int(calls.value), int(nbytes.value)
 
+    def set_timing(self, on: bool) -> None:
+        """Bracket every collective with a HIP event pair (diagnostic steps only: the pairs cost stream time)."""
+        hip.check(self.lib.ams_comm_set_timing(self._h, int(bool(on))), "ams_comm_set_timing")
+
+    def timing(self) -> Tuple[float, float, int]:
+        """(summed ms, longest ms, count) of the collectives' spans since ``set_timing``; synchronises the device."""
+        import ctypes as C
+        tot, mx, n = C.c_double(), C.c_double(), C.c_int64()
+        hip.check(self.lib.ams_comm_timing_read(self._h, C.byref(tot), C.byref(mx), C.byref(n)), "ams_comm_timing_read")
+        return float(tot.value), float(mx.value), int(n.value)
+
     def rank_world(self) -> Tuple[int, int]:
         """(rank, world size) as the library's communicator sees them (RCCL's own view, not the launcher's environment)."""
         import ctypes as C

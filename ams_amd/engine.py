@@ -224,7 +224,7 @@ class StudentEngine:
     def set_fuse_operand_bn(self, bits: int) -> None:
         """Fine-tune step: elementwise BN passes applied by the consuming 1x1 GEMM / weight-gradient kernel on its operand loads (same bits as the
         separate passes): bit 0 BN + activation of the depthwise layers, bit 1 dz of the project layers, bit 2 dz of the stride-16 expand layers.
-        Default 3; 0 = every pass written."""
+        Default 1 (bits 1 and 2 are measured slower); 0 = every pass written."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_OPERAND_BN, int(bits)), "ams_student_set_option")
 
     def set_train_recompute(self, on: bool, fuse_dgrad_bn: Optional[bool] = None, fuse_gemm_red: Optional[int] = None) -> None:

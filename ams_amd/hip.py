@@ -87,6 +87,8 @@ SIGNATURES = {
     "ams_comm_create": (C.c_int, [_vp, _sz, _i32, _i32, C.POINTER(_vp)]),
     "ams_comm_destroy": (None, [_vp]),
     "ams_comm_stats": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64)]),
+    "ams_comm_set_timing": (C.c_int, [_vp, _i32]),
+    "ams_comm_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ams_comm_allreduce": (C.c_int, [_vp, _vp, _sz, _i32, _vp]),
     "ams_student_train_step_rccl": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "ams_student_set_option": (C.c_int, [_vp, _i32, _i32]),

@@ -193,6 +193,12 @@ int ams_comm_unique_id(uint8_t* id_out, size_t cap);
 int ams_comm_create(const uint8_t* id, size_t id_len, int32_t rank, int32_t world, ams_comm** out);
 void ams_comm_destroy(ams_comm* c);
 int ams_comm_stats(const ams_comm* c, int32_t* rank, int32_t* world, int64_t* calls, int64_t* bytes);
+/* Diagnostics of a multi-GPU run (bench.py `collective_ms_per_step`): with timing enabled every collective the communicator issues is
+ * bracketed by a HIP event pair on its stream (the pair costs a few microseconds of stream time per collective: enable it for a few
+ * diagnostic steps, not for the timed ones).  ams_comm_timing_read synchronises the device and returns the summed and the longest span and
+ * their count since the last ams_comm_set_timing; a span is the time the stream spent INSIDE the collective (wait for the peers included). */
+int ams_comm_set_timing(ams_comm* c, int32_t enable);
+int ams_comm_timing_read(ams_comm* c, double* total_ms, double* max_ms, int64_t* spans);
 int ams_comm_allreduce(ams_comm* c, void* buf_dev, size_t count, int32_t dtype, void* stream);
 int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
                                 int32_t batch, int32_t global_batch, float lr, const uint8_t* mask_dev, double* loss_dev,
@@ -212,7 +218,8 @@ enum { AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: elementwise BN passes app
                                         Bit 0: BN + activation of every depthwise layer that feeds a project layer — the project GEMM and the project
                                         weight gradient apply it, the depthwise activation is never written.  Bit 1: dz = A dy + B + C z of every
                                         project layer — formed by its input-gradient GEMM and its weight gradient.  Bit 2: the same for the
-                                        stride-16 expand layers (their GEMM then pulls two f32 operands).  Default 3; 0 = separate passes. */,
+                                        stride-16 expand layers (their GEMM then pulls two f32 operands).  Default 1: bits 1 and 2 are measured SLOWER on MI355X (8.32 -> 8.74 / 8.87 ms per 8-frame step: the consuming GEMMs
+                                        are bound by their operand path and the second operand stream costs more than the small passes it removes); 0 = every pass written. */,
        AMS_OPT_NAN_GRADS = 18 /* fine-tune step on a batch WITHOUT a valid pixel: 1 (default) the reference's result — loss = 0 / 0 and every gradient
                                   NaN (utils/graph_utils.py:408: sum(w ce) / sum(w)), so the Adam update poisons the masked parameters exactly as
                                   TensorFlow's would; 0 = NaN loss but zero gradients (the weights survive) */,

@@ -75,12 +75,12 @@ def test_recompute_step_is_reproducible():
 def test_operand_transforms_change_no_bit(H, B, layerwise):
     """AMS_OPT_FUSE_OPERAND_BN moves elementwise BN passes into the operand loads of their consumers with the same IEEE operations in the same
     order: gradients, parameters after two steps and moving statistics must be BIT-identical with the passes written (0), with the default
-    (3: depthwise activations + project-layer dz) and with the stride-16 expand layers' dz as well (7) — in the fused step and in the
+    (1: depthwise activations), with the project layers' dz as well (3) and with the stride-16 expand layers' dz too (7) — in the fused step and in the
     layer-by-layer step (where most consumers take the materialising fallback)."""
     W0 = Wt.synthetic_weights(S.build_spec(), 5)
     fr, lb = synth.SyntheticVideo(H, B, CI, seed=5).clip()
     ref = None
-    for bits in (0, 3, 7):
+    for bits in (0, 1, 3, 7):
         eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
         eng.load_variables(W0)
         if layerwise:

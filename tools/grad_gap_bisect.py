@@ -7,6 +7,7 @@ ones, where a ratio far above 1 is a kernel's arithmetic and not the graph's noi
 
     python tools/grad_gap_bisect.py [H=64] [B=2] [seed=0] [tensor=aspp0/weights:0]
     python tools/grad_gap_bisect.py layers [H=64] [B=2] [seed=0]
+    python tools/grad_gap_bisect.py seeds [H=64] [B=2] [n=8]
 
 ``layers``: the layer-by-layer step (every fine-tune fusion off, so that every tensor exists; ams_student_layer_tensor) compared tensor by
 tensor with the f64 oracle: raw conv outputs z and activations a on the way forward, gradients with respect to z on the way back (autograd
@@ -59,7 +60,10 @@ def layers_main():
     for dt in (torch.float64, torch.float32):
         o = StudentOracle(W0, CI, dtype=dt)
         taps, ztaps = {}, {}
-        z = o.reduced_logits(o.logits_full(fr32, "train", None, taps, ztaps))
+        params = dict(o.vars)
+        for v in sp.trainable:
+            params[v.name] = o.vars[v.name].clone().requires_grad_(True)
+        z = o.reduced_logits(o.logits_full(fr32, "train", params, taps, ztaps))
         target, weight = o.label_targets(labels)
         loss = o.loss_from_reduced(z, target, weight)
         names = list(ztaps)
@@ -94,9 +98,61 @@ def layers_main():
         eng.close()
 
 
+def seeds_main():
+    """The head's ReLUs as the source of the gap: per seed, the head tensors' gradient errors (HIP default step and f32 CPU oracle, vs f64)
+    beside the number of aspp0 / concat_projection activations each evaluation puts on the other side of zero than the f64 oracle does."""
+    H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+    sp = spec.build_spec()
+    heads = ["aspp0", "concat_projection"]
+    hl = {l.scope: l for l in sp.layers}
+    names = ["aspp0/weights:0", "concat_projection/weights:0", "logits/semantic/weights:0", "MobilenetV2/expanded_conv_16/project/weights:0"]
+    print("seed | flips vs f64 (aspp0, concat_projection): HIP / f32 CPU | elements within 1e-4 rms of zero | L2 error of "
+          + ", ".join(x.replace(":0", "") for x in names) + ": HIP / f32 CPU")
+    for seed in range(n):
+        W0 = weights.synthetic_weights(sp, seed=seed)
+        frames, labels = synth.SyntheticVideo(H, B, CI, seed=7 + seed).clip()
+        fr32 = frames.astype(np.float32)
+        taps = {}
+        grads = {}
+        for dt in (torch.float64, torch.float32):
+            o = StudentOracle(W0, CI, dtype=dt)
+            tp = {}
+            params = dict(o.vars)
+            for v in sp.trainable:
+                params[v.name] = o.vars[v.name].clone().requires_grad_(True)
+            z = o.reduced_logits(o.logits_full(fr32, "train", params, tp))
+            target, weight = o.label_targets(labels)
+            loss = o.loss_from_reduced(z, target, weight)
+            g = torch.autograd.grad(loss, [params[v.name] for v in sp.trainable])
+            grads[dt] = {v.name: gg for v, gg in zip(sp.trainable, g)}
+            taps[dt] = {k: tp[k].detach().numpy().astype(np.float64) for k in heads}
+        eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+        eng.load_variables(W0)
+        eng.train_step(frames, labels, 1e-3)
+        torch.cuda.synchronize()
+        g = eng.grads.cpu().numpy().astype(np.float64)
+        e_hip = errors(sp, g, grads[torch.float64])
+        e_32 = errors(sp, {k: v.numpy() for k, v in grads[torch.float32].items()}, grads[torch.float64])
+        flips_hip, flips_32, risk = [], [], []
+        for k in heads:
+            t64 = taps[torch.float64][k]
+            a_hip = layer_view(eng, hl[k].idx, 1, *t64.shape)
+            flips_hip.append(int(((a_hip > 0) != (t64 > 0)).sum()))
+            flips_32.append(int(((taps[torch.float32][k] > 0) != (t64 > 0)).sum()))
+            pos = t64[t64 > 0]
+            risk.append(int((pos < 1e-4 * np.sqrt((t64 ** 2).mean())).sum()))      # just above zero (those just below are invisible after the ReLU)
+        eng.close()
+        print("%4d | %s / %s | %s | %s" % (seed, flips_hip, flips_32, risk,
+                                            "  ".join("%.1e / %.1e" % (e_hip[x][1], e_32[x][1]) for x in names)))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "layers":
         return layers_main()
+    if len(sys.argv) > 1 and sys.argv[1] == "seeds":
+        return seeds_main()
     H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0

@@ -54,6 +54,8 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
         std::vector<float> ones(1024, 1.0f), zeros(1024, 0.0f);
         hipError_t e = hipMemcpy(s->vec_ones, ones.data(), 1024 * sizeof(float), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(s->vec_zeros, zeros.data(), 1024 * sizeof(float), hipMemcpyHostToDevice);
+        std::vector<float> inv(1024, (float)(1.0 / ((double)s->h * s->w)));
+        if (e == hipSuccess) e = hipMemcpy(s->vec_inv_hw, inv.data(), 1024 * sizeof(float), hipMemcpyHostToDevice);
         if (e != hipSuccess) { set_error("create: uploading constants -> %s", hipGetErrorString(e)); delete s; return AMS_E_HIP; }
     }
     if (!s->tp_jobs.empty()) {
@@ -269,7 +271,7 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_OPERAND_BN) {
-        s->fuse_operand_bn = value & 7;
+        s->fuse_operand_bn = value & 1;
         return AMS_OK;
     }
     if (option == AMS_OPT_NAN_GRADS) {

@@ -104,19 +104,18 @@ struct ams_student {
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
     int emulate_bf16_storage = 0;      // study only (AMS_OPT_EMULATE_BF16_STORAGE): round d and the block inputs of the stride-16 section to bf16
     int fuse_gemm_red = 3;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics, bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
-    int fuse_operand_bn = 1;           // fine-tune step: elementwise BN passes folded into the operand loads of the consuming 1x1 GEMMs / weight-gradient kernels
-                                       // (AMS_OPT_FUSE_OPERAND_BN): bit 0 BN + activation of a depthwise layer (a_d is never written), bit 1 dz of a project layer
-                                       // (A dy + B + C z formed by its input-gradient GEMM and its weight gradient), bit 2 the same for the stride-16 expand layers
+    int fuse_operand_bn = 1;           // fine-tune step: BN + activation of a depthwise layer applied by the project layer's GEMM and weight gradient on their
+                                       // operand loads — the depthwise activation is never written (AMS_OPT_FUSE_OPERAND_BN)
     int fuse_dgrad_bn = 2;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
     float *vec_ones = nullptr, *vec_zeros = nullptr;             // [1024] each: identity BN for a fused kernel's raw output
+    float* vec_inv_hw = nullptr;                                  // [1024] x 1 / (h w): d(global mean) / d(feature), the pool branch's backward scale
     float* act[4] = {nullptr, nullptr, nullptr, nullptr};   // inference ping-pong pool
     size_t act_elems = 0;
     float *pooled = nullptr, *pool_a = nullptr, *img_bias = nullptr;          // [B,cin_head], [B,256], [B,256]
     float *d_img_bias = nullptr, *d_pool_a = nullptr, *d_pool_z = nullptr, *d_pooled = nullptr;
     float* im2col = nullptr;         // [B*px1, 32]
-    float* dz = nullptr;             // head: gradient wrt a raw conv output, max layer size (the backbone writes dz in place, LayerRt::dzp)
     // Backward overlap: the weight gradient of a layer runs on a side stream beside the input gradient / BN backward chain of the
     // main stream (it only feeds the optimizer); the side stream has its own reduction scratch.
     float* scratch2 = nullptr;
@@ -232,7 +231,6 @@ static inline int sync_doubles(const SyncCtx* sc, double* p, size_t n, hipStream
 // ---- engine_forward.hip ----------------------------------------------------------------------------------
 bool split_pays(const PwArgs& a);
 int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st);
-bool live_pointwise_transforms_on_load(const ams_student* s, const PwArgs& a);
 int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st, bool* wrote_parts = nullptr, bool force_split = false);
 bool train_recompute_block(const ams_student* s, int i);
 bool dw_fused_train(const ams_student* s, int i, int B);

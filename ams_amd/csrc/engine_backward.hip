@@ -7,11 +7,10 @@ namespace ams {
 // =======================================================================================================
 // backward + update
 // =======================================================================================================
-// BN backward of layer l given da (gradient wrt the layer's activated output): writes dz into s->dz, dgamma/dbeta into grads
-// apply == false: only the sums and the coefficients (A, B, C): the layer's consumers form dz = A dy + B + C z on their operand loads
+// BN backward of layer l given da (gradient wrt the layer's activated output): writes dz (default: in place over da), dgamma/dbeta into grads
 static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_local, double n_global, const SyncCtx* sc,
-                       hipStream_t st, float* dz = nullptr, bool apply = true) {
-    if (!dz) dz = s->dz;
+                       hipStream_t st, float* dz = nullptr) {
+    if (!dz) dz = const_cast<float*>(da);
     if (!sc || !sc->cb) {
         RUNK(0, 8.0 * M_local * l.d.cout,
              launch_bn_bwd_reduce_coef(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.mean, l.rstd, l.bsums, s->scratch,
@@ -26,22 +25,19 @@ static int bn_backward(ams_student* s, LayerRt& l, const float* da, int64_t M_lo
         RUN(launch_bn_bwd_coef(l.bsums, n_global, l.d.cout, s->params + l.d.gamma_off, l.mean, l.rstd, l.cA, l.cB, l.cC,
                                nullptr, nullptr, st));
     }
-    if (!apply) return AMS_OK;
     RUNK(0, 12.0 * M_local * l.d.cout,
          launch_bn_bwd_apply(da, l.z, M_local, l.d.cout, l.scale, l.shift, l.d.act, l.cA, l.cB, l.cC, dz, st));
     return AMS_OK;
 }
 
-// xa: the layer whose BN + activation the x operand still needs (x = its raw output z); dl: the layer whose dz the dy operand stands for
-// (dy = the gradient wrt its BN output, masked already where it has an activation) — WgArgs x_mode 1 / dy_mode 2
+// xa: the layer whose BN + activation the x operand still needs (x = its raw output z): WgArgs x_mode 1
 static int pw_wgrad(ams_student* s, const float* x, int ldx, int K, const float* dy, int ldy, int N, int64_t M, float* dw,
-                    hipStream_t st, float* scratch = nullptr, const LayerRt* xa = nullptr, const LayerRt* dl = nullptr) {
+                    hipStream_t st, float* scratch = nullptr, const LayerRt* xa = nullptr) {
     WgArgs a;
     a.x = x; a.ldx = ldx; a.K = K; a.dy = dy; a.ldy = ldy; a.N = N; a.M = M; a.dw = dw;
     a.scratch = scratch ? scratch : s->scratch; a.scratch_floats = s->scratch_floats;
     a.allow_split = s->matmul_mode != AMS_MATMUL_F32;
     if (xa) { a.x = xa->z; a.x_mode = 1; a.x_act = xa->d.act; a.x_v0 = xa->scale; a.x_v1 = xa->shift; }
-    if (dl) { a.dy = dy; a.dy_mode = 2; a.dy_v0 = dl->cA; a.dy_v1 = dl->cB; a.dy_v2 = dl->cC; a.dy2 = dl->z; }
     RUNK(0, 4.0 * ((double)M * (K + N) + (double)K * N), launch_pointwise_wgrad(a, st));
     return AMS_OK;
 }
@@ -70,58 +66,9 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
     else
         RUNK(0, 0.0, launch_ce_grad(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher, NC, s->loss_buf,
                                     s->dlogits, 32, st, empty_val));
-    // logits layer: bias, weights, input gradient
-    RUN(launch_colsum(s->dlogits, M, 32, 32, s->tmp_c, s->scratch, st));
-    RUN(launch_copy(G + ll.d.gamma_off, s->tmp_c, NC, st));
-    RUN(pw_wgrad(s, lc.a, lc.d.cout, lc.d.cout, s->dlogits, 32, NC, M, G + ll.d.w_off, st));
-    {
-        PwArgs a = dgrad_args(s->dlogits, M, 32, 32, P + ll.d.w_off, ll.d.cin, lc.da);
-        a.Kw = NC; a.w_sn = NC;        // w is [cin][NC]; dlogits columns >= NC are zero
-        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
-    }
-    // concat_projection
-    RUN(bn_backward(s, lc, lc.da, M, nHW, sc, st));
-    const float* Wc_top = P + lc.d.w_off;
-    const float* Wc_bot = P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout;
-    RUN(pw_wgrad(s, la.a, la.d.cout, la.d.cout, s->dz, lc.d.cout, lc.d.cout, M, G + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, st));
-    {
-        PwArgs a = dgrad_args(s->dz, M, lc.d.cout, lc.d.cout, Wc_bot, la.d.cout, la.da);
-        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
-    }
-    // pool branch: the per-image bias collects the column sums of dz_proj
-    RUN(launch_image_colsum(s->dz, B, HW, lc.d.cout, lc.d.cout, s->d_img_bias, s->scratch, st));
-    RUN(pw_wgrad(s, lp.a, lp.d.cout, lp.d.cout, s->d_img_bias, lc.d.cout, lc.d.cout, B, G + lc.d.w_off, st));
-    {
-        PwArgs a = dgrad_args(s->d_img_bias, B, lc.d.cout, lc.d.cout, Wc_top, lp.d.cout, s->d_pool_a);
-        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
-    }
-    {   // BN (over the batch) + ReLU of the pool branch; its dz goes to d_pool_z instead of s->dz (still in use? no: consumed)
-        RUN(launch_bn_bwd_reduce(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.mean, lp.rstd, lp.bsums, s->scratch, st));
-        RUN(launch_bn_param_grads(lp.bsums, lp.d.cout, G + lp.d.gamma_off, G + lp.d.beta_off, st));
-        RUN(sync_doubles(sc, lp.bsums, 2 * (size_t)lp.d.cout, st));
-        RUN(launch_bn_bwd_coef(lp.bsums, (double)global_B, lp.d.cout, P + lp.d.gamma_off, lp.mean, lp.rstd, lp.cA, lp.cB, lp.cC,
-                               nullptr, nullptr, st));
-        RUN(launch_bn_bwd_apply(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.cA, lp.cB, lp.cC, s->d_pool_z, st));
-        RUN(pw_wgrad(s, s->pooled, lp.d.cin, lp.d.cin, s->d_pool_z, lp.d.cout, lp.d.cout, B, G + lp.d.w_off, st));
-        PwArgs a = dgrad_args(s->d_pool_z, B, lp.d.cout, lp.d.cout, P + lp.d.w_off, lp.d.cin, s->d_pooled);
-        a.scale = s->tmp_c + 2048;      // d mean / d feat = 1/HW, applied as a uniform scale
-        RUN(launch_fill(s->tmp_c + 2048, lp.d.cin, (float)(1.0 / (double)HW), st));
-        a.shift = s->tmp_c + 3072;
-        RUN(launch_fill(s->tmp_c + 3072, lp.d.cin, 0.f, st));
-        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
-    }
-    // aspp0: its input gradient also receives the pooled gradient, broadcast over the image
-    LayerRt& lf = s->L[s->n_backbone];
-    RUN(bn_backward(s, la, la.da, M, nHW, sc, st));
-    RUN(pw_wgrad(s, lf.a, la.d.cin, la.d.cin, s->dz, la.d.cout, la.d.cout, M, G + la.d.w_off, st));
-    {
-        PwArgs a = dgrad_args(s->dz, M, la.d.cout, la.d.cout, P + la.d.w_off, la.d.cin, lf.da);
-        a.img_bias = s->d_pooled; a.rows_per_img = HW;
-        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
-    }
-    // backbone, last layer to first.  A layer's weight gradient only feeds the optimizer: it runs on the side stream while the main
-    // stream goes on with the input gradient and the next layer's BN backward (many of these kernels are latency-bound at 8 frames
-    // and share the chip well).  Nothing the side stream reads is overwritten inside the step (dz lives in per-layer memory), so the main
+    // A layer's weight gradient only feeds the optimizer: it runs on the side stream while the main stream goes on with the input gradient
+    // and the next layer's BN backward (many of these kernels are latency-bound at 8 frames and share the chip well).  Nothing the side
+    // stream reads is overwritten inside the step (every dz lives in per-layer memory — in the head too: in place over da), so the main
     // stream never waits for it before the final join.
     const bool overlap = s->overlap_wgrad && !s->prof.on && s->scratch2;
     if (overlap && !s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
@@ -129,6 +76,72 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_xt, hipEventDisableTiming));
     }
+    // the side stream picks up after everything the main stream has issued so far; -> stream and reduction scratch of a weight gradient
+    auto fork_wgrad = [&](hipStream_t* wst, float** wscratch) -> int {
+        *wst = st; *wscratch = s->scratch;
+        if (!overlap) return AMS_OK;
+        AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+        AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+        *wst = s->side; *wscratch = s->scratch2;
+        return AMS_OK;
+    };
+    hipStream_t hst = st;
+    float* hscr = s->scratch;
+    // logits layer: bias, weights, input gradient
+    RUN(launch_colsum(s->dlogits, M, 32, 32, s->tmp_c, s->scratch, st));
+    RUN(launch_copy(G + ll.d.gamma_off, s->tmp_c, NC, st));
+    RUN(fork_wgrad(&hst, &hscr));
+    RUN(pw_wgrad(s, lc.a, lc.d.cout, lc.d.cout, s->dlogits, 32, NC, M, G + ll.d.w_off, hst, hscr));
+    {
+        PwArgs a = dgrad_args(s->dlogits, M, 32, 32, P + ll.d.w_off, ll.d.cin, lc.da);
+        a.Kw = NC; a.w_sn = NC;        // w is [cin][NC]; dlogits columns >= NC are zero
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
+    }
+    // concat_projection (dz in place over da, like every backbone layer: the side stream may still be reading it when aspp0's dz is formed)
+    float* dz_c = lc.da;
+    RUN(bn_backward(s, lc, lc.da, M, nHW, sc, st, dz_c));
+    const float* Wc_top = P + lc.d.w_off;
+    const float* Wc_bot = P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout;
+    RUN(fork_wgrad(&hst, &hscr));
+    RUN(pw_wgrad(s, la.a, la.d.cout, la.d.cout, dz_c, lc.d.cout, lc.d.cout, M, G + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, hst, hscr));
+    {
+        PwArgs a = dgrad_args(dz_c, M, lc.d.cout, lc.d.cout, Wc_bot, la.d.cout, la.da);
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
+    }
+    // pool branch: the per-image bias collects the column sums of dz_proj
+    RUN(launch_image_colsum(dz_c, B, HW, lc.d.cout, lc.d.cout, s->d_img_bias, s->scratch, st));
+    RUN(fork_wgrad(&hst, &hscr));
+    RUN(pw_wgrad(s, lp.a, lp.d.cout, lp.d.cout, s->d_img_bias, lc.d.cout, lc.d.cout, B, G + lc.d.w_off, hst, hscr));
+    {
+        PwArgs a = dgrad_args(s->d_img_bias, B, lc.d.cout, lc.d.cout, Wc_top, lp.d.cout, s->d_pool_a);
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
+    }
+    {   // BN (over the batch) + ReLU of the pool branch; its dz goes to d_pool_z
+        RUN(launch_bn_bwd_reduce(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.mean, lp.rstd, lp.bsums, s->scratch, st));
+        RUN(launch_bn_param_grads(lp.bsums, lp.d.cout, G + lp.d.gamma_off, G + lp.d.beta_off, st));
+        RUN(sync_doubles(sc, lp.bsums, 2 * (size_t)lp.d.cout, st));
+        RUN(launch_bn_bwd_coef(lp.bsums, (double)global_B, lp.d.cout, P + lp.d.gamma_off, lp.mean, lp.rstd, lp.cA, lp.cB, lp.cC,
+                               nullptr, nullptr, st));
+        RUN(launch_bn_bwd_apply(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.cA, lp.cB, lp.cC, s->d_pool_z, st));
+        RUN(fork_wgrad(&hst, &hscr));
+        RUN(pw_wgrad(s, s->pooled, lp.d.cin, lp.d.cin, s->d_pool_z, lp.d.cout, lp.d.cout, B, G + lp.d.w_off, hst, hscr));
+        PwArgs a = dgrad_args(s->d_pool_z, B, lp.d.cout, lp.d.cout, P + lp.d.w_off, lp.d.cin, s->d_pooled);
+        a.scale = s->vec_inv_hw;        // d mean / d feat = 1/HW, applied as a uniform scale (constants uploaded at create)
+        a.shift = s->vec_zeros;
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
+    }
+    // aspp0: its input gradient also receives the pooled gradient, broadcast over the image
+    LayerRt& lf = s->L[s->n_backbone];
+    float* dz_a = la.da;
+    RUN(bn_backward(s, la, la.da, M, nHW, sc, st, dz_a));
+    RUN(fork_wgrad(&hst, &hscr));
+    RUN(pw_wgrad(s, lf.a, la.d.cin, la.d.cin, dz_a, la.d.cout, la.d.cout, M, G + la.d.w_off, hst, hscr));
+    {
+        PwArgs a = dgrad_args(dz_a, M, la.d.cout, la.d.cout, P + la.d.w_off, la.d.cin, lf.da);
+        a.img_bias = s->d_pooled; a.rows_per_img = HW;
+        RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
+    }
+    // backbone, last layer to first
     const bool three = overlap && s->overlap_wgrad >= 2 && s->scratch3;      // depthwise weight gradients on a third stream
     if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
     bool xt_pending = false;
@@ -150,20 +163,6 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         // never waits for a weight gradient (with two alternating dz buffers it did, ~40 times a step: 0.2 ms of real stalls behind
         // weight gradients that sharing the chip had stretched)
         float* dz = l.dzp ? l.dzp : l.da;
-        // this layer's dz is not written: its input-gradient GEMM and its weight gradient form A dy + B + C z on their operand loads
-        // (project layers: BN without activation; stride-16 expand layers whose masked gradient the depthwise kernel left in da)
-        bool lazy_dz = i >= 3 && l.d.cout % 4 == 0 && l.d.cout <= 1024 &&
-                       (((s->fuse_operand_bn & 2) && l.d.role == AMS_ROLE_PROJECT && l.d.act == AMS_ACT_NONE) ||
-                        ((s->fuse_operand_bn & 4) && l.d.role == AMS_ROLE_EXPAND && fused_rows > 0 && !train_recompute_block(s, i)));
-        if (lazy_dz) {
-            // only where the input-gradient GEMM really transforms on load: its fallback would write dz over da, which the weight gradient
-            // on the side stream reads as the untransformed gradient
-            PwArgs probe = dgrad_args(l.da, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, s->L[i - 1].da);
-            probe.x_mode = 2; probe.x_act = AMS_ACT_NONE; probe.x_v0 = l.cA; probe.x_v1 = l.cB; probe.x_v2 = l.cC; probe.x2 = l.z;
-            if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) { probe.res = s->L[i + 2].da; probe.ldr = l.d.cin; }
-            if ((s->fuse_gemm_red & 2) && i - 1 >= 2) probe.red_mode = 2;
-            lazy_dz = !probe.res && live_pointwise_transforms_on_load(s, probe);      // (with a residual operand the kernel choice depends on the reduction's row capacity)
-        }
         if (fused_rows > 0) {
             // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the
             // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z
@@ -181,10 +180,10 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             if (fused_dw && !(fused_buf != s->scratch &&
                               deferred.add(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, fused_stride)))
                 RUN(launch_reduce_splits(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st, fused_stride));
-            if (!lazy_dz) RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
+            RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
             fused_rows = 0;
         } else {
-            RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz, !lazy_dz));
+            RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz));
         }
         if (l.d.role == AMS_ROLE_DEPTHWISE && train_recompute_block(s, i - 1)) {
             // early block: from dz of the depthwise layer straight to the gradient of the block input; da_e / dz_e / a_e are recomputed
@@ -302,14 +301,13 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             else RUNK(i, dw_bytes(l, B), launch_depthwise_wgrad(prev.a, dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off,
                                                                 wscratch, s->scratch_floats, wst));
         } else {
-            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, lazy_dz ? l.da : dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch,
-                         (l.d.role == AMS_ROLE_PROJECT && operand_bn_act(s, i - 1)) ? &prev : nullptr, lazy_dz ? &l : nullptr));
+            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch,
+                         (l.d.role == AMS_ROLE_PROJECT && operand_bn_act(s, i - 1)) ? &prev : nullptr));
         }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
         } else {
             PwArgs a = dgrad_args(dz, Mo, l.d.cout, l.d.cout, P + l.d.w_off, l.d.cin, prev.da);
-            if (lazy_dz) { a.x = l.da; a.x_mode = 2; a.x_act = AMS_ACT_NONE; a.x_v0 = l.cA; a.x_v1 = l.cB; a.x_v2 = l.cC; a.x2 = l.z; a.x_tmp = dz; }
             // the block input also feeds the residual add at the end of this block: add that gradient here
             if (l.d.role == AMS_ROLE_EXPAND && i + 2 <= s->n_backbone && s->L[i + 2].d.residual_from == i - 1) {
                 a.res = s->L[i + 2].da; a.ldr = l.d.cin;

@@ -12,13 +12,6 @@ bool split_pays(const PwArgs& a) {
     return a.M < 32768 || !pointwise_stream_applies(a) || (int64_t)a.K * a.N >= 40 * (int64_t)(a.K + a.N);
 }
 
-// live_pointwise(a) would apply a.x_mode on its operand loads (else it writes x' to a.x_tmp first: the caller must not alias x_tmp with
-// anything another stream still reads)
-bool live_pointwise_transforms_on_load(const ams_student* s, const PwArgs& a) {
-    const bool split = s->matmul_mode != AMS_MATMUL_F32 && s->panel_scratch && split_pays(a) && a.Kw == a.K && a.ldx % 4 == 0;
-    return split ? pointwise_split3_transforms_on_load(a) : pointwise_transforms_on_load(a);
-}
-
 // live (training) 1x1 layer or its input gradient: same split-bf16 rule as the frozen path, the weights are split right
 // before the launch because they change every step (one small kernel; the panels live in one shared scratch buffer)
 int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {

@@ -239,12 +239,12 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
         }
         s->vec_ones = cv.take<float>(1024);
         s->vec_zeros = cv.take<float>(1024);
+        s->vec_inv_hw = cv.take<float>(1024);
         s->d_img_bias = cv.take<float>((size_t)B * aspp_c);
         s->d_pool_a = cv.take<float>((size_t)B * aspp_c);
         s->d_pool_z = cv.take<float>((size_t)B * aspp_c);
         s->d_pooled = cv.take<float>((size_t)B * head_cin);
         s->im2col = cv.take<float>((size_t)B * s->L[1].px_out * 32);
-        s->dz = cv.take<float>((size_t)B * max_elems);
         s->scratch2 = cv.take<float>(sc);
         s->scratch3 = cv.take<float>(sc);
         for (int i = 1; i <= c.n_layers; ++i) {

@@ -221,11 +221,10 @@ class StudentEngine:
                   "ams_pack_masked_fp16")
         return out[:int(cnt.item())]
 
-    def set_fuse_operand_bn(self, bits: int) -> None:
-        """Fine-tune step: elementwise BN passes applied by the consuming 1x1 GEMM / weight-gradient kernel on its operand loads (same bits as the
-        separate passes): bit 0 BN + activation of the depthwise layers, bit 1 dz of the project layers, bit 2 dz of the stride-16 expand layers.
-        Default 1 (bits 1 and 2 are measured slower); 0 = every pass written."""
-        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_OPERAND_BN, int(bits)), "ams_student_set_option")
+    def set_fuse_operand_bn(self, on: bool) -> None:
+        """Fine-tune step: BN + activation of the depthwise layers applied by the project GEMM / project weight gradient on their operand loads
+        (default on; the depthwise activation is never written); bit-identical to off = the pass written."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_OPERAND_BN, int(bool(on))), "ams_student_set_option")
 
     def set_train_recompute(self, on: bool, fuse_dgrad_bn: Optional[bool] = None, fuse_gemm_red: Optional[int] = None) -> None:
         """Fine-tune step of the early blocks without their 6x-expanded tensors (default on); off = every tensor materialised.

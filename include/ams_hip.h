@@ -213,13 +213,12 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: elementwise BN passes applied by the CONSUMER on its operand loads instead of being written
-                                        (PwArgs / WgArgs x_mode, dy_mode; the same IEEE operations in the same order: bit-identical to the passes).
-                                        Bit 0: BN + activation of every depthwise layer that feeds a project layer — the project GEMM and the project
-                                        weight gradient apply it, the depthwise activation is never written.  Bit 1: dz = A dy + B + C z of every
-                                        project layer — formed by its input-gradient GEMM and its weight gradient.  Bit 2: the same for the
-                                        stride-16 expand layers (their GEMM then pulls two f32 operands).  Default 1: bits 1 and 2 are measured SLOWER on MI355X (8.32 -> 8.74 / 8.87 ms per 8-frame step: the consuming GEMMs
-                                        are bound by their operand path and the second operand stream costs more than the small passes it removes); 0 = every pass written. */,
+enum { AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: 1 (default) BN + activation of every depthwise layer that feeds a project layer is applied by the
+                                        CONSUMERS on their operand loads (project GEMM forward, project weight gradient backward: PwArgs / WgArgs
+                                        x_mode 1) with the same IEEE operations in the same order, and the depthwise activation is never written:
+                                        bit-identical to 0 = the pass written (bn_act).  The same move for dz = A dy + B + C z of the project and the
+                                        stride-16 expand layers (x_mode / dy_mode 2, kept at kernel level: ams_k_pointwise_xform) measured SLOWER in
+                                        the step on MI355X (8.31 -> 8.64 / 8.87 ms: those GEMMs are bound by their operand path) and is not wired in. */,
        AMS_OPT_NAN_GRADS = 18 /* fine-tune step on a batch WITHOUT a valid pixel: 1 (default) the reference's result — loss = 0 / 0 and every gradient
                                   NaN (utils/graph_utils.py:408: sum(w ce) / sum(w)), so the Adam update poisons the masked parameters exactly as
                                   TensorFlow's would; 0 = NaN loss but zero gradients (the weights survive) */,

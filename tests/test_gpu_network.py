@@ -183,8 +183,15 @@ def test_train_step_matches_oracle(W0, clip64):
         order = np.argsort(errs_gpu)[::-1][:4]
         print("step %d worst gradient tensors vs f64 (HIP, f32 CPU):" % step,
               [(eng.spec.trainable[k].name, "%.2e" % errs_gpu[k], "%.2e" % errs_f32[k]) for k in order])
+        well = [k for k in range(len(errs_f32)) if errs_f32[k] < 1e-3]
+        ratios = sorted(((errs_gpu[k] / max(errs_f32[k], 1e-12), eng.spec.trainable[k].name) for k in well), reverse=True)[:5]
+        print("step %d worst HIP / f32-CPU ratios among the %d tensors whose f32-CPU error is < 1e-3:" % (step, len(well)),
+              [(n, "x%.1f" % r) for r, n in ratios])
         for k, v in enumerate(eng.spec.trainable):
-            assert errs_gpu[k] <= max(6e-2, 4 * errs_f32[k]), "gradient of %s: HIP %.2e vs f32 CPU %.2e" % (v.name, errs_gpu[k], errs_f32[k])
+            # a tensor the f32 CPU evaluation gets to < 7.5e-3 must come out below 3e-2 (one flipped ReLU6 element upstream costs up to
+            # ~1e-2 on a small tensor); the noisier ones are held to 4x the f32 CPU oracle's own error, 6e-2 at least
+            bar = max(3e-2, 4 * errs_f32[k]) if errs_f32[k] < 7.5e-3 else max(6e-2, 4 * errs_f32[k])
+            assert errs_gpu[k] <= bar, "gradient of %s: HIP %.2e vs f32 CPU %.2e (bar %.1e)" % (v.name, errs_gpu[k], errs_f32[k], bar)
         assert np.median(errs_gpu) <= 3 * np.median(errs_f32) + 5e-3, (np.median(errs_gpu), np.median(errs_f32))
         o.train_step(fr.astype(np.float32), lb, lr)
         _compare_train_state(eng, o, before, lr, 1, "after step %d" % (step + 1), grads_o)
@@ -229,6 +236,69 @@ def test_gradient_error_class_over_seeds():
     assert max(worst_gpu) < 6e-2
     assert np.mean(worst_gpu) <= 1.5 * np.mean(worst_f32) + 2e-3
     assert np.mean(med_gpu) <= 1.5 * np.mean(med_f32) + 2e-3
+
+def _layer_a(eng, layer_idx, shape):
+    import ctypes as C
+    off, n = C.c_size_t(), C.c_size_t()
+    hip.check(eng.lib.ams_student_layer_tensor(eng._h, layer_idx, 1, C.byref(off), C.byref(n)))
+    b, h, w, c = shape
+    return eng.arena[off.value:off.value + 4 * b * h * w * c].view(torch.float32).view(b, h, w, c).cpu().numpy()
+
+
+def test_head_gradients_are_f32_level_unless_a_relu_element_flips():
+    """Where the "30x head-gradient gap" of round 3 comes from, as a test.  At 64x128 x 2 frames the head's two ReLUs see
+    90 x 256 values whose forward f32 error is ~2e-5 relative, so about ONE element per evaluation sits within that of zero; an f32
+    evaluation that puts it on the other side than the f64 oracle changes the head's gradient tensors by 1e-3 .. 1e-2 (one element of 23 040
+    is 1 / sqrt(23040) = 6.6e-3 of the tensor's norm).  It happens to the HIP path and to the f32 CPU oracle alike, on different seeds
+    (tools/grad_gap_bisect.py seeds).  So: on every seed where NEITHER evaluation flips a head ReLU, every head tensor of the HIP step must be
+    within 4x the f32 CPU oracle's own distance from f64 (no floor); with a flip on either side the bar is the gross one."""
+    H, B = 64, 2
+    sp = S.build_spec()
+    heads = {l.scope: l for l in sp.layers if l.scope in ("aspp0", "concat_projection")}
+    names = [v.name for v in sp.trainable if v.name.split("/")[0] in ("aspp0", "concat_projection", "logits")] + \
+            ["MobilenetV2/expanded_conv_16/project/weights:0"]
+    tight = 0
+    for seed in range(8):
+        W = Wt.synthetic_weights(sp, seed=seed)
+        fr, lb = synth.SyntheticVideo(H, B, CI, seed=seed + 7).clip()
+        ref = {}
+        for dt in (torch.float64, torch.float32):
+            o = _oracle(W, dt)
+            taps = {}
+            params = dict(o.vars)
+            for v in sp.trainable:
+                params[v.name] = o.vars[v.name].clone().requires_grad_(True)
+            z = o.reduced_logits(o.logits_full(fr.astype(np.float32), "train", params, taps))
+            target, weight = o.label_targets(lb)
+            g = torch.autograd.grad(o.loss_from_reduced(z, target, weight), [params[n] for n in names])
+            ref[dt] = ({n: x.numpy().astype(np.float64).reshape(-1) for n, x in zip(names, g)}, {k: taps[k].detach().numpy() for k in heads})
+        eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+        eng.load_variables(W)
+        eng.train_step(fr, lb, 1e-3)
+        torch.cuda.synchronize()
+        g = eng.grads.cpu().numpy().astype(np.float64)
+        flips_hip = sum(int(((_layer_a(eng, l.idx, ref[torch.float64][1][k].shape) > 0) != (ref[torch.float64][1][k] > 0)).sum()) for k, l in heads.items())
+        flips_f32 = sum(int(((ref[torch.float32][1][k] > 0) != (ref[torch.float64][1][k] > 0)).sum()) for k in heads)
+        eng_spec = eng.spec
+        eng.close()
+        rows = []
+        for n in names:
+            v = eng_spec.by_name[n]
+            want = ref[torch.float64][0][n]
+            e_hip = np.linalg.norm(g[v.offset:v.offset + v.size] - want) / np.linalg.norm(want)
+            e_f32 = np.linalg.norm(ref[torch.float32][0][n] - want) / np.linalg.norm(want)
+            rows.append((n, e_hip, e_f32))
+        worst = max(rows, key=lambda r: r[1] / max(r[2], 1e-12))
+        print("seed %d: head ReLU elements on the other side of zero than f64: HIP %d, f32 CPU %d; worst ratio %s HIP %.1e / f32 CPU %.1e"
+              % (seed, flips_hip, flips_f32, worst[0], worst[1], worst[2]))
+        for n, e_hip, e_f32 in rows:
+            if flips_hip == 0 and flips_f32 == 0:
+                assert e_hip <= 4 * e_f32 + 1e-7, "seed %d, no flipped head ReLU: %s HIP %.2e vs f32 CPU %.2e" % (seed, n, e_hip, e_f32)
+            else:
+                assert e_hip <= max(3e-2, 4 * e_f32), "seed %d: %s HIP %.2e vs f32 CPU %.2e" % (seed, n, e_hip, e_f32)
+        tight += int(flips_hip == 0 and flips_f32 == 0)
+    assert tight >= 1, "no seed without a flipped head ReLU: the tight bar was never exercised"
+
 
 def test_free_running_schedule_tracks_oracle(W0):
     """a short free-running distillation schedule (no re-synchronisation with the oracle between steps).  Two

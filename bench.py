@@ -562,13 +562,41 @@ def main():
             calls, nbytes = sync.stats()
             distill["collectives_per_step"] = round(calls / (n_train + 2), 1)
             distill["bytes_reduced_per_step"] = round(nbytes / (n_train + 2))
+
+        def collective_split(engine, tf_, tl_, global_batch, step_ms):
+            """Diagnostic, after the timed steps: three more steps with a HIP event pair around every collective (ams_comm_set_timing) ->
+            how much of a step the launch stream spends INSIDE ncclAllReduce (waiting for the peers included), per rank."""
+            if sync is None or not hasattr(sync, "set_timing"):
+                return None
+            sync.set_timing(True)
+            for _ in range(3):
+                engine.train_step(tf_, tl_, 1e-3, global_batch=global_batch, **kw)
+            tot, mx, n = sync.timing()
+            sync.set_timing(False)
+            per = tot / 3.0
+            t = torch.tensor([per], dtype=torch.float64, device=dev)
+            if dist is not None and backend == "nccl":
+                gathered = [torch.zeros_like(t) for _ in range(world)]
+                dist.all_gather(gathered, t)
+                per_rank = [round(float(x.item()), 3) for x in gathered]
+            else:
+                per_rank = [round(per, 3)]
+            return {"collective_ms_per_step": round(max(per_rank), 3), "collective_ms_per_step_by_rank": per_rank,
+                    "collectives_timed_per_step": round(n / 3.0, 1), "longest_collective_ms": round(mx, 4),
+                    "compute_ms_per_step_estimate": round(step_ms - max(per_rank), 3),
+                    "note": "HIP events around each ncclAllReduce on the launch stream over three extra (untimed) steps; a span includes the wait "
+                            "for the slowest peer, so compute = step - collective is a lower bound of the pure kernel time"}
+        cs = collective_split(teng, tf, tl, TB * n_gpus, ms)
+        if cs:
+            distill.update(cs)
         # configs[4]'s shape: ONE 8-frame batch split over the ranks (strong scaling; SyncBN keeps full-batch semantics)
         if dist is not None and TB % n_gpus == 0:
             per = TB // n_gpus
             lo = rank * per
             tfs, tls = tf[lo:lo + per].contiguous(), tl[lo:lo + per].contiguous()
             tt2, loss2 = time_steps(teng, tfs, tls, kw, TB, n_train)
-            distill_strong = {"steps_per_sec": round(n_train / tt2, 3), "ms_per_step": round(1e3 * tt2 / n_train, 3), "batch_per_gpu": per,
+            cs2 = collective_split(teng, tfs, tls, TB, 1e3 * tt2 / n_train) or {}
+            distill_strong = {**cs2, "steps_per_sec": round(n_train / tt2, 3), "ms_per_step": round(1e3 * tt2 / n_train, 3), "batch_per_gpu": per,
                               "global_batch": TB, "scaling": "strong", "loss": round(loss2, 5),
                               "note": "BASELINE.json configs[4] shape: one stream's 8-frame fine-tune batch sharded over the GPUs; 110 latency-bound "
                                       "collectives per step (SURVEY 8 e4: communication-latency-bound by construction)"}

@@ -584,4 +584,14 @@ def test_rccl_communicator_inside_the_engine(W0):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
     calls, nbytes = comm.stats()
     assert calls == 1 + 54 * 2 + 2 and nbytes > 4 * 2113043           # the probe above, BN forward + backward per layer, loss, gradients
+    # diagnostic timing (bench.py collective_ms_per_step): a HIP event pair around every collective of one step
+    eng = StudentEngine(CI, 64, 128, max_batch=2, trainable=True)
+    eng.load_variables(W0)
+    comm.set_timing(True)
+    ls_t = eng.train_step(frames, labels, 1e-3, comm=comm, global_batch=2).cpu().numpy()
+    total_ms, longest_ms, spans = comm.timing()
+    comm.set_timing(False)
+    eng.close()
+    assert spans == 54 * 2 + 2 and 0.0 < longest_ms <= total_ms < 1e3
+    assert np.array_equal(ls_t, outs[0][0])                            # timing changes nothing
     comm.close()

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
     // global -> register staging of one 32-pixel step (branch-free: clamped addresses, zero select)
     float4 rx[NLX], ry[NLY];
     float4 rz[XD ? NLY : 1];                                      // dy_mode 2: the raw output beside the gradient
-    unsigned ry_ok = 0;                                           // ... and which of this thread's dy pieces lie inside the problem
+    unsigned rx_ok = 0, ry_ok = 0;                                // which of this thread's pieces lie inside the problem (XD: raw values are kept until they are staged)
     float4 vxs[XD ? NLX : 1], vxh[XD ? NLX : 1], vA[XD ? NLY : 1], vB[XD ? NLY : 1], vC[XD ? NLY : 1];
     if constexpr (XD) {
 #pragma unroll
@@ -111,14 +111,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
             const bool ok = e < 32 * VX && m < m_end && k < a.K;
             if (m > a.M - 1) m = a.M - 1;
             if (k > a.K - 4) k = a.K - 4;
-            float4 v = ld4(a.x + m * (int64_t)a.ldx + k);
+            const float4 v = ld4(a.x + m * (int64_t)a.ldx + k);
             if constexpr (XD) {
-                if (a.x_mode == 1) {
-                    const float4 y = muladd4_pk(v, vxs[u], vxh[u]);
-                    v = make_float4(apply_act(y.x, a.x_act), apply_act(y.y, a.x_act), apply_act(y.z, a.x_act), apply_act(y.w, a.x_act));
-                }
+                // raw value now, transform when it is staged: arithmetic on the loaded value HERE would make the wave wait for the load
+                // it has just issued, i.e. take the prefetch out from under the MFMAs of the current step
+                rx[u] = v;
+                rx_ok = ok ? (rx_ok | (1u << u)) : (rx_ok & ~(1u << u));
+            } else {
+                rx[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             }
-            rx[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
 #pragma unroll
         for (int u = 0; u < NLY; ++u) {
@@ -129,13 +130,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
             if (m > a.M - 1) m = a.M - 1;
             if (n > a.N - 4) n = a.N - 4;
             const float4 v = ld4(a.dy + m * (int64_t)a.ldy + n);
-            ry[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             if constexpr (XD) {
-                if (a.dy_mode == 2) {
-                    const float4 z = ld4(a.dy2 + m * (int64_t)a.ldy + n);
-                    rz[u] = make_float4(ok ? z.x : 0.f, ok ? z.y : 0.f, ok ? z.z : 0.f, ok ? z.w : 0.f);
-                    ry_ok = ok ? (ry_ok | (1u << u)) : (ry_ok & ~(1u << u));
-                }
+                ry[u] = v;
+                ry_ok = ok ? (ry_ok | (1u << u)) : (ry_ok & ~(1u << u));
+                if (a.dy_mode == 2) rz[u] = ld4(a.dy2 + m * (int64_t)a.ldy + n);
+            } else {
+                ry[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             }
         }
     };
@@ -143,18 +143,26 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
 #pragma unroll
         for (int u = 0; u < NLX; ++u) {
             const int e = tid + 256 * u, row = e / VX, c4 = (e - row * VX) * 4;
+            if constexpr (XD) {
+                float4 v = rx[u];
+                if (a.x_mode == 1) {
+                    const float4 y = muladd4_pk(v, vxs[u], vxh[u]);
+                    v = make_float4(apply_act(y.x, a.x_act), apply_act(y.y, a.x_act), apply_act(y.z, a.x_act), apply_act(y.w, a.x_act));
+                }
+                const bool inside = (rx_ok >> u) & 1u;                 // rows / columns outside the problem contribute zeros
+                rx[u] = make_float4(inside ? v.x : 0.f, inside ? v.y : 0.f, inside ? v.z : 0.f, inside ? v.w : 0.f);
+            }
             if (e < 32 * VX) split_store(rx[u], sX + row * PX + c4, PLX);
         }
 #pragma unroll
         for (int u = 0; u < NLY; ++u) {
             const int e = tid + 256 * u, row = e / VY, c4 = (e - row * VY) * 4;
             if constexpr (XD) {
-                if (a.dy_mode == 2) {
-                    // (A g + B) + C z as bn_bwd_apply_kernel evaluates it; rows / columns outside the problem stay zero (B is not)
-                    const bool inside = (ry_ok >> u) & 1u;
-                    const float4 y = add4_pk(add4_pk(mul4_pk(vA[u], ry[u]), vB[u]), mul4_pk(vC[u], rz[u]));
-                    ry[u] = inside ? y : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                float4 y = ry[u];
+                // (A g + B) + C z as bn_bwd_apply_kernel evaluates it; rows / columns outside the problem stay zero (B is not)
+                if (a.dy_mode == 2) y = add4_pk(add4_pk(mul4_pk(vA[u], ry[u]), vB[u]), mul4_pk(vC[u], rz[u]));
+                const bool inside = (ry_ok >> u) & 1u;
+                ry[u] = inside ? y : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             if (e < 32 * VY) split_store(ry[u], sY + row * PY + c4, PLY);
         }

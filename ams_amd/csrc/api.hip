@@ -259,7 +259,7 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_DGRAD_BN) {
-        s->fuse_dgrad_bn = value < 0 ? 0 : (value > 2 ? 2 : value);
+        s->fuse_dgrad_bn = value < 0 ? 0 : (value > 3 ? 3 : value);
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_GEMM_RED) {
@@ -604,6 +604,20 @@ int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W
     AMS_REQUIRE(scratch_floats >= depthwise_dgrad_bn_scratch(B, H, W, C), "depthwise3x3_dgrad_bn: scratch too small");
     int rows = 0;
     int rc = launch_depthwise_dgrad_bn(dz, B, H, W, C, w, rate, z_prev, scale, shift, act, mean, rstd, out, scratch, &rows, (hipStream_t)stream);
+    *rows_out = rows;
+    return rc;
+}
+
+size_t ams_k_depthwise3x3_dgrad_bn_apply_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate) { return depthwise_dgrad_bn2_scratch(B, H, W, C, rate); }
+int ams_k_depthwise3x3_dgrad_bn_apply(const float* dy, const float* zd, const float* cA, const float* cB, const float* cC, int32_t B, int32_t H, int32_t W,
+                                      int32_t C, const float* w, int32_t rate, const float* z_prev, const float* scale, const float* shift, int32_t act,
+                                      const float* mean, const float* rstd, float* out, float* scratch, size_t scratch_floats, int32_t* rows_out,
+                                      void* stream) {
+    AMS_REQUIRE(dy && zd && cA && cB && cC && w && z_prev && scale && shift && mean && rstd && out && scratch && rows_out, "depthwise3x3_dgrad_bn_apply: null pointer");
+    AMS_REQUIRE(rate == 1 || rate == 2, "depthwise3x3_dgrad_bn_apply: rate %d", rate);
+    AMS_REQUIRE(scratch_floats >= depthwise_dgrad_bn2_scratch(B, H, W, C, rate), "depthwise3x3_dgrad_bn_apply: scratch too small");
+    int rows = 0;
+    int rc = launch_depthwise_dgrad_bn2(dy, zd, cA, cB, cC, B, H, W, C, w, rate, z_prev, scale, shift, act, mean, rstd, out, scratch, &rows, (hipStream_t)stream);
     *rows_out = rows;
     return rc;
 }

@@ -53,7 +53,7 @@ struct LayerRt {
     // project layer of a residual block): those layers get a tensor of their own
     float* dzp = nullptr;
     // stride-1 depthwise layer (training): partial rows of its one-kernel backward, kept until the step's batched reduction of the taps
-    float* dw_rows = nullptr;
+    float* dw_rows = nullptr; size_t dw_rows_floats = 0;
     // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
@@ -106,7 +106,7 @@ struct ams_student {
     int fuse_gemm_red = 3;             // fine-tune step: BN column reductions in the 1x1 GEMM epilogues: bit 0 forward statistics, bit 1 backward sums (AMS_OPT_FUSE_GEMM_RED)
     int fuse_operand_bn = 1;           // fine-tune step: BN + activation of a depthwise layer applied by the project layer's GEMM and weight gradient on their
                                        // operand loads — the depthwise activation is never written (AMS_OPT_FUSE_OPERAND_BN)
-    int fuse_dgrad_bn = 2;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
+    int fuse_dgrad_bn = 3;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
     int train_recompute = 1;
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
     float *vec_ones = nullptr, *vec_zeros = nullptr;             // [1024] each: identity BN for a fused kernel's raw output

@@ -163,6 +163,10 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         // never waits for a weight gradient (with two alternating dz buffers it did, ~40 times a step: 0.2 ms of real stalls behind
         // weight gradients that sharing the chip had stretched)
         float* dz = l.dzp ? l.dzp : l.da;
+        // stride-16 depthwise layer whose masked gradient and sums came out of the project layer's input-gradient GEMM: its apply pass
+        // (dz = A dy + B + C z) is formed inside the depthwise backward kernel below, on the way into that kernel's LDS ring (k_dw_train.hip)
+        const bool fold_apply = s->fuse_dgrad_bn >= 3 && fused_rows > 0 && !fused_dw && l.d.role == AMS_ROLE_DEPTHWISE && dw_fused_train(s, i, B) &&
+                                l.dw_rows && depthwise_dgrad_bn2_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate) <= l.dw_rows_floats;
         if (fused_rows > 0) {
             // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the
             // partial sums (launch_depthwise_dgrad_bn): second stage of the reduction, then dz = A dy + B + C z
@@ -180,7 +184,7 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             if (fused_dw && !(fused_buf != s->scratch &&
                               deferred.add(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, fused_stride)))
                 RUN(launch_reduce_splits(fused_buf + 2 * (int64_t)l.d.cout, fused_rows, 9 * (int64_t)l.d.cout, G + s->L[i + 1].d.w_off, st, fused_stride));
-            RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
+            if (!fold_apply) RUNK(0, 12.0 * Mo * l.d.cout, launch_bn_bwd_apply(l.da, l.z, Mo, l.d.cout, l.scale, l.shift, AMS_ACT_NONE, l.cA, l.cB, l.cC, dz, st));
             fused_rows = 0;
         } else {
             RUN(bn_backward(s, l, l.da, Mo, (double)global_B * l.px_out, sc, st, dz));
@@ -279,6 +283,11 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         if (dw_fused_train(s, i, B)) {
             // input gradient + activation derivative + BN-backward sums of the expand layer + this layer's weight gradient in one kernel
             // (k_conv.hip): prev.da <- dy, partial rows in s->scratch until the next iteration's second stage
+            if (fold_apply)
+                RUNK(i, dw_bytes(l, B) + 8.0 * B * l.px_in * l.d.cin,
+                     launch_depthwise_dgrad_bn2(l.da, l.z, l.cA, l.cB, l.cC, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, prev.z, prev.scale,
+                                                prev.shift, prev.d.act, prev.mean, prev.rstd, prev.da, l.dw_rows, &fused_rows, st));
+            else
             RUNK(i, dw_bytes(l, B) + 4.0 * B * l.px_in * l.d.cin,
                  launch_depthwise_dgrad_bn(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, prev.z, prev.scale, prev.shift, prev.d.act, prev.mean,
                                            prev.rstd, prev.da, l.dw_rows ? l.dw_rows : s->scratch, &fused_rows, st));

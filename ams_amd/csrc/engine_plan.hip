@@ -255,8 +255,11 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.a = cv.take<float>(e);
             l.da = cv.take<float>(e);
             if (l.d.residual_from) l.dzp = cv.take<float>(e);
-            if (l.d.role == AMS_ROLE_DEPTHWISE && l.d.stride == 1 && i >= 3 && l.d.cin <= 1024)
-                l.dw_rows = cv.take<float>(depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin));
+            if (l.d.role == AMS_ROLE_DEPTHWISE && l.d.stride == 1 && i >= 3 && l.d.cin <= 1024) {
+                const size_t n1 = depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin), n2 = depthwise_dgrad_bn2_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate);
+                l.dw_rows_floats = n2 != (size_t)-1 && n2 > n1 ? n2 : n1;
+                l.dw_rows = cv.take<float>(l.dw_rows_floats);
+            }
         }
     }
     *bytes_out = (cv.off + 255) & ~(size_t)255;

@@ -22,6 +22,7 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     int pwx_rm = 0, pwx_nt = 0;                  // AMS_PWX_FORCE=<RM>,<NT>
     bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE
     bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
+    int wg6_split_cap = 0;                       // AMS_WG6_SPLITS: most pixel splits of the six-product weight gradient (default 64)
 };
 const Knobs& knobs();
 
@@ -152,6 +153,12 @@ size_t depthwise_dgrad_bn_scratch(int B, int H, int W, int C);
 int launch_depthwise_dgrad_bn(const float* dy, int B, int H, int W, int C, const float* w, int rate, const float* z, const float* scale,
                               const float* shift, int act, const float* mean, const float* rstd, float* out, float* scratch, int* rows_out,
                               hipStream_t st);
+// k_dw_train.hip: the same with the depthwise layer's own BN-backward apply pass folded in — dz_d = cA dy + cB + cC zd is formed once per
+// element on the way into an LDS ring (bit-identical to bn_bwd_apply_kernel followed by the kernel above; partial rows in a different split)
+size_t depthwise_dgrad_bn2_scratch(int B, int H, int W, int C, int rate);
+int launch_depthwise_dgrad_bn2(const float* dy, const float* zd, const float* cA, const float* cB, const float* cC, int B, int H, int W, int C,
+                               const float* w, int rate, const float* ze, const float* scale, const float* shift, int act, const float* mean,
+                               const float* rstd, float* out, float* scratch, int* rows_out, hipStream_t st);
 size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate);
 int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
                            float* dw, float* scratch, size_t scratch_floats, hipStream_t st);

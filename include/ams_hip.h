@@ -239,7 +239,8 @@ enum { AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: 1 (default) BN + activati
                                      the expand layer's activation derivative and BN-backward sums, and the depthwise weight gradient come out of
                                      ONE kernel (k_conv.hip: dw3x3_dgrad_bn_kernel); 2 (default) the forward too: the depthwise conv applies the
                                      expand layer's BN + activation on its tap loads and leaves the statistics of its result (dw3x3_fwd_bn_kernel) —
-                                     the expand activation is never written; 0 separate passes.  Same mathematics, f32-level differences */,
+                                     the expand activation is never written; 3 (default) the depthwise layer's OWN apply pass (dz_d = A dy + B + C z_d) is folded into
+                                     that backward kernel too, through an LDS ring (k_dw_train.hip); 0 separate passes.  Same mathematics, f32-level differences */,
        AMS_OPT_FUSE_GEMM_RED = 17 /* fine-tune step, BN column reductions in the epilogue of the 1x1 GEMM that holds the values in registers
                                      (pw_common.hpp pw_red_*): bit 0 the forward statistics of the GEMM's own result, bit 1 the BN-backward sums of the
                                      layer whose output gradient the dgrad GEMM produces.  Default 3; 0 = separate reduction passes.  Same mathematics,
@@ -466,6 +467,14 @@ size_t ams_k_depthwise3x3_dgrad_bn_scratch(int32_t B, int32_t H, int32_t W, int3
 int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate,
                                 const float* z_prev, const float* scale, const float* shift, int32_t act, const float* mean,
                                 const float* rstd, float* out, float* scratch, size_t scratch_floats, int32_t* rows_out, void* stream);
+/* ... with the depthwise layer's own BN-backward apply pass folded in (AMS_OPT_FUSE_DGRAD_BN = 3, k_dw_train.hip): the gradient entering the
+ * transposed conv is dz_d = cA dy + cB + cC zd, formed once per element on the way into an LDS ring (the unfused operations of the apply pass:
+ * `out` is bit-identical to ams_k_depthwise3x3_dgrad_bn on the materialised dz_d); partial rows [rows][11][C] as above, split differently. */
+size_t ams_k_depthwise3x3_dgrad_bn_apply_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate);
+int ams_k_depthwise3x3_dgrad_bn_apply(const float* dy, const float* zd, const float* cA, const float* cB, const float* cC, int32_t B, int32_t H, int32_t W,
+                                      int32_t C, const float* w, int32_t rate, const float* z_prev, const float* scale, const float* shift, int32_t act,
+                                      const float* mean, const float* rstd, float* out, float* scratch, size_t scratch_floats, int32_t* rows_out,
+                                      void* stream);
 
 /* The fine-tune step of an early inverted-residual block WITHOUT its 6x-expanded tensors (k_xdw_train.hip; Cin 8..32, Cexp 32..192 in 16s,
  * depthwise stride 1 | 2, rate 1): every pass recomputes z_e = x . w_exp from the block input x [B,H,W,Cin].  KP = Cin rounded up to 16.

@@ -38,5 +38,10 @@ def test_engine_follows_the_reference_graph(tag, nc, ci):
         margin = srt[..., -1] - srt[..., -2]
         bad = lab != want_lab
         assert not np.any(bad & (margin > 2 * tol * np.abs(want_low).max())), "label mismatch away from a tie"
-        assert bad.sum() <= 2, "%d of %d labels differ from the executor of the reference graph" % (int(bad.sum()), bad.size)
+        # ... and only where the f64 margin between the two best classes is smaller than twice the logit error actually measured in this
+        # run (a pixel can change hands only if the two logits cross): a count bar would depend on how many such ties the clip holds
+        err_abs = np.abs(np.asarray(got_low, np.float64) - want_low).max()
+        assert not np.any(bad & (margin > 2 * err_abs)), "label mismatch where the margin exceeds twice the measured logit error %.2e" % err_abs
+        print("%s %s: logits rel err %.2e, %d of %d labels differ (all at f64 margins < %.2e)" % (tag, name, rel(got_low, want_low), int(bad.sum()), bad.size, 2 * err_abs))
+        assert bad.sum() <= 1e-3 * bad.size
     eng.close()

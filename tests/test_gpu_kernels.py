@@ -338,6 +338,67 @@ def test_depthwise_fine_tune_kernels(lib, H, W, Cn, rate, act):
     assert rel_err(part[2:].reshape(3, 3, Cn), wt.grad.permute(2, 3, 0, 1).numpy()[..., 0]) < 2e-5
 
 
+@pytest.mark.parametrize("H,W,Cn,rate,act", [(33, 65, 384, 1, "relu6"), (33, 65, 960, 2, "relu6"), (17, 31, 576, 1, "relu6"), (9, 9, 64, 2, "none"),
+                                             (20, 7, 36, 1, "relu6"), (130, 70, 32, 1, "relu6"), (5, 3, 1024, 2, "relu6"), (4, 33, 100, 2, "relu6"),
+                                             (34, 66, 960, 2, "relu6")])
+def test_depthwise_backward_with_folded_apply(lib, H, W, Cn, rate, act):
+    """k_dw_train.hip (AMS_OPT_FUSE_DGRAD_BN = 3): the depthwise layer's BN-backward apply pass dz_d = A dy + B + C z_d formed inside the
+    one-kernel depthwise backward, through an LDS ring.  Against f64 math on ragged sizes (column strips of unequal width, a 1-column and a
+    3-column map, odd and even sizes under rate 2 — the four parity classes have different extents —, a channel count that ends inside a
+    64-channel chunk, row bands), and the written gradient BIT FOR BIT against the apply pass followed by dw3x3_dgrad_bn_kernel."""
+    import ctypes as C
+    rng = np.random.default_rng(H * W + Cn + rate + 17)
+    B = 2
+    ze = rng.standard_normal((B, H, W, Cn)).astype(np.float32) * 2.0
+    w = (rng.standard_normal((3, 3, Cn, 1)) * 0.4).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cn).astype(np.float32)
+    shift = rng.standard_normal(Cn).astype(np.float32)
+    mean = rng.standard_normal(Cn).astype(np.float32) * 0.2
+    rstd = rng.uniform(0.5, 2.0, Cn).astype(np.float32)
+    dy_d = rng.standard_normal((B, H, W, Cn)).astype(np.float32)
+    z_d = rng.standard_normal((B, H, W, Cn)).astype(np.float32)
+    cA = rng.uniform(0.5, 1.5, Cn).astype(np.float32)
+    cB = (rng.standard_normal(Cn) * 0.3).astype(np.float32)
+    cC = (rng.standard_normal(Cn) * 0.3).astype(np.float32)
+    act_id = hip.ACT_RELU6 if act == "relu6" else hip.ACT_NONE
+    _, pt, pb = S.same_pad(H, 3, 1, rate)
+    _, pl, pr = S.same_pad(W, 3, 1, rate)
+    dz32 = ((cA * dy_d + cB) + cC * z_d).astype(np.float32)            # the apply pass's own f32 arithmetic
+    dz64 = cA.astype(np.float64) * dy_d + cB + cC.astype(np.float64) * z_d
+    zt = torch.as_tensor(ze).double().permute(0, 3, 1, 2)
+    y = zt * torch.as_tensor(scale).double().view(1, -1, 1, 1) + torch.as_tensor(shift).double().view(1, -1, 1, 1)
+    a_e = (torch.clamp(y, 0, 6) if act == "relu6" else y).requires_grad_(True)
+    wt = torch.as_tensor(w).double().permute(2, 3, 0, 1).requires_grad_(True)
+    zd_ref = F.conv2d(F.pad(a_e, (pl, pr, pt, pb)), wt, dilation=rate, groups=Cn)
+    zd_ref.backward(torch.as_tensor(dz64).permute(0, 3, 1, 2))
+    mask = ((y > 0) & (y < 6)).double() if act == "relu6" else torch.ones_like(y)
+    dy_ref = (a_e.grad * mask).permute(0, 2, 3, 1).numpy()
+    xhat = (ze.astype(np.float64) - mean) * rstd
+    n_scr = lib.ams_k_depthwise3x3_dgrad_bn_apply_scratch(B, H, W, Cn, rate)
+    scr = torch.full((n_scr,), float("nan"), device=DEV)
+    out = torch.full((B, H, W, Cn), float("nan"), device=DEV)
+    rows = C.c_int32(0)
+    hip.check(lib.ams_k_depthwise3x3_dgrad_bn_apply(PD(dy_d), PD(z_d), PD(cA), PD(cB), PD(cC), B, H, W, Cn, PD(w), rate, PD(ze), PD(scale), PD(shift),
+                                                    act_id, PD(mean), PD(rstd), P(out), P(scr), n_scr, C.byref(rows), stream()))
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all(), "an output pixel was not written"
+    assert rel_err(got, dy_ref) < 1e-5
+    part = scr[: rows.value * 11 * Cn].cpu().numpy().astype(np.float64)
+    assert np.isfinite(part).all(), "a partial-row entry was not written"
+    part = part.reshape(rows.value, 11, Cn).sum(axis=0)
+    assert rel_err(part[0], dy_ref.sum(axis=(0, 1, 2))) < 2e-5
+    assert rel_err(part[1], (dy_ref * xhat).sum(axis=(0, 1, 2))) < 2e-5
+    assert rel_err(part[2:].reshape(3, 3, Cn), wt.grad.permute(2, 3, 0, 1).numpy()[..., 0]) < 2e-5
+    # the pass it replaces + the kernel it replaces: same bits in the written gradient
+    if Cn <= 1024:
+        n2 = lib.ams_k_depthwise3x3_dgrad_bn_scratch(B, H, W, Cn)
+        scr2 = torch.empty(n2, device=DEV)
+        out2 = torch.empty((B, H, W, Cn), device=DEV)
+        hip.check(lib.ams_k_depthwise3x3_dgrad_bn(PD(dz32), B, H, W, Cn, PD(w), rate, PD(ze), PD(scale), PD(shift), act_id, PD(mean), PD(rstd), P(out2),
+                                                  P(scr2), n2, C.byref(rows), stream()))
+        assert torch.equal(out, out2), "folded apply differs from the separate pass by %g" % (out - out2).abs().max().item()
+
+
 @pytest.mark.parametrize("H,W,Cin,Cexp,stride", [(20, 37, 24, 144, 1), (21, 38, 24, 144, 2), (22, 37, 24, 144, 2), (16, 16, 16, 96, 2),
                                                  (9, 50, 32, 192, 1), (33, 65, 32, 192, 2), (8, 8, 8, 32, 1), (5, 3, 12, 48, 2), (64, 128, 16, 96, 1)])
 def test_recompute_block_kernels(lib, H, W, Cin, Cexp, stride):

@@ -608,6 +608,18 @@ int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W
     return rc;
 }
 
+size_t ams_k_depthwise3x3_fwd_bn_tiles_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate) { return depthwise_fwd_bn2_scratch(B, H, W, C, rate); }
+int ams_k_depthwise3x3_fwd_bn_tiles(const float* ze, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate, const float* scale,
+                                    const float* shift, int32_t act, const float* center, float* zd, float* scratch, size_t scratch_floats,
+                                    int32_t* rows_out, void* stream) {
+    AMS_REQUIRE(ze && w && scale && shift && zd && scratch && rows_out, "depthwise3x3_fwd_bn_tiles: null pointer");
+    AMS_REQUIRE(scratch_floats >= depthwise_fwd_bn2_scratch(B, H, W, C, rate), "depthwise3x3_fwd_bn_tiles: scratch too small");
+    int rows = 0;
+    int rc = launch_depthwise_fwd_bn2(ze, B, H, W, C, w, rate, scale, shift, act, center, zd, scratch, &rows, (hipStream_t)stream);
+    *rows_out = rows;
+    return rc;
+}
+
 size_t ams_k_depthwise3x3_dgrad_bn_apply_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate) { return depthwise_dgrad_bn2_scratch(B, H, W, C, rate); }
 int ams_k_depthwise3x3_dgrad_bn_apply(const float* dy, const float* zd, const float* cA, const float* cB, const float* cC, int32_t B, int32_t H, int32_t W,
                                       int32_t C, const float* w, int32_t rate, const float* z_prev, const float* scale, const float* shift, int32_t act,

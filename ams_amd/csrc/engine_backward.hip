@@ -165,7 +165,7 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         float* dz = l.dzp ? l.dzp : l.da;
         // stride-16 depthwise layer whose masked gradient and sums came out of the project layer's input-gradient GEMM: its apply pass
         // (dz = A dy + B + C z) is formed inside the depthwise backward kernel below, on the way into that kernel's LDS ring (k_dw_train.hip)
-        const bool fold_apply = s->fuse_dgrad_bn >= 3 && fused_rows > 0 && !fused_dw && l.d.role == AMS_ROLE_DEPTHWISE && dw_fused_train(s, i, B) &&
+        const bool fold_apply = s->fuse_dgrad_bn >= 3 && fused_rows > 0 && !fused_dw && l.d.role == AMS_ROLE_DEPTHWISE && l.d.cin % 64 == 0 && dw_fused_train(s, i, B) &&
                                 l.dw_rows && depthwise_dgrad_bn2_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate) <= l.dw_rows_floats;
         if (fused_rows > 0) {
             // the depthwise input-gradient kernel of the layer behind this one already applied the activation's derivative and left the

@@ -461,6 +461,11 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
         if (l.d.role == AMS_ROLE_DEPTHWISE && dw_fused_train_fwd(s, i, B)) {
             // BN + activation of the expand layer on the tap loads (its `a` was not written), the statistics of the result on the way out
             const LayerRt& le = s->L[i - 1];
+            // (from 64 channels on in the LDS-tile form of k_dw_train.hip: BN + activation once per element instead of once per tap load)
+            if (s->fuse_dgrad_bn >= 3 && l.d.cin % 64 == 0 && depthwise_fwd_bn2_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate) <= s->scratch_floats)
+                RUNK(i, dw_bytes(l, B), launch_depthwise_fwd_bn2(le.z, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, le.scale, le.shift, le.d.act,
+                                                                 s->stats + l.d.mean_off, l.z, s->scratch, &pre_rows, st));
+            else
             RUNK(i, dw_bytes(l, B), launch_depthwise_fwd_bn(le.z, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.rate, le.scale, le.shift, le.d.act,
                                                             s->stats + l.d.mean_off, l.z, s->scratch, &pre_rows, st));
         } else if (l.d.role == AMS_ROLE_DEPTHWISE) {

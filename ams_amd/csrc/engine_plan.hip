@@ -181,8 +181,10 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
                 }
                 if (l.d.stride == 1 && l.d.cin <= 1024) {       // the one-kernel forms of the blocks that keep their tensors
                     const size_t n1 = depthwise_dgrad_bn_scratch(B, l.Hin, l.Win, l.d.cin), n2 = depthwise_fwd_bn_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate);
+                    const size_t n3 = depthwise_fwd_bn2_scratch(B, l.Hin, l.Win, l.d.cin, l.d.rate);
                     if (n1 > need) need = n1;
                     if (n2 > need) need = n2;
+                    if (n3 != (size_t)-1 && n3 > need) need = n3;
                 }
             } else if (l.d.role == AMS_ROLE_STEM) need = pointwise_wgrad_scratch(M, 27, l.d.cout);
             else {

@@ -159,6 +159,10 @@ size_t depthwise_dgrad_bn2_scratch(int B, int H, int W, int C, int rate);
 int launch_depthwise_dgrad_bn2(const float* dy, const float* zd, const float* cA, const float* cB, const float* cC, int B, int H, int W, int C,
                                const float* w, int rate, const float* ze, const float* scale, const float* shift, int act, const float* mean,
                                const float* rstd, float* out, float* scratch, int* rows_out, hipStream_t st);
+// ... and the training forward in the same tile form (a_e formed once per element on its way into LDS; z_d bit-identical to launch_depthwise_fwd_bn)
+size_t depthwise_fwd_bn2_scratch(int B, int H, int W, int C, int rate);
+int launch_depthwise_fwd_bn2(const float* ze, int B, int H, int W, int C, const float* w, int rate, const float* scale, const float* shift, int act,
+                             const float* center, float* zd, float* scratch, int* rows_out, hipStream_t st);
 size_t depthwise_wgrad_scratch(int B, int H, int W, int C, int stride, int rate);
 int launch_depthwise_wgrad(const float* x, const float* dy, int B, int H, int W, int C, int stride, int rate,
                            float* dw, float* scratch, size_t scratch_floats, hipStream_t st);

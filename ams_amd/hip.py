@@ -130,6 +130,8 @@ SIGNATURES = {
     "ams_k_depthwise3x3_dgrad_bn_scratch": (_sz, [_i32, _i32, _i32, _i32]),
     "ams_k_depthwise3x3_dgrad_bn": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz,
                                              C.POINTER(_i32), _vp]),
+    "ams_k_depthwise3x3_fwd_bn_tiles_scratch": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "ams_k_depthwise3x3_fwd_bn_tiles": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, C.POINTER(_i32), _vp]),
     "ams_k_depthwise3x3_dgrad_bn_apply_scratch": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "ams_k_depthwise3x3_dgrad_bn_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz,
                                                     C.POINTER(_i32), _vp]),

@@ -471,6 +471,11 @@ int ams_k_depthwise3x3_dgrad_bn(const float* dz, int32_t B, int32_t H, int32_t W
  * transposed conv is dz_d = cA dy + cB + cC zd, formed once per element on the way into an LDS ring (the unfused operations of the apply pass:
  * `out` is bit-identical to ams_k_depthwise3x3_dgrad_bn on the materialised dz_d); partial rows [rows][11][C] as above, split differently. */
 size_t ams_k_depthwise3x3_dgrad_bn_apply_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate);
+/* the forward in the same LDS-tile form (act(ze scale + shift) formed once per element; zd bit-identical to ams_k_depthwise3x3_fwd_bn) */
+size_t ams_k_depthwise3x3_fwd_bn_tiles_scratch(int32_t B, int32_t H, int32_t W, int32_t C, int32_t rate);
+int ams_k_depthwise3x3_fwd_bn_tiles(const float* ze, int32_t B, int32_t H, int32_t W, int32_t C, const float* w, int32_t rate, const float* scale,
+                                    const float* shift, int32_t act, const float* center, float* zd, float* scratch, size_t scratch_floats,
+                                    int32_t* rows_out, void* stream);
 int ams_k_depthwise3x3_dgrad_bn_apply(const float* dy, const float* zd, const float* cA, const float* cB, const float* cC, int32_t B, int32_t H, int32_t W,
                                       int32_t C, const float* w, int32_t rate, const float* z_prev, const float* scale, const float* shift, int32_t act,
                                       const float* mean, const float* rstd, float* out, float* scratch, size_t scratch_floats, int32_t* rows_out,

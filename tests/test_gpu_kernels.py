@@ -389,6 +389,27 @@ def test_depthwise_backward_with_folded_apply(lib, H, W, Cn, rate, act):
     assert rel_err(part[0], dy_ref.sum(axis=(0, 1, 2))) < 2e-5
     assert rel_err(part[1], (dy_ref * xhat).sum(axis=(0, 1, 2))) < 2e-5
     assert rel_err(part[2:].reshape(3, 3, Cn), wt.grad.permute(2, 3, 0, 1).numpy()[..., 0]) < 2e-5
+    # ---- the forward in the same tile form: against f64 math, and z_d bit for bit against dw3x3_fwd_bn_kernel
+    center = (rng.standard_normal(Cn) * 0.1).astype(np.float32)
+    n_f = lib.ams_k_depthwise3x3_fwd_bn_tiles_scratch(B, H, W, Cn, rate)
+    scr_f = torch.full((n_f,), float("nan"), device=DEV)
+    zd_t = torch.full((B, H, W, Cn), float("nan"), device=DEV)
+    hip.check(lib.ams_k_depthwise3x3_fwd_bn_tiles(PD(ze), B, H, W, Cn, PD(w), rate, PD(scale), PD(shift), act_id, PD(center), P(zd_t), P(scr_f), n_f,
+                                                  C.byref(rows), stream()))
+    want_zd = zd_ref.detach().permute(0, 2, 3, 1).numpy()
+    assert np.isfinite(zd_t.cpu().numpy()).all() and rel_err(zd_t.cpu().numpy(), want_zd) < 1e-5
+    part_f = scr_f[: rows.value * 2 * Cn].cpu().numpy().astype(np.float64)
+    assert np.isfinite(part_f).all()
+    part_f = part_f.reshape(rows.value, 2, Cn).sum(axis=0)
+    dctr = want_zd - center.astype(np.float64)
+    assert rel_err(part_f[0], dctr.sum(axis=(0, 1, 2))) < 2e-5 and rel_err(part_f[1], (dctr * dctr).sum(axis=(0, 1, 2))) < 2e-5
+    if Cn <= 1024:
+        n_o = lib.ams_k_depthwise3x3_fwd_bn_scratch(B, H, W, Cn, rate)
+        scr_o = torch.empty(n_o, device=DEV)
+        zd_o = torch.empty((B, H, W, Cn), device=DEV)
+        hip.check(lib.ams_k_depthwise3x3_fwd_bn(PD(ze), B, H, W, Cn, PD(w), rate, PD(scale), PD(shift), act_id, PD(center), P(zd_o), P(scr_o), n_o,
+                                                C.byref(rows), stream()))
+        assert torch.equal(zd_t, zd_o), "tile-form forward differs from dw3x3_fwd_bn_kernel by %g" % (zd_t - zd_o).abs().max().item()
     # the pass it replaces + the kernel it replaces: same bits in the written gradient
     if Cn <= 1024:
         n2 = lib.ams_k_depthwise3x3_dgrad_bn_scratch(B, H, W, Cn)

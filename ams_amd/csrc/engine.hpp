@@ -99,6 +99,8 @@ struct ams_student {
     uint16_t* tp_panels = nullptr; size_t tp_elems = 0;
     int64_t tp_blocks = 0;
     bool tp_fresh = false;                                       // panels hold the split of the CURRENT parameters (this step)
+    bool tp_wait = false;                                        // ... once the side stream's split launch (ev_tp) is done: the first GEMM that uses them waits
+    hipEvent_t ev_tp = nullptr;
     float* dlogits = nullptr;
     float* ce_scratch = nullptr;       // unnormalised CE gradient planes of the one-pass loss kernel (k_head.hip)
     // fine-tune step of the early blocks without their 6x-expanded tensors (k_xdw_train.hip): AMS_OPT_TRAIN_RECOMPUTE, default on
@@ -148,6 +150,7 @@ struct ams_student {
         if (side) (void)hipStreamDestroy(side);
         if (side2) (void)hipStreamDestroy(side2);
         if (ev_xt) (void)hipEventDestroy(ev_xt);
+        if (ev_tp) (void)hipEventDestroy(ev_tp);
     }
     float* scratch = nullptr; size_t scratch_floats = 0;
     float* tmp_c = nullptr;          // [1024] small per-channel temp

@@ -25,8 +25,10 @@ int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
         auto it = s->tp_index.find({a.w, a.w_sk == 1 ? 1 : 0});
         if (it != s->tp_index.end()) {
             const SplitJob& j = s->tp_jobs[it->second];
-            if (j.K == a.K && j.N == a.N && j.sk == a.w_sk && j.sn == a.w_sn)
+            if (j.K == a.K && j.N == a.N && j.sk == a.w_sk && j.sn == a.w_sn) {
+                if (s->tp_wait) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_tp, 0)); s->tp_wait = false; }      // the split ran on the side stream
                 return launch_pointwise_split3(a, j.p0, j.p0 + j.plane, j.p0 + 2 * j.plane, j.Kp, st);
+            }
         }
     }
     AMS_REQUIRE(3 * plane <= s->panel_elems, "live_pointwise: panel scratch too small");
@@ -406,8 +408,21 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
     const float* P = s->params;
     // the parameters may have changed since the last call (Adam, restore): all live weight panels in one launch
     s->tp_fresh = false;
+    s->tp_wait = false;
     if (s->matmul_mode != AMS_MATMUL_F32 && !s->tp_jobs.empty()) {
-        RUNK(0, 0.0, launch_split_batch(s->tp_jobs_dev, (int)s->tp_jobs.size(), s->tp_blocks, st));
+        // the first GEMM that reads a panel is a millisecond away (the early blocks run exact f32): the split runs on the side stream beside
+        // the stem and the first blocks, and that GEMM waits for its event (live_pointwise)
+        hipStream_t ts = st;
+        if (s->overlap_wgrad && !s->prof.on && s->scratch2) {
+            if (!s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+            if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+            if (!s->ev_tp) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_tp, hipEventDisableTiming));
+            AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+            AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
+            ts = s->side;
+        }
+        RUNK(0, 0.0, launch_split_batch(s->tp_jobs_dev, (int)s->tp_jobs.size(), s->tp_blocks, ts));
+        if (ts != st) { AMS_CHECK_HIP(hipEventRecord(s->ev_tp, ts)); s->tp_wait = true; }
         s->tp_fresh = true;
     }
     {
@@ -511,6 +526,7 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
         d.shift = P + ll.d.gamma_off;
         RUNK(0, pw_bytes(d), live_pointwise(s, d, st));
     }
+    if (s->tp_wait) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_tp, 0)); s->tp_wait = false; }      // no GEMM used a panel (tiny frames): join anyway
     return AMS_OK;
 }
 

@@ -256,7 +256,9 @@ int wgrad_x6_splits(int64_t M, int K, int N) {
     int64_t want = (512 + tiles - 1) / tiles;              // ~2 blocks per CU
     const int64_t max_by_rows = (M + 255) / 256;          // at least 8 steps per block
     if (want > max_by_rows) want = max_by_rows;
-    const int cap = knobs().wg6_split_cap > 0 ? knobs().wg6_split_cap : 64;        // tuning knob AMS_WG6_SPLITS
+    // 32 pixel splits at most (the sweep at 8 x 512x1024: 64 -> 8.10 ms a step, 48 -> 8.07, 32 -> 8.04, 24 -> 8.03, 16 -> 8.3: the partial
+    // products and their reduction are traffic the main stream's kernels compete with)
+    const int cap = knobs().wg6_split_cap > 0 ? knobs().wg6_split_cap : 32;        // tuning knob AMS_WG6_SPLITS
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     return (int)want;

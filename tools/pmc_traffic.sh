@@ -6,7 +6,7 @@
 tag=$1; shift
 args=("$@")
 export AMS_DUAL_STREAM=0      # per-kernel traffic of the one-stream plan, whose launches bench.py prices in `roofline`
-[ ${#args[@]} -eq 0 ] && args=(--steps 3 --warmup 1 --settle 0 --only-timed)      # default batch of bench.py
+[ ${#args[@]} -eq 0 ] && args=(--steps 3 --warmup 1 --settle 0 --windows 1 --only-timed)      # default batch of bench.py
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmc_$tag
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag/fetch -o p -- python3 bench.py "${args[@]}" > gpurun_out/pmc_${tag}_fetch.log 2>&1

@@ -1,4 +1,4 @@
-"""Python handle over the C++/HIP student engine (ams_amd/csrc/engine.hip).
+"""Python handle over the C++/HIP student engine (ams_amd/csrc/engine_*.hip, api.hip).
 
 PyTorch-ROCm is plumbing here: it owns the device arena (one ``torch.uint8`` tensor the engine carves up),
 the H2D/D2H copies and the stream; all arithmetic happens in libams_hip.so.  There is no CPU path: creating

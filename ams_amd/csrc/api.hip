@@ -267,7 +267,7 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         return AMS_OK;
     }
     if (option == AMS_OPT_TRAIN_RECOMPUTE) {
-        s->train_recompute = value != 0;
+        s->train_recompute = value < 0 ? 0 : (value > 2 ? 2 : value);
         return AMS_OK;
     }
     if (option == AMS_OPT_FUSE_OPERAND_BN) {
@@ -632,6 +632,18 @@ int ams_k_depthwise3x3_dgrad_bn_apply(const float* dy, const float* zd, const fl
     int rc = launch_depthwise_dgrad_bn2(dy, zd, cA, cB, cC, B, H, W, C, w, rate, z_prev, scale, shift, act, mean, rstd, out, scratch, &rows, (hipStream_t)stream);
     *rows_out = rows;
     return rc;
+}
+
+size_t ams_k_xx_gram_scratch(int64_t M, int32_t Cin) { return xx_stats_scratch_doubles(M, Cin); }
+int ams_k_xx_gram(const float* x, int64_t M, int32_t Cin, double* scratch, size_t scratch_doubles, double* xx64, float* xx32, void* stream) {
+    AMS_REQUIRE(scratch_doubles >= xx_stats_scratch_doubles(M, Cin), "xx_gram: scratch too small");
+    return launch_xx_gram(x, M, Cin, scratch, xx64, xx32, (hipStream_t)stream);
+}
+int ams_k_expand_stats(const double* xx64, int32_t Cin, const float* w_exp, int32_t Cexp, double n, const float* center, const float* gamma,
+                       const float* beta, float eps, float one_minus_decay, float* moving_mean, float* moving_var, float* scale, float* shift,
+                       float* save_mean, float* save_rstd, double* sums, void* stream) {
+    return launch_expand_stats(xx64, Cin, w_exp, Cexp, n, center, gamma, beta, eps, one_minus_decay, moving_mean, moving_var, scale, shift, save_mean,
+                               save_rstd, sums, (hipStream_t)stream);
 }
 
 size_t ams_k_xdw_train_scratch(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cexp) { return xdw_train_scratch(B, H, W, Cin, Cexp); }

@@ -58,6 +58,7 @@ struct LayerRt {
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
     float* blk_vecs = nullptr;             // expand layer of a whole-block kernel: [13][cout] table of BN vectors + depthwise taps (freeze)
+    double* xx64 = nullptr;                // ... the same sums as doubles (k_xx_stats.hip): the expand layer's BN statistics follow from them
     float* xx_g0 = nullptr;                // expand layer of a recompute block (training): sum x x^T [KP][KP] | sum x [KP] of the last live forward
 };
 
@@ -109,7 +110,8 @@ struct ams_student {
     int fuse_operand_bn = 1;           // fine-tune step: BN + activation of a depthwise layer applied by the project layer's GEMM and weight gradient on their
                                        // operand loads — the depthwise activation is never written (AMS_OPT_FUSE_OPERAND_BN)
     int fuse_dgrad_bn = 3;             // fine-tune step: depthwise input gradient + mask + BN-backward sums of the expand layer in one kernel (AMS_FUSE_DGRAD_BN)
-    int train_recompute = 1;
+    int train_recompute = 2;           // 1: the expand layer's statistics by recomputing z_e (round 3); 2: from the Gram matrix of the block input (k_xx_stats.hip)
+    double* xx_scratch = nullptr; size_t xx_scratch_doubles = 0;       // partial rows of xx_f64_kernel
     float* xt_scratch = nullptr; size_t xt_floats = 0;           // partial rows of those kernels
     float *vec_ones = nullptr, *vec_zeros = nullptr;             // [1024] each: identity BN for a fused kernel's raw output
     float* vec_inv_hw = nullptr;                                  // [1024] x 1 / (h w): d(global mean) / d(feature), the pool branch's backward scale

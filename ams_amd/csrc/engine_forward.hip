@@ -443,6 +443,16 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
             float* mm = update_ema ? s->stats + l.d.mean_off : nullptr;
             float* mv = update_ema ? s->stats + l.d.var_off : nullptr;
             const double n_e = (double)global_B * l.px_out;
+            if (s->train_recompute >= 2 && l.xx64 && s->xx_scratch && l.d.cin <= 32 &&
+                xx_stats_scratch_doubles((int64_t)B * l.px_in, l.d.cin) <= s->xx_scratch_doubles) {
+                // z_e is linear in x: its sums follow from XX = x^T x and g0 = sum x, formed in f64 in ONE cheap pass over x (k_xx_stats.hip);
+                // the float copy is what the expand weight gradient reads (this rank's pixels), the doubles are summed over the ranks first
+                const int KP = (l.d.cin + 15) / 16 * 16;
+                RUNK(i, 4.0 * B * l.px_in * l.d.cin, launch_xx_gram(x, (int64_t)B * l.px_in, l.d.cin, s->xx_scratch, l.xx64, l.xx_g0, st));
+                RUN(sync_doubles(sc, l.xx64, (size_t)KP * KP + KP, st));
+                RUN(launch_expand_stats(l.xx64, l.d.cin, P + l.d.w_off, l.d.cout, n_e, center, s->params + l.d.gamma_off, s->params + l.d.beta_off,
+                                        l.d.bn_eps, omd, mm, mv, l.scale, l.shift, l.mean, l.rstd, l.fsums, st));
+            } else {
             int rows = 0;
             int64_t fstride = 0;
             RUNK(i, 4.0 * B * l.px_in * l.d.cin,
@@ -460,6 +470,7 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
                 RUN(sync_doubles(sc, l.fsums, 2 * (size_t)l.d.cout, st));
                 RUN(launch_bn_finalize(l.fsums, n_e, l.d.cout, center, s->params + l.d.gamma_off, s->params + l.d.beta_off, l.d.bn_eps, omd,
                                        mm, mv, l.scale, l.shift, l.mean, l.rstd, st));
+            }
             }
             // ... which leaves the statistics of that raw output behind as one partial row per tile (no separate pass over z_d)
             int d_rows = 0;

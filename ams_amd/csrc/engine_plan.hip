@@ -237,8 +237,12 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
                 xdw_train_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate)) {
                 const int KP = (l.d.cin + 15) / 16 * 16;
                 l.xx_g0 = cv.take<float>((size_t)KP * KP + KP);
+                l.xx64 = cv.take<double>((size_t)KP * KP + KP);
+                const size_t nd = xx_stats_scratch_doubles((int64_t)B * l.px_in, l.d.cin);
+                if (nd > s->xx_scratch_doubles) s->xx_scratch_doubles = nd;
             }
         }
+        s->xx_scratch = s->xx_scratch_doubles ? cv.take<double>(s->xx_scratch_doubles) : nullptr;
         s->vec_ones = cv.take<float>(1024);
         s->vec_zeros = cv.take<float>(1024);
         s->vec_inv_hw = cv.take<float>(1024);

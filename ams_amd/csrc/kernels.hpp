@@ -204,6 +204,14 @@ int launch_xdw_bwd_dx(const float* x, int B, int H, int W, int Cin, const float*
 int launch_xdw_dwe(const float* G1, const float* xx_g0, int Cin, int Cexp, const float* w_exp, const float* cA, const float* cB, const float* cC,
                    float* dw, hipStream_t st);
 
+// ---- k_xx_stats.hip : BN statistics of an early block's expand layer from the Gram matrix of the block input (f64 matrix pipe)
+int xx_stats_blocks(int64_t M);
+size_t xx_stats_scratch_doubles(int64_t M, int Cin);
+int launch_xx_gram(const float* x, int64_t M, int Cin, double* scratch, double* xx64, float* xx32, hipStream_t st);
+int launch_expand_stats(const double* xx64, int Cin, const float* w_exp, int Cexp, double n, const float* center, const float* gamma,
+                        const float* beta, float eps, float one_minus_decay, float* moving_mean, float* moving_var, float* scale, float* shift,
+                        float* save_mean, float* save_rstd, double* sums, hipStream_t st);
+
 // ---- k_block.hip : a whole early inverted-residual block (expand -> depthwise -> project [+ input]) in one kernel ----
 bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bool residual);
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,

@@ -230,7 +230,7 @@ class StudentEngine:
         """Fine-tune step of the early blocks without their 6x-expanded tensors (default on); off = every tensor materialised.
         ``fuse_dgrad_bn``: the one-kernel depthwise backward of the stride-16 blocks (default on).
         ``fuse_gemm_red``: BN column reductions in the 1x1 GEMM epilogues, bit 0 forward statistics, bit 1 backward sums (default 3)."""
-        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_TRAIN_RECOMPUTE, int(bool(on))), "ams_student_set_option")
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_TRAIN_RECOMPUTE, 2 if on is True else int(on)), "ams_student_set_option")
         if fuse_gemm_red is not None:
             hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_GEMM_RED, int(fuse_gemm_red)), "ams_student_set_option")
         if fuse_dgrad_bn is not None:

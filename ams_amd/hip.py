@@ -135,6 +135,9 @@ SIGNATURES = {
     "ams_k_depthwise3x3_dgrad_bn_apply_scratch": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "ams_k_depthwise3x3_dgrad_bn_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz,
                                                     C.POINTER(_i32), _vp]),
+    "ams_k_xx_gram_scratch": (_sz, [_i64, _i32]),
+    "ams_k_xx_gram": (C.c_int, [_vp, _i64, _i32, _vp, _sz, _vp, _vp, _vp]),
+    "ams_k_expand_stats": (C.c_int, [_vp, _i32, _vp, _i32, C.c_double, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ams_k_xdw_train_scratch": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "ams_k_xdw_fwd_stats": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _sz, C.POINTER(_i32), C.POINTER(_i64), _vp]),
     "ams_k_xdw_bwd_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _sz,

@@ -245,9 +245,11 @@ enum { AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: 1 (default) BN + activati
                                      (pw_common.hpp pw_red_*): bit 0 the forward statistics of the GEMM's own result, bit 1 the BN-backward sums of the
                                      layer whose output gradient the dgrad GEMM produces.  Default 3; 0 = separate reduction passes.  Same mathematics,
                                      f32-level differences (partial sums per row strip instead of per column chunk) */,
-       AMS_OPT_TRAIN_RECOMPUTE = 11 /* fine-tune step: 1 (default) the early blocks (block input <= 32 channels) run without their 6x-expanded
+       AMS_OPT_TRAIN_RECOMPUTE = 11 /* fine-tune step: >= 1 the early blocks (block input <= 32 channels) run without their 6x-expanded
                                        tensors — every consumer recomputes z_e = x . W_e from the block input (k_xdw_train.hip); 0 the
-                                       layer-by-layer step (every tensor materialised).  Same mathematics, f32-level differences (summation order). */,
+                                       layer-by-layer step (every tensor materialised); 2 (default) the expand layer's BN statistics additionally come from the
+                                       Gram matrix of the block input (z_e is linear in x: sum z = g0 . w, sum z^2 = w^T XX w, XX accumulated in f64 in one
+                                       cheap pass over x, k_xx_stats.hip) instead of a pass that recomputes z_e.  Same mathematics, f32-level differences. */,
        AMS_OPT_DUAL_STREAM = 10 /* frozen inference: a batch as two to four parts on as many streams (the caller's and up to three the student
                                    owns, created with the student; one fork and one join per call), each frame computed exactly as in a batch of the
                                    part's size.  0 never; 1 (default) a fixed function of the batch size (two parts at 32-36 and 64 frames, three at
@@ -489,6 +491,17 @@ int ams_k_depthwise3x3_dgrad_bn_apply(const float* dy, const float* zd, const fl
  *   bwd_dx    : dx [B,H,W,Cin] = (cA dy_e + cB + cC z_e) . w_exp^T (+ res)
  *   dwe       : dw_exp [Cin][Cexp] = cA G1 + g0^T cB + cC (XX . w_exp) from the REDUCED rows (G1; XX | g0 contiguous)
  * rows of *stride_out floats, *rows_out of them, in scratch (>= ams_k_xdw_train_scratch floats). */
+/* BN statistics of an early block's expand layer from the Gram matrix of the block input (AMS_OPT_TRAIN_RECOMPUTE = 2, k_xx_stats.hip; what
+ * FusedBatchNormV3's reduction over z_e = x . W_e is to the reference's graph): ams_k_xx_gram forms XX = x^T x [KP][KP] and g0 = sum x [KP]
+ * (KP = Cin rounded up to 16, Cin <= 32) over the M rows of x [M, Cin] on the f64 matrix pipe — xx64: KP KP + KP doubles, xx32 (may be NULL) the
+ * same as floats; ams_k_expand_stats turns them into scale / shift / saved mean / rstd (and the moving averages, sums [2][Cexp] about
+ * `center`, both optional) of the BN over n pixels: sum z = g0 . w, sum z^2 = w^T XX w per channel, in f64. */
+size_t ams_k_xx_gram_scratch(int64_t M, int32_t Cin);
+int ams_k_xx_gram(const float* x, int64_t M, int32_t Cin, double* scratch, size_t scratch_doubles, double* xx64, float* xx32, void* stream);
+int ams_k_expand_stats(const double* xx64, int32_t Cin, const float* w_exp, int32_t Cexp, double n, const float* center, const float* gamma,
+                       const float* beta, float eps, float one_minus_decay, float* moving_mean, float* moving_var, float* scale, float* shift,
+                       float* save_mean, float* save_rstd, double* sums, void* stream);
+
 size_t ams_k_xdw_train_scratch(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cexp);
 int ams_k_xdw_fwd_stats(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, int32_t Cexp, const float* center,
                         float* scratch, size_t scratch_floats, int32_t* rows_out, int64_t* stride_out, void* stream);

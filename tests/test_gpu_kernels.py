@@ -957,3 +957,49 @@ def test_pointwise_wgrad_with_operand_transforms(lib, M, K, N, split, modes):
     else:
         hip.check(lib.ams_k_pointwise_wgrad(PD(xp32), PD(dp32), M, K, N, P(dw2), P(scr), n_scr, stream()))
     assert torch.equal(dw, dw2), "transforms on load differ from the materialised operands by %g" % (dw - dw2).abs().max().item()
+
+
+@pytest.mark.parametrize("M,Cin,Cexp", [(265224, 24, 144), (67080, 32, 192), (1027, 16, 96), (33, 8, 32), (5000, 12, 48), (4, 32, 64)])
+def test_expand_statistics_from_gram_matrix(lib, M, Cin, Cexp):
+    """k_xx_stats.hip (AMS_OPT_TRAIN_RECOMPUTE = 2): XX = x^T x and g0 = sum x on the f64 matrix pipe, then the BN statistics of z = x . W per
+    channel from them.  x has channel means several sigma away from zero (the cancellation inside w^T XX w is what f64 is there for); row
+    counts that are not multiples of 4, fewer rows than waves, channel counts below a 16-wide chunk.  XX / g0 against NumPy f64 to 1e-12;
+    scale / shift / saved statistics / moving averages against the statistics of the f64 product z to f32 rounding."""
+    rng = np.random.default_rng(M + Cin + Cexp)
+    x = (rng.standard_normal((M, Cin)) * rng.uniform(0.2, 2.0, Cin) + rng.standard_normal(Cin) * 3.0).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cexp)) / np.sqrt(Cin)).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
+    beta = (rng.standard_normal(Cexp) * 0.1).astype(np.float32)
+    center = (rng.standard_normal(Cexp) * 0.1).astype(np.float32)
+    mm0 = (rng.standard_normal(Cexp) * 0.1).astype(np.float32)
+    mv0 = rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
+    eps, omd = 1e-3, 0.1
+    KP = (Cin + 15) // 16 * 16
+    n_scr = int(lib.ams_k_xx_gram_scratch(M, Cin))
+    scr = torch.full((n_scr,), float("nan"), dtype=torch.float64, device=DEV)
+    xx64 = torch.full((KP * KP + KP,), float("nan"), dtype=torch.float64, device=DEV)
+    xx32 = torch.full((KP * KP + KP,), float("nan"), device=DEV)
+    hip.check(lib.ams_k_xx_gram(PD(x), M, Cin, P(scr), n_scr, P(xx64), P(xx32), stream()))
+    x64 = x.astype(np.float64)
+    XX = np.zeros((KP, KP)); XX[:Cin, :Cin] = x64.T @ x64
+    g0 = np.zeros(KP); g0[:Cin] = x64.sum(axis=0)
+    got = xx64.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got[:KP * KP].reshape(KP, KP) - XX).max() <= 1e-12 * np.abs(XX).max()
+    assert np.abs(got[KP * KP:] - g0).max() <= 1e-12 * max(np.abs(g0).max(), 1.0)
+    assert np.allclose(xx32.cpu().numpy(), got.astype(np.float32), rtol=1e-6, atol=0)
+    scale, shift, smean, srstd = (torch.empty(Cexp, device=DEV) for _ in range(4))
+    mm, mv = dev(mm0), dev(mv0)
+    sums = torch.empty(2 * Cexp, dtype=torch.float64, device=DEV)
+    hip.check(lib.ams_k_expand_stats(P(xx64), Cin, PD(w), Cexp, float(M), PD(center), PD(gamma), PD(beta), eps, omd, P(mm), P(mv), P(scale), P(shift),
+                                     P(smean), P(srstd), P(sums), stream()))
+    z = x64 @ w.astype(np.float64)
+    mean, var = z.mean(axis=0), z.var(axis=0)
+    rstd = 1.0 / np.sqrt(var + eps)
+    assert rel_err(smean.cpu().numpy(), mean) < 1e-6 and rel_err(srstd.cpu().numpy(), rstd) < 1e-6
+    assert rel_err(scale.cpu().numpy(), gamma * rstd) < 1e-6 and rel_err(shift.cpu().numpy(), beta - mean * gamma * rstd) < 2e-6
+    unbiased = var * (M / max(M - 1, 1))
+    assert rel_err(mm.cpu().numpy(), mm0 - (mm0 - mean) * omd) < 1e-6 and rel_err(mv.cpu().numpy(), mv0 - (mv0 - unbiased) * omd) < 1e-6
+    d = z - center.astype(np.float64)
+    s = sums.cpu().numpy()
+    assert rel_err(s[:Cexp], d.sum(axis=0)) < 1e-9 and rel_err(s[Cexp:], (d * d).sum(axis=0)) < 1e-9

@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256) void xx_f64_kernel(const float* __restrict__ x
     int coff[KC];
 #pragma unroll
     for (int c = 0; c < KC; ++c) { cok[c] = 16 * c + l15 < Cin; coff[c] = cok[c] ? 16 * c + l15 : 0; }
-    for (int64_t g = g_lo; g < g_hi; g += 2) {               // two groups in flight
-        float v[2][KC];
+    constexpr int NG = 8;                                    // groups (32 pixels) in flight: the loads are 4-byte gathers, latency is what they cost
+    for (int64_t g = g_lo; g < g_hi; g += NG) {
+        float v[NG][KC];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NG; ++h) {
             const int64_t p = 4 * (g + h) + q;
             const bool ok = g + h < g_hi && p < M;
             const float* px = x + (ok ? p : 0) * (int64_t)Cin;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void xx_f64_kernel(const float* __restrict__ x
             for (int c = 0; c < KC; ++c) { const float t = px[coff[c]]; v[h][c] = (ok && cok[c]) ? t : 0.f; }
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NG; ++h) {
             double d[KC];
 #pragma unroll
             for (int c = 0; c < KC; ++c) { d[c] = (double)v[h][c]; g0[c] += d[c]; }
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(256) void xx_f64_kernel(const float* __restrict__ x
                 for (int r = 0; r < 4; ++r) {
                     double s = acc[i][j][r];
                     for (int w = 0; w < 3; ++w) s += sred[w][((i * KC + j) * 4 + r) * 64 + lane];
-                    // D layout of the 16x16x4 MFMA: row 4 q + r (A index), column l15 (B index)
-                    out[(16 * i + 4 * q + r) * KP + 16 * j + l15] = s;
+                    // D layout of the f64 16x16x4 MFMA: register r of lane (q, l15) holds row 4 r + q (A index), column l15 (B index) — not the
+                    // 4 q + r of the f32 form (XX is symmetric, so only the row interleave matters; pinned by the kernel-level test)
+                    out[(16 * i + 4 * r + q) * KP + 16 * j + l15] = s;
                 }
         if (q == 0) {
 #pragma unroll
@@ -108,49 +110,61 @@ __global__ __launch_bounds__(256) void xx_f64_kernel(const float* __restrict__ x
     }
 }
 
-// out64[i] = sum over the partial rows, ascending; out32 = the same as floats
+// out64[i] = sum over the partial rows; out32 = the same as floats.  A block owns 16 outputs: thread (kpart, col) sums every 16th row with all
+// its loads in flight, the 16 partials of an output are added in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void xx_reduce_kernel(const double* __restrict__ part, int rows, int n, double* __restrict__ out64,
                                                         float* __restrict__ out32) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
-        s0 += part[(int64_t)r * n + i]; s1 += part[(int64_t)(r + 1) * n + i];
-        s2 += part[(int64_t)(r + 2) * n + i]; s3 += part[(int64_t)(r + 3) * n + i];
+    __shared__ double sacc[16][17];
+    const int col = threadIdx.x & 15, kpart = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < n) {
+        int r = kpart;
+        for (; r + 16 < rows; r += 32) { s0 += part[(int64_t)r * n + i]; s1 += part[(int64_t)(r + 16) * n + i]; }
+        if (r < rows) s0 += part[(int64_t)r * n + i];
     }
-    for (; r < rows; ++r) s0 += part[(int64_t)r * n + i];
-    const double s = (s0 + s1) + (s2 + s3);
-    out64[i] = s;
-    if (out32) out32[i] = (float)s;
+    sacc[kpart][col] = s0 + s1;
+    __syncthreads();
+    if (threadIdx.x < 16 && i < n) {
+        double t = 0.0;
+        for (int k = 0; k < 16; ++k) t += sacc[k][col];
+        out64[i] = t;
+        if (out32) out32[i] = (float)t;
+    }
 }
 
+// block = 8 channels x 32 k: thread (c, k) forms t_k = sum_k2 XX[k][k2] w[k2] and its share w_k t_k of S2 = w^T XX w and g0_k w_k of S1;
+// the 32 shares of a channel are added in ascending k (deterministic)
 __global__ __launch_bounds__(256) void expand_stats_kernel(const double* __restrict__ xx, int KP, int Cin, const float* __restrict__ w_exp, int Cexp,
                                                            double* __restrict__ sums, BnFwdFin fin) {
-    extern __shared__ double sxx[];                          // XX [KP][KP] | g0 [KP]
+    __shared__ double sxx[32 * 32 + 32];                      // XX [KP][KP] | g0 [KP]
+    __shared__ double sw[8][33], sp1[8][33], sp2[8][33];
     for (int e = threadIdx.x; e < KP * KP + KP; e += 256) sxx[e] = xx[e];
+    const int cl = threadIdx.x >> 5, k = threadIdx.x & 31;
+    const int c = blockIdx.x * 8 + cl;
+    const bool live = c < Cexp && k < Cin;
+    sw[cl][k] = live ? (double)w_exp[(int64_t)k * Cexp + c] : 0.0;
     __syncthreads();
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= Cexp) return;
-    double w[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) w[k] = k < Cin ? (double)w_exp[(int64_t)k * Cexp + c] : 0.0;
-    double S1 = 0.0, S2 = 0.0;
-    for (int k = 0; k < Cin; ++k) {
-        S1 += sxx[KP * KP + k] * w[k];
-        double t = 0.0;
-        for (int k2 = 0; k2 < Cin; ++k2) t += sxx[k * KP + k2] * w[k2];
-        S2 += w[k] * t;
+    double t = 0.0;
+    if (live)
+        for (int k2 = 0; k2 < Cin; ++k2) t += sxx[k * KP + k2] * sw[cl][k2];
+    sp1[cl][k] = live ? sxx[KP * KP + k] * sw[cl][k] : 0.0;
+    sp2[cl][k] = sw[cl][k] * t;
+    __syncthreads();
+    if (k == 0 && c < Cexp) {
+        double S1 = 0.0, S2 = 0.0;
+        for (int kk = 0; kk < 32; ++kk) { S1 += sp1[cl][kk]; S2 += sp2[cl][kk]; }
+        const double ctr = fin.center ? (double)fin.center[c] : 0.0;
+        const double s0 = S1 - fin.n * ctr, s1 = S2 - 2.0 * ctr * S1 + fin.n * ctr * ctr;
+        if (sums) { sums[c] = s0; sums[Cexp + c] = s1; }
+        fin(c, Cexp, s0, s1 < 0.0 ? 0.0 : s1);
     }
-    const double ctr = fin.center ? (double)fin.center[c] : 0.0;
-    const double s0 = S1 - fin.n * ctr, s1 = S2 - 2.0 * ctr * S1 + fin.n * ctr * ctr;
-    if (sums) { sums[c] = s0; sums[Cexp + c] = s1; }
-    fin(c, Cexp, s0, s1 < 0.0 ? 0.0 : s1);
 }
 
 int xx_stats_blocks(int64_t M) {
-    int64_t b = (M + 1023) / 1024;                           // >= 256 pixels per wave
-    if (b > 512) b = 512;
+    int64_t b = (M + 255) / 256;                             // >= 64 pixels per wave
+    if (b > 1024) b = 1024;                                  // four waves per SIMD hide the gathers' latency (256 blocks: 88 us on 1 M pixels; every
+                                                             // partial row is KP KP + KP doubles for the second stage)
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -169,7 +183,7 @@ int launch_xx_gram(const float* x, int64_t M, int Cin, double* scratch, double* 
     if (KC == 1) hipLaunchKernelGGL((xx_f64_kernel<1>), dim3(blocks), dim3(256), 0, st, x, M, Cin, scratch);
     else hipLaunchKernelGGL((xx_f64_kernel<2>), dim3(blocks), dim3(256), 0, st, x, M, Cin, scratch);
     AMS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(xx_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, (const double*)scratch, blocks, n, xx64, xx32);
+    hipLaunchKernelGGL(xx_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, (const double*)scratch, blocks, n, xx64, xx32);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -181,8 +195,7 @@ int launch_expand_stats(const double* xx64, int Cin, const float* w_exp, int Cex
     AMS_REQUIRE(xx64 && w_exp && gamma && beta && scale && shift && Cin >= 4 && Cin <= 32 && Cexp > 0, "expand_stats: bad arguments");
     const int KP = (Cin + 15) / 16 * 16;
     const BnFwdFin fin{n, center, gamma, beta, eps, one_minus_decay, moving_mean, moving_var, scale, shift, save_mean, save_rstd};
-    hipLaunchKernelGGL(expand_stats_kernel, dim3(cdiv(Cexp, 256)), dim3(256), (size_t)(KP * KP + KP) * sizeof(double), st, xx64, KP, Cin, w_exp, Cexp,
-                       sums, fin);
+    hipLaunchKernelGGL(expand_stats_kernel, dim3(cdiv(Cexp, 8)), dim3(256), 0, st, xx64, KP, Cin, w_exp, Cexp, sums, fin);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

@@ -36,7 +36,17 @@ def test_recompute_step_matches_layerwise_step(H, B):
     a = _step(H, B, True)
     b = _step(H, B, False)
     assert a["loss"][0][1] == b["loss"][0][1]
-    assert a["loss"][0][0] == pytest.approx(b["loss"][0][0], rel=1e-5)
+    # the two forms take their BN statistics differently (f32 partial sums / the Gram matrix of the block input in f64): the loss sums agree
+    # to 3e-5, and the fused form is no further from the f64 oracle's loss than the layer-wise one (+ 5e-6)
+    assert a["loss"][0][0] == pytest.approx(b["loss"][0][0], rel=3e-5)
+    import torch
+    from oracle.student_torch import StudentOracle
+    W0 = Wt.synthetic_weights(S.build_spec(), 3)
+    fr, lb = synth.SyntheticVideo(H, B, CI, seed=3).clip()
+    loss64, _ = StudentOracle(W0, CI, dtype=torch.float64).gradients(fr.astype(np.float32), lb)
+    ea, eb = (abs(x["loss"][0][0] / x["loss"][0][1] - loss64) / abs(loss64) for x in (a, b))
+    print("loss vs the f64 oracle: fused %.2e, layer-wise %.2e" % (ea, eb))
+    assert ea <= eb + 5e-6
     spec = a["spec"]
     worst = []
     gmax = float(np.abs(b["grads"]).max())

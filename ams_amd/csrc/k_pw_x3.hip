@@ -316,6 +316,12 @@ __global__ __launch_bounds__(256, (RM * NT > 12 ? 2 : (RM * NT <= 8 && NT * NP <
 
 struct SplitPanels { const uint16_t* base; int64_t plane; int np; };     // part p at base + p * plane
 
+// One frame per call (M <= 2400 rows): the launch is one block's chain of K / 32 stages (~0.33 us each, 10 us for K = 960 whatever the
+// width).  Two other forms of that chain were built and measured in round 4, both bit-identical and both SLOWER: three stages in flight
+// instead of one (0.505 vs 0.481 ms per frame), and a kernel without LDS or barriers in which every wave owns a 16 x 32 tile and loads its
+// weight fragments straight from the panels (0.722 ms: 64-byte row pieces from panels that are not L2-resident between frames cost more
+// latency than two stages of prefetch cover, and deeper rings do not fit the registers).
+
 // Tail plan.  A launch of equal tiles whose block count is 1.05x or 2.1x the number of resident blocks ends with a round that
 // leaves most of the chip idle (68640 rows x 320 columns at two blocks per CU: 1074 blocks on 512 slots).  The launcher may give
 // the first k * slots blocks the full height and the remaining rows to half-height blocks (32 * RM rows, half the accumulators in
@@ -387,7 +393,9 @@ static int launch_pw_x3_e(const PwArgs& a, const SplitPanels& w, int Kp, hipStre
         RUN_RC(pointwise_materialize_x(a, &b, st));
         return launch_pw_x3_e<RM, NT, EPI>(b, w, Kp, st);
     }
-    // D = 4 is no faster (measured): the stage loop is bound by the LDS hand-over of the weight pieces, not by HBM latency
+    // D = 4 is no faster (measured): at full occupancy the stage loop is bound by the LDS hand-over of the weight pieces, not by latency; and
+    // at one frame per call (at most one block per CU, the launch = one block's chain of K / 32 stages) three stages in flight are SLOWER
+    // (0.505 vs 0.481 ms per frame, round 4): the chain is the barrier + LDS hand-over per stage, not the L2 round trip
     if (w.np == 3) return launch_pw_x3_d<RM, NT, EPI, 2, 3>(a, w, Kp, st);
     if (w.np == 1) return launch_pw_x3_d<RM, NT, EPI, 2, 1>(a, w, Kp, st);
     return launch_pw_x3_d<RM, NT, EPI, 2, 2>(a, w, Kp, st);

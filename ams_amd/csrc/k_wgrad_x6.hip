@@ -55,13 +55,21 @@ constexpr int wg_pitch(int channels) {       // bf16 elements per LDS row: multi
 
 // XD: the operand transforms of WgArgs applied between the global load and the split into the LDS image (a thread's float4 covers the
 // same four channels in every step: the per-channel vectors are loaded once)
-template <int KT, int NW, bool XD = false>
-__global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, int64_t rows_per_split) {
+// NWV = 8 (wide tiles): eight waves share one staged tile, split 4 (k) x 2 (n) — a wave owns KT / 4 k-tiles and half of the n-tiles, so the
+// dy fragments are re-read by four waves instead of all of them and two waves per SIMD overlap one's LDS reads and split with the other's
+// MFMAs (with four waves of 120 MFMAs each, one per SIMD, nothing overlapped: 104-185 us on the 960-wide layers inside the step).  The
+// order of the products of every output element is unchanged: same bits as NWV = 4.
+template <int KT, int NW, int XD = 0, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, int64_t rows_per_split) {
+    constexpr int NTH = 64 * NWV;                              // threads of a block
+    constexpr int NSPL = NWV / 4;                              // n-split of the waves (1 | 2)
+    constexpr int NWH = (NW + NSPL - 1) / NSPL;                // n-tiles per wave
+    constexpr bool XT = (XD & 1) != 0, DT = (XD & 2) != 0;     // operand transform on x (WgArgs::x_mode 1) / on dy (dy_mode 2)
     constexpr int CX = 16 * KT, CY = 16 * NW;                 // channels per tile side
     constexpr int PX = wg_pitch(CX), PY = wg_pitch(CY);       // LDS row pitch in bf16 elements
     constexpr int PLX = 32 * PX, PLY = 32 * PY;               // one part plane (32 pixels)
     constexpr int VX = CX / 4, VY = CY / 4;                   // float4 per tile row
-    constexpr int NLX = (32 * VX + 255) / 256, NLY = (32 * VY + 255) / 256;
+    constexpr int NLX = (32 * VX + NTH - 1) / NTH, NLY = (32 * VY + NTH - 1) / NTH;
     static_assert(KT % 4 == 0, "k-tiles are dealt to the four waves evenly");
     constexpr int MYK = KT / 4;                                // k-tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
@@ -71,7 +79,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
     const int tile = blockIdx.y, tk = tile / tiles_n, tn = tile - tk * tiles_n;
     const int k0 = tk * CX, n0 = tn * CY;
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: the k-tile offsets below stay wave-uniform
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the tile offsets below stay wave-uniform
+    const int wave = wave_id & 3, wn = wave_id >> 2;                    // k-tiles wave, wave + 4, ...; n-tiles wn * NWH ...
     const int64_t m_begin = (int64_t)blockIdx.x * rows_per_split;
     int64_t m_end = m_begin + rows_per_split;
     if (m_end > a.M) m_end = a.M;
@@ -79,40 +88,42 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
 
     // global -> register staging of one 32-pixel step (branch-free: clamped addresses, zero select)
     float4 rx[NLX], ry[NLY];
-    float4 rz[XD ? NLY : 1];                                      // dy_mode 2: the raw output beside the gradient
-    unsigned rx_ok = 0, ry_ok = 0;                                // which of this thread's pieces lie inside the problem (XD: raw values are kept until they are staged)
-    float4 vxs[XD ? NLX : 1], vxh[XD ? NLX : 1], vA[XD ? NLY : 1], vB[XD ? NLY : 1], vC[XD ? NLY : 1];
-    if constexpr (XD) {
+    float4 rz[DT ? NLY : 1];                                      // dy_mode 2: the raw output beside the gradient
+    unsigned rx_ok = 0, ry_ok = 0;                                // which of this thread's pieces lie inside the problem (raw values are kept until they are staged)
+    float4 vxs[XT ? NLX : 1], vxh[XT ? NLX : 1], vA[DT ? NLY : 1], vB[DT ? NLY : 1], vC[DT ? NLY : 1];
+    if constexpr (XT) {
 #pragma unroll
         for (int u = 0; u < NLX; ++u) {
-            const int e = tid + 256 * u, row = e / VX, c4 = (e - row * VX) * 4;
+            const int e = tid + NTH * u, row = e / VX, c4 = (e - row * VX) * 4;
             int k = k0 + c4;
             if (k > a.K - 4) k = a.K - 4;
-            vxs[u] = a.x_mode == 1 ? ld4(a.x_v0 + k) : make_float4(1.f, 1.f, 1.f, 1.f);
-            vxh[u] = a.x_mode == 1 ? ld4(a.x_v1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vxs[u] = ld4(a.x_v0 + k);
+            vxh[u] = ld4(a.x_v1 + k);
         }
+    }
+    if constexpr (DT) {
 #pragma unroll
         for (int u = 0; u < NLY; ++u) {
-            const int e = tid + 256 * u, row = e / VY, c4 = (e - row * VY) * 4;
+            const int e = tid + NTH * u, row = e / VY, c4 = (e - row * VY) * 4;
             int n = n0 + c4;
             if (n > a.N - 4) n = a.N - 4;
-            vA[u] = a.dy_mode == 2 ? ld4(a.dy_v0 + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-            vB[u] = a.dy_mode == 2 ? ld4(a.dy_v1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-            vC[u] = a.dy_mode == 2 ? ld4(a.dy_v2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            vA[u] = ld4(a.dy_v0 + n);
+            vB[u] = ld4(a.dy_v1 + n);
+            vC[u] = ld4(a.dy_v2 + n);
         }
     }
     auto fetch = [&](int s) {
         const int64_t mb = m_begin + (int64_t)s * 32;
 #pragma unroll
         for (int u = 0; u < NLX; ++u) {
-            const int e = tid + 256 * u, row = e / VX, c4 = (e - row * VX) * 4;
+            const int e = tid + NTH * u, row = e / VX, c4 = (e - row * VX) * 4;
             int64_t m = mb + row;
             int k = k0 + c4;
             const bool ok = e < 32 * VX && m < m_end && k < a.K;
             if (m > a.M - 1) m = a.M - 1;
             if (k > a.K - 4) k = a.K - 4;
             const float4 v = ld4(a.x + m * (int64_t)a.ldx + k);
-            if constexpr (XD) {
+            if constexpr (XT) {
                 // raw value now, transform when it is staged: arithmetic on the loaded value HERE would make the wave wait for the load
                 // it has just issued, i.e. take the prefetch out from under the MFMAs of the current step
                 rx[u] = v;
@@ -123,17 +134,17 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
         }
 #pragma unroll
         for (int u = 0; u < NLY; ++u) {
-            const int e = tid + 256 * u, row = e / VY, c4 = (e - row * VY) * 4;
+            const int e = tid + NTH * u, row = e / VY, c4 = (e - row * VY) * 4;
             int64_t m = mb + row;
             int n = n0 + c4;
             const bool ok = e < 32 * VY && m < m_end && n < a.N;
             if (m > a.M - 1) m = a.M - 1;
             if (n > a.N - 4) n = a.N - 4;
             const float4 v = ld4(a.dy + m * (int64_t)a.ldy + n);
-            if constexpr (XD) {
+            if constexpr (DT) {
                 ry[u] = v;
                 ry_ok = ok ? (ry_ok | (1u << u)) : (ry_ok & ~(1u << u));
-                if (a.dy_mode == 2) rz[u] = ld4(a.dy2 + m * (int64_t)a.ldy + n);
+                rz[u] = ld4(a.dy2 + m * (int64_t)a.ldy + n);
             } else {
                 ry[u] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             }
@@ -142,13 +153,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
     auto stage = [&]() {
 #pragma unroll
         for (int u = 0; u < NLX; ++u) {
-            const int e = tid + 256 * u, row = e / VX, c4 = (e - row * VX) * 4;
-            if constexpr (XD) {
-                float4 v = rx[u];
-                if (a.x_mode == 1) {
-                    const float4 y = muladd4_pk(v, vxs[u], vxh[u]);
-                    v = make_float4(apply_act(y.x, a.x_act), apply_act(y.y, a.x_act), apply_act(y.z, a.x_act), apply_act(y.w, a.x_act));
-                }
+            const int e = tid + NTH * u, row = e / VX, c4 = (e - row * VX) * 4;
+            if constexpr (XT) {
+                const float4 y = muladd4_pk(rx[u], vxs[u], vxh[u]);
+                const float4 v = make_float4(apply_act(y.x, a.x_act), apply_act(y.y, a.x_act), apply_act(y.z, a.x_act), apply_act(y.w, a.x_act));
                 const bool inside = (rx_ok >> u) & 1u;                 // rows / columns outside the problem contribute zeros
                 rx[u] = make_float4(inside ? v.x : 0.f, inside ? v.y : 0.f, inside ? v.z : 0.f, inside ? v.w : 0.f);
             }
@@ -156,11 +164,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
         }
 #pragma unroll
         for (int u = 0; u < NLY; ++u) {
-            const int e = tid + 256 * u, row = e / VY, c4 = (e - row * VY) * 4;
-            if constexpr (XD) {
-                float4 y = ry[u];
+            const int e = tid + NTH * u, row = e / VY, c4 = (e - row * VY) * 4;
+            if constexpr (DT) {
                 // (A g + B) + C z as bn_bwd_apply_kernel evaluates it; rows / columns outside the problem stay zero (B is not)
-                if (a.dy_mode == 2) y = add4_pk(add4_pk(mul4_pk(vA[u], ry[u]), vB[u]), mul4_pk(vC[u], rz[u]));
+                const float4 y = add4_pk(add4_pk(mul4_pk(vA[u], ry[u]), vB[u]), mul4_pk(vC[u], rz[u]));
                 const bool inside = (ry_ok >> u) & 1u;
                 ry[u] = inside ? y : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -168,11 +175,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
         }
     };
 
-    f32x4 acc[MYK][NW];
+    f32x4 acc[MYK][NWH];
 #pragma unroll
     for (int i = 0; i < MYK; ++i)
 #pragma unroll
-        for (int t = 0; t < NW; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NWH; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // per-lane transpose-read offsets inside a plane: rows 4q + (l15 >> 2) (+16 for the upper half), 4 columns at 4*(l15 & 3)
     const int tr_row = 4 * q + (l15 >> 2), tr_col = 4 * (l15 & 3);
@@ -191,11 +198,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
             }
         }
 #pragma unroll
-        for (int t = 0; t < NW; ++t) {
+        for (int t = 0; t < NWH; ++t) {
+            if (NSPL > 1 && wn * NWH + t >= NW) break;                  // an odd tile count leaves the second half one short (wave-uniform)
             bf16x8 yb[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                const unsigned short* b = sY + p * PLY + tr_row * PY + 16 * t + tr_col;
+                const unsigned short* b = sY + p * PLY + tr_row * PY + 16 * (wn * NWH + t) + tr_col;
                 yb[p] = tr_read8(b, b + 16 * PY);
             }
             // A = dy fragment (rows of D = n), B = x fragment (cols of D = k): a lane ends up with 4 consecutive n of one k
@@ -223,8 +231,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16x6(WgArgs a, int tiles_n, in
         const int k = k0 + 16 * kt + l15;
         if (k >= a.K) continue;
 #pragma unroll
-        for (int t = 0; t < NW; ++t) {
-            const int n = n0 + 16 * t + 4 * q;
+        for (int t = 0; t < NWH; ++t) {
+            if (NSPL > 1 && wn * NWH + t >= NW) break;
+            const int n = n0 + 16 * (wn * NWH + t) + 4 * q;
             if (n + 3 < a.N) st4(out + (int64_t)k * a.N + n, make_float4(acc[i][t][0], acc[i][t][1], acc[i][t][2], acc[i][t][3]));
             else {
 #pragma unroll
@@ -264,24 +273,37 @@ int wgrad_x6_splits(int64_t M, int K, int N) {
     return (int)want;
 }
 
+template <int KT, int NW, int XD, int NWV>
+static int launch_wg6_k(const WgArgs& a, int splits, int tiles_k, int tiles_n, int64_t rows, size_t lds, hipStream_t st) {
+    RUN_RC(func_allow_lds((const void*)pw_wgrad_bf16x6<KT, NW, XD, NWV>, lds));
+    hipLaunchKernelGGL((pw_wgrad_bf16x6<KT, NW, XD, NWV>), dim3(splits, tiles_k * tiles_n), dim3(64 * NWV), lds, st, a, tiles_n, rows);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 template <int KT, int NW>
 static int launch_wg6_t(const WgArgs& a, int splits, hipStream_t st) {
     const int tiles_k = cdiv(a.K, 16 * KT), tiles_n = cdiv(a.N, 16 * NW);
     int64_t rows = cdiv64(a.M, splits);
     rows = (rows + 31) / 32 * 32;
     const size_t lds = (size_t)3 * 32 * (wg_pitch(16 * KT) + wg_pitch(16 * NW)) * sizeof(unsigned short);
+    // eight waves per tile (from 96 output columns on): built and bit-identical, measured NEUTRAL in the step (7.99-8.02 ms either way: the
+    // weight gradients run beside the main chain, which is what the step waits for) — opt-in, tuning knob AMS_WG6_EIGHT_WAVES
+    constexpr bool kWide = NW >= 6;
+    const bool eight = kWide && knobs().wg6_eight_waves;
     static const std::string nm = "pw_wgrad_bf16x6<" + std::to_string(KT) + ", " + std::to_string(NW) + ">";
     note_kernel(nm.c_str());
-    if (a.x_mode != 0 || a.dy_mode != 0) {
-        RUN_RC(func_allow_lds((const void*)pw_wgrad_bf16x6<KT, NW, true>, lds));
-        hipLaunchKernelGGL((pw_wgrad_bf16x6<KT, NW, true>), dim3(splits, tiles_k * tiles_n), dim3(256), lds, st, a, tiles_n, rows);
-        AMS_CHECK_LAUNCH();
-        return AMS_OK;
+    const int xd = (a.x_mode != 0 ? 1 : 0) | (a.dy_mode != 0 ? 2 : 0);
+    if constexpr (kWide) {
+        if (eight && xd == 0) return launch_wg6_k<KT, NW, 0, 8>(a, splits, tiles_k, tiles_n, rows, lds, st);
+        if (eight && xd == 1) return launch_wg6_k<KT, NW, 1, 8>(a, splits, tiles_k, tiles_n, rows, lds, st);
     }
-    RUN_RC(func_allow_lds((const void*)pw_wgrad_bf16x6<KT, NW>, lds));
-    hipLaunchKernelGGL((pw_wgrad_bf16x6<KT, NW>), dim3(splits, tiles_k * tiles_n), dim3(256), lds, st, a, tiles_n, rows);
-    AMS_CHECK_LAUNCH();
-    return AMS_OK;
+    switch (xd) {
+        case 0: return launch_wg6_k<KT, NW, 0, 4>(a, splits, tiles_k, tiles_n, rows, lds, st);
+        case 1: return launch_wg6_k<KT, NW, 1, 4>(a, splits, tiles_k, tiles_n, rows, lds, st);
+        case 2: return launch_wg6_k<KT, NW, 2, 4>(a, splits, tiles_k, tiles_n, rows, lds, st);
+        default: return launch_wg6_k<KT, NW, 3, 4>(a, splits, tiles_k, tiles_n, rows, lds, st);
+    }
 }
 
 // writes `splits` partial [K,N] matrices into a.scratch; the caller reduces them

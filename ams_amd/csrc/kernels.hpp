@@ -22,6 +22,7 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     int pwx_rm = 0, pwx_nt = 0;                  // AMS_PWX_FORCE=<RM>,<NT>
     bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE
     bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
+    bool wg6_eight_waves = false;                // AMS_WG6_EIGHT_WAVES: the wide tiles of the six-product weight gradient with eight waves, split 4 (k) x 2 (n)
     int wg6_split_cap = 0;                       // AMS_WG6_SPLITS: most pixel splits of the six-product weight gradient (default 32)
 };
 const Knobs& knobs();

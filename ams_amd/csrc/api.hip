@@ -274,12 +274,17 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         s->fuse_operand_bn = value & 1;
         return AMS_OK;
     }
+    if (option == AMS_OPT_WGRAD_FORK_EVERY) {
+        AMS_REQUIRE(value >= 1 && value <= 64, "set_option: AMS_OPT_WGRAD_FORK_EVERY must be in 1 .. 64");
+        s->wgrad_fork_every = value;
+        return AMS_OK;
+    }
     if (option == AMS_OPT_NAN_GRADS) {
         s->nan_grads = value != 0;
         return AMS_OK;
     }
     if (option == AMS_OPT_OVERLAP_WGRAD) {
-        s->overlap_wgrad = value < 0 ? 0 : (value > 2 ? 2 : value);
+        s->overlap_wgrad = value < 0 ? 0 : (value > 3 ? 3 : value);
         return AMS_OK;
     }
     if (option == AMS_OPT_OVERLAP_HEAD) {

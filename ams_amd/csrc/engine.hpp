@@ -142,6 +142,7 @@ struct ams_student {
                                      // Off: measured 3.63 vs 3.61 ms at 32 frames and 1.90 k vs 2.01 k frames/s at one — the fork / join events
                                      // cost more than the three small launches they hide
     int overlap_wgrad = 1;
+    int wgrad_fork_every = 1;        // weight gradients per hand-over to the side stream (AMS_OPT_WGRAD_FORK_EVERY)
     int nan_grads = 1;               // a batch without a valid pixel: NaN loss AND NaN gradients, as the reference's 0 / 0 (AMS_OPT_NAN_GRADS; 0 = zero gradients)
     ~ams_student() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);

@@ -1,6 +1,8 @@
 // The student engine, part 3 of 4: loss, backward and update of the fine-tune step (reference SemanticNetwork.py:253-260 _train,
 // utils/graph_utils.py:403-408 loss, :457-496 optimizer / BN update / masked assignment).
 #include "engine.hpp"
+#include <functional>
+#include <vector>
 
 namespace ams {
 
@@ -71,27 +73,49 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
     // stream reads is overwritten inside the step (every dz lives in per-layer memory — in the head too: in place over da), so the main
     // stream never waits for it before the final join.
     const bool overlap = s->overlap_wgrad && !s->prof.on && s->scratch2;
-    if (overlap && !s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    if (overlap && !s->side) RUN(create_side_stream(&s->side));
     if (overlap && !s->ev_xt) {
         if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
         AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_xt, hipEventDisableTiming));
     }
-    // the side stream picks up after everything the main stream has issued so far; -> stream and reduction scratch of a weight gradient
-    auto fork_wgrad = [&](hipStream_t* wst, float** wscratch) -> int {
-        *wst = st; *wscratch = s->scratch;
-        if (!overlap) return AMS_OK;
-        AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
-        AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-        *wst = s->side; *wscratch = s->scratch2;
+    // Weight gradients are queued and handed to the side stream AMS_OPT_WGRAD_FORK_EVERY at a time.  Every hand-over is an event on the main
+    // stream (6-8 us gaps in profiles/r04_train_timeline.txt, ~55 a step) and nothing a queued job reads is overwritten inside the step, so a
+    // job may run any time after its operands exist — but batching measured SLOWER (7.98 -> 8.07 / 8.2 / 8.3 / 8.6 ms for 2 / 4 / 8 / 16): a
+    // weight gradient that runs beside the input-gradient GEMM of the same dz shares its cache lines.  Default 1 = hand over at once.
+    // Without the side stream a job runs where it is queued.
+    using WgJob = std::function<int(hipStream_t, float*)>;
+    std::vector<WgJob> pend;
+    // AMS_OPT_OVERLAP_WGRAD = 3: hand-overs alternate between the two side streams (each has its own reduction scratch), so a weight gradient
+    // starts at its hand-over even while the one before it is still running
+    const bool alt = overlap && s->overlap_wgrad >= 3 && s->scratch3;
+    if (alt && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
+    bool alt_second = false;
+    hipStream_t last_wst = st;
+    auto flush_wgrads = [&]() -> int {
+        if (pend.empty()) return AMS_OK;
+        hipStream_t wst = st;
+        float* wscr = s->scratch;
+        if (overlap) {
+            wst = alt && alt_second ? s->side2 : s->side;
+            wscr = alt && alt_second ? s->scratch3 : s->scratch2;
+            alt_second = !alt_second;
+            AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+            AMS_CHECK_HIP(hipStreamWaitEvent(wst, s->ev_fork, 0));
+        }
+        last_wst = wst;
+        for (auto& j : pend) RUN(j(wst, wscr));
+        pend.clear();
         return AMS_OK;
     };
-    hipStream_t hst = st;
-    float* hscr = s->scratch;
+    const int fork_every = overlap ? (s->wgrad_fork_every > 1 ? s->wgrad_fork_every : 1) : 1;
+    auto queue_wgrad = [&](WgJob j) -> int {
+        pend.push_back(std::move(j));
+        return (int)pend.size() >= fork_every ? flush_wgrads() : AMS_OK;
+    };
     // logits layer: bias, weights, input gradient
     RUN(launch_colsum(s->dlogits, M, 32, 32, s->tmp_c, s->scratch, st));
     RUN(launch_copy(G + ll.d.gamma_off, s->tmp_c, NC, st));
-    RUN(fork_wgrad(&hst, &hscr));
-    RUN(pw_wgrad(s, lc.a, lc.d.cout, lc.d.cout, s->dlogits, 32, NC, M, G + ll.d.w_off, hst, hscr));
+    RUN(queue_wgrad([=, &lc, &ll](hipStream_t ws, float* wscr) { return pw_wgrad(s, lc.a, lc.d.cout, lc.d.cout, s->dlogits, 32, NC, M, G + ll.d.w_off, ws, wscr); }));
     {
         PwArgs a = dgrad_args(s->dlogits, M, 32, 32, P + ll.d.w_off, ll.d.cin, lc.da);
         a.Kw = NC; a.w_sn = NC;        // w is [cin][NC]; dlogits columns >= NC are zero
@@ -102,16 +126,16 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
     RUN(bn_backward(s, lc, lc.da, M, nHW, sc, st, dz_c));
     const float* Wc_top = P + lc.d.w_off;
     const float* Wc_bot = P + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout;
-    RUN(fork_wgrad(&hst, &hscr));
-    RUN(pw_wgrad(s, la.a, la.d.cout, la.d.cout, dz_c, lc.d.cout, lc.d.cout, M, G + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, hst, hscr));
+    RUN(queue_wgrad([=, &la, &lc, &lp](hipStream_t ws, float* wscr) {
+        return pw_wgrad(s, la.a, la.d.cout, la.d.cout, dz_c, lc.d.cout, lc.d.cout, M, G + lc.d.w_off + (int64_t)lp.d.cout * lc.d.cout, ws, wscr);
+    }));
     {
         PwArgs a = dgrad_args(dz_c, M, lc.d.cout, lc.d.cout, Wc_bot, la.d.cout, la.da);
         RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
     // pool branch: the per-image bias collects the column sums of dz_proj
     RUN(launch_image_colsum(dz_c, B, HW, lc.d.cout, lc.d.cout, s->d_img_bias, s->scratch, st));
-    RUN(fork_wgrad(&hst, &hscr));
-    RUN(pw_wgrad(s, lp.a, lp.d.cout, lp.d.cout, s->d_img_bias, lc.d.cout, lc.d.cout, B, G + lc.d.w_off, hst, hscr));
+    RUN(queue_wgrad([=, &lp, &lc](hipStream_t ws, float* wscr) { return pw_wgrad(s, lp.a, lp.d.cout, lp.d.cout, s->d_img_bias, lc.d.cout, lc.d.cout, B, G + lc.d.w_off, ws, wscr); }));
     {
         PwArgs a = dgrad_args(s->d_img_bias, B, lc.d.cout, lc.d.cout, Wc_top, lp.d.cout, s->d_pool_a);
         RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
@@ -123,8 +147,7 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
         RUN(launch_bn_bwd_coef(lp.bsums, (double)global_B, lp.d.cout, P + lp.d.gamma_off, lp.mean, lp.rstd, lp.cA, lp.cB, lp.cC,
                                nullptr, nullptr, st));
         RUN(launch_bn_bwd_apply(s->d_pool_a, lp.z, B, lp.d.cout, lp.scale, lp.shift, lp.d.act, lp.cA, lp.cB, lp.cC, s->d_pool_z, st));
-        RUN(fork_wgrad(&hst, &hscr));
-        RUN(pw_wgrad(s, s->pooled, lp.d.cin, lp.d.cin, s->d_pool_z, lp.d.cout, lp.d.cout, B, G + lp.d.w_off, hst, hscr));
+        RUN(queue_wgrad([=, &lp](hipStream_t ws, float* wscr) { return pw_wgrad(s, s->pooled, lp.d.cin, lp.d.cin, s->d_pool_z, lp.d.cout, lp.d.cout, B, G + lp.d.w_off, ws, wscr); }));
         PwArgs a = dgrad_args(s->d_pool_z, B, lp.d.cout, lp.d.cout, P + lp.d.w_off, lp.d.cin, s->d_pooled);
         a.scale = s->vec_inv_hw;        // d mean / d feat = 1/HW, applied as a uniform scale (constants uploaded at create)
         a.shift = s->vec_zeros;
@@ -134,15 +157,14 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
     LayerRt& lf = s->L[s->n_backbone];
     float* dz_a = la.da;
     RUN(bn_backward(s, la, la.da, M, nHW, sc, st, dz_a));
-    RUN(fork_wgrad(&hst, &hscr));
-    RUN(pw_wgrad(s, lf.a, la.d.cin, la.d.cin, dz_a, la.d.cout, la.d.cout, M, G + la.d.w_off, hst, hscr));
+    RUN(queue_wgrad([=, &lf, &la](hipStream_t ws, float* wscr) { return pw_wgrad(s, lf.a, la.d.cin, la.d.cin, dz_a, la.d.cout, la.d.cout, M, G + la.d.w_off, ws, wscr); }));
     {
         PwArgs a = dgrad_args(dz_a, M, la.d.cout, la.d.cout, P + la.d.w_off, la.d.cin, lf.da);
         a.img_bias = s->d_pooled; a.rows_per_img = HW;
         RUNK(0, pw_bytes(a), live_pointwise(s, a, st));
     }
     // backbone, last layer to first
-    const bool three = overlap && s->overlap_wgrad >= 2 && s->scratch3;      // depthwise weight gradients on a third stream
+    const bool three = overlap && s->overlap_wgrad >= 2 && s->scratch3;      // depthwise weight gradients on a third stream (3: see `alt`)
     if (three && !s->side2) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side2, hipStreamNonBlocking));
     bool xt_pending = false;
     // > 0: the kernel that produced this layer's da already multiplied it by the activation's derivative and left the BN-backward partial
@@ -198,10 +220,10 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             int rows = 0;
             int64_t stride = 0;
             if (overlap && deferred.n > 0) {
-                // the stride-16 blocks are behind us: their deferred reductions (80 MB of partial rows) run on the side stream under the early blocks
-                AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
-                AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-                RUN(launch_reduce_batch(deferred, s->side));
+                // the stride-16 blocks are behind us: their deferred reductions (80 MB of partial rows) run on the side stream under the early
+                // blocks (queued: handed over with this block's own reductions below)
+                ReduceJobs dj = deferred;
+                pend.push_back([dj](hipStream_t xs, float*) mutable { return launch_reduce_batch(dj, xs); });
                 deferred.n = 0;
             }
             if (xt_pending) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0)); xt_pending = false; }     // xt_scratch is free again
@@ -234,20 +256,26 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             const int KP = (le.d.cin + 15) / 16 * 16;
             const int64_t n_dw = 9 * (int64_t)le.d.cout, n_g = (int64_t)KP * le.d.cout;
             float* reduced = s->xt_scratch + (int64_t)rows * stride;
-            hipStream_t xs = st;
-            if (overlap) {
-                AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
-                AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
-                xs = s->side;
+            {
+                float* xt = s->xt_scratch;
+                const int cin_e = le.d.cin, cout_e = le.d.cout;
+                const float* g0 = le.xx_g0;
+                const float *we = P + le.d.w_off, *cA = le.cA, *cB = le.cB, *cC = le.cC;
+                float *gdw = G + l.d.w_off, *gwe = G + le.d.w_off;
+                pend.push_back([=](hipStream_t xs, float*) -> int {
+                    RUN(launch_reduce_splits(xt + 2 * (int64_t)cout_e, rows, n_dw, gdw, xs, stride));
+                    RUN(launch_reduce_splits(xt + 11 * (int64_t)cout_e, rows, n_g, reduced, xs, stride));
+                    RUN(launch_xdw_dwe(reduced, g0, cin_e, cout_e, we, cA, cB, cC, gwe, xs));
+                    return AMS_OK;
+                });
+                RUN(flush_wgrads());                  // with whatever weight gradients are queued: one event for all of them
             }
-            RUN(launch_reduce_splits(s->xt_scratch + 2 * (int64_t)le.d.cout, rows, n_dw, G + l.d.w_off, xs, stride));
-            RUN(launch_reduce_splits(s->xt_scratch + 11 * (int64_t)le.d.cout, rows, n_g, reduced, xs, stride));
-            RUN(launch_xdw_dwe(reduced, le.xx_g0, le.d.cin, le.d.cout, P + le.d.w_off, le.cA, le.cB, le.cC, G + le.d.w_off, xs));
-            if (overlap) { AMS_CHECK_HIP(hipEventRecord(s->ev_xt, s->side)); xt_pending = true; }
+            if (overlap) { AMS_CHECK_HIP(hipEventRecord(s->ev_xt, last_wst)); xt_pending = true; }
             --i;                                       // the expand layer is done
             continue;
         }
         if (i == 2 && stem_fused_train(s)) {
+            RUN(flush_wgrads());                      // the last weight gradients start under the stem kernels, not behind them
             // first block: the stem is the "expand" layer of this depthwise conv (a 1x1 conv over the 27-tap patch of the frame).  One pass
             // over dz and the frames gives the stem's BN-backward sums, the depthwise weight gradient and the pieces of the stem weight
             // gradient; da / dz of the stem, its im2col matrix and a_stem are never read or written in backward
@@ -296,22 +324,24 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             fused_buf = l.dw_rows ? l.dw_rows : s->scratch;
             continue;
         }
-        hipStream_t wst = st;
-        float* wscratch = s->scratch;
-        if (overlap) {
-            const bool on2 = three && l.d.role == AMS_ROLE_DEPTHWISE;
-            wst = on2 ? s->side2 : s->side;
-            wscratch = on2 ? s->scratch3 : s->scratch2;
-            AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
-            AMS_CHECK_HIP(hipStreamWaitEvent(wst, s->ev_fork, 0));
-        }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
+            hipStream_t wst = st;
+            float* wscratch = s->scratch;
+            if (overlap) {
+                wst = three ? s->side2 : s->side;
+                wscratch = three ? s->scratch3 : s->scratch2;
+                AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
+                AMS_CHECK_HIP(hipStreamWaitEvent(wst, s->ev_fork, 0));
+            }
             if (overlap) RUN(launch_depthwise_wgrad(prev.a, dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off, wscratch, s->scratch_floats, wst));
             else RUNK(i, dw_bytes(l, B), launch_depthwise_wgrad(prev.a, dz, B, l.Hin, l.Win, l.d.cin, l.d.stride, l.d.rate, G + l.d.w_off,
                                                                 wscratch, s->scratch_floats, wst));
         } else {
-            RUN(pw_wgrad(s, prev.a, l.d.cin, l.d.cin, dz, l.d.cout, l.d.cout, Mo, G + l.d.w_off, wst, wscratch,
-                         (l.d.role == AMS_ROLE_PROJECT && operand_bn_act(s, i - 1)) ? &prev : nullptr));
+            const LayerRt* xa = (l.d.role == AMS_ROLE_PROJECT && operand_bn_act(s, i - 1)) ? &prev : nullptr;
+            const float* xop = prev.a;
+            const int cin = l.d.cin, cout = l.d.cout;
+            float* dwp = G + l.d.w_off;
+            RUN(queue_wgrad([=](hipStream_t ws, float* wscr) { return pw_wgrad(s, xop, cin, cin, dz, cout, cout, Mo, dwp, ws, wscr, xa); }));
         }
         if (l.d.role == AMS_ROLE_DEPTHWISE) {
             RUNK(i, dw_bytes(l, B), launch_depthwise_dgrad(dz, B, l.Hin, l.Win, l.d.cin, P + l.d.w_off, l.d.stride, l.d.rate, prev.da, st));
@@ -332,6 +362,7 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
             if (red_rows > 0) { fused_rows = red_rows; fused_stride = 2 * (int64_t)l.d.cin; fused_dw = false; fused_buf = s->scratch; }
         }
     }
+    RUN(flush_wgrads());
     RUN(launch_reduce_batch(deferred, st));
     // the optimizer (and the gradient all-reduce) wait for every weight gradient
     if (xt_pending) AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_xt, 0));

@@ -259,7 +259,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
         const bool fork = s->overlap_head && !s->prof.on;
         hipStream_t ps = st;
         if (fork) {
-            if (!s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+            if (!s->side) RUN(create_side_stream(&s->side));
             if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
             if (!s->ev_head) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
             AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
@@ -414,7 +414,7 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
         // the stem and the first blocks, and that GEMM waits for its event (live_pointwise)
         hipStream_t ts = st;
         if (s->overlap_wgrad && !s->prof.on && s->scratch2) {
-            if (!s->side) AMS_CHECK_HIP(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+            if (!s->side) RUN(create_side_stream(&s->side));
             if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
             if (!s->ev_tp) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_tp, hipEventDisableTiming));
             AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));

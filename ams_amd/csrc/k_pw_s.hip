@@ -180,6 +180,11 @@ static int pw_stream_nt(const PwArgs& a, int force_nt) {
     const int kpad = (a.K + 15) / 16 * 16;
     int nt = n16;
     if (n16 > 6) { const int parts = cdiv(n16, 6); nt = cdiv(n16, parts); }     // column tiles of at most 6 x 16
+    // Short contraction, wide result with the plain epilogue (the early blocks' input-gradient GEMMs of the fine-tune step, K = 16 .. 64 ->
+    // N = 96 .. 192, with the BN-backward reduction in the epilogue): the kernel is a stream over z and y, and the 96-wide tile costs
+    // 236 + 48 registers = ONE wave per SIMD.  48-wide tiles run three waves per SIMD; x is read once per column tile, but x is the small
+    // tensor here.  tools/sweep_red.sh on MI355X: 74 -> 59 us (265224 x 24 -> 96), 55 -> 43 (67080 x 32 -> 192), 103 -> 99, 43 -> 39.
+    if (epi == EPI_PLAIN && a.K <= 64 && n16 > 3) { const int parts = cdiv(n16, 3); nt = cdiv(n16, parts); }
     if (force_nt > 0) nt = force_nt;
     if ((size_t)kpad * (16 * nt + 4) * 4 > 56 * 1024) return 0;
     return nt;

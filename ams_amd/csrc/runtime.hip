@@ -90,9 +90,21 @@ const Knobs& knobs() {
         if (const char* e = getenv("AMS_XWR_FORCE")) { v.xwr_set = true; sscanf(e, "%d,%d,%d,%d,%d", &v.xwr[0], &v.xwr[1], &v.xwr[2], &v.xwr[3], &v.xwr[4]); }
         if (const char* e = getenv("AMS_WG6_SPLITS")) v.wg6_split_cap = atoi(e);
         v.wg6_eight_waves = getenv("AMS_WG6_EIGHT_WAVES") != nullptr;
+        if (const char* e = getenv("AMS_SIDE_CU_MASK")) v.side_cu_mask = (unsigned)strtoul(e, nullptr, 16);
         return v;
     }();
     return k;
+}
+
+int create_side_stream(hipStream_t* out) {
+    if (knobs().side_cu_mask) {
+        uint32_t mask[8];
+        for (int i = 0; i < 8; ++i) mask[i] = knobs().side_cu_mask;
+        AMS_CHECK_HIP(hipExtStreamCreateWithCUMask(out, 8, mask));
+        return AMS_OK;
+    }
+    AMS_CHECK_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return AMS_OK;
 }
 
 }  // namespace ams

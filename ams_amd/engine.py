@@ -27,6 +27,7 @@ _ENV_OPTIONS = {
     "AMS_OVERLAP_HEAD": hip.OPT_OVERLAP_HEAD, "AMS_FUSE_BLOCK": hip.OPT_FUSE_BLOCK, "AMS_FUSE_XDS": hip.OPT_FUSE_EXPAND_DW_STREAM,
     "AMS_OVERLAP_WGRAD": hip.OPT_OVERLAP_WGRAD, "AMS_FUSE_DGRAD_BN": hip.OPT_FUSE_DGRAD_BN, "AMS_FUSE_GEMM_RED": hip.OPT_FUSE_GEMM_RED,
     "AMS_TRAIN_RECOMPUTE": hip.OPT_TRAIN_RECOMPUTE, "AMS_NAN_GRADS": hip.OPT_NAN_GRADS, "AMS_FUSE_OPERAND_BN": hip.OPT_FUSE_OPERAND_BN,
+    "AMS_WGRAD_FORK_EVERY": hip.OPT_WGRAD_FORK_EVERY,
 }
 
 
@@ -225,6 +226,11 @@ class StudentEngine:
         """Fine-tune step: BN + activation of the depthwise layers applied by the project GEMM / project weight gradient on their operand loads
         (default on; the depthwise activation is never written); bit-identical to off = the pass written."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_OPERAND_BN, int(bool(on))), "ams_student_set_option")
+
+    def set_wgrad_fork_every(self, n: int) -> None:
+        """Fine-tune step: weight gradients handed to the side stream ``n`` at a time (default 1: each as soon as its operands exist; larger
+        n = fewer events on the main stream, measured slower on MI355X).  Bit-identical for every n."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_WGRAD_FORK_EVERY, int(n)), "ams_student_set_option")
 
     def set_train_recompute(self, on: bool, fuse_dgrad_bn: Optional[bool] = None, fuse_gemm_red: Optional[int] = None) -> None:
         """Fine-tune step of the early blocks without their 6x-expanded tensors (default on); off = every tensor materialised.

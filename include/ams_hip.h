@@ -213,7 +213,13 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: 1 (default) BN + activation of every depthwise layer that feeds a project layer is applied by the
+enum { AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRAD: weight gradients handed to the side stream n at a time, 1 .. 64
+                                         (default 1 = each as soon as its operands exist).  A hand-over is an event on the main stream (a gap of
+                                         6-8 us in the rocprofv3 timeline), and a weight gradient feeds only the optimizer, so it may start late —
+                                         but measured on MI355X batching is SLOWER: 7.98 / 8.07 / 8.16-8.30 / 8.30 / 8.58 ms per step for n = 1 / 2 /
+                                         4 / 8 / 16 (a weight gradient that runs beside the input-gradient GEMM of the same dz shares its cache
+                                         lines).  Bit-identical for every n. */,
+       AMS_OPT_FUSE_OPERAND_BN = 22 /* fine-tune step: 1 (default) BN + activation of every depthwise layer that feeds a project layer is applied by the
                                         CONSUMERS on their operand loads (project GEMM forward, project weight gradient backward: PwArgs / WgArgs
                                         x_mode 1) with the same IEEE operations in the same order, and the depthwise activation is never written:
                                         bit-identical to 0 = the pass written (bn_act).  The same move for dz = A dy + B + C z of the project and the

@@ -106,3 +106,26 @@ def test_operand_transforms_change_no_bit(H, B, layerwise):
             for k, (x, y) in enumerate(zip(ref, out)):
                 assert np.array_equal(x, y), "fuse_operand_bn=%d changes %s (max diff %g)" % (bits, ("the loss", "the gradients", "the parameters", "the moving statistics")[k],
                                                                                          np.abs(x.astype(np.float64) - y).max())
+
+
+def test_weight_gradient_hand_over_batching_changes_no_bit():
+    """AMS_OPT_WGRAD_FORK_EVERY only moves the moment a weight gradient is handed to the side stream (nothing it reads is overwritten inside
+    the step): loss, gradients, parameters after two steps and moving statistics are BIT-identical for 1 (default), 3 and 64 per hand-over."""
+    H, B = 96, 3
+    W0 = Wt.synthetic_weights(S.build_spec(), 6)
+    fr, lb = synth.SyntheticVideo(H, B, CI, seed=6).clip()
+    ref = None
+    for n in (1, 3, 64):
+        eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
+        eng.load_variables(W0)
+        eng.set_wgrad_fork_every(n)
+        l0 = eng.train_step(fr, lb, 1e-3).cpu().numpy().copy()
+        g = eng.grads.cpu().numpy().copy()
+        eng.train_step(fr, lb, 1e-3)
+        out = (l0, g, eng.params.cpu().numpy().copy(), eng.stats.cpu().numpy().copy())
+        eng.close()
+        if ref is None:
+            ref = out
+        else:
+            for k, (x, y) in enumerate(zip(ref, out)):
+                assert np.array_equal(x, y), "wgrad_fork_every=%d changes %s" % (n, ("the loss", "the gradients", "the parameters", "the moving statistics")[k])

@@ -18,6 +18,10 @@ fr, lb = synth.SyntheticVideo(H, B, CI).clip()
 eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=True)
 eng.load_variables(W0)
 f, l = torch.from_numpy(fr).cuda(), torch.from_numpy(lb).cuda()
+import os
+if os.environ.get("AMS_LOOP_OWN_STREAM"):        # a stream of its own instead of the null stream (a CU-masked side stream is a blocking stream)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.Stream())
 for _ in range(warm):
     eng.train_step(f, l, 1e-3)
 torch.cuda.synchronize()

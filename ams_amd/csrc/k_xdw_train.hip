@@ -442,8 +442,11 @@ __global__ __launch_bounds__(std::is_void<TIn>::value ? 768 : 128) void xdw_trai
 
 // ---- pass 2: dx.  A wave owns tiles and walks the 16-channel chunks: the patch of the next chunk is in flight (registers) while the
 // current one is consumed from LDS.
+// Registers: the stride-1 form with two k chunks (Cin 17 .. 32: blocks 2, 4, 5) took 256 + 48 of them = ONE wave per SIMD for a kernel that waits on
+// its patch loads; the per-channel constants of the fused reduction and the pixels' offsets are re-formed in the epilogue instead of living across
+// the chunk loop, and the bound of two blocks per CU holds the rest under 256 (two waves per SIMD).
 template <int S, int KC>
-__global__ __launch_bounds__(256) void xdw_dx_kernel(XtArgs a) {
+__global__ __launch_bounds__(256, KC == 1 ? 3 : 2) void xdw_dx_kernel(XtArgs a) {
     typedef XtGeo<S> G;
     constexpr int NTO = KC;                              // 16-wide tiles of dx (Cin <= 16 KC)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -461,31 +464,24 @@ __global__ __launch_bounds__(256) void xdw_dx_kernel(XtArgs a) {
     const float lo = a.act_e == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi = a.act_e == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     const int chunks = a.Cexp / 16;
     const bool red = a.red_part != nullptr;              // block-uniform
-    float4 rs1[NTO], rs2[NTO], rmu[NTO], rrs[NTO];
+    float4 rs1[NTO], rs2[NTO];
 #pragma unroll
-    for (int tt = 0; tt < NTO; ++tt) {
-        const int c4 = 16 * tt + 4 * q;
-        const int c4c = c4 < a.Cin ? c4 : 0;
-        rs1[tt] = make_float4(0.f, 0.f, 0.f, 0.f); rs2[tt] = rs1[tt];
-        rmu[tt] = red ? ld4(a.red_mean + c4c) : rs1[tt];
-        rrs[tt] = red ? ld4(a.red_rstd + c4c) : rs1[tt];
-    }
+    for (int tt = 0; tt < NTO; ++tt) { rs1[tt] = make_float4(0.f, 0.f, 0.f, 0.f); rs2[tt] = rs1[tt]; }
     for (int t = blockIdx.x * 4 + wave; t < a.n_tiles; t += gridDim.x * 4) {
         const XtTileCtx tc = xt_tile<S>(a, t);
         float4 x4[4][KC];
-        int64_t xoff[4];
-        bool live[4];
+        const int64_t img_off = (int64_t)tc.b * a.H * a.W * a.Cin;      // wave-uniform; a pixel's offset inside its image fits 32 bits (checked on the host)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             int iy, ix;
-            live[rg] = xt_pixel<S>(a, tc, rg, l15, iy, ix);
-            xoff[rg] = (((int64_t)tc.b * a.H + iy) * a.W + ix) * a.Cin;
+            xt_pixel<S>(a, tc, rg, l15, iy, ix);
+            const float* px = a.x + img_off + (iy * a.W + ix) * a.Cin;
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
                 int koff = 16 * c + 4 * q;
                 const bool ok = koff < a.Cin;
                 if (koff > a.Cin - 4) koff = a.Cin - 4;
-                const float4 v = ld4(a.x + xoff[rg] + koff);
+                const float4 v = ld4(px + koff);
                 x4[rg][c] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             }
         }
@@ -554,19 +550,23 @@ __global__ __launch_bounds__(256) void xdw_dx_kernel(XtArgs a) {
         }
         // epilogue: + the gradient over the skip connection, 16-byte stores (lane: pixel l15, channels 16t + 4q ..)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            if (!live[rg]) continue;
+        for (int tt = 0; tt < NTO; ++tt) {
+            const int c4 = 16 * tt + 4 * q;
+            if (c4 >= a.Cin) continue;
+            float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rsd = mu;
+            if (red) { mu = ld4(a.red_mean + c4); rsd = ld4(a.red_rstd + c4); }
 #pragma unroll
-            for (int tt = 0; tt < NTO; ++tt) {
-                const int c4 = 16 * tt + 4 * q;
-                if (c4 >= a.Cin) continue;
+            for (int rg = 0; rg < 4; ++rg) {
+                int iy, ix;
+                if (!xt_pixel<S>(a, tc, rg, l15, iy, ix)) continue;
+                const int64_t off = img_off + (iy * a.W + ix) * a.Cin + c4;
                 float4 v = make_float4(out[rg][tt][0], out[rg][tt][1], out[rg][tt][2], out[rg][tt][3]);
-                if (a.res) v = add4_pk(v, ld4(a.res + xoff[rg] + c4));
-                st4(a.dx + xoff[rg] + c4, v);
+                if (a.res) v = add4_pk(v, ld4(a.res + off));
+                st4(a.dx + off, v);
                 if (red) {
-                    const float4 zp = ld4(a.red_z + xoff[rg] + c4);
+                    const float4 zp = ld4(a.red_z + off);
                     rs1[tt] = add4_pk(rs1[tt], v);
-                    rs2[tt] = add4_pk(rs2[tt], mul4_pk(mul4_pk(v, sub4_pk(zp, rmu[tt])), rrs[tt]));
+                    rs2[tt] = add4_pk(rs2[tt], mul4_pk(mul4_pk(v, sub4_pk(zp, mu)), rsd));
                 }
             }
         }
@@ -734,6 +734,7 @@ int launch_xdw_bwd_dx(const float* x, int B, int H, int W, int Cin, const float*
                       const float* res, float* dx, hipStream_t st, const float* red_z, const float* red_mean, const float* red_rstd,
                       float* red_part, int* red_rows_out) {
     AMS_REQUIRE(xdw_train_supported(Cin, Cexp, stride, 1), "xdw_bwd_dx: unsupported shape Cin=%d Cexp=%d s=%d", Cin, Cexp, stride);
+    AMS_REQUIRE((int64_t)H * W * (Cexp > Cin ? Cexp : Cin) < 0x7fffffffLL, "xdw_bwd_dx: image too large for 32-bit element offsets");
     XtArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.w_exp = w_exp; a.Cexp = Cexp;

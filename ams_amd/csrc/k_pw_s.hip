@@ -10,7 +10,7 @@ namespace ams {
 // operand fragment before it feeds the matrix pipe (per-k vectors in LDS behind everything else); same unfused multiply / add as
 // bn_act_kernel / bn_bwd_apply_kernel: bit-identical products.
 template <int RM, int NT, int EPI, int XF = 0>
-__global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, int64_t n_groups) {
+__global__ __launch_bounds__(256, (NT <= 3 ? 3 : NT <= 4 ? 2 : 1)) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, int64_t n_groups) {
     constexpr int PITCH = 16 * NT + 4;
     extern __shared__ __attribute__((aligned(16))) float sW[];          // [Kpad][PITCH] then scale[16NT], shift[16NT]
     const int tile_n = blockIdx.y;
@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256) void pw_gemm_f32_s(PwArgs a, int n_tiles_n, in
     float4 a_cur[RM], a_nxt[RM];
     float4 z_cur[XF == 2 ? RM : 1], z_nxt[XF == 2 ? RM : 1];
     fetch(g_first < n_groups ? g_first : n_groups - 1, 0, a_cur, z_cur);
+    // (Requesting the epilogue's z elements one row group ahead — before the stores of the current one, parked in LDS across the MFMA loop —
+    // was built and measured: 61 -> 57 us on the 96-column layer, 90 -> 97 on the 144-column one, nothing on the step.  The kernel tops out at
+    // 4.0 - 4.8 TB/s whatever the tile covers; at the step's sizes the fixed costs of a launch are the rest.)
     f32x4 acc[RM][NT];
     int64_t g = g_first;
     int c = 0;
@@ -151,7 +154,9 @@ static int launch_pw_s_e(const PwArgs& a, hipStream_t st) {
     RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f32_s<RM, NT, EPI, XF>, 256, lds, &per_cu));
     RUN_RC(device_cus(&cus));
     if (knobs().pw_percu > 0) per_cu = knobs().pw_percu;                  // tuning knob AMS_PW_PERCU (tools/bench_kernel.py)
-    if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
+    // (the column tiles are the grid's y dimension: the co-resident blocks are shared between them)
+    const int64_t resident = (int64_t)cus * per_cu / n_tiles_n > 0 ? (int64_t)cus * per_cu / n_tiles_n : 1;
+    if (blocks > resident) blocks = resident;
     static const std::string nm = "pw_gemm_f32_s<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + (XF ? ", " + std::to_string(XF) + ">" : ">");
     note_kernel(nm.c_str());
     PwArgs b = a;

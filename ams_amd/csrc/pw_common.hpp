@@ -116,14 +116,20 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
 #pragma unroll
             for (int t = 0; t < NT; ++t) { acc[r][t][0] += bv[t].x; acc[r][t][1] += bv[t].y; acc[r][t][2] += bv[t].z; acc[r][t][3] += bv[t].w; }
         }
+        // no affine, no activation (every 1x1 product of the fine-tune step: its BN needs the complete statistics first): the tile goes to the
+        // slab as it is — the multiply by 1, add of 0 and the activation switch were ~5 VALU instructions per element of a kernel whose
+        // SIMDs spend a third of their time on VALU work (profiles: tools/pmc_f32s.sh)
+        const bool ident = !a.scale && !a.shift && a.act == AMS_ACT_NONE;          // kernel-uniform
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int c4 = 16 * t + 4 * q;
-            const float4 sc = ld4(sSc + c4), sh = ld4(sSh + c4);
-            float4 v;
-            const float4 bn = muladd4_pk(make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]), sc, sh);   // packed, two roundings
-            v.x = apply_act(bn.x, a.act); v.y = apply_act(bn.y, a.act);
-            v.z = apply_act(bn.z, a.act); v.w = apply_act(bn.w, a.act);
+            float4 v = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+            if (!ident) {
+                const float4 sc = ld4(sSc + c4), sh = ld4(sSh + c4);
+                const float4 bn = muladd4_pk(v, sc, sh);   // packed, two roundings
+                v.x = apply_act(bn.x, a.act); v.y = apply_act(bn.y, a.act);
+                v.z = apply_act(bn.z, a.act); v.w = apply_act(bn.w, a.act);
+            }
             st4(sOut + l15 * OP + c4, v);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -202,6 +208,7 @@ __device__ __forceinline__ void pw_red_rowgroups(const PwArgs& a, f32x4 (&acc)[R
         if (r >= nrg) break;
         int64_t m = m_base + r * 16 + l15;
         const float w = m < a.M ? 1.f : 0.f;               // rows beyond M (tail tiles) add nothing
+        const bool whole = m_base + r * 16 + 16 <= a.M;    // wave-uniform: every row of this group exists (no weighting needed)
         if (m > a.M - 1) m = a.M - 1;
         if (a.red_mode == 2) {
             float4 zv[NT];
@@ -230,7 +237,7 @@ __device__ __forceinline__ void pw_red_rowgroups(const PwArgs& a, f32x4 (&acc)[R
                 d.z = (y.z > lo && y.z < hi) ? acc[r][t][2] : 0.f; d.w = (y.w > lo && y.w < hi) ? acc[r][t][3] : 0.f;
                 acc[r][t][0] = d.x; acc[r][t][1] = d.y; acc[r][t][2] = d.z; acc[r][t][3] = d.w;
                 if (n0 + c4 < a.N) {
-                    const float4 dw = make_float4(d.x * w, d.y * w, d.z * w, d.w * w);
+                    const float4 dw = whole ? d : make_float4(d.x * w, d.y * w, d.z * w, d.w * w);
                     s1[t] = add4_pk(s1[t], dw);
                     s2[t] = add4_pk(s2[t], mul4_pk(mul4_pk(dw, sub4_pk(zv[t], mu)), rs));
                 }
@@ -242,7 +249,7 @@ __device__ __forceinline__ void pw_red_rowgroups(const PwArgs& a, f32x4 (&acc)[R
                 if (n0 + c4 >= a.N) continue;
                 const float4 ctr = ld4(sRedVec + c4);
                 float4 d = sub4_pk(make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]), ctr);
-                d = make_float4(d.x * w, d.y * w, d.z * w, d.w * w);
+                if (!whole) d = make_float4(d.x * w, d.y * w, d.z * w, d.w * w);
                 s1[t] = add4_pk(s1[t], d);
                 s2[t] = add4_pk(s2[t], mul4_pk(d, d));
             }

@@ -16,6 +16,11 @@ P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = [(8 * 257 * 513, 16, 32), (8 * 129 * 257, 24, 96), (8 * 129 * 257, 24, 144), (8 * 65 * 129, 32, 144), (8 * 65 * 129, 32, 192), (8 * 65 * 129, 32, 192),
           (8 * 33 * 65, 64, 192)]
+import os
+if os.environ.get("BENCH_RED_SHAPES"):
+    SHAPES = [tuple(int(v) for v in s.split(",")) for s in os.environ["BENCH_RED_SHAPES"].split(";")]
+if os.environ.get("BENCH_RED_ONLY"):
+    SHAPES = [SHAPES[int(os.environ["BENCH_RED_ONLY"])]]
 for M, K, N in SHAPES:
     x = torch.randn(M, K, device=dev)
     w = torch.randn(N, K, device=dev) / K ** 0.5          # dgrad orientation: w is [N_out_of_forward = K here ...]; trans_w = 1 -> w [N, K]

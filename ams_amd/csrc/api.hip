@@ -46,9 +46,9 @@ int ams_student_create(const ams_student_config* cfg, const ams_layer_desc* laye
     {   // events are free; STREAMS are not: the runtime multiplexes them onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by
         // default), and two streams that land on one queue serialise.  A student therefore owns only the streams it uses: the part
         // streams appear with the first multi-part call (never inside a graph capture: ensure_part_streams).
-        hipError_t e = hipEventCreateWithFlags(&s->ev_fork_dual, hipEventDisableTiming);
-        for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&s->part_done[k], hipEventDisableTiming);
-        if (e != hipSuccess) { set_error("create: events -> %s", hipGetErrorString(e)); delete s; return AMS_E_HIP; }
+        int e = create_sync_event(&s->ev_fork_dual);
+        for (int k = 0; k < 3 && e == AMS_OK; ++k) e = create_sync_event(&s->part_done[k]);
+        if (e != AMS_OK) { delete s; return e; }
     }
     if (s->vec_ones) {
         std::vector<float> ones(1024, 1.0f), zeros(1024, 0.0f);

@@ -75,8 +75,8 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
     const bool overlap = s->overlap_wgrad && !s->prof.on && s->scratch2;
     if (overlap && !s->side) RUN(create_side_stream(&s->side));
     if (overlap && !s->ev_xt) {
-        if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-        AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_xt, hipEventDisableTiming));
+        if (!s->ev_fork) RUN(create_sync_event(&s->ev_fork));
+        RUN(create_sync_event(&s->ev_xt));
     }
     // Weight gradients are queued and handed to the side stream AMS_OPT_WGRAD_FORK_EVERY at a time.  Every hand-over is an event on the main
     // stream (6-8 us gaps in profiles/r04_train_timeline.txt, ~55 a step) and nothing a queued job reads is overwritten inside the step, so a

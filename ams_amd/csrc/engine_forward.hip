@@ -260,8 +260,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
         hipStream_t ps = st;
         if (fork) {
             if (!s->side) RUN(create_side_stream(&s->side));
-            if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-            if (!s->ev_head) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
+            if (!s->ev_fork) RUN(create_sync_event(&s->ev_fork));
+            if (!s->ev_head) RUN(create_sync_event(&s->ev_head));
             AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
             AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
             ps = s->side;
@@ -415,8 +415,8 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
         hipStream_t ts = st;
         if (s->overlap_wgrad && !s->prof.on && s->scratch2) {
             if (!s->side) RUN(create_side_stream(&s->side));
-            if (!s->ev_fork) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-            if (!s->ev_tp) AMS_CHECK_HIP(hipEventCreateWithFlags(&s->ev_tp, hipEventDisableTiming));
+            if (!s->ev_fork) RUN(create_sync_event(&s->ev_fork));
+            if (!s->ev_tp) RUN(create_sync_event(&s->ev_tp));
             AMS_CHECK_HIP(hipEventRecord(s->ev_fork, st));
             AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
             ts = s->side;

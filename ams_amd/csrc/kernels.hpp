@@ -24,10 +24,12 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
     bool wg6_eight_waves = false;                // AMS_WG6_EIGHT_WAVES: the wide tiles of the six-product weight gradient with eight waves, split 4 (k) x 2 (n)
     int wg6_split_cap = 0;                       // AMS_WG6_SPLITS: most pixel splits of the six-product weight gradient (default 32)
+    int event_flags = -1;                        // AMS_EVENT_FLAGS=<hex>: flags of the stream-ordering events (default: hipEventDisableTiming)
     unsigned side_cu_mask = 0;                   // AMS_SIDE_CU_MASK=<hex word>: the fine-tune step's side stream only on the CUs whose bit is set (word repeated over the chip)
 };
 const Knobs& knobs();
 int create_side_stream(hipStream_t* out);        // non-blocking stream for the weight gradients (runtime.hip)
+int create_sync_event(hipEvent_t* out);          // event that orders streams of ONE device (runtime.hip)
 
 // ---- comm.hip : RCCL communicator (resolved at run time) ------------------------------------------------
 int comm_allreduce(ams_comm* c, void* p, size_t n, int dtype, hipStream_t st);

@@ -91,9 +91,20 @@ const Knobs& knobs() {
         if (const char* e = getenv("AMS_WG6_SPLITS")) v.wg6_split_cap = atoi(e);
         v.wg6_eight_waves = getenv("AMS_WG6_EIGHT_WAVES") != nullptr;
         if (const char* e = getenv("AMS_SIDE_CU_MASK")) v.side_cu_mask = (unsigned)strtoul(e, nullptr, 16);
+        if (const char* e = getenv("AMS_EVENT_FLAGS")) v.event_flags = (int)strtoul(e, nullptr, 16);
         return v;
     }();
     return k;
+}
+
+// The events of the engine order streams of one device (fork / join of the weight-gradient stream, of the parts of the two-stream inference
+// plan).  Measured on the fine-tune step (~110 records a step, tools/train_ab.sh with AMS_EVENT_FLAGS): hipEventReleaseToDevice changes nothing
+// (7.48 ms either way); hipEventDisableSystemFence gives 7.48 -> 7.41 ms, but its contract only covers timing events ("do not require ... to
+// synchronize-with the work"), so it is NOT used: plain no-timing events.
+int create_sync_event(hipEvent_t* out) {
+    const unsigned flags = knobs().event_flags >= 0 ? (unsigned)knobs().event_flags : (unsigned)hipEventDisableTiming;
+    AMS_CHECK_HIP(hipEventCreateWithFlags(out, flags));
+    return AMS_OK;
 }
 
 int create_side_stream(hipStream_t* out) {

@@ -332,6 +332,7 @@ int launch_depthwise_dgrad_bn2(const float* dy, const float* zd, const float* cA
 
 size_t depthwise_fwd_bn2_scratch(int B, int H, int W, int C, int rate) {
     if (C % 4 != 0 || C < 4 || (rate != 1 && rate != 2)) return (size_t)-1;
+    if ((int64_t)H * W * C >= 0x7fffffffLL) return (size_t)-1;                 // 32-bit element offsets inside an image: such a map takes the older kernel
     Dg2Args a;
     dg2_plan(B, H, W, C, rate, &a);
     return (size_t)B * rate * rate * a.tiles_y * a.tiles_x * 2 * (size_t)C;

@@ -634,6 +634,7 @@ int xdw_train_blocks(int B, int H, int W, int Cexp) {
 }
 
 size_t xdw_train_scratch(int B, int H, int W, int Cin, int Cexp) {
+    if ((int64_t)H * W * (Cexp > Cin ? Cexp : Cin) >= 0x7fffffffLL) return (size_t)-1;      // the kernels use 32-bit element offsets inside an image: such a map takes the layer-by-layer step
     const int KP = (Cin + 15) / 16 * 16;
     // partial rows + the reduced row
     const int64_t st = xt_part_stride(KP, Cexp) > xt_fwd_stride(KP, Cexp) ? xt_part_stride(KP, Cexp) : xt_fwd_stride(KP, Cexp);

@@ -229,7 +229,8 @@ enum { AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRA
                                   NaN (utils/graph_utils.py:408: sum(w ce) / sum(w)), so the Adam update poisons the masked parameters exactly as
                                   TensorFlow's would; 0 = NaN loss but zero gradients (the weights survive) */,
        AMS_OPT_OVERLAP_WGRAD = 19 /* fine-tune step: 1 (default) weight gradients on a side stream beside the input-gradient chain, 2 depthwise ones on a
-                                     third stream (measured slower), 0 everything on the caller's stream.  Same bits */,
+                                     third stream (measured slower), 3 hand-overs alternate between two side streams (measured slower: 8.14 vs 7.98 ms),
+                                     0 everything on the caller's stream.  Same bits */,
        AMS_OPT_OVERLAP_HEAD = 20 /* frozen inference: 1 = the image-pooling branch on a side stream beside the aspp0 GEMM; 0 (default): measured slower */,
        AMS_OPT_STREAM_MIN_ROWS = 21 /* frozen inference: rows (frames x pixels at the block's resolution) from which the streaming expand+depthwise
                                        kernels run (default 16384) */,

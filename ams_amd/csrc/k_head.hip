@@ -421,10 +421,11 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
         if (tb == 0) partT[(((int64_t)b * g.h + i0) * g.w + j) * KMAX + k] = s;
         else if (i0 + 1 < g.h) partB[(((int64_t)b * g.h + i0 + 1) * g.w + j) * KMAX + k] = s;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {                   // the block's pair (no atomics: ce_loss_sum_kernel adds the pairs)
         double ls = 0; int cn = 0;
         for (int i = 0; i < 3; ++i) { ls += s_loss[i]; cn += s_cnt[i]; }
-        if (cn) { atomicAdd(&loss[0], ls * (1.0 / 1048576.0)); atomicAdd(&loss[1], (double)cn); }
+        double* mine = loss + 2 * (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        mine[0] = ls; mine[1] = (double)cn;
     }
 }
 
@@ -456,7 +457,23 @@ bool ce_loss_grad_supported(int w, int W) {
     return (kCeCB + 1) * per_cell + 2 <= 192;
 }
 
-size_t ce_loss_grad_scratch(int B, int h, int w, int K) { return (size_t)2 * B * h * w * (K <= 8 ? 8 : K <= 20 ? 20 : 32); }
+// two gradient planes, then the blocks' (loss, count) pairs as doubles (4 floats per block)
+size_t ce_loss_grad_scratch(int B, int h, int w, int K) {
+    return (size_t)2 * B * h * w * (K <= 8 ? 8 : K <= 20 ? 20 : 32) + 4 + (size_t)4 * cdiv(w, kCeCB) * h * B;
+}
+
+// loss[0] = sum of the blocks' loss sums, loss[1] = sum of their valid-pixel counts: exact (integer multiples of 2^-20 / integers in f64), so the
+// order does not matter; replaces 2 x 1848 atomicAdd(double) on ONE pair of addresses, which took 60 of the loss kernel's 73 us at 8 frames
+// (device-scope atomics of eight XCDs on one line are serialised at the memory side)
+__global__ __launch_bounds__(256) void ce_loss_sum_kernel(const double* __restrict__ blk, int n, double* __restrict__ loss) {
+    __shared__ double s0[4], s1[4];
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { a += blk[2 * (int64_t)i]; c += blk[2 * (int64_t)i + 1]; }
+    a = wave_sum(a); c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = a; s1[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) { loss[0] = ((s0[0] + s0[1]) + (s0[2] + s0[3])) * (1.0 / 1048576.0); loss[1] = (s1[0] + s1[1]) + (s1[2] + s1[3]); }
+}
 
 // pass 1: loss[0] += CE sum, loss[1] += valid pixels (loss zeroed here), unnormalised gradient planes into scratch
 int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W, const uint8_t* teacher,
@@ -469,15 +486,18 @@ int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const 
     // a block's pixel columns: (CB + 1) source columns' worth
     const int per_cell = w > 1 ? (W - 1 + w - 2) / (w - 1) + 1 : W;
     AMS_REQUIRE((kCeCB + 1) * per_cell + 2 <= 192, "ce_loss_grad: %d output columns per source column do not fit a block", per_cell);
-    AMS_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(double) * 2, st));
     const int KM = K <= 8 ? 8 : K <= 20 ? 20 : 32;
     float* partT = scratch;
     float* partB = scratch + (size_t)B * h * w * KM;
     const dim3 grid(cdiv(w, kCeCB), h, B);
+    const size_t planes = (size_t)2 * B * h * w * KM;
+    double* blk = reinterpret_cast<double*>(scratch + (planes + 3) / 4 * 4);          // 16-byte aligned behind the planes
     note_kernel("ce_loss_grad_kernel");
-    if (KM == 8) hipLaunchKernelGGL(ce_loss_grad_kernel<8>, grid, dim3(192), 0, st, logits, g, ct, teacher, loss, partT, partB);
-    else if (KM == 20) hipLaunchKernelGGL(ce_loss_grad_kernel<20>, grid, dim3(192), 0, st, logits, g, ct, teacher, loss, partT, partB);
-    else hipLaunchKernelGGL(ce_loss_grad_kernel<32>, grid, dim3(192), 0, st, logits, g, ct, teacher, loss, partT, partB);
+    if (KM == 8) hipLaunchKernelGGL(ce_loss_grad_kernel<8>, grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB);
+    else if (KM == 20) hipLaunchKernelGGL(ce_loss_grad_kernel<20>, grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB);
+    else hipLaunchKernelGGL(ce_loss_grad_kernel<32>, grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB);
+    AMS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_loss_sum_kernel, dim3(1), dim3(256), 0, st, blk, (int)(grid.x * grid.y * grid.z), loss);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

@@ -165,12 +165,14 @@ def test_pointwise_wgrad_split(lib, M, K, N):
 
 @pytest.mark.parametrize("M,K,N,split,trans", [(4290, 160, 960, 1, 1), (16421, 960, 160, 1, 0), (17160, 576, 96, 1, 1), (2145, 384, 64, 1, 0),
                                                 (33001, 64, 384, 1, 0), (40003, 24, 144, 0, 1), (33000, 32, 192, 0, 0), (65537, 16, 96, 0, 1),
-                                                (70001, 144, 24, 0, 0)])
+                                                (70001, 144, 24, 0, 0), (200003, 24, 96, 0, 1), (131075, 32, 192, 0, 1)])
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_pointwise_with_fused_column_reduction(lib, M, K, N, split, trans, mode):
     """1x1 GEMMs whose epilogue also reduces (PwArgs::red_mode): forward statistics (mode 1), BN-backward sums with the activation's
     derivative applied to the stored result (mode 2), the same with a residual gradient added first (3 = mode 2 + res) — tiled three-part
-    kernel and streaming exact-f32 kernel, ragged row counts (tail strips, half-height tail blocks), both weight orientations."""
+    kernel and streaming exact-f32 kernel, ragged row counts (tail strips, half-height tail blocks), both weight orientations; the last two
+    shapes are the early blocks' input-gradient GEMMs at row counts where every wave of the streaming kernel's co-resident grid walks several row
+    groups of its 48-wide column tile."""
     import ctypes as C
     rng = np.random.default_rng(M + K + N + mode)
     x = rng.standard_normal((M, K)).astype(np.float32)

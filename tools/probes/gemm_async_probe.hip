@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <utility>
 #include "common.hpp"
 #include "split_bf16.hpp"
 using namespace ams;
@@ -77,34 +78,20 @@ __global__ __launch_bounds__(256, 1) void gemm_async(const float* __restrict__ x
     for (int r = 0; r < RM; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d) issue(d);
-    for (int s = 0; s < n_stages; ++s) {
-        wait_vm<8 * (D - 2)>();
-        if (getenv_dbg & 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (getenv_dbg & 2) __syncthreads();
-        // this wave's loads of stage s have landed (8 per stage, D - 2 younger stages in flight)
-        __builtin_amdgcn_s_barrier();                      // (no fence: __syncthreads() makes hipcc drain every LDS-direct load in flight) ... and everybody's; every wave is also done reading the slot stage s + D - 1 goes into
-        if (dump && s == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int i = tid; i < STAGE / 4; i += 256) dump[i] = reinterpret_cast<const unsigned*>(smem)[i];
-            __syncthreads();
-        }
-        issue(s + D - 1);
+    // Software pipeline (GAP_PIPE): the fragments of stage s + 1 are read from LDS into a second register set while the MFMAs of stage s run;
+    // a slot of the ring is free again as soon as every wave has its fragments in registers.
+    auto read_frags = [&](int s, u32x4 (&xr)[RM][2], u32x4 (&wq)[NT][3]) {
         const unsigned base = lds0 + (unsigned)(s % D) * STAGE;
-        u32x4 xr[RM][2];
 #pragma unroll
         for (int r = 0; r < RM; ++r)
 #pragma unroll
             for (int j = 0; j < 2; ++j) xr[r][j] = lds_read16(base + wave * (RM * 2 * 1024) + (r * 2 + j) * 1024 + lane * 16);
-        u32x4 wq[NT][3];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int p = 0; p < 3; ++p) wq[t][p] = lds_read16(base + X_STAGE + (t * 3 + p) * 1024 + lane * 16);
-        wait_lgkm0();
-        // the reads above are asm outputs hipcc knows nothing about: pin every fragment to a point AFTER the wait, or their uses may be scheduled before it
+    };
+    auto pin = [&](u32x4 (&xr)[RM][2], u32x4 (&wq)[NT][3]) {
 #pragma unroll
         for (int r = 0; r < RM; ++r)
 #pragma unroll
@@ -113,17 +100,13 @@ __global__ __launch_bounds__(256, 1) void gemm_async(const float* __restrict__ x
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(wq[t][p]));
-        if (dump && s == 0 && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
-            unsigned* o = dump + STAGE / 4 + lane * 12;
-            o[0] = xr[0][0].x; o[1] = xr[0][0].y; o[2] = xr[0][0].z; o[3] = xr[0][0].w;
-            o[4] = xr[0][1].x; o[5] = xr[0][1].y; o[6] = xr[0][1].z; o[7] = xr[0][1].w;
-            o[8] = wq[0][0].x; o[9] = wq[0][0].y; o[10] = wq[0][0].z; o[11] = wq[0][0].w;
-        }
+    };
+    auto compute = [&](const u32x4 (&xr)[RM][2], const u32x4 (&wq)[NT][3]) {
         bf16x8 x0[RM], x1[RM], x2[RM];
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
-            const float4 u = make_float4(__builtin_bit_cast(float, xr[r][0].x), __builtin_bit_cast(float, xr[r][0].y), __builtin_bit_cast(float, xr[r][0].z), __builtin_bit_cast(float, xr[r][0].w));
-            const float4 v = make_float4(__builtin_bit_cast(float, xr[r][1].x), __builtin_bit_cast(float, xr[r][1].y), __builtin_bit_cast(float, xr[r][1].z), __builtin_bit_cast(float, xr[r][1].w));
+            const f32x4 uf = __builtin_bit_cast(f32x4, xr[r][0]), vf = __builtin_bit_cast(f32x4, xr[r][1]);
+            const float4 u = make_float4(uf[0], uf[1], uf[2], uf[3]), v = make_float4(vf[0], vf[1], vf[2], vf[3]);
             split8(u, v, x0[r], x1[r], x2[r]);
         }
 #pragma unroll
@@ -133,6 +116,47 @@ __global__ __launch_bounds__(256, 1) void gemm_async(const float* __restrict__ x
             TERM(q2, x0) TERM(q0, x2) TERM(q1, x1) TERM(q1, x0) TERM(q0, x1) TERM(q0, x0)
 #undef TERM
         }
+    };
+    if (getenv_dbg & 8) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d);
+        u32x4 xa[RM][2], wa[NT][3], xb[RM][2], wb[NT][3];
+        wait_vm<8 * (D - 1)>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, xa, wa);
+        wait_lgkm0();
+        pin(xa, wa);
+        for (int s = 0; s < n_stages; s += 2) {
+            // even stage: compute on (xa, wa), fetch stage s + 1 into (xb, wb)
+            wait_vm<8 * (D - 2)>();
+            __builtin_amdgcn_s_barrier();
+            issue(s + D);
+            read_frags(s + 1, xb, wb);
+            compute(xa, wa);
+            wait_lgkm0();
+            pin(xb, wb);
+            if (s + 1 >= n_stages) break;
+            wait_vm<8 * (D - 2)>();
+            __builtin_amdgcn_s_barrier();
+            issue(s + 1 + D);
+            read_frags(s + 2, xa, wa);
+            compute(xb, wb);
+            wait_lgkm0();
+            pin(xa, wa);
+        }
+    } else {
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) issue(d);
+    for (int s = 0; s < n_stages; ++s) {
+        wait_vm<8 * (D - 2)>();
+        __builtin_amdgcn_s_barrier();                      // (no fence: __syncthreads() makes hipcc drain every LDS-direct load in flight)
+        issue(s + D - 1);
+        u32x4 xr[RM][2], wq[NT][3];
+        read_frags(s, xr, wq);
+        wait_lgkm0();
+        pin(xr, wq);
+        compute(xr, wq);
+    }
     }
     if (dump && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0) {
         unsigned* o = dump + STAGE / 4 + 64 * 12 + lane * 4;
@@ -254,6 +278,29 @@ int main(int argc, char** argv) {
         {
             std::vector<float> hy2((size_t)M * N);
             (void)hipMemcpy(hy2.data(), dy, hy2.size() * 4, hipMemcpyDeviceToHost);
+            if (K == 32 && !getenv("GAP_PAT")) {
+                // which k contribute?  least squares for c_k in y = sum_k c_k x[m][k] w[k][n]
+                std::vector<double> A(32 * 32, 0.0), b(32, 0.0);
+                for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+                    double f[32];
+                    for (int k = 0; k < 32; ++k) f[k] = (double)hx[(size_t)m * K + k] * hw[(size_t)k * N + n];
+                    for (int i = 0; i < 32; ++i) { b[i] += f[i] * hy2[(size_t)m * N + n]; for (int j = 0; j < 32; ++j) A[i * 32 + j] += f[i] * f[j]; }
+                }
+                // Gaussian elimination
+                for (int i = 0; i < 32; ++i) {
+                    int piv = i; for (int r2 = i + 1; r2 < 32; ++r2) if (fabs(A[r2 * 32 + i]) > fabs(A[piv * 32 + i])) piv = r2;
+                    for (int j = 0; j < 32; ++j) std::swap(A[i * 32 + j], A[piv * 32 + j]); std::swap(b[i], b[piv]);
+                    for (int r2 = i + 1; r2 < 32; ++r2) { const double fct = A[r2 * 32 + i] / A[i * 32 + i]; for (int j = i; j < 32; ++j) A[r2 * 32 + j] -= fct * A[i * 32 + j]; b[r2] -= fct * b[i]; }
+                }
+                double c[32];
+                for (int i = 31; i >= 0; --i) { double s2 = b[i]; for (int j = i + 1; j < 32; ++j) s2 -= A[i * 32 + j] * c[j]; c[i] = s2 / A[i * 32 + i]; }
+                printf("  coefficient of each k in the result:");
+                for (int k = 0; k < 32; ++k) printf(" %.2f", c[k]);
+                printf("\n");
+            }
+            int nz = 0;
+            for (size_t i = 0; i < hy2.size(); ++i) if (hy2[i] != 0.f) { if (nz < 6) printf("  nonzero y[%zu][%zu] = %g\n", i / N, i % N, hy2[i]); ++nz; }
+            printf("  %d nonzero of %zu\n", nz, hy2.size());
             printf("  after the dump launch: y[0][0..3] = %g %g %g %g, y[1][0] = %g, y[17][5] = %g (want %g)\n", hy2[0], hy2[1], hy2[2], hy2[3], hy2[N], hy2[17 * N + 5],
                    (double)hx[17 * K + 5] * hw[5 * N + 5]);
         }

@@ -136,6 +136,9 @@ int ams_student_freeze(ams_student* s, void* stream) {
         const int K = l.d.cin - l.split_k0;
         RUN(launch_split_weights3(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whi, l.wlo,
                                   l.wlo3, st));
+        if (l.whf)
+            RUN(launch_split_weights_f16(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whf,
+                                         l.whf + (size_t)l.d.cout * l.Kp, st));
     }
     s->frozen_ready = true;
     return AMS_OK;
@@ -207,7 +210,8 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     AMS_REQUIRE(s, "set_option: null student");
     s->dual_choice.clear();                            // any option may change the plans the autotune compared
     if (option == AMS_OPT_MATMUL) {
-        AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16 || value == AMS_MATMUL_SPLIT_BF16_X6 || value == AMS_MATMUL_BF16,
+        AMS_REQUIRE(value == AMS_MATMUL_F32 || value == AMS_MATMUL_SPLIT_BF16 || value == AMS_MATMUL_SPLIT_BF16_X6 || value == AMS_MATMUL_BF16 ||
+                        value == AMS_MATMUL_SPLIT_F16,
                     "set_option: unknown matmul mode %d", value);
         s->matmul_mode = value;
         return AMS_OK;
@@ -392,6 +396,55 @@ int ams_k_pointwise_split3(const float* x, int64_t M, int32_t K, const float* w,
     a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
     if (scale && !shift) { set_error("pointwise_split3: scale without shift"); return AMS_E_INVALID; }
     return launch_pointwise_split3(a, panels, panels + plane, panels + 2 * plane, Kp, st);
+}
+
+int ams_k_pack_h2i(const float* x, int64_t M, int32_t Cn, float* out, void* stream) { return launch_pack_h2i(x, M, Cn, out, (hipStream_t)stream); }
+
+int ams_k_pointwise_split_f16(const float* x, int64_t M, int32_t K, const float* w, int32_t N, const float* scale, const float* shift, int32_t act,
+                              const float* res, float* y, uint16_t* panels, size_t panel_elems, float* x_h2i, uint16_t* y_parts, void* stream) {
+    const int Kp = (K + 31) / 32 * 32;
+    const size_t plane = (size_t)N * Kp;
+    AMS_REQUIRE(panels && panel_elems >= 2 * plane, "pointwise_split_f16: panel scratch too small (need %zu)", 2 * plane);
+    hipStream_t st = (hipStream_t)stream;
+    RUN(launch_split_weights_f16(w, N, 1, K, N, Kp, panels, panels + plane, st));
+    PwArgs a = pw_args(x, M, K, K, w, N, y, N);
+    a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
+    if (scale && !shift) { set_error("pointwise_split_f16: scale without shift"); return AMS_E_INVALID; }
+    if (x_h2i) {                                   // the operand as fp16 pairs, as the streaming expand + depthwise kernels leave it
+        RUN(launch_pack_h2i(x, M, K, x_h2i, st));
+        a.x = x_h2i; a.x_fmt = 1;
+    }
+    if (y_parts) {                                 // the result also as two fp16 part planes [2][M][N] (the next block's operand)
+        AMS_REQUIRE(pointwise_split_writes_parts(a), "pointwise_split_f16: this shape has no vector epilogue to write parts from");
+        a.ysplit = y_parts; a.ysplit_plane = M * (int64_t)N; a.ysplit_np = 2; a.ysplit_fmt = 1;
+    }
+    AMS_REQUIRE(pointwise_f16_applies(a), "pointwise_split_f16: unsupported shape M=%lld K=%d", (long long)M, K);
+    return launch_pointwise_split_f16(a, panels, (int64_t)plane, Kp, st);
+}
+
+int ams_k_expand_dw_stream_f16(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
+                               const float* shift_e, int32_t Cexp, const float* w_dw, int32_t rate, const float* scale_d, const float* shift_d,
+                               float* y, uint16_t* panels, size_t panel_elems, int32_t presplit, int32_t y_h2i, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!expand_dw_stream_supported(Cin, Cexp, 1, rate) || Cin < 64) {
+        set_error("expand_dw_stream_f16: unsupported shape Cin=%d Cexp=%d rate=%d", Cin, Cexp, rate);
+        return AMS_E_INVALID;
+    }
+    const size_t plane = (size_t)Cexp * Cin, xplane = (size_t)B * H * W * Cin;
+    AMS_REQUIRE(panels && panel_elems >= 2 * plane + (presplit ? 2 * xplane : 0), "expand_dw_stream_f16: panel scratch too small (need %zu)",
+                2 * plane + (presplit ? 2 * xplane : 0));
+    RUN(launch_split_weights_f16(w_exp, Cexp, 1, Cin, Cexp, Cin, panels, panels + plane, st));
+    const uint16_t* xp = nullptr;
+    if (presplit) {                                // the operand as two fp16 part planes, as a producing GEMM leaves it (PwArgs::ysplit_fmt 1)
+        uint16_t* xq = panels + 2 * plane;
+        RUN(launch_split_weights_f16(x, 1, Cin, Cin, (int)((int64_t)B * H * W), Cin, xq, xq + xplane, st));
+        xp = xq;
+    }
+    if (presplit == 2)
+        return launch_expand_dw_wreg(xp, (int64_t)xplane, B, H, W, Cin, panels, (int64_t)plane, AMS_NP_F16, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw,
+                                     rate, scale_d, shift_d, AMS_ACT_RELU6, y, st, y_h2i ? 1 : 0);
+    return launch_expand_dw_stream(x, xp, (int64_t)xplane, B, H, W, Cin, nullptr, panels, (int64_t)plane, AMS_NP_F16, scale_e, shift_e, AMS_ACT_RELU6,
+                                   Cexp, w_dw, 1, rate, scale_d, shift_d, AMS_ACT_RELU6, y, st, y_h2i ? 1 : 0);
 }
 
 int ams_ingest_resize_u8(const uint8_t* src, int32_t Hs, int32_t Ws, int32_t Cn, int32_t mode, int32_t swap_rb, uint8_t* dst, int32_t H,

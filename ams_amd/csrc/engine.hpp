@@ -56,6 +56,7 @@ struct LayerRt {
     float* dw_rows = nullptr; size_t dw_rows_floats = 0;
     // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
+    uint16_t* whf = nullptr;               // the same panels as two fp16 parts (hi | lo 2^11), plane = cout * Kp apart (AMS_MATMUL_SPLIT_F16)
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
     float* blk_vecs = nullptr;             // expand layer of a whole-block kernel: [13][cout] table of BN vectors + depthwise taps (freeze)
     double* xx64 = nullptr;                // ... the same sums as doubles (k_xx_stats.hip): the expand layer's BN statistics follow from them

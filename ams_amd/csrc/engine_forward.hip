@@ -46,7 +46,11 @@ int frozen_pointwise(ams_student* s, int layer, PwArgs a, hipStream_t st, bool* 
     const bool parts = split && a.ysplit && pointwise_split_writes_parts(a);
     if (!parts) a.ysplit = nullptr;
     if (wrote_parts) *wrote_parts = parts;
-    if (split && s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6) RUNK(layer, pw_bytes(a), launch_pointwise_split3(a, l.whi, l.wlo, l.wlo3, l.Kp, st));
+    if (split && s->matmul_mode == AMS_MATMUL_SPLIT_F16 && l.whf && pointwise_f16_applies(a))
+        RUNK(layer, pw_bytes(a), launch_pointwise_split_f16(a, l.whf, (int64_t)l.d.cout * l.Kp, l.Kp, st));
+    else if (a.x_fmt != 0) { set_error("frozen_pointwise: layer %d was handed fp16 pairs but does not run the fp16 product", layer); return AMS_E_STATE; }
+    else if (split && s->matmul_mode == AMS_MATMUL_SPLIT_F16) RUNK(layer, pw_bytes(a), launch_pointwise_split3(a, l.whi, l.wlo, l.wlo3, l.Kp, st));
+    else if (split && s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6) RUNK(layer, pw_bytes(a), launch_pointwise_split3(a, l.whi, l.wlo, l.wlo3, l.Kp, st));
     else if (split && s->matmul_mode == AMS_MATMUL_BF16) RUNK(layer, pw_bytes(a), launch_pointwise_split1(a, l.whi, l.Kp, st));
     else if (split) RUNK(layer, pw_bytes(a), launch_pointwise_split(a, l.whi, l.wlo, l.Kp, st));
     else RUNK(layer, pw_bytes(a), launch_pointwise(a, st));
@@ -119,6 +123,7 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
         const float* block_in = cur;
         const float* x = cur;
         int x_i = cur_i;
+        bool d_h2i = false;                    // x (the depthwise result) is stored as fp16 pairs (PwArgs::x_fmt 1)
         if (s->fuse_block && i + 2 <= s->n_backbone && s->L[i].d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
             s->L[i + 2].d.role == AMS_ROLE_PROJECT && (!s->L[i + 2].d.residual_from || s->L[i + 2].d.residual_from == i - 1) &&
             block_fused_supported(s->L[i].d.cin, s->L[i].d.cout, s->L[i + 2].d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate,
@@ -165,19 +170,29 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
             LayerRt& le = s->L[i];
             LayerRt& ld = s->L[i + 1];
             const int o = other(cur_i, -1);
-            const int np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : s->matmul_mode == AMS_MATMUL_BF16 ? 1 : 2;
+            const bool h16 = s->matmul_mode == AMS_MATMUL_SPLIT_F16 && le.whf;
+            const int np = h16 ? AMS_NP_F16 : s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 || s->matmul_mode == AMS_MATMUL_SPLIT_F16 ? 3 : s->matmul_mode == AMS_MATMUL_BF16 ? 1 : 2;
+            const uint16_t* wparts = h16 ? le.whf : le.whi;
+            const int64_t wplane = h16 ? (int64_t)le.d.cout * le.Kp : (int64_t)(le.wlo - le.whi);
+            // fp16 form: the depthwise result goes to the project GEMM as fp16 pairs (PwArgs::x_fmt 1) when that GEMM will run the fp16 product
+            d_h2i = false;
+            if (h16 && i + 2 <= s->n_backbone && s->L[i + 2].d.role == AMS_ROLE_PROJECT && s->L[i + 2].whf && ld.d.cout % 8 == 0 && !s->emulate_bf16_storage) {
+                const LayerRt& lj = s->L[i + 2];
+                PwArgs pj = pw_args(nullptr, (int64_t)B * lj.px_in, lj.d.cin, lj.d.cin, nullptr, lj.d.cout, nullptr, lj.d.cout);
+                d_h2i = split_pays(pj) && pointwise_f16_applies(pj);
+            }
             const double bytes = 4.0 * ((double)B * (le.px_in * le.d.cin + ld.px_out * ld.d.cout) + (double)le.d.cin * le.d.cout + 9.0 * ld.d.cin);
             const int64_t xplane = (int64_t)B * le.px_in * le.d.cin;
             if (le.d.cin > 96 && cur_parts)
                 // 160 -> 960: expand weights in registers, the operand staged once per block in LDS (k_xdw_wreg.hip); with 30 channel
                 // chunks the LDS-weight form is bound by its passes over the operand
-                RUNK(i + 1, bytes, launch_expand_dw_wreg(cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale,
+                RUNK(i + 1, bytes, launch_expand_dw_wreg(cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, wparts, wplane, np, le.fscale,
                                                          le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
-                                                         s->act[o], st));
+                                                         s->act[o], st, d_h2i ? 1 : 0));
             else
-                RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.whi, (int64_t)(le.wlo - le.whi), np, le.fscale,
+                RUNK(i + 1, bytes, launch_expand_dw_stream(x, cur_parts, xplane, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, wparts, wplane, np, le.fscale,
                                                            le.fshift, le.d.act, le.d.cout, P + ld.d.w_off, ld.d.stride, ld.d.rate, ld.fscale, ld.fshift, ld.d.act,
-                                                           s->act[o], st));
+                                                           s->act[o], st, d_h2i ? 1 : 0));
             x = s->act[o]; x_i = o; i += 2;
             if (s->emulate_bf16_storage && ld.px_out == (int64_t)s->h * s->w)
                 RUN(launch_round_bf16(s->act[o], (int64_t)B * ld.px_out * ld.d.cout, st));          // d as bf16 storage would hold it
@@ -229,11 +244,13 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
             PwArgs a = pw_args(x, (int64_t)B * l.px_in, l.d.cin, l.d.cin, P + l.d.w_off, l.d.cout, s->act[o], l.d.cout);
             a.scale = l.fscale; a.shift = l.fshift; a.act = l.d.act;
             if (l.d.residual_from) { a.res = block_in; a.ldr = l.d.cout; }
+            a.x_fmt = d_h2i ? 1 : 0;
             bool wrote = false;
             if (stream_ok(i + 1) && s->xsplit && (size_t)a.M * a.N <= s->xsplit_plane) {
                 // the next block streams: its expand GEMM takes this result as bf16 parts, written here once instead of being
                 // split by every channel-chunk block there
                 a.ysplit = s->xsplit; a.ysplit_plane = a.M * a.N; a.ysplit_np = s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 ? 3 : s->matmul_mode == AMS_MATMUL_BF16 ? 1 : 2;
+                a.ysplit_fmt = s->matmul_mode == AMS_MATMUL_SPLIT_F16 ? 1 : 0;
             }
             if (s->emulate_bf16_storage && l.px_out == (int64_t)s->h * s->w) a.ysplit = nullptr;      // the parts would be those of the unrounded result
             RUN(frozen_pointwise(s, i, a, st, &wrote));

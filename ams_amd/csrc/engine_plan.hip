@@ -117,6 +117,7 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.whi = cv.take<uint16_t>(3 * plane);          // one allocation: the planes must be equally spaced
             l.wlo = l.whi ? l.whi + plane : nullptr;
             l.wlo3 = l.whi ? l.whi + 2 * plane : nullptr;
+            l.whf = cv.take<uint16_t>(2 * plane);
         }
     }
     if (s->n_backbone >= 3 && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE) {

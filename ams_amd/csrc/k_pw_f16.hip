@@ -1,0 +1,282 @@
+// 1x1 convolutions of frozen inference on TWO fp16 parts per operand (AMS_MATMUL_SPLIT_F16): see split_bf16.hpp for the split and its
+// error bound, k_pw_x3.hip for the three-part bf16 form this replaces on the forward path (6 MFMAs per 32 k, 6 bytes per stored value —
+// here 3 MFMAs and 4 bytes).
+//
+//   x ~ xh + xl 2^-11,  w ~ wh + wl 2^-11      (xh, xl, wh, wl fp16; xl, wl scaled by 2^11 so that they are normal numbers)
+//   x w ~ xh wh + 2^-11 (xh wl + xl wh)         acc += wh xh;  accx += wl xh;  accx += wh xl;   result = acc + accx 2^-11
+//
+// The cross terms have an accumulator of their own (the matrix pipe has no scaled accumulate, and a 2^-11-scaled copy of one part would
+// fall into fp16's subnormals); the two meet in the epilogue with one fma per value.
+//
+// Operand forms (PwArgs::x_fmt):
+//   0  f32 activations [M][ldx], split in registers stage by stage (3 VALU per value);
+//   1  "H2I": the producer already left the activation as fp16 pairs, interleaved per 8 channels — 16 bytes of hi, then 16 bytes of lo,
+//      row pitch 4 C bytes: the SAME bytes per value and the same 32-byte lane pieces as f32 (so the operand path of this kernel, which
+//      is what bounds it, is unchanged), and no split work at all.  The depthwise result of the stride-16 blocks is written this way by
+//      the streaming expand + depthwise kernels (its only reader is this GEMM); round 3 tried the same hand-over with three bf16 planes
+//      and lost to the 6 bytes per value.
+// Weight panels [part][N][Kp] fp16 (hi, lo 2^11), Kp = K rounded up to 32, split once per ams_student_freeze.
+#include <type_traits>
+
+#include "pw_common.hpp"
+#include "split_bf16.hpp"
+
+namespace ams {
+
+__global__ void split_w_f16_kernel(const float* __restrict__ w, int64_t sk, int64_t sn, int K, int N, int Kp, unsigned short* __restrict__ hi,
+                                   unsigned short* __restrict__ lo) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * Kp) return;
+    const int n = (int)(i / Kp), k = (int)(i % Kp);
+    const float v = k < K ? w[k * sk + n * sn] : 0.f;
+    unsigned short h, l;
+    split1_f16(v, h, l);
+    hi[i] = h;
+    lo[i] = l;
+}
+
+int launch_split_weights_f16(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st) {
+    const int64_t n = (int64_t)N * Kp;
+    hipLaunchKernelGGL(split_w_f16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, sk, sn, K, N, Kp, hi, lo);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+// f32 [M][C] -> H2I (tests, and the fallback when a producer that cannot write the form feeds a consumer that wants it); C % 8 == 0
+__global__ void pack_h2i_kernel(const float* __restrict__ x, int64_t n8, u32x4* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const float4 u = ld4(x + 8 * i), v = ld4(x + 8 * i + 4);
+    f16x8 h, l;
+    split8_f16(u, v, h, l);
+    out[2 * i] = __builtin_bit_cast(u32x4, h);
+    out[2 * i + 1] = __builtin_bit_cast(u32x4, l);
+}
+
+int launch_pack_h2i(const float* x, int64_t M, int C, float* out, hipStream_t st) {
+    AMS_REQUIRE(C % 8 == 0 && M > 0, "pack_h2i: C (%d) must be a multiple of 8", C);
+    const int64_t n8 = M * (C / 8);
+    hipLaunchKernelGGL(pack_h2i_kernel, dim3((unsigned)cdiv64(n8, 256)), dim3(256), 0, st, x, n8, reinterpret_cast<u32x4*>(out));
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+__device__ __forceinline__ f32x4 mma_f16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+constexpr int pwh_waves(int rm, int nt) { return rm * nt > 12 ? 1 : rm * nt > 6 ? 2 : 3; }
+
+// Same frame as pw_gemm_bf16x3_l (64 RM x 16 NT tiles, four waves with RM row groups each, weight stages double-buffered in XOR-swizzled
+// 64-byte LDS rows, operand ring of depth 2 in registers, all loads unconditional, half-height tail blocks) with NP = 2 and two
+// accumulators per tile.
+template <int RM, int NT, int EPI, int XP>
+__global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane, int Kp,
+                                                                          int n_tiles_n, unsigned nblocks, unsigned n_full) {
+    constexpr int D = 2, NP = 2;
+    constexpr int PITCH = 32;
+    constexpr int ROWS = 16 * NT;
+    constexpr int NPIECE = NP * ROWS * 4;
+    constexpr int NREG = (NPIECE + 255) / 256;
+    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = (EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4)) * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES > OUT_BYTES ? W_BYTES : OUT_BYTES];
+    typedef unsigned short (*WStage)[NP][ROWS * PITCH];
+    WStage sW = reinterpret_cast<WStage>(smem);
+    float* sOutAll = reinterpret_cast<float*>(smem);
+    __shared__ __attribute__((aligned(16))) float sSc[16 * NT], sSh[16 * NT];
+    const bool half = blockIdx.x >= n_full;
+    const unsigned lb = half ? xcd_remap(blockIdx.x - n_full, nblocks - n_full) : xcd_remap(blockIdx.x, n_full);
+    const int tile_n = lb % n_tiles_n;
+    const int64_t tile_m = lb / n_tiles_n;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int n0 = tile_n * ROWS;
+    const int nrg = half ? RM / 2 : RM;
+    const int64_t m_base = half ? (int64_t)(n_full / n_tiles_n) * (64 * RM) + tile_m * (32 * RM) + wave * (8 * RM)
+                                : tile_m * (64 * RM) + wave * (16 * RM);
+    const int K = a.K, n_stages = Kp / 32;
+    const int n_iter = (n_stages + D - 1) / D * D;
+
+    u32x4 wring[D][NREG];
+    const unsigned short* wsrc[NREG];
+    int wdst[NREG];
+#pragma unroll
+    for (int u = 0; u < NREG; ++u) {
+        const int e = tid + u * 256 < NPIECE ? tid + u * 256 : NPIECE - 1;
+        const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
+        int nn = n0 + n;
+        if (nn > a.N - 1) nn = a.N - 1;
+        wsrc[u] = w0 + which * plane + (int64_t)nn * Kp + part * 8;
+        wdst[u] = which * (ROWS * PITCH) + n * PITCH + (part ^ (((n >> 3) & 1) << 1)) * 8;
+    }
+    auto load_stage = [&](int s, u32x4 (&wreg)[NREG]) {
+        if (s > n_stages - 1) s = n_stages - 1;
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) wreg[u] = *reinterpret_cast<const u32x4*>(wsrc[u] + s * 32);
+    };
+    auto store_stage = [&](int buf, const u32x4 (&wreg)[NREG]) {
+        unsigned short* base = &sW[buf][0][0];
+#pragma unroll
+        for (int u = 0; u < NREG; ++u) *reinterpret_cast<u32x4*>(base + wdst[u]) = wreg[u];
+    };
+    // a row of the operand is K floats (f32) or K fp16 pairs (H2I): 4 K bytes either way, and the lane's 8 k of a stage are the 32 bytes
+    // at float offset 32 s + 8 q in both — 2 x float4 (f32: k .. k+3 | k+4 .. k+7; H2I: hi of the 8 k | lo of the 8 k)
+    const float* arow[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        int64_t m = m_base + (r < nrg ? r : nrg - 1) * 16 + l15;
+        if (m > a.M - 1) m = a.M - 1;
+        arow[r] = a.x + m * (int64_t)a.ldx;
+    }
+    float4 abuf[D][RM][2];
+    auto load_a = [&](int s, float4 (&dst)[RM][2], auto Rc) {
+        constexpr int R = decltype(Rc)::value;
+        int koff = s * 32 + 8 * q;
+        if (koff > K - 8) koff = K - 8;                 // k >= K repeats the last 8 k of the row: the weight panels are zero there
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            dst[r][0] = ld4(arow[r] + koff);
+            dst[r][1] = ld4(arow[r] + koff + 4);
+        }
+    };
+    typedef std::integral_constant<int, RM> RFull;
+    typedef std::integral_constant<int, (RM >= 2 ? RM / 2 : RM)> RHalf;
+    load_stage(0, wring[0]);
+    load_a(0, abuf[0], RFull{});
+    f32x4 acc[RM][NT], accx[RM][NT];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    pw_stage_affine<NT>(a, sSc, sSh, n0, tid, 256);
+    store_stage(0, wring[0]);
+    __syncthreads();
+    auto main_loop = [&](auto Rc) {
+        constexpr int R = decltype(Rc)::value;
+        for (int s0 = 0; s0 < n_iter; s0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int s = s0 + d;
+                load_stage(s + 1, wring[(d + 1) % D]);
+                load_a(s + 1, abuf[(d + 1) % D], Rc);
+                if (s < n_stages) {
+                    u32x4 xh[RM], xl[RM];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if constexpr (XP) {
+                            xh[r] = __builtin_bit_cast(u32x4, abuf[d][r][0]);
+                            xl[r] = __builtin_bit_cast(u32x4, abuf[d][r][1]);
+                        } else {
+                            f16x8 h, l;
+                            split8_f16(abuf[d][r][0], abuf[d][r][1], h, l);
+                            xh[r] = __builtin_bit_cast(u32x4, h);
+                            xl[r] = __builtin_bit_cast(u32x4, l);
+                        }
+                    }
+                    const unsigned short* bw = &sW[d & 1][0][l15 * PITCH + 8 * (q ^ ((l15 >> 3) << 1))];
+                    constexpr int TG = (NT >= 2 && RM <= 2) ? 2 : 1;
+#pragma unroll
+                    for (int t0 = 0; t0 < NT; t0 += TG) {
+                        u32x4 qh[TG], ql[TG];
+#pragma unroll
+                        for (int g = 0; g < TG; ++g) {
+                            if (t0 + g >= NT) continue;
+                            qh[g] = *reinterpret_cast<const u32x4*>(bw + (t0 + g) * 16 * PITCH);
+                            ql[g] = *reinterpret_cast<const u32x4*>(bw + (ROWS * PITCH) + (t0 + g) * 16 * PITCH);
+                        }
+                        // fixed order per accumulator pair: cross terms (wl xh, then wh xl), then the main term
+#pragma unroll
+                        for (int g = 0; g < TG; ++g)
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                if (t0 + g < NT) accx[r][t0 + g] = mma_f16(ql[g], xh[r], accx[r][t0 + g]);
+#pragma unroll
+                        for (int g = 0; g < TG; ++g)
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                if (t0 + g < NT) accx[r][t0 + g] = mma_f16(qh[g], xl[r], accx[r][t0 + g]);
+#pragma unroll
+                        for (int g = 0; g < TG; ++g)
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                if (t0 + g < NT) acc[r][t0 + g] = mma_f16(qh[g], xh[r], acc[r][t0 + g]);
+                    }
+                }
+                store_stage((d + 1) & 1, wring[(d + 1) % D]);
+                __syncthreads();
+            }
+        }
+    };
+    if (RM >= 2 && half) main_loop(RHalf{});
+    else main_loop(RFull{});
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[r][t] = combine_f16(acc[r][t], accx[r][t]);
+    if (EPI == EPI_GENERIC) pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q, sSc, sSh, nrg);
+    else pw_epilogue_t<RM, NT, EPI, true>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)), nrg);
+}
+
+template <int RM, int NT, int EPI, int XP>
+static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
+    const int n_tiles_n = cdiv(a.N, 16 * NT);
+    int per_cu = 1, cus = 256;
+    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP>, 256, 0, &per_cu));
+    RUN_RC(device_cus(&cus));
+    int64_t half_strips = 0;
+    const int64_t full_strips = pw_plan_tail(a.M, RM, n_tiles_n, per_cu * cus, &half_strips);
+    const int64_t n_full = full_strips * n_tiles_n;
+    const int64_t nblocks = n_full + half_strips * n_tiles_n;
+    static const std::string nm = "pw_gemm_f16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(XP) + ">";
+    note_kernel(nm.c_str());
+    hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP>), dim3((unsigned)nblocks), dim3(256), 0, st, a, w, plane, Kp, n_tiles_n, (unsigned)nblocks,
+                       (unsigned)n_full);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
+template <int RM, int NT>
+static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
+    const int epi = pw_pick_epi(a);
+    if (a.x_fmt == 1) {
+        switch (epi) {
+            case EPI_PLAIN: return launch_pw_f16_d<RM, NT, EPI_PLAIN, 1>(a, w, plane, Kp, st);
+            case EPI_RES: return launch_pw_f16_d<RM, NT, EPI_RES, 1>(a, w, plane, Kp, st);
+            case EPI_BIAS: return launch_pw_f16_d<RM, NT, EPI_BIAS, 1>(a, w, plane, Kp, st);
+            default: return launch_pw_f16_d<RM, NT, EPI_GENERIC, 1>(a, w, plane, Kp, st);
+        }
+    }
+    switch (epi) {
+        case EPI_PLAIN: return launch_pw_f16_d<RM, NT, EPI_PLAIN, 0>(a, w, plane, Kp, st);
+        case EPI_RES: return launch_pw_f16_d<RM, NT, EPI_RES, 0>(a, w, plane, Kp, st);
+        case EPI_BIAS: return launch_pw_f16_d<RM, NT, EPI_BIAS, 0>(a, w, plane, Kp, st);
+        default: return launch_pw_f16_d<RM, NT, EPI_GENERIC, 0>(a, w, plane, Kp, st);
+    }
+}
+
+// the two-fp16-part product can take this problem (frozen inference: no fused reduction, no operand transform)
+bool pointwise_f16_applies(const PwArgs& a) {
+    return a.M > 0 && a.K >= 32 && a.K % 8 == 0 && a.ldx % 4 == 0 && a.Kw == a.K && a.red_mode == 0 && a.x_mode == 0 && (a.x_fmt == 0 || a.ldx == a.K);
+}
+
+// y = epilogue(x @ w), w as fp16 panels [part][N][Kp] (hi at whi, lo 2^11 at whi + plane)
+int launch_pointwise_split_f16(const PwArgs& a, const uint16_t* whi, int64_t plane, int Kp, hipStream_t st) {
+    AMS_REQUIRE(pointwise_f16_applies(a) && Kp % 32 == 0 && Kp >= a.K, "pointwise_split_f16: bad problem (M %lld K %d ldx %d)", (long long)a.M, a.K, a.ldx);
+    int rm, nt;
+    pw_pick_tile(a.M, a.N, &rm, &nt);
+    if (rm == 2) {
+        if (a.N == 96 || a.N == 960) nt = 6;
+        else if (a.N == 320) nt = 5;
+    }
+    if (a.M <= 2400 && rm == 1 && a.N % 32 == 0 && a.N >= 64) nt = 2;          // one frame per call: as launch_pointwise_parts
+    if (knobs().pwx_rm > 0) { rm = knobs().pwx_rm; nt = knobs().pwx_nt; }
+#define PW_H(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_f16<RM_, NT_>(a, whi, plane, Kp, st);
+    PW_H(2, 6) PW_H(2, 5) PW_H(2, 4) PW_H(2, 3) PW_H(2, 2) PW_H(2, 1)
+    PW_H(1, 6) PW_H(1, 5) PW_H(1, 4) PW_H(1, 3) PW_H(1, 2) PW_H(1, 1)
+    PW_H(2, 8) PW_H(2, 10) PW_H(4, 4) PW_H(4, 3)
+#undef PW_H
+    set_error("pointwise_split_f16: no tile configuration");
+    return AMS_E_INVALID;
+}
+
+}  // namespace ams

@@ -322,34 +322,6 @@ struct SplitPanels { const uint16_t* base; int64_t plane; int np; };     // part
 // weight fragments straight from the panels (0.722 ms: 64-byte row pieces from panels that are not L2-resident between frames cost more
 // latency than two stages of prefetch cover, and deeper rings do not fit the registers).
 
-// Tail plan.  A launch of equal tiles whose block count is 1.05x or 2.1x the number of resident blocks ends with a round that
-// leaves most of the chip idle (68640 rows x 320 columns at two blocks per CU: 1074 blocks on 512 slots).  The launcher may give
-// the first k * slots blocks the full height and the remaining rows to half-height blocks (32 * RM rows, half the accumulators in
-// use).  Cost model from measurements on MI355X (68640 x 960 -> 160 and -> 320, tools/probes/README.md): a round that fills the
-// fraction f of the slots costs 0.35 + 0.65 f of a full one (a lone block per CU is bound by its own load -> split -> MFMA ->
-// barrier chain, not by throughput), and a half-height round 0.79 of the full-height round with the same f.  Returns the number
-// of full-height strips; the half-height strips that follow through *half_strips_out.
-static int64_t pw_plan_tail(int64_t M, int rm, int n_tiles_n, int slots, int64_t* half_strips_out) {
-    const int64_t rows_full = 64 * rm, rows_half = 32 * rm;
-    const int64_t full_all = cdiv64(M, rows_full);
-    *half_strips_out = 0;
-    if (rm < 2 || slots <= 0 || knobs().pwx_no_tail) return full_all;
-    const int64_t spr = slots / n_tiles_n > 0 ? slots / n_tiles_n : 1;          // strips per round
-    auto rounds = [&](int64_t strips) {
-        const int64_t whole = strips / spr, rest = strips % spr;
-        return (double)whole + (rest ? 0.35 + 0.65 * (double)rest / (double)spr : 0.0);
-    };
-    double best = rounds(full_all);
-    int64_t best_full = full_all;
-    for (int64_t k = 0; k * spr < full_all; ++k) {
-        const int64_t full = k * spr;
-        const int64_t halves = cdiv64(M - full * rows_full, rows_half);
-        const double cost = (double)k + 0.79 * rounds(halves);
-        if (cost < best - 1e-9) { best = cost; best_full = full; *half_strips_out = halves; }
-    }
-    return best_full;
-}
-
 template <int RM, int NT, int EPI, int D, int NP, int XF = 0>
 static int launch_pw_x3_d(const PwArgs& a, const SplitPanels& w, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);

@@ -57,6 +57,7 @@ struct XdsArgs {
     int chunks;                      // Cexp / (16 * NT)
     int items;                       // B * rate^2 * nsy * nsx work items per chunk
     int groups;                      // blocks per chunk; block g walks items g, g + groups, ...
+    int y_fmt;                       // 0: y as f32; 1 (H16 only): y as fp16 pairs interleaved per 8 channels ("H2I", PwArgs::x_fmt) — same bytes
 };
 
 // Roles: waves [0, NWE) run the E-steps (operand loads, split, MFMAs, BN + ReLU6 into the ring), waves [NWE, NWE + NWD) the
@@ -65,8 +66,11 @@ struct XdsArgs {
 // F32 (Cin <= 32: the early blocks): exact-f32 products on v_mfma_f32_16x16x4_f32, KS = number of 16-k chunks, k order of
 // pw_gemm_f32_s / expand_dw_kernel (bit-identical to them); the contraction is so short that the f32 matrix pipe costs no more
 // than six bf16 MFMAs plus the split.  Otherwise KS = 32-k stages of the split-bf16 product.
-template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32, int S = 1>
+// H16: parts are the two fp16 parts of split_bf16.hpp (NP = 2): three MFMAs per 32 k with the cross terms in an accumulator of their own,
+// products and order of pw_gemm_f16x3_l.
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32, int S = 1, bool H16 = false>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a, unsigned nblocks) {
+    static_assert(!H16 || (NP == 2 && !F32 && S == 1), "the fp16 form: two parts, stride 1");
     constexpr int NC = 16 * NT;                      // expanded channels per block
     constexpr int CG = NC / 4;                       // channel groups (float4) of the D-step
     constexpr int STEP = 16 * NWE;                   // pixels per step
@@ -168,9 +172,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
             }
             for (int t = 0; t < a.T; ++t) {
                 const bool inside = in_next;
-                f32x4 acc[NT];
+                f32x4 acc[NT], accx[H16 ? NT : 1];
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tt = 0; tt < (H16 ? NT : 1); ++tt) accx[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 e_row += qS; e_col += rS;
                 if (e_col >= Wp) { e_col -= Wp; ++e_row; }
                 const int64_t pn = next_pixel();                      // pixel of step t + 1
@@ -194,6 +200,10 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                             x0 = __builtin_bit_cast(bf16x8, rawp[s][0]);
                             if (NP >= 2) x1 = __builtin_bit_cast(bf16x8, rawp[s][NP >= 2 ? 1 : 0]);
                             if (NP == 3) x2 = __builtin_bit_cast(bf16x8, rawp[s][NP - 1]);
+                        } else if constexpr (H16) {
+                            f16x8 h, l;
+                            split8_f16(raw[s][0], raw[s][1], h, l);
+                            x0 = __builtin_bit_cast(bf16x8, h); x1 = __builtin_bit_cast(bf16x8, l);
                         } else {
                             if (NP == 3) split8(raw[s][0], raw[s][1], x0, x1, x2);
                             else if (NP == 2) split8(raw[s][0], raw[s][1], x0, x1);
@@ -208,6 +218,14 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                             if (NP >= 2) q1[tt] = *reinterpret_cast<const bf16x8*>(bw + KS * 4 * NC + 16 * tt);
                             if (NP == 3) q2[tt] = *reinterpret_cast<const bf16x8*>(bw + 2 * KS * 4 * NC + 16 * tt);
                         }
+                        if constexpr (H16) {                              // cross terms (wl xh, wh xl), then the main term
+    #pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, q1[tt]), __builtin_bit_cast(f16x8, x0), accx[tt], 0, 0, 0);
+    #pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) accx[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, q0[tt]), __builtin_bit_cast(f16x8, x1), accx[tt], 0, 0, 0);
+    #pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, q0[tt]), __builtin_bit_cast(f16x8, x0), acc[tt], 0, 0, 0);
+                        } else {
                         if (NP == 3) {                                    // smallest terms first
     #pragma unroll
                             for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q2[tt], x0, acc[tt], 0, 0, 0);
@@ -224,6 +242,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                         }
     #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0[tt], x0, acc[tt], 0, 0, 0);
+                        }
                     }
                 }
                 {
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                         // depthwise conv, halo outside the sub-image)
                         const float lo = inside ? (a.act_e == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f) : 0.f;
                         const float hi = inside ? (a.act_e == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf()) : 0.f;
+                        if constexpr (H16) acc[tt] = combine_f16(acc[tt], accx[H16 ? tt : 0]);
                         const float4 bn = muladd4_pk(make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]), sc, sh);
                         v.x = __builtin_amdgcn_fmed3f(bn.x, lo, hi); v.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
                         v.z = __builtin_amdgcn_fmed3f(bn.z, lo, hi); v.w = __builtin_amdgcn_fmed3f(bn.w, lo, hi);
@@ -261,7 +281,8 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
 #pragma unroll
         for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + nch);
         const float4 dsc = ld4(a.sc_d + nch), dsh = ld4(a.sh_d + nch);
-        const unsigned ych = (unsigned)nch * 4u;
+        // byte offset of the thread's four channels within a pixel: f32, or (y_fmt 1) the hi half of its 8-channel group (k_xdw_wreg.hip)
+        const unsigned ych = a.y_fmt ? (unsigned)(nch >> 3) * 32u + (unsigned)(nch & 7) * 2u : (unsigned)nch * 4u;
         // ring position of this thread's first tap, (first centre - Wp - 1) mod R, carried across items like sbase
         int cb = (2 * R - 2 * Wp - 2 + pt * PX) % R;
         for (int item = group; item < a.items; item += a.groups) {
@@ -367,8 +388,16 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                             if (col >= Wp) { col -= Wp; ++row; }
                         const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
                         const unsigned off = ok ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
+                        if (H16 && a.y_fmt) {                        // wave-uniform
+                            unsigned h[2], l[2];
+                            split4_f16(o, h, l);
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){h[0], h[1]}, yrsrc, off, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){l[0], l[1]}, yrsrc, off, 16, 0);
+                        } else {
                         const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
                         __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                        }
                     }
                 }
                 d_row += qS; d_col += rS;
@@ -455,15 +484,15 @@ bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate) {
     return Cexp % 16 == 0 && Cexp >= 32;
 }
 
-template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32 = false, int S = 1>
+template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32 = false, int S = 1, bool H16 = false>
 static int launch_xds_p(XdsArgs a, const XdsPlan& p, hipStream_t st) {
-    RUN_RC(func_allow_lds((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S>, p.lds));
+    RUN_RC(func_allow_lds((const void*)xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S, H16>, p.lds));
     const int64_t nblocks = (int64_t)a.groups * a.chunks;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_stream: bad grid");
     static const std::string nm = "xdw_stream_kernel<" + std::to_string(KS) + ", " + std::to_string(NT) + ", " + std::to_string(NP) + ", " +
-                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ", " + std::to_string((int)F32) + ", " + std::to_string(S) + ">";
+                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ", " + std::to_string((int)F32) + ", " + std::to_string(S) + (H16 ? ", 1>" : ">");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S, H16>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -488,6 +517,13 @@ static int launch_xds_f32(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
     return launch_xds_p<KC, 2, 3, 4, 4, false, true>(a, p, st);
 }
 
+// fp16 form: 4 + 4 waves (what the plan picks unless forced)
+template <int KS>
+static int launch_xds_h16(const XdsArgs& a, const XdsPlan& p, hipStream_t st) {
+    if (p.nt == 4) return a.xs ? launch_xds_p<KS, 4, 2, 4, 4, true, false, 1, true>(a, p, st) : launch_xds_p<KS, 4, 2, 4, 4, false, false, 1, true>(a, p, st);
+    return a.xs ? launch_xds_p<KS, 2, 2, 4, 4, true, false, 1, true>(a, p, st) : launch_xds_p<KS, 2, 2, 4, 4, false, false, 1, true>(a, p, st);
+}
+
 template <int KS>
 static int launch_xds_ks(const XdsArgs& a, const XdsPlan& p, int np, hipStream_t st) {
     if (p.nt == 4) return np == 3 ? launch_xds_w<KS, 4, 3>(a, p, st) : np == 1 ? launch_xds_w<KS, 4, 1>(a, p, st) : launch_xds_w<KS, 4, 2>(a, p, st);
@@ -501,8 +537,11 @@ static int launch_xds_ks(const XdsArgs& a, const XdsPlan& p, int np, hipStream_t
 int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const float* w_f32,
                             const uint16_t* w_parts, int64_t plane, int np,
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int stride, int rate, const float* sc_d,
-                            const float* sh_d, int act_d, float* y, hipStream_t st) {
+                            const float* sh_d, int act_d, float* y, hipStream_t st, int y_fmt) {
     const bool f32 = Cin <= 32;
+    const bool h16 = !f32 && np == AMS_NP_F16;       // two fp16 parts
+    if (h16) np = 2;
+    AMS_REQUIRE(y_fmt == 0 || (h16 && Cexp % 8 == 0 && stride == 1), "expand_dw_stream: the fp16-pair output needs the fp16 form and Cexp %% 8 == 0");
     AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, stride, rate) && (f32 ? w_f32 != nullptr : (w_parts && np >= 1 && np <= 3)),
                 "expand_dw_stream: unsupported shape Cin=%d Cexp=%d rate=%d", Cin, Cexp, rate);
     if (f32) { np = 0; x_parts = nullptr; }
@@ -525,6 +564,15 @@ int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_p
     a.SH = p.SH; a.SW = p.SW; a.Wp = p.SW + 2; a.T = ((p.SH + 2) * a.Wp + step - 1) / step; a.ring = p.ring;
     a.nsy = p.nsy; a.nsx = p.nsx; a.chunks = (Cexp + 16 * p.nt - 1) / (16 * p.nt);
     a.items = B * rate * rate * p.nsy * p.nsx; a.groups = p.groups;
+    a.y_fmt = y_fmt;
+    if (h16) {
+        AMS_REQUIRE(p.nwe == 4 && p.nwd == 4, "expand_dw_stream: the fp16 form runs with 4 + 4 waves");
+        switch (Cin / 32) {
+            case 2: return launch_xds_h16<2>(a, p, st);
+            case 3: return launch_xds_h16<3>(a, p, st);
+            default: return launch_xds_h16<5>(a, p, st);
+        }
+    }
     if (f32) return Cin <= 16 ? launch_xds_f32<1>(a, p, st) : launch_xds_f32<2>(a, p, st);
     switch (Cin / 32) {
         case 2: return launch_xds_ks<2>(a, p, np, st);

@@ -42,10 +42,14 @@ struct XwrArgs {
     int nsy, nsx;
     int cgroups;                     // channel groups of 32 * NWE channels
     int items, groups;               // work items per channel group; blocks per channel group
+    int y_fmt;                       // 0: y as f32; 1 (H16 only): y as fp16 pairs interleaved per 8 channels ("H2I", PwArgs::x_fmt) — same bytes
 };
 
-template <int KS, int NP, int NWE, int NWD, int NRG>
+// H16: the operand and weight parts are the two fp16 parts of split_bf16.hpp (hi | lo 2^11; NP = 2): three MFMAs per 32 k, the cross terms
+// in an accumulator of their own, products and order of pw_gemm_f16x3_l (bit-identical to it followed by the depthwise kernel).
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, unsigned nblocks) {
+    static_assert(!H16 || NP == 2, "the fp16 form has two parts");
     constexpr int STEP = 16 * NRG;                   // pixels per step: NRG MFMA row groups per E-wave (2 * NRG accumulator chains)
     constexpr int NCB = 32 * NWE;                    // channels per block
     constexpr int CG = NCB / 4;                      // channel groups (float4) of the D-step
@@ -155,9 +159,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                     if (e_col[rg] >= Wp) { e_col[rg] -= Wp; ++e_row[rg]; }
                 }
                 load_pieces(loader_pixel());                          // tile of step t + 1: lands during the MFMAs
-                f32x4 acc[NRG][2];
+                f32x4 acc[NRG][2], accx[H16 ? NRG : 1][2];
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg) { acc[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int rg = 0; rg < (H16 ? NRG : 1); ++rg) { accx[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
                 if (active) {
                     const u32x4* ap = sA + par * AUNITS + q * 16 + l15;
                     // the operand fragments of k-step s + 1 are requested before the MFMAs of k-step s: with one E-wave per SIMD nothing
@@ -186,6 +192,15 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
     _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg)                                                               \
         _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                             \
             acc[rg][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[WP][s][tt], XB[rg], acc[rg][tt], 0, 0, 0);
+#define AMS_XWR_TERM_H(ACC, WP, XB)                                                                                   \
+    _Pragma("unroll") for (int rg = 0; rg < NRG; ++rg)                                                               \
+        _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                             \
+            ACC[H16 ? rg : 0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wq[WP][s][tt]), __builtin_bit_cast(f16x8, XB[rg]), ACC[H16 ? rg : 0][tt], 0, 0, 0);
+                        if constexpr (H16) {
+                            AMS_XWR_TERM_H(accx, 1, x0)
+                            AMS_XWR_TERM_H(accx, 0, x1)
+                            AMS_XWR_TERM_H(acc, 0, x0)
+                        } else {
                         if (NP == 3) {
                             AMS_XWR_TERM(NP - 1, x0)
                             AMS_XWR_TERM(0, x2)
@@ -196,7 +211,9 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                             AMS_XWR_TERM(0, x1)
                         }
                         AMS_XWR_TERM(0, x0)
+                        }
 #undef AMS_XWR_TERM
+#undef AMS_XWR_TERM_H
                     }
                 }
 #pragma unroll
@@ -209,6 +226,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         float4 v;
+                        if constexpr (H16) acc[rg][tt] = combine_f16(acc[rg][tt], accx[H16 ? rg : 0][tt]);
                         const float4 bn = muladd4_pk(make_float4(acc[rg][tt][0], acc[rg][tt][1], acc[rg][tt][2], acc[rg][tt][3]), esc[tt], esh[tt]);
                         v.x = __builtin_amdgcn_fmed3f(bn.x, lo, hi);
                         v.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
@@ -238,7 +256,9 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #pragma unroll
         for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + nchc);
         const float4 dsc = ld4(a.sc_d + nchc), dsh = ld4(a.sh_d + nchc);
-        const unsigned ych = (unsigned)nchc * 4u;
+        // byte offset of the thread's four channels within a pixel: f32, or (y_fmt 1) the hi half of its 8-channel group — 32-byte groups of
+        // 16 bytes hi | 16 bytes lo, this thread's 8 bytes of each at (nch % 8) * 2
+        const unsigned ych = a.y_fmt ? (unsigned)(nchc >> 3) * 32u + (unsigned)(nchc & 7) * 2u : (unsigned)nchc * 4u;
         int cb = (2 * R - 2 * Wp - 2 + pt * PX) % R;                 // ring slot of the thread's first tap, carried across items
         for (int item = group; item < a.items; item += a.groups) {
             int u1 = item;
@@ -291,8 +311,16 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                             if (col >= Wp) { col -= Wp; ++row; }
                         const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
                         const unsigned off = ok ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
+                        if (H16 && a.y_fmt) {                        // wave-uniform
+                            unsigned h[2], l[2];
+                            split4_f16(o, h, l);
+                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){h[0], h[1]}, yrsrc, off, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){l[0], l[1]}, yrsrc, off, 16, 0);
+                        } else {
                         const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
                         __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                        }
                     }
                 }
                 d_row += qS; d_col += rS;
@@ -310,33 +338,36 @@ static size_t xwr_lds(int Kp, int np, int nwe, int nrg, int ring) {
     return (size_t)2 * nrg * np * (Kp / 8) * 16 * 16 + (size_t)(ring + 4) * (32 * nwe + 4) * 4;
 }
 
-template <int KS, int NP, int NWE, int NWD, int NRG>
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false>
 static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
-    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG>, lds));
+    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16>, lds));
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");
     static const std::string nm = "xdw_wreg_kernel<" + std::to_string(KS) + ", " + std::to_string(NP) + ", " + std::to_string(NWE) + ", " +
-                                  std::to_string(NWD) + ", " + std::to_string(NRG) + ">";
+                                  std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", 1>" : ">");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
 
-template <int KS, int NP>
+template <int KS, int NP, bool H16 = false>
 static int launch_xwr_w(const XwrArgs& a, int nwe, int nrg, size_t lds, hipStream_t st) {
-    if (nwe == 8) return launch_xwr_k<KS, NP, 8, 4, 1>(a, lds, st);
-    if (nrg == 2) return launch_xwr_k<KS, NP, 4, 4, 2>(a, lds, st);
-    return launch_xwr_k<KS, NP, 4, 4, 1>(a, lds, st);
+    if (nwe == 8) return launch_xwr_k<KS, NP, 8, 4, 1, H16>(a, lds, st);
+    if (nrg == 2) return launch_xwr_k<KS, NP, 4, 4, 2, H16>(a, lds, st);
+    return launch_xwr_k<KS, NP, 4, 4, 1, H16>(a, lds, st);
 }
 
 // the weight-register form; x_parts is required (bf16 parts of the input, np of them).  AMS_XWR_FORCE = "E-waves (4|8),row
 // segments,column strips,blocks per channel group,row groups per E-wave and step (1|2; 2 only with 4 E-waves)" (0 = automatic).
 int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane,
                           int np, const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
-                          const float* sh_d, int act_d, float* y, hipStream_t st) {
+                          const float* sh_d, int act_d, float* y, hipStream_t st, int y_fmt) {
+    const bool h16 = np == AMS_NP_F16;               // two fp16 parts (split_bf16.hpp)
+    if (h16) np = 2;
     AMS_REQUIRE(expand_dw_stream_supported(Cin, Cexp, 1, rate) && Cin >= 64 && np >= 1 && np <= 3 && x_parts, "expand_dw_wreg: unsupported shape Cin=%d Cexp=%d rate=%d",
                 Cin, Cexp, rate);
+    AMS_REQUIRE(y_fmt == 0 || (h16 && Cexp % 8 == 0), "expand_dw_wreg: the fp16-pair output needs the fp16 form and Cexp %% 8 == 0");
     AMS_REQUIRE(B > 0 && H > 0 && W > 0, "expand_dw_wreg: empty input");
     AMS_REQUIRE((int64_t)H * W * Cexp * 4 < 0x7fffffffLL, "expand_dw_wreg: a frame of the output exceeds 2 GiB");
     int nwe = 4, nsy_force = 0, nsx_force = 0, groups_force = 0, nrg = 2;
@@ -367,10 +398,18 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     a.SH = (Hs + nsy - 1) / nsy; a.SW = SW; a.Wp = SW + 2; a.T = ((a.SH + 2) * a.Wp + step - 1) / step; a.ring = ring;
     a.nsy = nsy; a.nsx = nsx; a.cgroups = cgroups;
     a.items = B * rate * rate * nsy * nsx;
+    a.y_fmt = y_fmt;
     int64_t groups = groups_force > 0 ? groups_force : (512 + cgroups - 1) / cgroups;      // one block per CU (LDS), twice over
     if (groups > a.items) groups = a.items;
     a.groups = (int)groups;
     const size_t lds = xwr_lds(Cin, np, nwe, nrg, ring);
+    if (h16) {
+        switch (Cin / 32) {
+            case 2: return launch_xwr_w<2, 2, true>(a, nwe, nrg, lds, st);
+            case 3: return launch_xwr_w<3, 2, true>(a, nwe, nrg, lds, st);
+            default: return launch_xwr_w<5, 2, true>(a, nwe, nrg, lds, st);
+        }
+    }
     switch (Cin / 32) {
         case 2: return np == 3 ? launch_xwr_w<2, 3>(a, nwe, nrg, lds, st) : np == 1 ? launch_xwr_w<2, 1>(a, nwe, nrg, lds, st) : launch_xwr_w<2, 2>(a, nwe, nrg, lds, st);
         case 3: return np == 3 ? launch_xwr_w<3, 3>(a, nwe, nrg, lds, st) : np == 1 ? launch_xwr_w<3, 1>(a, nwe, nrg, lds, st) : launch_xwr_w<3, 2>(a, nwe, nrg, lds, st);

@@ -58,6 +58,10 @@ struct PwArgs {
     uint16_t* ysplit;
     int64_t ysplit_plane;
     int ysplit_np;
+    int ysplit_fmt;        // 0: bf16 parts; 1: two fp16 parts (hi | lo 2^11; ysplit_np = 2), the operand format of the fp16 streaming kernels
+    // operand storage (launch_pointwise_split_f16 only): 0 = f32; 1 = "H2I", fp16 (hi | lo 2^11) pairs interleaved per 8 channels — 16 bytes
+    // of hi, 16 bytes of lo — at the same 4 K bytes per row as f32 (requires ldx == K)
+    int x_fmt;
     // optional column reduction fused into the epilogue (fine-tune step; plain epilogues only: no scale / shift / bias; a residual
     // operand only in mode 2 of the tiled split-bf16 kernel, where it joins the product before the mask and the sums):
     //   red_mode 1  forward BN statistics of y:  sum(y - red_center), sum((y - red_center)^2)
@@ -103,6 +107,11 @@ int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t
 struct SplitJob { const float* w; int64_t sk, sn; int K, N, Kp; uint16_t* p0; int64_t plane; int64_t first_block; };
 int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st);
 int launch_pointwise_split1(const PwArgs& a, const uint16_t* whi, int Kp, hipStream_t st);      // one part: plain bf16 products
+// two fp16 parts (k_pw_f16.hip; AMS_MATMUL_SPLIT_F16): panels [part][N][Kp] fp16, hi at whi, lo 2^11 at whi + plane; 3 MFMAs per 32 k
+int launch_split_weights_f16(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st);
+bool pointwise_f16_applies(const PwArgs& a);
+int launch_pointwise_split_f16(const PwArgs& a, const uint16_t* whi, int64_t plane, int Kp, hipStream_t st);
+int launch_pack_h2i(const float* x, int64_t M, int C, float* out, hipStream_t st);      // f32 [M][C] -> H2I (PwArgs::x_fmt 1)
 bool pointwise_split_writes_parts(const PwArgs& a);      // the split kernels will honour a.ysplit (vector epilogue)
 
 // dw[K,N] = x[M,K]^T @ dy[M,N];  scratch holds the per-split partial products.
@@ -231,18 +240,22 @@ int launch_first_block_tiles(const void* frames, int dtype, int B, int H, int W,
                              const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st, const float* vecs = nullptr);
 int launch_block_pack(const float* sc_e, const float* sh_e, const float* sc_d, const float* sh_d, const float* w_dw, int Cexp, float* out, hipStream_t st);
 
+constexpr int AMS_NP_F16 = 4;   // `np` of the streaming launchers: the two fp16 parts of split_bf16.hpp
 // ---- k_xdw_stream.hip : the same fusion for the stride-16 blocks (Cin 64 / 96 / 160, stride 1, rate 1 | 2): raster-order
 // streaming through an LDS ring, split-bf16 products from the expand layer's bf16 panels (np = 2 | 3 parts, `plane` apart)
 bool expand_dw_stream_supported(int Cin, int Cexp, int stride, int rate);
 int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const float* w_f32,
                             const uint16_t* w_parts, int64_t plane, int np,
                             const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int stride, int rate, const float* sc_d,
-                            const float* sh_d, int act_d, float* y, hipStream_t st);
+                            const float* sh_d, int act_d, float* y, hipStream_t st, int y_fmt = 0);
 
 // ---- k_xdw_wreg.hip : the streaming fusion with the expand weights in registers and the operand staged in LDS (160 -> 960)
 int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H, int W, int Cin, const uint16_t* w_parts, int64_t plane,
                           int np, const float* sc_e, const float* sh_e, int act_e, int Cexp, const float* w_dw, int rate, const float* sc_d,
-                          const float* sh_d, int act_d, float* y, hipStream_t st);
+                          const float* sh_d, int act_d, float* y, hipStream_t st, int y_fmt = 0);
+// np of the two streaming launchers: 1 .. 3 bf16 parts, or AMS_NP_F16 = the two fp16 parts of split_bf16.hpp (hi | lo 2^11; planes as for
+// np = 2).  y_fmt 1 (fp16 form only): the result as fp16 pairs interleaved per 8 channels (PwArgs::x_fmt 1) instead of f32
+
 
 // ---- k_elementwise.hip : BN pieces, pooling, reductions, Adam ------------------------------------------
 // per-image column reductions; scratch >= image_colsum_scratch(B, C) floats

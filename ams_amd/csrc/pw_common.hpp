@@ -5,6 +5,7 @@
 #include <string>
 
 #include "kernels.hpp"
+#include "split_bf16.hpp"
 
 namespace ams {
 
@@ -156,7 +157,14 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
             float4 v = ld4(sOut + row * OP + c4);
             if (EPI == EPI_RES) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
             if (m < a.M && n0 + c4 < a.N) st4(a.y + m * a.ldy + n0 + c4, v);
-            if (SPLIT_OUT && a.ysplit && m < a.M && n0 + c4 < a.N) {
+            if (SPLIT_OUT && a.ysplit && a.ysplit_fmt == 1 && m < a.M && n0 + c4 < a.N) {
+                // two fp16 parts (hi | lo 2^11, split_bf16.hpp): planes [part][M][N]
+                unsigned h[2], l[2];
+                split4_f16(v, h, l);
+                uint16_t* sp = a.ysplit + m * (int64_t)a.N + n0 + c4;
+                *reinterpret_cast<uint2*>(sp) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2*>(sp + a.ysplit_plane) = make_uint2(l[0], l[1]);
+            } else if (SPLIT_OUT && a.ysplit && m < a.M && n0 + c4 < a.N) {
                 const float f[4] = {v.x, v.y, v.z, v.w};
                 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                 bf16x4 p0, p1, p2;
@@ -313,6 +321,34 @@ static inline void pw_pick_tile(int64_t M, int N, int* rm_out, int* nt_out) {
     const int tiles_n = cdiv(N, 16 * nt);
     *rm_out = (cdiv64(M, 128) * tiles_n >= 512) ? 2 : 1;
     *nt_out = nt;
+}
+
+// Tail plan.  A launch of equal tiles whose block count is 1.05x or 2.1x the number of resident blocks ends with a round that
+// leaves most of the chip idle (68640 rows x 320 columns at two blocks per CU: 1074 blocks on 512 slots).  The launcher may give
+// the first k * slots blocks the full height and the remaining rows to half-height blocks (32 * RM rows, half the accumulators in
+// use).  Cost model from measurements on MI355X (68640 x 960 -> 160 and -> 320, tools/probes/README.md): a round that fills the
+// fraction f of the slots costs 0.35 + 0.65 f of a full one (a lone block per CU is bound by its own load -> split -> MFMA ->
+// barrier chain, not by throughput), and a half-height round 0.79 of the full-height round with the same f.  Returns the number
+// of full-height strips; the half-height strips that follow through *half_strips_out.
+static inline int64_t pw_plan_tail(int64_t M, int rm, int n_tiles_n, int slots, int64_t* half_strips_out) {
+    const int64_t rows_full = 64 * rm, rows_half = 32 * rm;
+    const int64_t full_all = cdiv64(M, rows_full);
+    *half_strips_out = 0;
+    if (rm < 2 || slots <= 0 || knobs().pwx_no_tail) return full_all;
+    const int64_t spr = slots / n_tiles_n > 0 ? slots / n_tiles_n : 1;          // strips per round
+    auto rounds = [&](int64_t strips) {
+        const int64_t whole = strips / spr, rest = strips % spr;
+        return (double)whole + (rest ? 0.35 + 0.65 * (double)rest / (double)spr : 0.0);
+    };
+    double best = rounds(full_all);
+    int64_t best_full = full_all;
+    for (int64_t k = 0; k * spr < full_all; ++k) {
+        const int64_t full = k * spr;
+        const int64_t halves = cdiv64(M - full * rows_full, rows_half);
+        const double cost = (double)k + 0.79 * rounds(halves);
+        if (cost < best - 1e-9) { best = cost; best_full = full; *half_strips_out = halves; }
+    }
+    return best_full;
 }
 
 // one 16-k chunk: 4 MFMA k-steps x NT column tiles x RM row groups; sB points at this lane's (k = 4q, n = l15) element

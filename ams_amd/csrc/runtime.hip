@@ -78,8 +78,7 @@ int device_cus(int* cus) {
     return AMS_OK;
 }
 
-const Knobs& knobs() {
-    static const Knobs k = [] {
+static Knobs read_knobs() {
         Knobs v;
         if (const char* e = getenv("AMS_BLK_TILE")) sscanf(e, "%dx%d", &v.blk_th, &v.blk_tw);
         if (const char* e = getenv("AMS_PW_FORCE")) sscanf(e, "%c,%d,%d", &v.pw_force, &v.pw_rm, &v.pw_nt);
@@ -93,9 +92,12 @@ const Knobs& knobs() {
         if (const char* e = getenv("AMS_SIDE_CU_MASK")) v.side_cu_mask = (unsigned)strtoul(e, nullptr, 16);
         if (const char* e = getenv("AMS_EVENT_FLAGS")) v.event_flags = (int)strtoul(e, nullptr, 16);
         return v;
-    }();
+}
+static Knobs& knobs_storage() {
+    static Knobs k = read_knobs();
     return k;
 }
+const Knobs& knobs() { return knobs_storage(); }
 
 // The events of the engine order streams of one device (fork / join of the weight-gradient stream, of the parts of the two-stream inference
 // plan).  Measured on the fine-tune step (~110 records a step, tools/train_ab.sh with AMS_EVENT_FLAGS): hipEventReleaseToDevice changes nothing
@@ -119,6 +121,12 @@ int create_side_stream(hipStream_t* out) {
 }
 
 }  // namespace ams
+
+// tests and tools/ only: read the tuning environment again (the library reads it once, at first use; not thread-safe against running launches)
+extern "C" int ams_debug_reload_knobs(void) {
+    ams::knobs_storage() = ams::read_knobs();
+    return AMS_OK;
+}
 
 extern "C" int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_t lds) {
     return ams::launch_table_needs_attr(device, (const void*)(uintptr_t)kernel_key, lds) ? 1 : 0;

@@ -50,4 +50,49 @@ __device__ __forceinline__ void split8(const float4& u, const float4& v, bf16x8&
     p2 = __builtin_bit_cast(bf16x8, l);
 }
 
+// ---- two fp16 parts, 22 significand bits: x ~ hi + lo * 2^-11 with hi = f16(x), lo = f16((x - hi) * 2^11) ----------------------------
+// (AMS_MATMUL_SPLIT_F16).  hi carries 11 bits; the remainder x - hi is exact in f32 and at most half an ulp of hi, so scaled by 2^11 it
+// is back in hi's binade or below — normal in fp16 whenever hi is — and lo keeps 11 more bits: |x - (hi + lo 2^-11)| <= 2^-22 |x| (worst
+// case; 2^-23.8 rms).  The product of two such operands is formed as  hi*hi  +  2^-11 (hi*lo + lo*hi)  with the cross terms in an
+// accumulator of their own (3 MFMAs, v_mfma_f32_16x16x32_f16; the dropped lo*lo term is <= 2^-22 of the product): per product ~3 2^-22
+// worst case against 2^-24 for the three-part bf16 split (6 MFMAs) — below the f32 accumulation error of a K >= 64 contraction (measured:
+// 512x1024 logits 4e-5 from f64 either way) — at 4 bytes per value instead of 6 where the parts are stored.  Values beyond fp16's range (|x| >= 65520) become inf: the engine uses the
+// form only on layers whose operands are activations and weights of O(1).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+constexpr float kF16LoScale = 2048.f, kF16LoInv = 1.f / 2048.f;
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& h, unsigned& l) {
+    const f32x2s_t f = {a, b};
+    const f16x2_t hh = __builtin_convertvector(f, f16x2_t);                     // v_cvt_pk_f16_f32 (RNE)
+    h = __builtin_bit_cast(unsigned, hh);
+    const f32x2s_t s = f * (f32x2s_t){kF16LoScale, kF16LoScale};
+    const f32x2s_t r = {fmaf((float)hh.x, -kF16LoScale, s.x), fmaf((float)hh.y, -kF16LoScale, s.y)};     // (x - hi) 2^11, exact
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+__device__ __forceinline__ void split8_f16(const float4& u, const float4& v, f16x8& p0, f16x8& p1) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair_f16(u.x, u.y, h0, l0);
+    split_pair_f16(u.z, u.w, h1, l1);
+    split_pair_f16(v.x, v.y, h2, l2);
+    split_pair_f16(v.z, v.w, h3, l3);
+    const u32x4 h = {h0, h1, h2, h3}, l = {l0, l1, l2, l3};
+    p0 = __builtin_bit_cast(f16x8, h);
+    p1 = __builtin_bit_cast(f16x8, l);
+}
+// four values -> (hi, lo) as two dwords each
+__device__ __forceinline__ void split4_f16(const float4& v, unsigned (&h)[2], unsigned (&l)[2]) {
+    split_pair_f16(v.x, v.y, h[0], l[0]);
+    split_pair_f16(v.z, v.w, h[1], l[1]);
+}
+// scalar form (weight panels): bit patterns of (hi, lo)
+__device__ __forceinline__ void split1_f16(float v, unsigned short& h, unsigned short& l) {
+    const _Float16 hh = (_Float16)v;
+    h = __builtin_bit_cast(unsigned short, hh);
+    l = __builtin_bit_cast(unsigned short, (_Float16)fmaf((float)hh, -kF16LoScale, v * kF16LoScale));
+}
+// acc (hi*hi) and accx (cross terms, scaled 2^11) -> the product
+__device__ __forceinline__ f32x4 combine_f16(const f32x4& acc, const f32x4& accx) {
+    return (f32x4){fmaf(accx[0], kF16LoInv, acc[0]), fmaf(accx[1], kF16LoInv, acc[1]), fmaf(accx[2], kF16LoInv, acc[2]), fmaf(accx[3], kF16LoInv, acc[3])};
+}
+
 }  // namespace ams

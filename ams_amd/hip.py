@@ -42,7 +42,7 @@ OPT_OVERLAP_HEAD = 20
 OPT_STREAM_MIN_ROWS = 21
 OPT_FUSE_OPERAND_BN = 22
 OPT_WGRAD_FORK_EVERY = 23
-MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16 = 0, 1, 2, 3
+MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16, MATMUL_SPLIT_F16 = 0, 1, 2, 3, 4
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)
 
@@ -104,6 +104,9 @@ SIGNATURES = {
     "ams_k_pointwise": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "ams_k_pointwise_split": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "ams_k_pointwise_split3": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "ams_k_pack_h2i": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "ams_k_pointwise_split_f16": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "ams_k_expand_dw_stream_f16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _i32, _i32, _vp]),
     "ams_ingest_resize_u8": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "ams_k_dw_project": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ams_k_block_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
@@ -117,6 +120,7 @@ SIGNATURES = {
     "ams_k_ce_loss_grad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ams_k_ce_loss_grad_scratch": (_sz, [_i32, _i32, _i32, _i32]),
     "ams_debug_launch_table_needs_attr": (C.c_int, [_i32, C.c_uint64, _sz]),
+    "ams_debug_reload_knobs": (C.c_int, []),
     "ams_k_pointwise_wgrad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_pointwise_wgrad_scratch": (_sz, [_i64, _i32, _i32]),
     "ams_k_pointwise_wgrad_split": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),

@@ -211,6 +211,7 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *   AMS_MATMUL_SPLIT_BF16_X6 (default) operands split into three bf16 parts (all 24 significand bits), 6 bf16 MFMAs per 32 k,
  *                            f32 accumulate: products at f32 rounding level; 512x1024 logits 4e-5 from the f64 oracle, the
  *                            same as exact f32 and as the f32 CPU oracle (tools/logit_error.py)
+ *   AMS_MATMUL_SPLIT_F16     frozen inference with two fp16 parts / 3 MFMAs, f32-level (see the enum below)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
 enum { AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRAD: weight gradients handed to the side stream n at a time, 1 .. 64
@@ -282,6 +283,14 @@ enum { AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRA
                                             that stride), 2 every supported block (Cin 160 too) */,
        AMS_OPT_MATMUL = 1, AMS_OPT_FUSE_EXPAND_DW = 2 /* 0 never, 1 (default) blocks where the fused kernel is faster, 2 every supported block */ };
 enum { AMS_MATMUL_F32 = 0, AMS_MATMUL_SPLIT_BF16 = 1, AMS_MATMUL_SPLIT_BF16_X6 = 2,
+       AMS_MATMUL_SPLIT_F16 = 4 /* frozen inference: every operand of those layers as TWO fp16 parts, x ~ hi + lo 2^-11 (22 significand bits),
+                                   products hi hi + 2^-11 (hi lo + lo hi) on v_mfma_f32_16x16x32_f16 with the cross terms in an accumulator of
+                                   their own: 3 MFMAs per 32 k instead of 6, and 4 bytes per value where parts are stored instead of 6 — the
+                                   depthwise result of the stride-16 blocks is handed to the project GEMM as ready-made fp16 pairs at the bytes of
+                                   f32.  Per product ~3 2^-22 against 2^-24: below the f32 accumulation error of these contractions (512x1024
+                                   logits 4e-5 from the f64 oracle, as the three-part form).  Operands must lie within fp16's range (|x| < 65504:
+                                   activations and weights of O(1)); the fine-tune step keeps the three-part bf16 form (its gradients span a range
+                                   fp16 cannot hold). */,
        AMS_MATMUL_BF16 = 3 /* opt-in bf16 inference variant (BASELINE.json configs[1] says "bf16"): the same late layers with ONE bf16 part per
                               operand = plain bf16 products, f32 accumulate, 1 MFMA per 32 k.  Storage stays f32 and the early blocks stay
                               exact f32.  NOT within the f32 tolerance: bench.py reports its label-mismatch fraction and mIoU delta against
@@ -370,6 +379,25 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
                            const float* shift_e, int32_t Cexp, const float* w_dw, int32_t rate, const float* scale_d,
                            const float* shift_d, float* y, uint16_t* panels, size_t panel_elems, int32_t parts, int32_t presplit,
                            void* stream);
+
+/* The two-fp16-part forms (AMS_MATMUL_SPLIT_F16; k_pw_f16.hip, split_bf16.hpp): every operand x ~ hi + lo 2^-11 with hi = f16(x),
+ * lo = f16((x - hi) 2^11); products hi hi + 2^-11 (hi lo + lo hi), 3 MFMAs per 32 k, f32 accumulate.
+ * ams_k_pack_h2i: f32 [M][C] (C % 8 == 0) -> "H2I": per 8 channels 16 bytes of hi then 16 bytes of lo, 4 C bytes per row (what the streaming
+ *   kernels write with y_h2i and the GEMM reads with x_h2i).
+ * ams_k_pointwise_split_f16: as ams_k_pointwise_split3 (K4; replaces the Conv2D nodes of model.meta `expanded_conv_N/project`, `aspp0`, ...);
+ *   panels >= 2*N*Kp uint16; x_h2i (optional, M*K floats of scratch): x is first packed into H2I and the GEMM loads its operand from there —
+ *   same result, bit for bit; y_parts (optional, 2*M*N uint16): the result also as two fp16 part planes.
+ * ams_k_expand_dw_stream_f16: as ams_k_expand_dw_stream with the fp16 parts (Cin 64 / 96 / 160); presplit 1 | 2 as there (2 = the
+ *   weight-register form; panels then needs 2*B*H*W*Cin more elements); y_h2i != 0: y is written in H2I instead of f32.  Bit-identical to
+ *   ams_k_pointwise_split_f16 followed by ams_k_depthwise3x3. */
+int ams_k_pack_h2i(const float* x, int64_t M, int32_t C, float* out, void* stream);
+int ams_k_pointwise_split_f16(const float* x, int64_t M, int32_t K, const float* w, int32_t N, const float* scale, const float* shift,
+                              int32_t act, const float* res, float* y, uint16_t* panels, size_t panel_elems, float* x_h2i, uint16_t* y_parts,
+                              void* stream);
+int ams_k_expand_dw_stream_f16(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
+                               const float* shift_e, int32_t Cexp, const float* w_dw, int32_t rate, const float* scale_d,
+                               const float* shift_d, float* y, uint16_t* panels, size_t panel_elems, int32_t presplit, int32_t y_h2i,
+                               void* stream);
 
 /* K3+K4 fused (frozen inference): y = bn_p(relu6(bn_d(dw3x3(e))) @ w_proj) (+ res) — the depthwise output never reaches
  * HBM; the product uses the two-part bf16 split of ams_k_pointwise_split.  e [B,H,W,C] (C % 32 == 0), w_dw [3,3,C,1],
@@ -536,6 +564,12 @@ int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint
  * when (device, kernel_key) has not yet been granted `lds` bytes — i.e. the launcher would call hipFuncSetAttribute now — and
  * records the grant; 0 otherwise.  Two students on two GPUs of one process each get their attributes set. */
 int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_t lds);
+/* Tests and tools/ only.  The tuning knobs (environment variables AMS_BLK_TILE, AMS_PW_FORCE, AMS_PW_PERCU, AMS_PWX_NO_TAIL, AMS_PWX_FORCE,
+ * AMS_XDS_FORCE, AMS_XWR_FORCE, AMS_WG6_SPLITS, AMS_WG6_EIGHT_WAVES: tile / grid overrides of single kernels; AMS_SIDE_CU_MASK=<hex>: the
+ * fine-tune step's side stream confined to the CUs whose bit is set; AMS_EVENT_FLAGS=<hex>: hipEventCreateWithFlags flags of the
+ * stream-ordering events — these two change stream semantics and exist for measurements only) are read ONCE, at first use; this re-reads
+ * them.  Not thread-safe against launches in flight. */
+int ams_debug_reload_knobs(void);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,32 @@ def golden_dir():
     return GOLDEN
 
 
+@pytest.fixture
+def knobs():
+    """Tuning knobs of libams_hip.so are environment variables the library reads ONCE; `knobs(AMS_XDS_FORCE="4,1,1", AMS_PWX_NO_TAIL=None)`
+    sets (or, with None, removes) them and makes the library read them again; the environment and the library's copy are restored afterwards."""
+    from ams_amd import hip
+    saved = {}
+
+    def set_knobs(**kv):
+        for k, v in kv.items():
+            assert k.startswith("AMS_")
+            saved.setdefault(k, os.environ.get(k))
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        hip.check(hip.lib().ams_debug_reload_knobs())
+
+    yield set_knobs
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    hip.check(hip.lib().ams_debug_reload_knobs())
+
+
 def has_gpu():
     try:
         import torch

@@ -620,7 +620,7 @@ def test_whole_block_kernel(lib, H, W, Cin, Cexp, Cout, stride, res):
                                                      (40, 7, 64, 96, 1, 2), (2, 2, 160, 320, 2, 3), (1, 70, 96, 192, 1, 3),
                                                      (33, 129, 32, 192, 1, 3), (12, 19, 32, 64, 1, 2), (37, 70, 24, 144, 1, 3),
                                                      (20, 33, 16, 96, 1, 3)])
-def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkeypatch):
+def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, knobs):
     """Streaming expand+depthwise vs f64, and bit-for-bit against the two kernels it replaces (Cin <= 32: exact-f32 products,
     compared with the f32 GEMM; Cin >= 64: split-bf16 products, compared with the split GEMM of the same number of parts).  Ragged sizes: column strips (W = 200), images
     smaller than one step, single rows, sub-images of unequal size (odd H, W at rate 2); every tile / segment geometry."""
@@ -650,14 +650,10 @@ def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkey
         unfused = unfused.cpu().numpy()
     # (16-channel tiles per block, row segments, column strips, E-waves, D-waves, blocks per channel chunk)
     for force in (None, "4,1,1", "2,3,2", "4,2,3", "2,1,1,4,4,5", "2,2,1,8,4,3", "4,1,2,8,4,1"):
-        if force is None:
-            monkeypatch.delenv("AMS_XDS_FORCE", raising=False)
-        else:
-            monkeypatch.setenv("AMS_XDS_FORCE", force)
         # operand split inside the kernel / loaded as bf16 parts (what the previous block's GEMM writes) / the weight-register
         # form of the kernel (k_xdw_wreg.hip: AMS_XWR_FORCE = E-waves, row segments, column strips, blocks per channel group,
         # row groups per E-wave and step)
-        monkeypatch.setenv("AMS_XWR_FORCE", {None: "4,0,0,0,2", "4,1,1": "8,1,1,0,1", "2,3,2": "4,3,2,0,1", "4,2,3": "8,2,3,2,1"}.get(force, "4,2,1,3,2"))
+        knobs(AMS_XDS_FORCE=force, AMS_XWR_FORCE={None: "4,0,0,0,2", "4,1,1": "8,1,1,0,1", "2,3,2": "4,3,2,0,1", "4,2,3": "8,2,3,2,1"}.get(force, "4,2,1,3,2"))
         for pre in ((0, 1, 2) if Cin >= 64 else (0,)):      # pre-split operands and the weight-register form: split products only
             y = torch.full((B, H, W, Cexp), np.nan, device=DEV)
             hip.check(lib.ams_k_expand_dw_stream(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), rate, PD(sd), PD(hd), P(y),
@@ -669,7 +665,7 @@ def test_fused_expand_depthwise_stream(lib, H, W, Cin, Cexp, rate, parts, monkey
 
 
 @pytest.mark.parametrize("H,W,Cin,Cexp", [(65, 129, 16, 96), (64, 130, 24, 144), (33, 40, 32, 192), (7, 9, 16, 32), (2, 3, 24, 48)])
-def test_fused_expand_depthwise_stream_stride2(lib, H, W, Cin, Cexp, monkeypatch):
+def test_fused_expand_depthwise_stream_stride2(lib, H, W, Cin, Cexp, knobs):
     """Stride-2 blocks on the streaming kernel (exact-f32 products): vs f64 and bit-for-bit against f32 GEMM + stride-2 depthwise.
     Odd and even sizes (SAME padding puts the window centres on even or odd input positions)."""
     rng = np.random.default_rng(H * 5 + W + Cin)
@@ -692,10 +688,7 @@ def test_fused_expand_depthwise_stream_stride2(lib, H, W, Cin, Cexp, monkeypatch
     hip.check(lib.ams_k_depthwise3x3(P(ebuf), B, H, W, Cexp, PD(wd), 2, 1, PD(sd), PD(hd), hip.ACT_RELU6, P(unfused), stream()))
     unfused = unfused.cpu().numpy()
     for force in (None, "4,1,1", "2,3,2", "4,2,3", "2,5,1"):
-        if force is None:
-            monkeypatch.delenv("AMS_XDS_FORCE", raising=False)
-        else:
-            monkeypatch.setenv("AMS_XDS_FORCE", force)
+        knobs(AMS_XDS_FORCE=force)
         y = torch.full((B, Ho, Wo, Cexp), np.nan, device=DEV)
         hip.check(lib.ams_k_expand_dw_stream(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), -2, PD(sd), PD(hd), P(y), None, 0, 3, 0,
                                              stream()))
@@ -703,6 +696,107 @@ def test_fused_expand_depthwise_stream_stride2(lib, H, W, Cin, Cexp, monkeypatch
         assert np.isfinite(got).all(), force
         assert rel_err(got, ref) < 2e-5, force
         assert np.array_equal(got, unfused), force
+
+
+def f16_parts(a):
+    """the two fp16 parts of split_bf16.hpp on the host: hi = f16(x), lo = f16((x - hi) 2^11), both round-to-nearest-even"""
+    a = np.asarray(a, dtype=np.float32)
+    hi = a.astype(np.float16)
+    lo = ((a - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    return hi, lo
+
+
+def h2i_pack(a):
+    """[M, C] f32 -> the H2I bytes as a uint16 array [M, C / 8, 2, 8] (per 8 channels: 8 hi, then 8 lo)"""
+    hi, lo = f16_parts(a)
+    M, C_ = a.shape
+    return np.stack([hi.reshape(M, C_ // 8, 8), lo.reshape(M, C_ // 8, 8)], axis=2).view(np.uint16)
+
+
+@pytest.mark.parametrize("M,K,N,res", [(2145, 960, 160, True), (17160, 160, 960, False), (2145, 384, 64, True), (4290, 576, 160, False),
+                                       (2145, 256, 19, False), (1000, 64, 384, False), (300, 320, 256, False), (68640 // 4 + 7, 960, 320, False),
+                                       (33, 96, 576, False), (5000, 576, 96, True), (129, 40, 24, False)])
+def test_pointwise_split_f16(lib, M, K, N, res, knobs):
+    """Two-fp16-part product (3 MFMAs per 32 k): f32-level against f64 (per product ~3 2^-22: 2e-6 of the output scale, the three-part bf16
+    form's bar); the operand pre-packed as fp16 pairs gives the same bits as the in-kernel split; the optional part planes of the result
+    equal the host's split of the f32 result; activations in [0, 6] like the depthwise results and N(0, 1) ones like block inputs; every
+    tile shape the launcher can pick and half-height tail blocks."""
+    rng = np.random.default_rng(M + K + N)
+    x = (np.clip(rng.standard_normal((M, K)) * 2 + 1, 0, 6) if res else rng.standard_normal((M, K))).astype(np.float32)
+    x[0, :8] = [0.0, 6.0, 1e-7, 3e-5, 6.1e-5, 1.0, 0.333333, 5.9999995]          # fp16 subnormal / boundary values of hi and lo
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    shift = rng.standard_normal(N).astype(np.float32)
+    r = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    Kp = (K + 31) // 32 * 32
+    panels = torch.zeros(2 * N * Kp, dtype=torch.int16, device=DEV)
+    want = (x.astype(np.float64) @ w.astype(np.float64)) * scale + shift + (r if res else 0.0)
+    vec = N % 4 == 0
+    outs = []
+    for force in (None, "1,2", "2,3", "1,5", "2,4", "2,6"):
+        knobs(AMS_PWX_FORCE=force)
+        y = torch.full((M, N), np.nan, device=DEV)
+        parts = torch.zeros((2, M, N), dtype=torch.int16, device=DEV) if vec else None
+        hip.check(lib.ams_k_pointwise_split_f16(PD(x), M, K, PD(w), N, PD(scale), PD(shift), hip.ACT_NONE, PD(r) if res else None, P(y), P(panels),
+                                                panels.numel(), None, P(parts), stream()))
+        got = y.cpu().numpy()
+        assert np.isfinite(got).all(), force
+        assert rel_err(got, want) < 2e-6, force
+        outs.append(got)
+        if vec:
+            hi, lo = f16_parts(got)
+            pp = parts.cpu().numpy().view(np.uint16)
+            assert np.array_equal(pp[0], hi.view(np.uint16)) and np.array_equal(pp[1], lo.view(np.uint16)), force
+        if K % 8 == 0:
+            xh = torch.full((M, K), np.nan, device=DEV)
+            y2 = torch.full((M, N), np.nan, device=DEV)
+            hip.check(lib.ams_k_pointwise_split_f16(PD(x), M, K, PD(w), N, PD(scale), PD(shift), hip.ACT_NONE, PD(r) if res else None, P(y2), P(panels),
+                                                    panels.numel(), P(xh), None, stream()))
+            assert np.array_equal(xh.cpu().numpy().view(np.uint16).reshape(M, K // 8, 2, 8), h2i_pack(x)), force
+            assert torch.equal(y2, y), force
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])              # same products in the same order whatever the tile
+
+
+@pytest.mark.parametrize("H,W,Cin,Cexp,rate", [(33, 65, 64, 384, 1), (33, 65, 96, 576, 1), (33, 65, 160, 960, 2), (17, 33, 160, 960, 2),
+                                               (9, 200, 64, 384, 1), (5, 3, 96, 576, 2), (40, 7, 64, 96, 1), (2, 2, 160, 320, 2), (1, 70, 96, 192, 1)])
+def test_fused_expand_depthwise_stream_f16(lib, H, W, Cin, Cexp, rate, knobs):
+    """The streaming expand + depthwise kernels on two fp16 parts: against f64, bit for bit against ams_k_pointwise_split_f16 followed by the
+    depthwise kernel, and — written as fp16 pairs (y_h2i) — bit for bit the host's packing of that result.  Geometries as in the bf16 test."""
+    rng = np.random.default_rng(H * 7 + W + Cin + rate)
+    B = 3
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    we = (rng.standard_normal((Cin, Cexp)) / np.sqrt(Cin)).astype(np.float32)
+    wd = (rng.standard_normal((3, 3, Cexp, 1)) * 0.4).astype(np.float32)
+    se, sd = rng.uniform(0.5, 1.5, Cexp).astype(np.float32), rng.uniform(0.5, 1.5, Cexp).astype(np.float32)
+    he, hd = rng.standard_normal(Cexp).astype(np.float32), rng.standard_normal(Cexp).astype(np.float32)
+    panels = torch.zeros(2 * Cexp * Cin + 2 * B * H * W * Cin, dtype=torch.int16, device=DEV)
+    e = np.clip((x.astype(np.float64) @ we.astype(np.float64)) * se + he, 0, 6)
+    et = torch.as_tensor(e).permute(0, 3, 1, 2)
+    raw = F.conv2d(F.pad(et, (rate, rate, rate, rate)), torch.as_tensor(wd).double().permute(2, 3, 0, 1), dilation=rate, groups=Cexp)
+    ref = torch.clamp(raw * torch.as_tensor(sd).view(1, -1, 1, 1) + torch.as_tensor(hd).view(1, -1, 1, 1), 0, 6).permute(0, 2, 3, 1).numpy()
+    M = B * H * W
+    ebuf = torch.empty((M, Cexp), device=DEV)
+    hip.check(lib.ams_k_pointwise_split_f16(PD(x), M, Cin, PD(we), Cexp, PD(se), PD(he), hip.ACT_RELU6, None, P(ebuf), P(panels), panels.numel(), None,
+                                            None, stream()))
+    unfused = torch.empty((B, H, W, Cexp), device=DEV)
+    hip.check(lib.ams_k_depthwise3x3(P(ebuf), B, H, W, Cexp, PD(wd), 1, rate, PD(sd), PD(hd), hip.ACT_RELU6, P(unfused), stream()))
+    unfused = unfused.cpu().numpy()
+    packed = h2i_pack(unfused.reshape(M, Cexp))
+    for force in (None, "4,1,1", "2,3,2", "4,2,3", "2,1,1,4,4,5"):
+        knobs(AMS_XDS_FORCE=force, AMS_XWR_FORCE={None: "4,0,0,0,2", "4,1,1": "8,1,1,0,1", "2,3,2": "4,3,2,0,1", "4,2,3": "8,2,3,2,1"}.get(force, "4,2,1,3,2"))
+        for pre in (0, 1, 2):
+            for y_h2i in (0, 1):
+                y = torch.full((B, H, W, Cexp), np.nan, device=DEV)
+                hip.check(lib.ams_k_expand_dw_stream_f16(PD(x), B, H, W, Cin, PD(we), PD(se), PD(he), Cexp, PD(wd), rate, PD(sd), PD(hd), P(y),
+                                                         P(panels), panels.numel(), pre, y_h2i, stream()))
+                got = y.cpu().numpy()
+                if y_h2i:
+                    assert np.array_equal(got.view(np.uint16).reshape(M, Cexp // 8, 2, 8), packed), (force, pre)
+                else:
+                    assert np.isfinite(got).all(), (force, pre)
+                    assert rel_err(got, ref) < 2e-5, (force, pre)
+                    assert np.array_equal(got, unfused), (force, pre)
 
 
 @pytest.mark.parametrize("H,W,C_,N,rate,res", [(33, 65, 384, 64, 1, True), (33, 65, 576, 160, 1, False), (9, 17, 960, 160, 2, True),
@@ -846,7 +940,7 @@ def test_adam_matches_tf1_form(lib):
 
 
 @pytest.mark.gpu
-def test_split_gemm_half_height_tail_blocks():
+def test_split_gemm_half_height_tail_blocks(knobs):
     """68640 x 64 -> 320 runs 160-wide tiles at two blocks per CU: 1074 full-height blocks would need 2.1 rounds, so the launcher ends the
     launch with half-height blocks (pw_plan_tail, k_pw_x3.hip).  Same products in the same order per output as the all-full plan: the
     two launches must agree bit for bit, and with a float64 product to the f32 level."""
@@ -869,12 +963,10 @@ def test_split_gemm_half_height_tail_blocks():
         torch.cuda.synchronize()
         return y
 
+    knobs(AMS_PWX_NO_TAIL=None)
     y_tail = run()
-    os.environ["AMS_PWX_NO_TAIL"] = "1"
-    try:
-        y_full = run()
-    finally:
-        del os.environ["AMS_PWX_NO_TAIL"]
+    knobs(AMS_PWX_NO_TAIL="1")
+    y_full = run()
     assert not torch.isnan(y_tail).any()
     assert torch.equal(y_tail, y_full)
     want = (x.double() @ w.double()) * sc.double() + sh.double()

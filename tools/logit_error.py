@@ -25,7 +25,8 @@ eng.load_variables(W0)
 eng.freeze()
 h, w = eng.lowres
 low = lambda B: eng.logits_lowres.view(-1, h, w, 32)[:B, :, :, :19].cpu().numpy()
-for name, mode, fb, fx in (("default plan", hip.MATMUL_SPLIT_BF16, True, 1), ("3-part split", hip.MATMUL_SPLIT_BF16_X6, True, 1),
+for name, mode, fb, fx in (("2-part bf16", hip.MATMUL_SPLIT_BF16, True, 1), ("3-part bf16", hip.MATMUL_SPLIT_BF16_X6, True, 1),
+                           ("2-part fp16", hip.MATMUL_SPLIT_F16, True, 1),
                            ("exact f32 plan", hip.MATMUL_F32, False, 0)):
     eng.set_matmul_mode(mode); eng.set_fuse_first_block(fb); eng.set_fuse_expand_dw(fx)
     eng.predict(frames)
@@ -34,4 +35,6 @@ for name, mode, fb, fx in (("default plan", hip.MATMUL_SPLIT_BF16, True, 1), ("3
     e2 = rel(low(2), ref)
     eng.predict(frames[:1])
     e1 = rel(low(1), ref[:1])
-    print("%-16s vs f64: batch 8 %.2e   batch 2 %.2e   batch 1 %.2e" % (name, e8, e2, e1))
+    lab = lambda z: z[..., CI].argmax(-1)
+    mism = int((lab(low(1)) != lab(ref[:1])).sum())
+    print("%-16s vs f64: batch 8 %.2e   batch 2 %.2e   batch 1 %.2e   low-res label mismatches (frame 0) %d" % (name, e8, e2, e1, mism))

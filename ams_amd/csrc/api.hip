@@ -483,6 +483,22 @@ int ams_k_block_fused(const float* x, int32_t B, int32_t H, int32_t W, int32_t C
                               scale_p, shift_p, AMS_ACT_NONE, Cout, residual != 0, y, st, nullptr, wparts, plane);
 }
 
+int ams_k_block_fused_f16(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e, const float* shift_e,
+                          int32_t Cexp, const float* w_dw, int32_t stride, const float* scale_d, const float* shift_d, const float* w_proj, int32_t Cout,
+                          const float* scale_p, const float* shift_p, int32_t residual, float* y, uint16_t* panels, size_t panel_elems, void* stream) {
+    if (!block_fused_supported(Cin, Cexp, Cout, stride, 1, residual != 0)) { set_error("block_fused_f16: unsupported shape"); return AMS_E_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const int kp_p = (Cexp + 31) / 32 * 32;
+    const int64_t pe = (int64_t)Cexp * 32, pp = (int64_t)Cout * kp_p;
+    AMS_REQUIRE(panels && Cin <= 32 && panel_elems >= (size_t)(2 * pe + 2 * pp), "block_fused_f16: panel scratch too small (need %zu)", (size_t)(2 * pe + 2 * pp));
+    uint16_t* he = panels;
+    uint16_t* hp = panels + 2 * pe;
+    RUN(launch_split_weights_f16(w_exp, Cexp, 1, Cin, Cexp, 32, he, he + pe, st));
+    RUN(launch_split_weights_f16(w_proj, Cout, 1, Cexp, Cout, kp_p, hp, hp + pp, st));
+    return launch_block_fused(x, B, H, W, Cin, w_exp, scale_e, shift_e, AMS_ACT_RELU6, Cexp, w_dw, stride, scale_d, shift_d, AMS_ACT_RELU6, w_proj,
+                              scale_p, shift_p, AMS_ACT_NONE, Cout, residual != 0, y, st, nullptr, nullptr, 0, he, pe, hp, pp, kp_p);
+}
+
 int ams_k_expand_dw(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
                     const float* shift_e, int32_t Cexp, const float* w_dw, int32_t stride, int32_t rate, const float* scale_d,
                     const float* shift_d, float* y, void* stream) {

@@ -162,7 +162,8 @@ struct ams_student {
     int64_t* conf_buf = nullptr;
     int64_t adam_t = 0;
     bool frozen_ready = false;
-    int matmul_mode = AMS_MATMUL_SPLIT_BF16_X6;   // late layers: three-part bf16 split (f32-level products) in inference and training
+    int matmul_mode = AMS_MATMUL_SPLIT_F16;       // frozen inference: two fp16 parts (3 MFMAs, f32-level); the fine-tune step: three bf16 parts (6 MFMAs) —
+                                                  // every mode but AMS_MATMUL_F32 trains on the three-part form
     int fuse_dw_project = 0;                   // frozen inference: depthwise + project in one kernel on the stride-16 blocks.
                                                // Off by default: measured equal to the two kernels at B = 8 (LDS-read bound:
                                                // 60 b128 reads per wave and 32 channels) and slower at B = 1 (45 blocks)

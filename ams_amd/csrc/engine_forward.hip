@@ -139,14 +139,17 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
             // algorithmic FLOPs (no halo, no padding): the kernel is bound by the exact-f32 matrix pipe, not by HBM
             // three-part split products for the expand layer when K >= 24 (not in the exact-f32 mode; the one- and two-part modes
             // concern the late layers only: the early blocks keep f32-level products there too)
-            const bool x6 = s->block_x6 && s->matmul_mode != AMS_MATMUL_F32 && le.whi && le.Kp == 32 && le.d.cin > 16;
-            const double fl_e = 2.0 * B * (double)le.px_in * le.d.cin * le.d.cout;
-            s->prof_flops = 2.0 * B * ((double)ld.px_out * 9.0 * ld.d.cin + (double)lj.px_out * lj.d.cin * lj.d.cout) + (x6 ? 0.0 : fl_e);
-            s->prof_flops_x6 = x6 ? fl_e : 0.0;
+            // fp16 form (AMS_MATMUL_SPLIT_F16): expand (any K, 16 included) and project products as 3 fp16 MFMAs each
+            const bool h16 = s->block_x6 && s->matmul_mode == AMS_MATMUL_SPLIT_F16 && le.whf && lj.whf && le.Kp == 32;
+            const bool x6 = !h16 && s->block_x6 && s->matmul_mode != AMS_MATMUL_F32 && le.whi && le.Kp == 32 && le.d.cin > 16;
+            const double fl_e = 2.0 * B * (double)le.px_in * le.d.cin * le.d.cout, fl_p = 2.0 * B * (double)lj.px_out * lj.d.cin * lj.d.cout;
+            s->prof_flops = 2.0 * B * (double)ld.px_out * 9.0 * ld.d.cin + (h16 ? 0.0 : fl_p) + (x6 || h16 ? 0.0 : fl_e);
+            s->prof_flops_x6 = h16 ? fl_e + fl_p : x6 ? fl_e : 0.0;
             RUNK(i + 2, bytes, launch_block_fused(cur, B, le.Hin, le.Win, le.d.cin, P + le.d.w_off, le.fscale, le.fshift, le.d.act, le.d.cout,
                                                   P + ld.d.w_off, ld.d.stride, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale, lj.fshift,
                                                   lj.d.act, lj.d.cout, res, s->act[o], st, le.blk_vecs, x6 ? le.whi : nullptr,
-                                                  (int64_t)(le.wlo - le.whi)));
+                                                  (int64_t)(le.wlo - le.whi), h16 ? le.whf : nullptr, (int64_t)le.d.cout * le.Kp, h16 ? lj.whf : nullptr,
+                                                  (int64_t)lj.d.cout * lj.Kp, lj.Kp));
             cur = s->act[o]; cur_i = o; i += 3;
             cur_parts = nullptr;
             continue;

@@ -52,6 +52,11 @@ struct BlkArgs {
     // parts `wplane` elements apart
     const uint16_t* wparts;
     int64_t wplane;
+    // H16 form (AMS_MATMUL_SPLIT_F16; split_bf16.hpp): expand AND project products on two fp16 parts, 3 MFMAs each (16x16x16 for K = 16, 16x16x32
+    // for K = 24 / 32, 16x16x16 per 16-channel chunk of the project layer) instead of 4 / 8 / 4 exact-f32 MFMAs of twice the latency:
+    // he = the expand layer's fp16 panels [part][Cexp][32], hp = the project layer's [part][Cout][kp_p] (k contiguous, zero-padded)
+    const uint16_t* he; int64_t he_plane;
+    const uint16_t* hp; int64_t hp_plane; int kp_p;
 };
 
 // value of the normalised, 127.5-padded frame at (iy, ix, ch) in padded coordinates; outside of it the stem's SAME zero padding
@@ -70,11 +75,20 @@ __device__ __forceinline__ float blk_frame_value(const TIn* img, int H, int W, i
 // TIn = void: the block input is an f32 activation tensor; uint8_t / float: STEM form, the input is the frame batch
 constexpr int blk_act_pitch(int s, int tw) { return s == 1 && tw == 16 ? 24 : 20; }
 
-template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false>
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mma16_f16(const u32x2_t& a, const u32x2_t& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
+}
+
+// HP (H16 only): the project products on fp16 parts too; false = exact-f32 project MFMAs behind an fp16 expand
+template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false, bool H16 = false, bool HP = H16>
 __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntiles) {
+    static_assert(!HP || H16, "HP is a refinement of H16");
     constexpr bool PKDW = S == 1 || TH == 2;          // packed f32 in the depthwise phase (see there)
     constexpr bool STEM = !std::is_void<TIn>::value;
-    static_assert(!(X6 && STEM), "the stem stays exact f32");
+    static_assert(!(X6 && STEM) && !(H16 && STEM) && !(X6 && H16), "the stem stays exact f32; one split form at a time");
+    constexpr bool H16W = H16 && KC == 2;             // expand fragments of 8 k per lane (16x16x32); KC == 1: 4 k per lane (16x16x16)
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NPIX = IH * IW;
     constexpr int NRG = (NPIX + 15) / 16;             // 16-pixel row groups of the wave's input tile (halo included)
@@ -117,8 +131,10 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     const float lo_d = a.act_d == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_d = a.act_d == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
     // ---- the wave's input fragments, requested up front and kept for all chunks (clamped addresses, branch-free)
     const float* xb = STEM ? nullptr : a.x + (int64_t)b * a.H * a.W * a.Cin;
-    float4 areg[X6 ? 1 : NRG][KC];
+    float4 areg[(X6 || H16) ? 1 : NRG][KC];
     bf16x8 xp[X6 ? NRG : 1][3];                        // X6: the fragments as bf16 parts (k = 8q .. 8q + 7 of the lane's pixel), split once
+    u32x4 xh8[H16W ? NRG : 1], xl8[H16W ? NRG : 1];    // H16, K = 24 / 32: the fragments as fp16 parts (k = 8q .. 8q + 7)
+    u32x2_t xh4[(H16 && !H16W) ? NRG : 1], xl4[(H16 && !H16W) ? NRG : 1];      // H16, K = 16: k = 4q .. 4q + 3
     unsigned inside_mask = 0;
     if constexpr (STEM) {
         // this lane's taps: k = 16c + 4q + j -> (dy, dx, channel) of the 3x3x3 receptive field, k >= 27 padding (value 0)
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
         if (m < NPIX && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) inside_mask |= 1u << rg;
         const int iyc = iy < 0 ? 0 : (iy > a.H - 1 ? a.H - 1 : iy), ixc = ix < 0 ? 0 : (ix > a.W - 1 ? a.W - 1 : ix);
         const float* px = xb + ((int64_t)iyc * a.W + ixc) * a.Cin;
-        if constexpr (X6) {
+        if constexpr (X6 || H16W) {
             int k0 = 8 * q, k1 = 8 * q + 4;
             const bool ok0 = k0 < a.Cin, ok1 = k1 < a.Cin;
             if (k0 > a.Cin - 4) k0 = a.Cin - 4;
@@ -183,7 +199,20 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
             float4 u = ld4(px + k0), v = ld4(px + k1);
             u = make_float4(ok0 ? u.x : 0.f, ok0 ? u.y : 0.f, ok0 ? u.z : 0.f, ok0 ? u.w : 0.f);
             v = make_float4(ok1 ? v.x : 0.f, ok1 ? v.y : 0.f, ok1 ? v.z : 0.f, ok1 ? v.w : 0.f);
-            split8(u, v, xp[rg][0], xp[rg][1], xp[rg][2]);
+            if constexpr (X6) split8(u, v, xp[rg][0], xp[rg][1], xp[rg][2]);
+            else {
+                f16x8 h, l;
+                split8_f16(u, v, h, l);
+                xh8[rg] = __builtin_bit_cast(u32x4, h); xl8[rg] = __builtin_bit_cast(u32x4, l);
+            }
+        } else if constexpr (H16) {
+            int koff = 4 * q;
+            const bool ok = koff < a.Cin;
+            if (koff > a.Cin - 4) koff = a.Cin - 4;
+            const float4 v = ld4(px + koff);
+            unsigned h[2], l[2];
+            split4_f16(make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f), h, l);
+            xh4[rg] = (u32x2_t){h[0], h[1]}; xl4[rg] = (u32x2_t){l[0], l[1]};
         } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c) {
@@ -212,13 +241,28 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     int ncl[NTO];                                      // column offset of output tile t, clamped into the row
 #pragma unroll
     for (int t = 0; t < NTO; ++t) ncl[t] = 16 * t + l15 < a.Cout ? 16 * t : 0;
-    float wa[KC][4], wp[4][NTO];
+    float wa[(X6 || H16) ? 1 : KC][4], wp[HP ? 1 : 4][NTO];
     bf16x8 wq[3];                                      // X6: this lane's expand-weight fragments (channel n0 + l15, k = 8q .. 8q + 7), three parts
     const uint16_t* pwq = X6 ? a.wparts + (int64_t)l15 * 32 + 8 * q : nullptr;
+    u32x4 wh8, wl8;                                    // H16: the same as fp16 parts (K = 24 / 32) ...
+    u32x2_t wh4, wl4;                                  // ... or k = 4q .. 4q + 3 (K = 16)
+    const uint16_t* pwh = H16 ? a.he + (int64_t)l15 * 32 + (H16W ? 8 : 4) * q : nullptr;
+    u32x2_t ph[HP ? NTO : 1], pl[HP ? NTO : 1];        // HP: project-weight fragments of the chunk (column 16t + l15, k = n0 + 4q .. + 3)
+    const uint16_t* pwj[HP ? NTO : 1];
+    if constexpr (HP) {
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) pwj[t] = a.hp + (int64_t)(16 * t + l15 < a.Cout ? 16 * t + l15 : 0) * a.kp_p + 4 * q;
+    }
     auto load_wa = [&](int n0) {
         if constexpr (X6) {
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) wq[pp] = *reinterpret_cast<const bf16x8*>(pwq + pp * a.wplane + (int64_t)n0 * 32);
+        } else if constexpr (H16W) {
+            wh8 = *reinterpret_cast<const u32x4*>(pwh + (int64_t)n0 * 32);
+            wl8 = *reinterpret_cast<const u32x4*>(pwh + a.he_plane + (int64_t)n0 * 32);
+        } else if constexpr (H16) {
+            wh4 = *reinterpret_cast<const u32x2_t*>(pwh + (int64_t)n0 * 32);
+            wl4 = *reinterpret_cast<const u32x2_t*>(pwh + a.he_plane + (int64_t)n0 * 32);
         } else {
 #pragma unroll
             for (int c = 0; c < KC; ++c)
@@ -227,19 +271,31 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
         }
     };
     auto load_wp = [&](int n0) {
+        if constexpr (HP) {
+#pragma unroll
+            for (int t = 0; t < NTO; ++t) {
+                ph[t] = *reinterpret_cast<const u32x2_t*>(pwj[t] + n0);
+                pl[t] = *reinterpret_cast<const u32x2_t*>(pwj[t] + a.hp_plane + n0);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int t = 0; t < NTO; ++t) wp[j][t] = pwp[j][(int64_t)n0 * a.Cout + ncl[t]];
+        }
     };
     load_wa(0);
     load_wp(0);
 
-    f32x4 out[MRO][NTO];
+    f32x4 out[MRO][NTO], outx[HP ? MRO : 1][HP ? NTO : 1];        // HP: the cross terms of the project products
 #pragma unroll
     for (int i = 0; i < MRO; ++i)
 #pragma unroll
         for (int t = 0; t < NTO; ++t) out[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (HP ? MRO : 1); ++i)
+#pragma unroll
+        for (int t = 0; t < (HP ? NTO : 1); ++t) outx[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                   // sVec is staged: the only block barrier of the kernel
 
     const int chunks = a.Cexp / 16;
@@ -259,6 +315,18 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[1], xp[rg][0], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0], xp[rg][1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[0], xp[rg][0], acc, 0, 0, 0);
+                } else if constexpr (H16) {            // cross terms (wl xh, wh xl) in their own accumulator, then the main term
+                    f32x4 accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (H16W) {
+                        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl8), __builtin_bit_cast(f16x8, xh8[rg]), accx, 0, 0, 0);
+                        accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh8), __builtin_bit_cast(f16x8, xl8[rg]), accx, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh8), __builtin_bit_cast(f16x8, xh8[rg]), acc, 0, 0, 0);
+                    } else {
+                        accx = mma16_f16(wl4, xh4[rg], accx);
+                        accx = mma16_f16(wh4, xl4[rg], accx);
+                        acc = mma16_f16(wh4, xh4[rg], acc);
+                    }
+                    acc = combine_f16(acc, accx);
                 } else {
 #pragma unroll
                     for (int c = 0; c < KC; ++c) {
@@ -320,10 +388,22 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
                                        : make_float4(acc.x * scd.x + shd.x, acc.y * scd.y + shd.y, acc.z * scd.z + shd.z, acc.w * scd.w + shd.w);
                 dv[0] = __builtin_amdgcn_fmed3f(bn.x, lo_d, hi_d); dv[1] = __builtin_amdgcn_fmed3f(bn.y, lo_d, hi_d);
                 dv[2] = __builtin_amdgcn_fmed3f(bn.z, lo_d, hi_d); dv[3] = __builtin_amdgcn_fmed3f(bn.w, lo_d, hi_d);
+                if constexpr (HP) {
+                    unsigned h[2], l[2];
+                    split4_f16(make_float4(dv[0], dv[1], dv[2], dv[3]), h, l);
+                    const u32x2_t dh = {h[0], h[1]}, dl = {l[0], l[1]};
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t) outx[i][t] = mma16_f16(pl[t], dh, outx[i][t]);
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t) outx[i][t] = mma16_f16(ph[t], dl, outx[i][t]);
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t) out[i][t] = mma16_f16(ph[t], dh, out[i][t]);
+                } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int t = 0; t < NTO; ++t) out[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t], dv[j], out[i][t], 0, 0, 0);
+                }
             }
         }
         load_wp(n_next);                               // in flight across the next chunk's expand phase
@@ -346,6 +426,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
             if (c4 >= a.Cout) continue;
             const float4 sc = ld4(a.sc_p + c4), sh = ld4(a.sh_p + c4);
             float4 v;
+            if constexpr (HP) out[i][t] = combine_f16(out[i][t], outx[HP ? i : 0][HP ? t : 0]);
             const float4 bn = muladd4_pk(make_float4(out[i][t][0], out[i][t][1], out[i][t][2], out[i][t][3]), sc, sh);
             v.x = apply_act(bn.x, a.act_p); v.y = apply_act(bn.y, a.act_p);
             v.z = apply_act(bn.z, a.act_p); v.w = apply_act(bn.w, a.act_p);
@@ -358,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     }
 }
 
-template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false>
+template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 = false, bool H16 = false, bool HP = H16>
 static int launch_blk_k(BlkArgs a, hipStream_t st) {
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int NRG = (IH * IW + 15) / 16;
@@ -372,9 +453,9 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
     static const std::string nm = "block_kernel<" + std::to_string(S) + ", " + std::to_string(KC) + ", " + std::to_string(NTO) + ", " +
                                   std::to_string(TH) + ", " + std::to_string(TW) +
                                   (std::is_void<TIn>::value ? ", void" : sizeof(typename std::conditional<std::is_void<TIn>::value, char, TIn>::type) == 1 ? ", unsigned char" : ", float") +
-                                  (X6 ? ", true>" : ", false>");
+                                  (H16 ? (HP ? ", false, true>" : ", false, true, false>") : X6 ? ", true>" : ", false>");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((block_kernel<S, KC, NTO, TH, TW, TIn, X6>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)ntiles);
+    hipLaunchKernelGGL((block_kernel<S, KC, NTO, TH, TW, TIn, X6, H16, HP>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)ntiles);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -382,6 +463,15 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
 template <int S, int TH, int TW>
 static int launch_blk_t(const BlkArgs& a, hipStream_t st) {
     const bool k1 = (a.Cin + 15) / 16 == 1, o2 = a.Cout <= 32;
+    if (a.he) {
+        // 64-wide project layers (four accumulator tiles per row group) keep the exact-f32 project MFMAs: measured 68 vs 81 us on the
+        // 32 -> 192 -> 64 block (AMS_BLK_HP = 0 | 1 forces either)
+        const bool hp = knobs().blk_hp >= 0 ? knobs().blk_hp != 0 : o2;
+        if (k1) return o2 ? (hp ? launch_blk_k<S, 1, 2, TH, TW, void, false, true>(a, st) : launch_blk_k<S, 1, 2, TH, TW, void, false, true, false>(a, st))
+                          : (hp ? launch_blk_k<S, 1, 4, TH, TW, void, false, true>(a, st) : launch_blk_k<S, 1, 4, TH, TW, void, false, true, false>(a, st));
+        return o2 ? (hp ? launch_blk_k<S, 2, 2, TH, TW, void, false, true>(a, st) : launch_blk_k<S, 2, 2, TH, TW, void, false, true, false>(a, st))
+                  : (hp ? launch_blk_k<S, 2, 4, TH, TW, void, false, true>(a, st) : launch_blk_k<S, 2, 4, TH, TW, void, false, true, false>(a, st));
+    }
     if (k1) return o2 ? launch_blk_k<S, 1, 2, TH, TW>(a, st) : launch_blk_k<S, 1, 4, TH, TW>(a, st);
     if (a.wparts) return o2 ? launch_blk_k<S, 2, 2, TH, TW, void, true>(a, st) : launch_blk_k<S, 2, 4, TH, TW, void, true>(a, st);
     return o2 ? launch_blk_k<S, 2, 2, TH, TW>(a, st) : launch_blk_k<S, 2, 4, TH, TW>(a, st);
@@ -436,7 +526,7 @@ bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bo
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
                        const float* w_dw, int stride, const float* sc_d, const float* sh_d, int act_d, const float* w_pj, const float* sc_p,
                        const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs, const uint16_t* wparts,
-                       int64_t wplane) {
+                       int64_t wplane, const uint16_t* h_exp, int64_t h_exp_plane, const uint16_t* h_pj, int64_t h_pj_plane, int h_pj_kp) {
     AMS_REQUIRE(block_fused_supported(Cin, Cexp, Cout, stride, 1, residual), "block kernel: unsupported shape Cin=%d Cexp=%d Cout=%d s=%d", Cin, Cexp,
                 Cout, stride);
     BlkArgs a;
@@ -444,12 +534,13 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
     a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.w_exp = w_exp; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e; a.Cexp = Cexp;
     a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.w_pj = w_pj; a.sc_p = sc_p; a.sh_p = sh_p; a.act_p = act_p; a.Cout = Cout;
     a.residual = residual ? 1 : 0; a.y = y; a.vecs = vecs;
-    if (wparts && Cin > 16) { a.wparts = wparts; a.wplane = wplane; }      // X6 pays from K = 24 on (at K = 16 half of every bf16 MFMA is padding)
+    if (h_exp && h_pj) { a.he = h_exp; a.he_plane = h_exp_plane; a.hp = h_pj; a.hp_plane = h_pj_plane; a.kp_p = h_pj_kp; }      // fp16 form: expand and project
+    else if (wparts && Cin > 16) { a.wparts = wparts; a.wplane = wplane; }      // X6 pays from K = 24 on (at K = 16 half of every bf16 MFMA is padding)
     same_pad(H, 3, stride, 1, &a.Ho, &a.pt);
     same_pad(W, 3, stride, 1, &a.Wo, &a.pl);
     // tile of output pixels per WAVE: the measured choice, or the next smaller one that fits LDS (blk_pick_tile)
     int th, tw;
-    AMS_REQUIRE(blk_pick_tile(Cexp, Cout, stride, a.wparts != nullptr, &th, &tw), "block kernel: no tile fits LDS for Cexp=%d", Cexp);
+    AMS_REQUIRE(blk_pick_tile(Cexp, Cout, stride, a.wparts != nullptr || a.he != nullptr, &th, &tw), "block kernel: no tile fits LDS for Cexp=%d", Cexp);
     if (knobs().blk_th > 0 && blk_lds_bytes(stride, knobs().blk_th, knobs().blk_tw, Cexp) <= 64 * 1024) {
         th = knobs().blk_th; tw = knobs().blk_tw;          // tuning knob AMS_BLK_TILE (tools/block_one.py); ignored when it does not fit
     }

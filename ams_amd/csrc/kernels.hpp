@@ -16,6 +16,7 @@ int device_cus(int* cus);
 bool launch_table_needs_attr(int device, const void* fn, size_t lds);
 struct Knobs {                   // tuning knobs of tools/*: environment variables, read at first use, never on the launch path
     int blk_th = 0, blk_tw = 0;                  // AMS_BLK_TILE=<th>x<tw>
+    int blk_hp = -1;                             // AMS_BLK_HP=<0|1>: fp16 whole-block kernels with exact-f32 (0) / fp16 (1) project products
     char pw_force = 0; int pw_rm = 0, pw_nt = 0; // AMS_PW_FORCE=<s|l>,<RM>,<NT>
     int pw_percu = 0;                            // AMS_PW_PERCU
     bool pwx_no_tail = false;                    // AMS_PWX_NO_TAIL
@@ -231,7 +232,10 @@ bool block_fused_supported(int Cin, int Cexp, int Cout, int stride, int rate, bo
 int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float* w_exp, const float* sc_e, const float* sh_e, int act_e, int Cexp,
                        const float* w_dw, int stride, const float* sc_d, const float* sh_d, int act_d, const float* w_pj, const float* sc_p,
                        const float* sh_p, int act_p, int Cout, bool residual, float* y, hipStream_t st, const float* vecs = nullptr,
-                       const uint16_t* wparts = nullptr, int64_t wplane = 0);
+                       const uint16_t* wparts = nullptr, int64_t wplane = 0, const uint16_t* h_exp = nullptr, int64_t h_exp_plane = 0,
+                       const uint16_t* h_pj = nullptr, int64_t h_pj_plane = 0, int h_pj_kp = 0);
+// h_exp / h_pj: optional fp16 panels (hi | lo 2^11, `plane` apart) of the expand layer [part][Cexp][32] and the project layer
+// [part][Cout][h_pj_kp]: with both, the expand and the project products run as 3 fp16 MFMAs each (AMS_MATMUL_SPLIT_F16; takes precedence over wparts)
 // wparts: optional three-part bf16 panels [part][Cexp][32] of the expand weights (parts `wplane` apart): with them the expand products of
 // a block with Cin 24 / 32 run as six bf16 MFMAs (f32-level) instead of eight exact-f32 MFMAs
 // vecs: optional [13][Cexp] table (sc_e | sh_e | sc_d | sh_d | w_dw[9]) built once by launch_block_pack (the engine: at freeze)

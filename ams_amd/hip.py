@@ -110,6 +110,7 @@ SIGNATURES = {
     "ams_ingest_resize_u8": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "ams_k_dw_project": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ams_k_block_fused": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "ams_k_block_fused_f16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_expand_dw": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ams_k_expand_dw_stream": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _i32, _i32, _vp]),
     "ams_k_global_mean": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp, _sz, _vp]),

@@ -391,6 +391,12 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
  *   weight-register form; panels then needs 2*B*H*W*Cin more elements); y_h2i != 0: y is written in H2I instead of f32.  Bit-identical to
  *   ams_k_pointwise_split_f16 followed by ams_k_depthwise3x3. */
 int ams_k_pack_h2i(const float* x, int64_t M, int32_t C, float* out, void* stream);
+/* ams_k_block_fused with the expand AND the project products on two fp16 parts (3 MFMAs each; K = 16 included); panels: scratch of
+ * >= 2*Cexp*32 + 2*Cout*roundup(Cexp, 32) uint16 */
+int ams_k_block_fused_f16(const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, const float* w_exp, const float* scale_e,
+                          const float* shift_e, int32_t Cexp, const float* w_dw, int32_t stride, const float* scale_d, const float* shift_d,
+                          const float* w_proj, int32_t Cout, const float* scale_p, const float* shift_p, int32_t residual, float* y,
+                          uint16_t* panels, size_t panel_elems, void* stream);
 int ams_k_pointwise_split_f16(const float* x, int64_t M, int32_t K, const float* w, int32_t N, const float* scale, const float* shift,
                               int32_t act, const float* res, float* y, uint16_t* panels, size_t panel_elems, float* x_h2i, uint16_t* y_parts,
                               void* stream);

@@ -568,7 +568,7 @@ def test_fused_expand_depthwise(lib, H, W, Cin, Cexp, stride):
 @pytest.mark.parametrize("H,W,Cin,Cexp,Cout,stride,res", [(33, 65, 16, 96, 24, 2, False), (40, 37, 24, 144, 24, 1, True), (33, 65, 24, 144, 32, 2, False),
                                                           (29, 50, 32, 192, 32, 1, True), (34, 66, 32, 192, 64, 2, False), (65, 129, 16, 96, 24, 1, False),
                                                           (7, 5, 24, 144, 24, 1, True), (16, 16, 32, 192, 32, 1, False)])
-def test_whole_block_kernel(lib, H, W, Cin, Cexp, Cout, stride, res):
+def test_whole_block_kernel(lib, H, W, Cin, Cexp, Cout, stride, res, knobs):
     """k_block.hip: expand + depthwise + project (+ block input) in one kernel.  Against f64 math, and bit for bit against the
     kernels it replaces (fused expand+depthwise, then the f32 GEMM with its epilogue) — same products, same k order."""
     rng = np.random.default_rng(H * 3 + Cin + Cout)
@@ -613,6 +613,17 @@ def test_whole_block_kernel(lib, H, W, Cin, Cexp, Cout, stride, res):
         assert not torch.equal(y3, y) and rel_err(y3.cpu().numpy(), got) < 2e-6
     else:
         assert torch.equal(y3, y)                      # K = 16: the exact-f32 form either way
+    # AMS_MATMUL_SPLIT_F16: expand and project products on two fp16 parts (3 MFMAs each, K = 16 included) — f32-level; tile knobs change no bit
+    hpan = torch.zeros(2 * Cexp * 32 + 2 * Cout * ((Cexp + 31) // 32 * 32), dtype=torch.int16, device=DEV)
+    outs = []
+    for tile in (None, "4x8", "2x8" if stride == 2 else "8x8"):
+        knobs(AMS_BLK_TILE=tile)
+        y4 = torch.full((B, Ho, Wo, Cout), np.nan, device=DEV)
+        hip.check(lib.ams_k_block_fused_f16(P(xd), B, H, W, Cin, P(wed), P(sed), P(hed), Cexp, P(wdd), stride, P(sdd), P(hdd), P(wpd), Cout, P(spd), P(hpd),
+                                            int(res), P(y4), P(hpan), hpan.numel(), stream()))
+        assert rel_err(y4.cpu().numpy(), ref) < 2e-5 and rel_err(y4.cpu().numpy(), got) < 4e-6, tile
+        outs.append(y4)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("H,W,Cin,Cexp,rate,parts", [(33, 65, 64, 384, 1, 3), (33, 65, 96, 576, 1, 2), (33, 65, 160, 960, 2, 3),

@@ -18,8 +18,10 @@ struct ams_comm {
     bool aborted = false;
     // diagnostic timing (ams_comm_set_timing): a HIP event pair around every collective on its stream; read back by ams_comm_timing_read
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;      // at most kMaxSpans: timing left on for a long run stops recording, it does not grow
     std::vector<hipEvent_t> pool;
+    int64_t event_failures = 0;          // hipEventCreate failed while timing: ams_comm_timing_read reports it instead of an undercount
+    static constexpr size_t kMaxSpans = 4096;      // ~37 steps of 110 collectives
     ~ams_comm() {
         for (auto& sp : spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
         for (auto e : pool) (void)hipEventDestroy(e);
@@ -82,10 +84,16 @@ int comm_allreduce(ams_comm* c, void* p, size_t n, int dtype, hipStream_t st) {
     Rccl& r = rccl();
     const ncclDataType_t dt = dtype == AMS_DT_F64 ? ncclFloat64 : ncclFloat32;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->timing) {
-        auto take = [&]() { hipEvent_t e = nullptr; if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    if (c->timing && c->spans.size() < ams_comm::kMaxSpans) {
+        auto take = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->pool.empty()) { e = c->pool.back(); c->pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) { e = nullptr; c->event_failures += 1; }
+            return e;
+        };
         e0 = take(); e1 = take();
-        if (e0) (void)hipEventRecord(e0, st);
+        if (e0 && e1) (void)hipEventRecord(e0, st);
+        else { if (e0) c->pool.push_back(e0); if (e1) c->pool.push_back(e1); e0 = e1 = nullptr; }
     }
     const ncclResult_t rc = r.AllReduce(p, p, n, dt, ncclSum, c->comm, st);
     if (c->timing && e0 && e1) { (void)hipEventRecord(e1, st); c->spans.emplace_back(e0, e1); }
@@ -168,6 +176,7 @@ int ams_comm_set_timing(ams_comm* c, int32_t enable) {
     AMS_CHECK_HIP(hipDeviceSynchronize());
     for (auto& sp : c->spans) { c->pool.push_back(sp.first); c->pool.push_back(sp.second); }
     c->spans.clear();
+    c->event_failures = 0;
     c->timing = enable != 0;
     return AMS_OK;
 }
@@ -183,6 +192,7 @@ int ams_comm_timing_read(ams_comm* c, double* total_ms, double* max_ms, int64_t*
         if (ms > mx) mx = ms;
     }
     *total_ms = tot; *max_ms = mx; *spans = (int64_t)c->spans.size();
+    if (c->event_failures) { set_error("comm_timing_read: hipEventCreate failed for %lld collective(s): the totals undercount", (long long)c->event_failures); return AMS_E_HIP; }
     return AMS_OK;
 }
 

@@ -144,7 +144,8 @@ struct ams_student {
                                      // cost more than the three small launches they hide
     int overlap_wgrad = 1;
     int wgrad_fork_every = 1;        // weight gradients per hand-over to the side stream (AMS_OPT_WGRAD_FORK_EVERY)
-    int nan_grads = 1;               // a batch without a valid pixel: NaN loss AND NaN gradients, as the reference's 0 / 0 (AMS_OPT_NAN_GRADS; 0 = zero gradients)
+    int nan_grads = 0;               // a batch without a valid pixel: NaN loss, ZERO gradients — what TensorFlow computes for utils/graph_utils.py:408
+                                     // (reduce_mean over the empty boolean_mask: its gradient is an empty tensor, densified to zeros); 1 = NaN gradients (AMS_OPT_NAN_GRADS)
     ~ams_student() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_head) (void)hipEventDestroy(ev_head);

@@ -60,8 +60,10 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
     const int64_t HW = (int64_t)s->h * s->w, M = (int64_t)B * HW;
     const double nHW = (double)global_B * HW;
     const int NC = c.num_classes;
-    // d loss / d logits (already divided by the global number of valid pixels); without one valid pixel the reference's loss is 0 / 0 and
-    // every gradient NaN (utils/graph_utils.py:408) — reproduced unless AMS_OPT_NAN_GRADS = 0
+    // d loss / d logits (already divided by the global number of valid pixels).  Without one valid pixel the reference's loss is NaN
+    // (utils/graph_utils.py:408: reduce_mean of an empty boolean_mask) but its gradients are ZERO: the backward of reduce_mean over a [0]-shaped
+    // tensor is an empty tensor, and boolean_mask's gather gradient densifies it to zeros — the weights survive such a batch.  Default;
+    // AMS_OPT_NAN_GRADS = 1 writes NaN gradients instead (a loud failure for callers that prefer one).
     const float empty_val = s->nan_grads ? __builtin_nanf("") : 0.f;
     if (ce_loss_grad_supported(s->w, c.width))           // second pass of the one-pass loss kernel (train_step_impl ran the first)
         RUNK(0, 0.0, launch_ce_combine(B, s->h, s->w, c.class_indices, c.n_selected, NC, s->loss_buf, s->ce_scratch, s->dlogits, 32, st, empty_val));
@@ -252,7 +254,9 @@ int backward(ams_student* s, const void* frames, int dtype, const uint8_t* teach
                                    red_dx ? s->scratch : nullptr, red_dx ? &dx_rows : nullptr));
             if (dx_rows > 0) { fused_rows = dx_rows; fused_stride = 2 * (int64_t)lin.d.cout; fused_dw = false; fused_buf = s->scratch; }
             // weight gradients from the partial rows: depthwise taps, then the expand weights from (G1 | XX | g0).  They only feed the
-            // optimizer: on the side stream, behind the coefficients (recorded before the dx pass, which does not touch the rows)
+            // optimizer: on the side stream, behind the coefficients.  The hand-over event is recorded AFTER the dx pass was queued (flush_wgrads
+            // below), so these reductions start when dx is done, not beside it: ordering is what matters here (xt_scratch and cA / cB / cC are
+            // final either way), and recording before the dx launch measured no faster
             const int KP = (le.d.cin + 15) / 16 * 16;
             const int64_t n_dw = 9 * (int64_t)le.d.cout, n_g = (int64_t)KP * le.d.cout;
             float* reduced = s->xt_scratch + (int64_t)rows * stride;

@@ -342,6 +342,7 @@ bool train_recompute_block(const ams_student* s, int i) {
     const LayerRt& ld = s->L[i + 1];
     return l.xx_g0 && l.d.role == AMS_ROLE_EXPAND && ld.d.role == AMS_ROLE_DEPTHWISE && xdw_train_supported(l.d.cin, l.d.cout, ld.d.stride, ld.d.rate) &&
            expand_dw_supported(l.d.cin, l.d.cout, ld.d.stride, ld.d.rate) && l.d.cout <= 1024 &&
+           xdw_train_scratch(s->cfg.max_batch, l.Hin, l.Win, l.d.cin, l.d.cout) != (size_t)-1 &&      // too large for 32-bit offsets: layer-by-layer
            xdw_train_scratch(s->cfg.max_batch, l.Hin, l.Win, l.d.cin, l.d.cout) <= s->xt_floats;
 }
 
@@ -360,7 +361,8 @@ bool dw_fused_train(const ams_student* s, int i, int B) {
 bool stem_fused_train(const ams_student* s) {
     const ams_student_config& c = s->cfg;
     return s->n_backbone >= 2 && s->train_recompute && s->L[1].d.role == AMS_ROLE_STEM && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE &&
-           s->L[2].d.stride == 1 && s->L[2].d.rate == 1 && s->xt_scratch && xdw_stem_scratch(c.max_batch, c.height, c.width) <= s->xt_floats;
+           s->L[2].d.stride == 1 && s->L[2].d.rate == 1 && s->xt_scratch && xdw_stem_scratch(c.max_batch, c.height, c.width) != (size_t)-1 &&
+           xdw_stem_scratch(c.max_batch, c.height, c.width) <= s->xt_floats;
 }
 bool dw_fused_train_fwd(const ams_student* s, int i, int B) {
     if (s->fuse_dgrad_bn < 2 || i < 2 || i > s->n_backbone) return false;

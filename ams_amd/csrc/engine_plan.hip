@@ -224,11 +224,11 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
             if (l.d.role == AMS_ROLE_EXPAND && s->L[i + 1].d.role == AMS_ROLE_DEPTHWISE &&
                 xdw_train_supported(l.d.cin, l.d.cout, s->L[i + 1].d.stride, s->L[i + 1].d.rate)) {
                 const size_t need = xdw_train_scratch(B, l.Hin, l.Win, l.d.cin, l.d.cout);
-                if (need > xt) xt = need;
+                if (need != (size_t)-1 && need > xt) xt = need;          // (size_t)-1: the map is too large for the kernels' 32-bit offsets — that block keeps the layer-by-layer step
             }
         }
         if (s->n_backbone >= 3 && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE && s->L[2].d.stride == 1 && s->L[2].d.rate == 1 &&
-            xdw_stem_scratch(B, c.height, c.width) > xt)
+            xdw_stem_scratch(B, c.height, c.width) != (size_t)-1 && xdw_stem_scratch(B, c.height, c.width) > xt)
             xt = xdw_stem_scratch(B, c.height, c.width);
         s->xt_floats = xt;
         s->xt_scratch = cv.take<float>(xt);

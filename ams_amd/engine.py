@@ -243,8 +243,8 @@ class StudentEngine:
             hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DGRAD_BN, 2 if fuse_dgrad_bn is True else int(fuse_dgrad_bn)), "ams_student_set_option")
 
     def set_nan_grads(self, on: bool) -> None:
-        """A fine-tune batch without one valid pixel: True (default) NaN loss and NaN gradients like the reference's 0 / 0
-        (utils/graph_utils.py:408); False NaN loss but zero gradients (the weights survive)."""
+        """A fine-tune batch without one valid pixel: False (default) NaN loss and ZERO gradients, TensorFlow's result for
+        utils/graph_utils.py:408 (reduce_mean over the empty boolean_mask: the weights survive); True NaN gradients instead."""
         hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_NAN_GRADS, int(bool(on))), "ams_student_set_option")
 
     def set_fuse_first_block(self, on: int) -> None:

@@ -43,6 +43,7 @@ OPT_STREAM_MIN_ROWS = 21
 OPT_FUSE_OPERAND_BN = 22
 OPT_WGRAD_FORK_EVERY = 23
 MATMUL_F32, MATMUL_SPLIT_BF16, MATMUL_SPLIT_BF16_X6, MATMUL_BF16, MATMUL_SPLIT_F16 = 0, 1, 2, 3, 4
+MATMUL_DEFAULT = MATMUL_SPLIT_F16      # frozen inference; the fine-tune step forms its split products on three bf16 parts in every mode but MATMUL_F32
 (REGION_PARAMS, REGION_STATS, REGION_GRADS, REGION_ADAM_M, REGION_ADAM_V, REGION_FROZEN, REGION_BN_SYNC,
  REGION_LOGITS) = range(8)
 

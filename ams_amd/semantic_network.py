@@ -287,15 +287,46 @@ class SemanticNetwork(object):
         if not keep_mask:
             self.mask = None
         self.process_lock.acquire()
+        # The reference's helper threads (SemanticNetwork.py:222-231, :679-704) have no failure path: if one dies — a frame of the wrong shape
+        # trips the assert in _fill_batch — _train polls its deque forever with process_lock held.  Here every helper hands its exception
+        # over through `ctx`, every wait loop watches ctx['abort'], and the caller gets the helper's exception with the lock released.
+        ctx = self._helpers = {"abort": threading.Event(), "error": None}
+        batch_thr = None
         try:
             batch_deque = deque()
-            batch_thr = threading.Thread(target=self._fill_batch, args=(batch_deque, frame_deque, label_deque,
-                                                                        num_of_iterations,))
+            batch_thr = threading.Thread(target=self._guarded, args=(ctx, self._fill_batch, batch_deque, frame_deque, label_deque,
+                                                                     num_of_iterations,))
             batch_thr.start()
             self._train(batch_deque, num_of_iterations, train_strategy)
-            batch_thr.join()
         finally:
+            ctx["abort"].set()                      # after a clean phase the helpers have returned already; after an error this stops them
+            if batch_thr is not None:
+                batch_thr.join()
+            fill_thr = ctx.pop("fill_thr", None)
+            if fill_thr is not None:
+                fill_thr.join()
+            self._helpers = None
+            self._release_staging()
             self.process_lock.release()
+        if ctx["error"] is not None:
+            raise ctx["error"]
+
+    @staticmethod
+    def _guarded(ctx, fn, *args):
+        """Body of a helper thread: the first exception of any helper is kept for the caller and stops the others."""
+        try:
+            fn(*args)
+        except BaseException as e:  # noqa: BLE001  (handed to the calling thread, which re-raises it)
+            if ctx["error"] is None:
+                ctx["error"] = e
+            ctx["abort"].set()
+
+    def _aborted(self):
+        h = getattr(self, "_helpers", None)
+        return h is not None and h["abort"].is_set()
+
+    class _Aborted(Exception):
+        """a wait was cut short because another helper of the same call failed"""
 
     def train_step(self, frames, labels_teacher, train_strategy='full_model'):
         """North-star alias: ONE optimisation step on an explicit batch; returns the loss (float)."""
@@ -316,7 +347,9 @@ class SemanticNetwork(object):
 
     def _train(self, batch_deque, num_of_iterations, train_strategy):
         signal_deque = deque()
-        fill_thr = threading.Thread(target=self._fill_queue, args=(batch_deque, num_of_iterations, signal_deque))
+        ctx = getattr(self, "_helpers", None) or {"abort": threading.Event(), "error": None}
+        fill_thr = threading.Thread(target=self._guarded, args=(ctx, self._fill_queue, batch_deque, num_of_iterations, signal_deque))
+        ctx["fill_thr"] = fill_thr                  # joined by train_with_deque's finally, whatever happens below
         fill_thr.start()
 
         _before, train_mask_ = self.get_train_mask(train_strategy)
@@ -329,16 +362,11 @@ class SemanticNetwork(object):
                 try:
                     staged = signal_deque.popleft()
                 except IndexError:
+                    if ctx["abort"].is_set():       # a helper died: its exception is raised by train_with_deque
+                        return
                     time.sleep(self.THREAD_SLEEP_INTERVAL)
             t1 = time.time()
-            frames_dev, labels_dev, ready = staged
-            compute = torch.cuda.current_stream(self.engine.device)
-            compute.wait_event(ready)
-            # the buffers were allocated on the stager's copy stream: tell the caching allocator that the compute stream uses
-            # them too, or dropping the references one iteration later hands the block back to the copy stream's pool while
-            # this step's kernels (the stem weight gradient re-reads the frames in backward) are still queued
-            frames_dev.record_stream(compute)
-            labels_dev.record_stream(compute)
+            frames_dev, labels_dev = self._consume_staged(staged)
             loss_dev = self.engine.train_step(frames_dev, labels_dev, self.lr, mask_dev)
             losses.append(loss_dev)
             if self.verbose:
@@ -365,6 +393,8 @@ class SemanticNetwork(object):
                     self.mask = train_mask_
                     mask_dev = self._mask_to_device(train_mask_)
         fill_thr.join()
+        if ctx["error"] is not None:
+            return
         stacked = torch.stack(losses).cpu().numpy() if losses else np.zeros((0, 2))
         self.last_losses = [float(s / c) if c > 0 else float("nan") for s, c in stacked]
         self._last_train_ms = (time.time() - t_phase) * 1000.0
@@ -377,6 +407,18 @@ class SemanticNetwork(object):
         else:
             self.train_params = [_after_train[k] for k in _after_train.keys()]
             self.curr_mask = [np.ones_like(_after_train[k], dtype=bool) for k in _after_train.keys()]
+
+    def _consume_staged(self, staged):
+        """Make the compute stream wait for a staged batch's copy; returns its device tensors."""
+        frames_dev, labels_dev, ready = staged
+        compute = torch.cuda.current_stream(self.engine.device)
+        compute.wait_event(ready)
+        # the buffers were allocated on the stager's copy stream: tell the caching allocator that the compute stream uses
+        # them too, or dropping the references one iteration later hands the block back to the copy stream's pool while
+        # this step's kernels (the stem weight gradient re-reads the frames in backward) are still queued
+        frames_dev.record_stream(compute)
+        labels_dev.record_stream(compute)
+        return frames_dev, labels_dev
 
     def delta_payload(self) -> bytes:
         """The downlink model delta of reference run.py:316-336 as bytes: per variable ``np.packbits(mask.flatten())``, then
@@ -439,6 +481,8 @@ class SemanticNetwork(object):
         fast = (list(self.scale) == [1] and all(f.shape[:2] == tuple(crop) for f in frames))
         fast = fast and all(f.dtype == np.uint8 for f in frames) and all(l.dtype == np.uint8 and l.shape == tuple(crop) for l in labels)
         for _ in range(number_of_batches):
+            if self._aborted():
+                return
             slot = None
             if fast:
                 picks = []
@@ -449,7 +493,10 @@ class SemanticNetwork(object):
                     random.randint(0, 0)      # column offset
                 # gathered straight into a pinned staging slot: one host copy per frame, none per batch (a fresh pin_memory() per batch
                 # costs a page-lock of 12-16 MB each time)
-                slot = self._staging_slot()
+                try:
+                    slot = self._staging_slot()
+                except self._Aborted:
+                    return
                 image_batch, label_batch = slot[0].numpy(), slot[1].numpy()
                 for j, p in enumerate(picks):
                     image_batch[j] = frames[p]
@@ -466,14 +513,15 @@ class SemanticNetwork(object):
         is handed out again only after the stager has issued the H2D copy that reads it AND that copy has finished (its event): the sampler runs
         at most four batches ahead of the copies."""
         ring = getattr(self, "_staging", None)
-        if ring is None:
-            shape = (self.mini_batch_size, self.height, 2 * self.height)
-            ring = self._staging = {"next": 0, "slots": [
-                [torch.empty(shape + (3,), dtype=torch.uint8).pin_memory(), torch.empty(shape, dtype=torch.uint8).pin_memory(), None, False]
-                for _ in range(4)]}
+        shape = (self.mini_batch_size, self.height, 2 * self.height)
+        if ring is None or ring["shape"] != shape:              # first use, or the instance's batch geometry changed since
+            ring = self._staging = {"next": 0, "shape": shape, "slots": [
+                [self._pinned(shape + (3,)), self._pinned(shape), None, False] for _ in range(4)]}
         slot = ring["slots"][ring["next"] % len(ring["slots"])]
         ring["next"] += 1
         while slot[3] and slot[2] is None:        # handed out earlier and still waiting in the batch deque for the stager
+            if self._aborted():                   # ... which has died: do not wait for it
+                raise self._Aborted()
             time.sleep(self.THREAD_SLEEP_INTERVAL)
         if slot[2] is not None:
             slot[2].synchronize()
@@ -481,40 +529,72 @@ class SemanticNetwork(object):
         slot[3] = True
         return slot
 
+    @staticmethod
+    def _pinned(shape):
+        t = torch.empty(shape, dtype=torch.uint8)
+        return t.pin_memory() if torch.cuda.is_available() else t
+
+    def _release_staging(self):
+        """After a phase (clean or failed) no slot is owed to a stager any more."""
+        ring = getattr(self, "_staging", None)
+        if ring is not None:
+            for slot in ring["slots"]:
+                if slot[2] is not None:
+                    slot[2].synchronize()
+                slot[2], slot[3] = None, False
+
     def _fill_queue(self, batch_deque, number_of_batches, signal_deque):
         """Stager thread (the FIFO queue of the reference graph, capacity 200): H2D on a side stream."""
-        dev = self.engine.device
-        copy_stream = torch.cuda.Stream(device=dev)
+        copy_stream = self._make_copy_stream()
+        max_staged = None
         for _ in range(number_of_batches):
             batch = None
             while batch is None:
                 try:
                     batch = batch_deque.popleft()
                 except IndexError:
+                    if self._aborted():
+                        return
                     time.sleep(self.THREAD_SLEEP_INTERVAL)
-            slot = batch.get('slot')
-            if slot is not None:              # already in pinned memory (_fill_batch's fast path)
-                with torch.cuda.stream(copy_stream):
-                    f_dev = slot[0].to(dev, non_blocking=True)
-                    l_dev = slot[1].to(dev, non_blocking=True)
-                    ready = torch.cuda.Event()
-                    ready.record(copy_stream)
-                slot[2] = ready
-            else:
-                fr = batch['frames']
-                fr = fr if fr.dtype == np.uint8 else fr.astype(np.float32)
-                lb = batch['labels']
-                if lb.dtype != np.uint8:
-                    li = lb.astype(np.float32).astype(np.int64)
-                    lb = np.where((li >= 0) & (li < 255), li, 255).astype(np.uint8)
-                with torch.cuda.stream(copy_stream):
-                    f_dev = torch.from_numpy(np.ascontiguousarray(fr)).pin_memory().to(dev, non_blocking=True)
-                    l_dev = torch.from_numpy(np.ascontiguousarray(lb)).pin_memory().to(dev, non_blocking=True)
-                    ready = torch.cuda.Event()
-                    ready.record(copy_stream)
-            while len(signal_deque) >= 200:
+            staged = self._stage_batch(batch, copy_stream)
+            if max_staged is None:
+                # the reference's FIFO queue holds 200 batches whatever their size (3 GB of device memory at batch 10 of 512x1024): here the
+                # staged-ahead set is bounded by BYTES — 1 GiB, at least two batches, at most the reference's 200 entries
+                nbytes = sum(int(t.numel()) * t.element_size() for t in staged[:2])
+                max_staged = max(2, min(200, (1 << 30) // max(nbytes, 1)))
+            while len(signal_deque) >= max_staged:
+                if self._aborted():
+                    return
                 time.sleep(self.THREAD_SLEEP_INTERVAL)
-            signal_deque.append((f_dev, l_dev, ready))
+            signal_deque.append(staged)
+
+    def _make_copy_stream(self):
+        return torch.cuda.Stream(device=self.engine.device)
+
+    def _stage_batch(self, batch, copy_stream):
+        """Host batch -> (frames on the device, labels on the device, event of the copies) on the copy stream."""
+        dev = self.engine.device
+        slot = batch.get('slot')
+        if slot is not None:              # already in pinned memory (_fill_batch's fast path)
+            with torch.cuda.stream(copy_stream):
+                f_dev = slot[0].to(dev, non_blocking=True)
+                l_dev = slot[1].to(dev, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+            slot[2] = ready
+        else:
+            fr = batch['frames']
+            fr = fr if fr.dtype == np.uint8 else fr.astype(np.float32)
+            lb = batch['labels']
+            if lb.dtype != np.uint8:
+                li = lb.astype(np.float32).astype(np.int64)
+                lb = np.where((li >= 0) & (li < 255), li, 255).astype(np.uint8)
+            with torch.cuda.stream(copy_stream):
+                f_dev = torch.from_numpy(np.ascontiguousarray(fr)).pin_memory().to(dev, non_blocking=True)
+                l_dev = torch.from_numpy(np.ascontiguousarray(lb)).pin_memory().to(dev, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+        return f_dev, l_dev, ready
 
     # ------------------------------------------------------------------ freeze / export
     def get_frozen_graph(self):

@@ -226,9 +226,10 @@ enum { AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRA
                                         bit-identical to 0 = the pass written (bn_act).  The same move for dz = A dy + B + C z of the project and the
                                         stride-16 expand layers (x_mode / dy_mode 2, kept at kernel level: ams_k_pointwise_xform) measured SLOWER in
                                         the step on MI355X (8.31 -> 8.64 / 8.87 ms: those GEMMs are bound by their operand path) and is not wired in. */,
-       AMS_OPT_NAN_GRADS = 18 /* fine-tune step on a batch WITHOUT a valid pixel: 1 (default) the reference's result — loss = 0 / 0 and every gradient
-                                  NaN (utils/graph_utils.py:408: sum(w ce) / sum(w)), so the Adam update poisons the masked parameters exactly as
-                                  TensorFlow's would; 0 = NaN loss but zero gradients (the weights survive) */,
+       AMS_OPT_NAN_GRADS = 18 /* fine-tune step on a batch WITHOUT a valid pixel: 0 (default) the reference's result — NaN loss (utils/graph_utils.py:408:
+                                  tf.reduce_mean over the empty tf.boolean_mask) and ZERO gradients (the backward of that mean over a [0]-shaped tensor is
+                                  empty, boolean_mask's gather gradient densifies it to zeros): parameters, Adam moments and BN statistics stay finite;
+                                  1 = every gradient NaN instead, for callers who want such a batch to fail loudly */,
        AMS_OPT_OVERLAP_WGRAD = 19 /* fine-tune step: 1 (default) weight gradients on a side stream beside the input-gradient chain, 2 depthwise ones on a
                                      third stream (measured slower), 3 hand-overs alternate between two side streams (measured slower: 8.14 vs 7.98 ms),
                                      0 everything on the caller's stream.  Same bits */,

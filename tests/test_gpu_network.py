@@ -54,7 +54,8 @@ def _check_labels(got, oracle_logits_sel, tol):
 @pytest.mark.parametrize("H,B,matmul", [(64, 2, hip.MATMUL_F32), (48, 3, hip.MATMUL_F32), (64, 2, hip.MATMUL_SPLIT_BF16),
                                         (128, 2, hip.MATMUL_SPLIT_BF16), (64, 2, hip.MATMUL_SPLIT_BF16_X6),
                                         (128, 3, hip.MATMUL_SPLIT_BF16_X6), (62, 3, hip.MATMUL_SPLIT_BF16_X6), (34, 5, hip.MATMUL_SPLIT_BF16_X6),
-                                        (50, 1, hip.MATMUL_SPLIT_BF16_X6)])
+                                        (50, 1, hip.MATMUL_SPLIT_BF16_X6), (64, 2, hip.MATMUL_SPLIT_F16), (128, 3, hip.MATMUL_SPLIT_F16),
+                                        (62, 3, hip.MATMUL_SPLIT_F16), (34, 5, hip.MATMUL_SPLIT_F16), (50, 1, hip.MATMUL_SPLIT_F16)])
 def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     frames, labels = synth.SyntheticVideo(H, B, CI, seed=3).clip()
     eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
@@ -391,6 +392,37 @@ def test_masked_step_reverts_weights_but_advances_moments(W0, clip64):
     changed = (after != b)
     assert changed[mask == 1].mean() > 0.9
     assert (eng.adam_m.cpu().numpy() != 0).mean() > 0.9
+    eng.close()
+
+
+@pytest.mark.parametrize("nan_grads", [False, True])
+def test_batch_without_a_valid_pixel(W0, clip64, nan_grads):
+    """utils/graph_utils.py:408 on a batch whose every teacher label is ignored (255): tf.reduce_mean over the empty tf.boolean_mask is NaN, but
+    its backward is an empty tensor that the mask's gather gradient densifies to zeros — TensorFlow's step leaves NaN loss and ZERO gradients.
+    Default: exactly that (weights, Adam moments, moving statistics finite, and the next ordinary step trains); AMS_OPT_NAN_GRADS = 1 turns
+    the gradients into NaN for callers that want such a batch to fail loudly."""
+    frames, labels = clip64
+    B = 2
+    eng = StudentEngine(CI, 64, 128, max_batch=B, trainable=True)
+    eng.load_variables(W0)
+    if nan_grads:
+        eng.set_nan_grads(True)
+    before = eng.params.clone()
+    ls = eng.train_step(frames[:B], np.full_like(labels[:B], 255), 1e-3).cpu().numpy()
+    assert ls[1] == 0                                               # no valid pixel: the API's loss is sum / count = NaN (semantic_network.py)
+    g = eng.grads.cpu().numpy()
+    if nan_grads:
+        assert np.isnan(g).any()
+        eng.close()
+        return
+    assert np.isfinite(g).all() and not g.any()                     # zero gradients everywhere, BN parameters included
+    assert torch.isfinite(eng.params).all() and torch.isfinite(eng.adam_m).all() and torch.isfinite(eng.adam_v).all()
+    assert torch.isfinite(eng.stats).all()
+    # Adam with g = 0 from zero moments: m = v = 0, step = 0 / (0 + eps) = 0 — the weights do not move at all
+    assert torch.equal(eng.params, before)
+    ls = eng.train_step(frames[:B], labels[:B], 1e-3).cpu().numpy()          # ... and the student still trains afterwards
+    assert ls[1] > 0 and np.isfinite(ls[0])
+    assert torch.isfinite(eng.params).all() and not torch.equal(eng.params, before)
     eng.close()
 
 

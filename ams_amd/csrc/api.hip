@@ -130,6 +130,7 @@ int ams_student_freeze(ams_student* s, void* stream) {
     }
     if (s->L[1].whi)        // stem: [27][32] -> parts [32][32], k = tap * 3 + channel
         RUN(launch_split_weights3(s->fparams + s->L[1].d.w_off, 32, 1, 27, 32, 32, s->L[1].whi, s->L[1].wlo, s->L[1].wlo3, st));
+    if (s->L[1].whf) RUN(launch_split_weights_f16(s->fparams + s->L[1].d.w_off, 32, 1, 27, 32, 32, s->L[1].whf, s->L[1].whf + 32 * 32, st));
     for (int i = 2; i <= s->cfg.n_layers; ++i) {
         LayerRt& l = s->L[i];
         if (!l.whi) continue;
@@ -411,7 +412,7 @@ int ams_k_pointwise_split_f16(const float* x, int64_t M, int32_t K, const float*
     a.scale = scale; a.shift = shift; a.act = act; a.res = res; a.ldr = N;
     if (scale && !shift) { set_error("pointwise_split_f16: scale without shift"); return AMS_E_INVALID; }
     if (x_h2i) {                                   // the operand as fp16 pairs, as the streaming expand + depthwise kernels leave it
-        RUN(launch_pack_h2i(x, M, K, x_h2i, st));
+        if (x_h2i != x) RUN(launch_pack_h2i(x, M, K, x_h2i, st));      // x_h2i == x: x IS the packed operand already (tools/bench_kernel.py)
         a.x = x_h2i; a.x_fmt = 1;
     }
     if (y_parts) {                                 // the result also as two fp16 part planes [2][M][N] (the next block's operand)

@@ -82,10 +82,12 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
                                                         l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
                                                         lj.fshift, lj.d.act, cur, st, l.blk_vecs));
             else {
-                const bool x6 = s->block_x6 && s->matmul_mode != AMS_MATMUL_F32 && l.whi;
+                const bool h16 = s->block_x6 && s->matmul_mode == AMS_MATMUL_SPLIT_F16 && l.whf && lj.whf && lj.Kp == 32;
+                const bool x6 = !h16 && s->block_x6 && s->matmul_mode != AMS_MATMUL_F32 && l.whi;
                 RUNK(3, bytes, launch_first_block(frames, dtype, B, c.height, c.width, c.pixel_scale, P + l.d.w_off, l.fscale, l.fshift,
                                                   l.d.act, P + ld.d.w_off, ld.fscale, ld.fshift, ld.d.act, P + lj.d.w_off, lj.fscale,
-                                                  lj.fshift, lj.d.act, cur, st, x6 ? l.whi : nullptr, 32 * 32));
+                                                  lj.fshift, lj.d.act, cur, st, x6 ? l.whi : nullptr, 32 * 32, h16 ? l.whf : nullptr, 32 * 32,
+                                                  h16 ? lj.whf : nullptr, (int64_t)lj.d.cout * lj.Kp));
             }
             i = 4;
         } else {

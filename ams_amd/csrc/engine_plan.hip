@@ -127,6 +127,7 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
         l1.whi = cv.take<uint16_t>(3 * 32 * 32);
         l1.wlo = l1.whi ? l1.whi + 32 * 32 : nullptr;
         l1.wlo3 = l1.whi ? l1.whi + 2 * 32 * 32 : nullptr;
+        l1.whf = cv.take<uint16_t>(2 * 32 * 32);           // ... and as two fp16 parts
     }
     for (int i = 2; i + 2 <= s->n_backbone; ++i) {      // whole-block kernels: packed per-channel tables, filled by freeze
         LayerRt& l = s->L[i];

@@ -33,6 +33,10 @@ struct FirstBlockArgs {
     int tiles_x, tiles_y;
     const uint16_t* w_parts;                // X6 form: stem weights as three bf16 parts [part][32 channels][32 k], parts w_plane apart
     int64_t w_plane;
+    // H16 form (AMS_MATMUL_SPLIT_F16): stem and project products on two fp16 parts (hi | lo 2^11, split_bf16.hpp), 3 MFMAs of 16x16x32 each:
+    // hs = the stem's panels [part][32 channels][32 k], hj = the project layer's [part][16 channels][32 k]
+    const uint16_t* hs; int64_t hs_plane;
+    const uint16_t* hj; int64_t hj_plane;
 };
 
 // X6 form: index into the normalisation table of the tap (0..255 the byte, 256 the 127.5 padding row / column, 257 = zero: outside)
@@ -63,9 +67,13 @@ __device__ __forceinline__ float fb_frame_value(const TIn* img, int H, int W, in
 // and the zero outside the padded frame), so the three parts of x * ps - 1 come from a 258-entry LDS table built per block: a tap
 // costs one byte load, one shift and one ds_read_b64 instead of convert + multiply + subtract + split.  Not bit-identical to the
 // exact-f32 stem (f32-level: the dropped terms are <= 2^-24 relative).
-template <typename TIn, bool X6 = false>
+// H16: the same with two fp16 parts: the table entry of a byte is ONE dword (hi | lo << 16: a tap = byte load + ds_read_b32 + a share of two
+// v_perm), three MFMAs per 16 channels, and the project layer's products likewise (the depthwise result is in [0, 6]).
+template <typename TIn, bool X6 = false, bool H16 = false>
 __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsigned nblocks) {
-    constexpr bool TAB = X6 && sizeof(TIn) == 1;      // float frames: the same parts by splitting in registers (same bits, more VALU)
+    static_assert(!(X6 && H16), "one split form at a time");
+    constexpr bool SPL = X6 || H16;                   // the lane's taps are k = 8q .. 8q + 7 (one 16x16x32 MFMA per product)
+    constexpr bool TAB = SPL && sizeof(TIn) == 1;     // float frames: the same parts by splitting in registers (same bits, more VALU)
     constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
     constexpr int NRG = (NPIX + 15) / 16;             // 12 row groups of stem positions
     constexpr int P = 36;                             // pitch of the 32-channel rows (stride 144 B: conflict-free b128 passes)
@@ -76,7 +84,8 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     __shared__ __attribute__((aligned(16))) float sDw[9 * 32];
     __shared__ __attribute__((aligned(16))) float sWp[32 * PW];
     __shared__ __attribute__((aligned(16))) float sAff[32 * 4 + 16 * 2];      // sc_s, sh_s, sc_d, sh_d, sc_p, sh_p
-    __shared__ __attribute__((aligned(8))) uint2 sTab[TAB ? 258 : 1];          // X6: {hi | mid << 16, lo} bf16 parts of the normalised value
+    __shared__ __attribute__((aligned(8))) uint2 sTab[(TAB && X6) ? 258 : 1];   // X6: {hi | mid << 16, lo} bf16 parts of the normalised value
+    __shared__ unsigned sTabH[(TAB && H16) ? 258 : 1];                          // H16: hi | lo << 16, fp16 parts
 
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
     const int tx = lb % a.tiles_x;
@@ -93,18 +102,25 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
         for (int e = tid; e < 258; e += 256) {
             const float raw = e < 256 ? (float)e : 127.5f;
             const float val = e < 257 ? __fsub_rn(__fmul_rn(raw, a.ps), 1.0f) : 0.f;
-            unsigned h, m, l;
-            split_pair(val, 0.f, h, m, l);
-            sTab[e] = make_uint2((h & 0xffffu) | (m << 16), l & 0xffffu);
+            if constexpr (H16) {
+                unsigned short h, l;
+                split1_f16(val, h, l);
+                sTabH[e] = (unsigned)h | ((unsigned)l << 16);
+            } else {
+                unsigned h, m, l;
+                split_pair(val, 0.f, h, m, l);
+                sTab[e] = make_uint2((h & 0xffffu) | (m << 16), l & 0xffffu);
+            }
         }
-    } else if constexpr (!X6) {
+    } else if constexpr (!SPL) {
         for (int e = tid; e < 28 * 32; e += 256) {
             const int kk = e >> 5, nn = e & 31;
             sW[kk * P + nn] = kk < 27 ? a.w_stem[kk * 32 + nn] : 0.f;
         }
     }
     for (int e = tid; e < 9 * 32; e += 256) sDw[e] = a.w_dw[e];
-    for (int e = tid; e < 32 * 16; e += 256) sWp[(e >> 4) * PW + (e & 15)] = a.w_pj[e];
+    if constexpr (!H16)
+        for (int e = tid; e < 32 * 16; e += 256) sWp[(e >> 4) * PW + (e & 15)] = a.w_pj[e];
     if (tid < 32) {
         sAff[tid] = a.sc_s[tid]; sAff[32 + tid] = a.sh_s[tid]; sAff[64 + tid] = a.sc_d[tid]; sAff[96 + tid] = a.sh_d[tid];
     } else if (tid < 48) {
@@ -115,7 +131,7 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     int tdy[8], tdx[8], tch[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int k = X6 ? 8 * q + u : 16 * (u >> 2) + 4 * q + (u & 3);      // X6: one bf16 MFMA covers k = 8q .. 8q + 7
+        const int k = SPL ? 8 * q + u : 16 * (u >> 2) + 4 * q + (u & 3);     // split forms: one 16x16x32 MFMA covers k = 8q .. 8q + 7
         const int tap = k / 3;
         tch[u] = k < 27 ? k - tap * 3 : -1;
         tdy[u] = tap / 3;
@@ -126,6 +142,14 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     float v[TAB ? 1 : MRG][8];
     int vi[TAB ? MRG : 1][8];                         // table form: table indices of the taps
     bool live[MRG];
+    u32x4 wh[2][2];                                   // H16: the same as fp16 parts [t][hi | lo]
+    if constexpr (H16) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+                wh[t][pp] = *reinterpret_cast<const u32x4*>(a.hs + pp * a.hs_plane + (int64_t)(16 * t + l15) * 32 + 8 * q);
+    }
     bf16x8 wq[2][3];                                  // X6: this lane's stem-weight fragments (channel 16 t + l15, k = 8q .. 8q + 7), three parts
     if constexpr (X6) {
 #pragma unroll
@@ -195,7 +219,32 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
             f32x4 acc[2];
             acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (X6) {
+            if constexpr (H16) {
+                unsigned e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if constexpr (TAB) e[u] = sTabH[vi[i][u]];
+                    else {
+                        unsigned short h, l;
+                        split1_f16(v[i][u], h, l);
+                        e[u] = (unsigned)h | ((unsigned)l << 16);
+                    }
+                }
+                u32x4 xh, xl;                                              // the lane's 8 taps: element u of the hi / lo part
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    xh[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);
+                    xl[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {                              // cross terms in their own accumulator, then the main term (k_pw_f16.hip)
+                    f32x4 accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[t][1]), __builtin_bit_cast(f16x8, xh), accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[t][0]), __builtin_bit_cast(f16x8, xl), accx, 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[t][0]), __builtin_bit_cast(f16x8, xh), acc[t], 0, 0, 0);
+                    acc[t] = combine_f16(acc[t], accx);
+                }
+            } else if constexpr (X6) {
                 uint2 e[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -296,6 +345,18 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     for (int i = 0; i < 2; ++i) {
         const int row = 2 * wave + i;
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (H16) {                           // k = 8q .. 8q + 7 of pixel l15: one 16x16x32 MFMA per product
+            const float* dp = sD + (row * TW + l15) * P + 8 * q;
+            f16x8 dh, dl;
+            split8_f16(ld4(dp), ld4(dp + 4), dh, dl);
+            const f16x8 jh = *reinterpret_cast<const f16x8*>(a.hj + (int64_t)l15 * 32 + 8 * q);
+            const f16x8 jl = *reinterpret_cast<const f16x8*>(a.hj + a.hj_plane + (int64_t)l15 * 32 + 8 * q);
+            f32x4 accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(jl, dh, accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(jh, dl, accx, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(jh, dh, acc, 0, 0, 0);
+            acc = combine_f16(acc, accx);
+        } else
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4 x4 = ld4(sD + (row * TW + l15) * P + 16 * c + 4 * q);
@@ -318,7 +379,7 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
 int launch_first_block(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem,
                        const float* sc_s, const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d,
                        int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st,
-                       const uint16_t* w_parts, int64_t w_plane) {
+                       const uint16_t* w_parts, int64_t w_plane, const uint16_t* h_stem, int64_t h_stem_plane, const uint16_t* h_pj, int64_t h_pj_plane) {
     AMS_REQUIRE(dtype == AMS_DT_U8 || dtype == AMS_DT_F32, "first_block: frames must be uint8 or float32");
     FirstBlockArgs a;
     memset(&a, 0, sizeof(a));
@@ -333,6 +394,14 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
     a.tiles_y = cdiv(a.Ho, 8);
     const int64_t nblocks = (int64_t)a.tiles_x * a.tiles_y * B;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "first_block: bad grid");
+    if (h_stem && h_pj) {                           // two fp16 parts in the stem and the project layer (takes precedence over w_parts)
+        a.hs = h_stem; a.hs_plane = h_stem_plane; a.hj = h_pj; a.hj_plane = h_pj_plane;
+        note_kernel(dtype == AMS_DT_U8 ? "first_block_kernel<unsigned char, false, true>" : "first_block_kernel<float, false, true>");
+        if (dtype == AMS_DT_U8) hipLaunchKernelGGL((first_block_kernel<uint8_t, false, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
+        else hipLaunchKernelGGL((first_block_kernel<float, false, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
+        AMS_CHECK_LAUNCH();
+        return AMS_OK;
+    }
     if (w_parts) {                                  // three-part split products in the stem (see the kernel)
         note_kernel(dtype == AMS_DT_U8 ? "first_block_kernel<unsigned char, true>" : "first_block_kernel<float, true>");
         if (dtype == AMS_DT_U8) hipLaunchKernelGGL((first_block_kernel<uint8_t, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);

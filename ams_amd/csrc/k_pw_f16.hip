@@ -65,20 +65,29 @@ __device__ __forceinline__ f32x4 mma_f16(const u32x4& a, const u32x4& b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-constexpr int pwh_waves(int rm, int nt) { return rm * nt > 12 ? 1 : rm * nt > 6 ? 2 : 3; }
+constexpr int pwh_waves(int rm, int nt, int nw) { return nw == 12 ? 3 : nw == 8 ? 2 : rm * nt > 12 ? 1 : rm * nt > 6 ? 2 : 3; }
 
 // Same frame as pw_gemm_bf16x3_l (64 RM x 16 NT tiles, four waves with RM row groups each, weight stages double-buffered in XOR-swizzled
 // 64-byte LDS rows, operand ring of depth 2 in registers, all loads unconditional, half-height tail blocks) with NP = 2 and two
 // accumulators per tile.
-template <int RM, int NT, int EPI, int XP>
-__global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane, int Kp,
-                                                                          int n_tiles_n, unsigned nblocks, unsigned n_full) {
-    constexpr int D = 2, NP = 2;
+// NW waves per block (4 | 8 | 12), each with its own 16 RM rows: a block's weight stages are staged once for all of them — with three
+// 4-wave blocks per CU every stage of the panel crosses the L2 -> CU fabric three times, and at K = 960 x N = 160 the panels re-staged
+// by 1074 blocks are MORE bytes than the activations (330 MB against 264).  D = stages of operands in flight per lane.
+// ABL: measurement-only ablations (tools/sweep_pwh_abl.sh; wrong results): 1 no activation loads in the loop, 2 no weight loads / LDS stores,
+// 4 no barrier, 8 no MFMAs
+template <int RM, int NT, int EPI, int XP, int NW = 4, int D = 2, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane, int Kp,
+                                                                                  int n_tiles_n, unsigned nblocks, unsigned n_full) {
+    constexpr int NP = 2, NTH = 64 * NW;
     constexpr int PITCH = 32;
     constexpr int ROWS = 16 * NT;
     constexpr int NPIECE = NP * ROWS * 4;
-    constexpr int NREG = (NPIECE + 255) / 256;
-    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = (EPI == EPI_GENERIC ? 4 : 4 * 16 * (16 * NT + 4)) * 4;
+    constexpr int NREG = (NPIECE + NTH - 1) / NTH;
+    // the epilogue's per-wave slabs share the weight stages' LDS; when NW of them would pass 60 KB the waves take turns, EPW at a time
+    constexpr int SLAB = 16 * (16 * NT + 4) * 4;
+    constexpr int EPW = (EPI == EPI_GENERIC || NW * SLAB <= 60 * 1024) ? NW : 4;
+    static_assert(NW % EPW == 0, "epilogue rounds");
+    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = EPI == EPI_GENERIC ? 16 : EPW * SLAB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES > OUT_BYTES ? W_BYTES : OUT_BYTES];
     typedef unsigned short (*WStage)[NP][ROWS * PITCH];
     WStage sW = reinterpret_cast<WStage>(smem);
@@ -91,8 +100,8 @@ __global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int n0 = tile_n * ROWS;
     const int nrg = half ? RM / 2 : RM;
-    const int64_t m_base = half ? (int64_t)(n_full / n_tiles_n) * (64 * RM) + tile_m * (32 * RM) + wave * (8 * RM)
-                                : tile_m * (64 * RM) + wave * (16 * RM);
+    const int64_t m_base = half ? (int64_t)(n_full / n_tiles_n) * (16 * NW * RM) + tile_m * (8 * NW * RM) + wave * (8 * RM)
+                                : tile_m * (16 * NW * RM) + wave * (16 * RM);
     const int K = a.K, n_stages = Kp / 32;
     const int n_iter = (n_stages + D - 1) / D * D;
 
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs
     int wdst[NREG];
 #pragma unroll
     for (int u = 0; u < NREG; ++u) {
-        const int e = tid + u * 256 < NPIECE ? tid + u * 256 : NPIECE - 1;
+        const int e = tid + u * NTH < NPIECE ? tid + u * NTH : NPIECE - 1;
         const int which = e / (ROWS * 4), r = e - which * (ROWS * 4), n = r >> 2, part = r & 3;
         int nn = n0 + n;
         if (nn > a.N - 1) nn = a.N - 1;
@@ -141,14 +150,18 @@ __global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs
     typedef std::integral_constant<int, RM> RFull;
     typedef std::integral_constant<int, (RM >= 2 ? RM / 2 : RM)> RHalf;
     load_stage(0, wring[0]);
-    load_a(0, abuf[0], RFull{});
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        if (d > 0) load_stage(d, wring[d]);
+        load_a(d, abuf[d], RFull{});
+    }
     f32x4 acc[RM][NT], accx[RM][NT];
 #pragma unroll
     for (int r = 0; r < RM; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) { acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    pw_stage_affine<NT>(a, sSc, sSh, n0, tid, 256);
+    pw_stage_affine<NT>(a, sSc, sSh, n0, tid, NTH);
     store_stage(0, wring[0]);
     __syncthreads();
     auto main_loop = [&](auto Rc) {
@@ -157,8 +170,8 @@ __global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int s = s0 + d;
-                load_stage(s + 1, wring[(d + 1) % D]);
-                load_a(s + 1, abuf[(d + 1) % D], Rc);
+                if constexpr (!(ABL & 2)) load_stage(s + D - 1, wring[(d + D - 1) % D]);
+                if constexpr (!(ABL & 1)) load_a(s + D - 1, abuf[(d + D - 1) % D], Rc);
                 if (s < n_stages) {
                     u32x4 xh[RM], xl[RM];
 #pragma unroll
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs
                             xl[r] = __builtin_bit_cast(u32x4, l);
                         }
                     }
-                    const unsigned short* bw = &sW[d & 1][0][l15 * PITCH + 8 * (q ^ ((l15 >> 3) << 1))];
+                    const unsigned short* bw = &sW[s & 1][0][l15 * PITCH + 8 * (q ^ ((l15 >> 3) << 1))];      // LDS stages alternate with s (D may be odd)
                     constexpr int TG = (NT >= 2 && RM <= 2) ? 2 : 1;
 #pragma unroll
                     for (int t0 = 0; t0 < NT; t0 += TG) {
@@ -189,21 +202,25 @@ __global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs
                         for (int g = 0; g < TG; ++g)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-                                if (t0 + g < NT) accx[r][t0 + g] = mma_f16(ql[g], xh[r], accx[r][t0 + g]);
+                                if (t0 + g < NT && !(ABL & 8)) accx[r][t0 + g] = mma_f16(ql[g], xh[r], accx[r][t0 + g]);
 #pragma unroll
                         for (int g = 0; g < TG; ++g)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-                                if (t0 + g < NT) accx[r][t0 + g] = mma_f16(qh[g], xl[r], accx[r][t0 + g]);
+                                if (t0 + g < NT && !(ABL & 8)) accx[r][t0 + g] = mma_f16(qh[g], xl[r], accx[r][t0 + g]);
 #pragma unroll
                         for (int g = 0; g < TG; ++g)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-                                if (t0 + g < NT) acc[r][t0 + g] = mma_f16(qh[g], xh[r], acc[r][t0 + g]);
+                                if (t0 + g < NT && !(ABL & 8)) acc[r][t0 + g] = mma_f16(qh[g], xh[r], acc[r][t0 + g]);
+                        if constexpr ((ABL & 8) != 0) {      // keep the fragment reads alive
+#pragma unroll
+                            for (int g = 0; g < TG; ++g) if (t0 + g < NT) { acc[0][t0 + g][0] += __uint_as_float(qh[g][0] ^ ql[g][1]); acc[0][t0 + g][1] += __uint_as_float(xh[0][0] ^ xl[RM - 1][1]); }
+                        }
                     }
                 }
-                store_stage((d + 1) & 1, wring[(d + 1) % D]);
-                __syncthreads();
+                if constexpr (!(ABL & 2)) store_stage((s + 1) & 1, wring[(d + 1) % D]);
+                if constexpr (!(ABL & 4)) __syncthreads();
             }
         }
     };
@@ -214,23 +231,30 @@ __global__ __launch_bounds__(256, pwh_waves(RM, NT)) void pw_gemm_f16x3_l(PwArgs
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = combine_f16(acc[r][t], accx[r][t]);
     if (EPI == EPI_GENERIC) pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q, sSc, sSh, nrg);
-    else pw_epilogue_t<RM, NT, EPI, true>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)), nrg);
+    else if constexpr (EPW == NW) pw_epilogue_t<RM, NT, EPI, true>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)), nrg);
+    else {
+        for (int round = 0; round < NW / EPW; ++round) {            // block-uniform
+            if (wave / EPW == round) pw_epilogue_t<RM, NT, EPI, true>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + (wave % EPW) * (16 * (16 * NT + 4)), nrg);
+            __syncthreads();
+        }
+    }
 }
 
-template <int RM, int NT, int EPI, int XP>
+template <int RM, int NT, int EPI, int XP, int NW = 4, int D = 2, int ABL = 0>
 static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     int per_cu = 1, cus = 256;
-    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP>, 256, 0, &per_cu));
+    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL>, 64 * NW, 0, &per_cu));
     RUN_RC(device_cus(&cus));
     int64_t half_strips = 0;
-    const int64_t full_strips = pw_plan_tail(a.M, RM, n_tiles_n, per_cu * cus, &half_strips);
+    const int64_t full_strips = pw_plan_tail(a.M, RM, n_tiles_n, per_cu * cus, &half_strips, 16 * NW * RM);
     const int64_t n_full = full_strips * n_tiles_n;
     const int64_t nblocks = n_full + half_strips * n_tiles_n;
-    static const std::string nm = "pw_gemm_f16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(XP) + ">";
+    static const std::string nm = "pw_gemm_f16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(XP) +
+                                  (NW != 4 || D != 2 ? ", " + std::to_string(NW) + ", " + std::to_string(D) : std::string()) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP>), dim3((unsigned)nblocks), dim3(256), 0, st, a, w, plane, Kp, n_tiles_n, (unsigned)nblocks,
-                       (unsigned)n_full);
+    hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL>), dim3((unsigned)nblocks), dim3(64 * NW), 0, st, a, w, plane, Kp, n_tiles_n,
+                       (unsigned)nblocks, (unsigned)n_full);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -238,6 +262,31 @@ static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, in
 template <int RM, int NT>
 static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
     const int epi = pw_pick_epi(a);
+    if constexpr (RM == 2 && NT == 5) {                    // MEASUREMENT ONLY (AMS_PWH_ABL=<bits>, wrong results): what the stage loop is made of
+        const int abl = knobs().pwh_abl;
+        if (abl && a.x_fmt == 1) {
+#define PWH_A(A_) if (abl == A_) return launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, 4, 2, A_>(a, w, plane, Kp, st);
+            PWH_A(1) PWH_A(2) PWH_A(3) PWH_A(4) PWH_A(6) PWH_A(7) PWH_A(8) PWH_A(9) PWH_A(10) PWH_A(11) PWH_A(15)
+#undef PWH_A
+        }
+    }
+    if constexpr (NT == 10 && RM <= 2) {                   // full-width 160-column tiles (the operand crosses L2 -> CU once), 8- / 12-wave blocks
+        int nw = knobs().pwh_nw, dd = knobs().pwh_d;
+        if (!knobs().pwh_set && RM == 1) { nw = 12; dd = 3; }      // what launch_pointwise_split_f16 picks the (1, 10) tile for
+        if (a.x_fmt == 1 && (epi == EPI_PLAIN || epi == EPI_RES) && (nw > 4 || dd > 2)) {
+#define PWH_V(NW_, D_) if (nw == NW_ && dd == D_) return epi == EPI_PLAIN ? launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, NW_, D_>(a, w, plane, Kp, st) : launch_pw_f16_d<RM, NT, EPI_RES, 1, NW_, D_>(a, w, plane, Kp, st);
+            PWH_V(8, 2) PWH_V(12, 2) PWH_V(8, 3) PWH_V(12, 3)
+#undef PWH_V
+        }
+    }
+    if constexpr (RM == 2 && (NT == 5 || NT == 4)) {       // EXPERIMENT (AMS_PWH_VARIANT=<waves>,<depth>): wider blocks / deeper operand rings
+        const int nw = knobs().pwh_nw, dd = knobs().pwh_d;
+        if (a.x_fmt == 1 && (epi == EPI_PLAIN || epi == EPI_RES) && (nw > 4 || dd > 2)) {
+#define PWH_V(NW_, D_) if (nw == NW_ && dd == D_) return epi == EPI_PLAIN ? launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, NW_, D_>(a, w, plane, Kp, st) : launch_pw_f16_d<RM, NT, EPI_RES, 1, NW_, D_>(a, w, plane, Kp, st);
+            PWH_V(4, 3) PWH_V(4, 4) PWH_V(8, 2) PWH_V(8, 3) PWH_V(12, 2) PWH_V(12, 3)
+#undef PWH_V
+        }
+    }
     if (a.x_fmt == 1) {
         switch (epi) {
             case EPI_PLAIN: return launch_pw_f16_d<RM, NT, EPI_PLAIN, 1>(a, w, plane, Kp, st);
@@ -269,11 +318,19 @@ int launch_pointwise_split_f16(const PwArgs& a, const uint16_t* whi, int64_t pla
         else if (a.N == 320) nt = 5;
     }
     if (a.M <= 2400 && rm == 1 && a.N % 32 == 0 && a.N >= 64) nt = 2;          // one frame per call: as launch_pointwise_parts
+    // 160 / 320 columns fed with fp16 pairs (the project layers behind the 576- and 960-channel depthwise results), many rows: ONE pass over
+    // the operand per 160 columns in 12-wave blocks of 16 rows per wave, three operand stages in flight (tools/sweep_pwh_wide.sh at 68640 rows:
+    // 960 -> 160 116 us against 139 for 128 x 80 tiles in 4-wave blocks, 576 -> 160 65 / 70, 960 -> 320 179 / 226).  What the stage loop is made
+    // of (tools/sweep_pwh_abl.sh, 138 us as built): without the activation loads 68, without the weight loads 98, without either 50, without
+    // MFMAs 110 — the loads do not hide behind the MFMAs, and the weight panels re-staged by every 4-wave block (330 MB at 960 x 160) weigh
+    // more than the activations (264 MB): wider blocks stage them once for three times the rows, full-width tiles read the activations once
+    const int epi0 = pw_pick_epi(a);
+    if (a.x_fmt == 1 && a.N % 160 == 0 && a.M >= 16384 && (epi0 == EPI_PLAIN || epi0 == EPI_RES)) { rm = 1; nt = 10; }
     if (knobs().pwx_rm > 0) { rm = knobs().pwx_rm; nt = knobs().pwx_nt; }
 #define PW_H(RM_, NT_) if (rm == RM_ && nt == NT_) return launch_pw_f16<RM_, NT_>(a, whi, plane, Kp, st);
     PW_H(2, 6) PW_H(2, 5) PW_H(2, 4) PW_H(2, 3) PW_H(2, 2) PW_H(2, 1)
     PW_H(1, 6) PW_H(1, 5) PW_H(1, 4) PW_H(1, 3) PW_H(1, 2) PW_H(1, 1)
-    PW_H(2, 8) PW_H(2, 10) PW_H(4, 4) PW_H(4, 3)
+    PW_H(2, 8) PW_H(2, 10) PW_H(1, 10) PW_H(4, 4) PW_H(4, 3)
 #undef PW_H
     set_error("pointwise_split_f16: no tile configuration");
     return AMS_E_INVALID;

@@ -21,6 +21,8 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     int pw_percu = 0;                            // AMS_PW_PERCU
     bool pwx_no_tail = false;                    // AMS_PWX_NO_TAIL
     int pwx_rm = 0, pwx_nt = 0;                  // AMS_PWX_FORCE=<RM>,<NT>
+    int pwh_abl = 0;                             // AMS_PWH_ABL=<bits>: measurement-only ablations of the fp16 GEMM's stage loop (wrong results)
+    bool pwh_set = false; int pwh_nw = 4, pwh_d = 2;                   // AMS_PWH_VARIANT=<waves per block>,<operand stages in flight>: experiment switch of the fp16 GEMM
     bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE
     bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
     bool wg6_eight_waves = false;                // AMS_WG6_EIGHT_WAVES: the wide tiles of the six-product weight gradient with eight waves, split 4 (k) x 2 (n)
@@ -143,7 +145,10 @@ int launch_pointwise_wgrad(const WgArgs& a, hipStream_t st);
 int launch_first_block(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem,
                        const float* sc_s, const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d,
                        int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st,
-                       const uint16_t* w_parts = nullptr, int64_t w_plane = 0);
+                       const uint16_t* w_parts = nullptr, int64_t w_plane = 0, const uint16_t* h_stem = nullptr, int64_t h_stem_plane = 0,
+                       const uint16_t* h_pj = nullptr, int64_t h_pj_plane = 0);
+// h_stem / h_pj: optional fp16 panels (hi | lo 2^11) of the stem [part][32][32] and of the project layer [part][16][32]: with both, the stem's and
+// the project layer's products run as 3 fp16 MFMAs each (AMS_MATMUL_SPLIT_F16; takes precedence over w_parts)
 // w_parts: optional three-part bf16 panels [part][32][32] of the stem weights (k = tap * 3 + channel, zero-padded 27 -> 32): with them and
 // uint8 frames the stem's products run as six bf16 MFMAs, operands from a 258-entry table of the normalised byte values (f32-level)
 

@@ -136,26 +136,33 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float4 rv[NT];
+        // wide tiles (NT > 6) take the slab in two halves: the residual operands of a whole 160-column row group are 40 registers
+        constexpr int UG = NT > 6 ? (NT + 1) / 2 : NT;
+#pragma unroll
+        for (int u0 = 0; u0 < NT; u0 += UG) {
+        float4 rv[UG];
         if (EPI == EPI_RES) {
 #pragma unroll
-            for (int u = 0; u < NT; ++u) {
+            for (int uu = 0; uu < UG; ++uu) {
+                const int u = u0 + uu < NT ? u0 + uu : NT - 1;
                 const int f = lane + 64 * u;
                 const int row = f / V4;
                 int col = n0 + (f - row * V4) * 4;
                 int64_t m = m0 + row;
                 if (m > a.M - 1) m = a.M - 1;
                 if (col > a.N - 4) col = a.N - 4;
-                rv[u] = ld4(a.res + m * a.ldr + col);
+                rv[uu] = ld4(a.res + m * a.ldr + col);
             }
         }
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
+        for (int uu = 0; uu < UG; ++uu) {
+            const int u = u0 + uu;
+            if (u >= NT) break;
             const int f = lane + 64 * u;
             const int row = f / V4, c4 = (f - row * V4) * 4;
             const int64_t m = m0 + row;
             float4 v = ld4(sOut + row * OP + c4);
-            if (EPI == EPI_RES) { v.x += rv[u].x; v.y += rv[u].y; v.z += rv[u].z; v.w += rv[u].w; }
+            if (EPI == EPI_RES) { v.x += rv[uu].x; v.y += rv[uu].y; v.z += rv[uu].z; v.w += rv[uu].w; }
             if (m < a.M && n0 + c4 < a.N) st4(a.y + m * a.ldy + n0 + c4, v);
             if (SPLIT_OUT && a.ysplit && a.ysplit_fmt == 1 && m < a.M && n0 + c4 < a.N) {
                 // two fp16 parts (hi | lo 2^11, split_bf16.hpp): planes [part][M][N]
@@ -180,6 +187,7 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
                 if (a.ysplit_np >= 2) *reinterpret_cast<bf16x4*>(sp + a.ysplit_plane) = p1;
                 if (a.ysplit_np == 3) *reinterpret_cast<bf16x4*>(sp + 2 * a.ysplit_plane) = p2;
             }
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -330,8 +338,9 @@ static inline void pw_pick_tile(int64_t M, int N, int* rm_out, int* nt_out) {
 // fraction f of the slots costs 0.35 + 0.65 f of a full one (a lone block per CU is bound by its own load -> split -> MFMA ->
 // barrier chain, not by throughput), and a half-height round 0.79 of the full-height round with the same f.  Returns the number
 // of full-height strips; the half-height strips that follow through *half_strips_out.
-static inline int64_t pw_plan_tail(int64_t M, int rm, int n_tiles_n, int slots, int64_t* half_strips_out) {
-    const int64_t rows_full = 64 * rm, rows_half = 32 * rm;
+static inline int64_t pw_plan_tail(int64_t M, int rm, int n_tiles_n, int slots, int64_t* half_strips_out, int64_t rows_full = 0) {
+    if (rows_full <= 0) rows_full = 64 * rm;             // four waves of 16 rm rows; blocks of more waves pass their own height
+    const int64_t rows_half = rows_full / 2;
     const int64_t full_all = cdiv64(M, rows_full);
     *half_strips_out = 0;
     if (rm < 2 || slots <= 0 || knobs().pwx_no_tail) return full_all;

@@ -387,7 +387,7 @@ int ams_k_expand_dw_stream(const float* x, int32_t B, int32_t H, int32_t W, int3
  *   kernels write with y_h2i and the GEMM reads with x_h2i).
  * ams_k_pointwise_split_f16: as ams_k_pointwise_split3 (K4; replaces the Conv2D nodes of model.meta `expanded_conv_N/project`, `aspp0`, ...);
  *   panels >= 2*N*Kp uint16; x_h2i (optional, M*K floats of scratch): x is first packed into H2I and the GEMM loads its operand from there —
- *   same result, bit for bit; y_parts (optional, 2*M*N uint16): the result also as two fp16 part planes.
+ *   same result, bit for bit (x_h2i == x: x is taken as packed already); y_parts (optional, 2*M*N uint16): the result also as two fp16 part planes.
  * ams_k_expand_dw_stream_f16: as ams_k_expand_dw_stream with the fp16 parts (Cin 64 / 96 / 160); presplit 1 | 2 as there (2 = the
  *   weight-register form; panels then needs 2*B*H*W*Cin more elements); y_h2i != 0: y is written in H2I instead of f32.  Bit-identical to
  *   ams_k_pointwise_split_f16 followed by ams_k_depthwise3x3. */

@@ -172,7 +172,9 @@ struct ams_student {
                                                // 0 three kernels, 1 tile per block (k_first_block.hip), 2 tile per wave (k_block.hip:
                                                // same bits, measured slower here: 488 vs 428 us at 32 frames — the 27-tap byte gather
                                                // per wave outweighs the barriers it saves)
-    int64_t stream_min_rows = 16384;           // rows (frames x pixels at the block's resolution) from which the streaming kernels run
+    int64_t stream_min_rows = 4096;            // rows (frames x pixels at the block's resolution) from which the streaming kernels run: two frames of
+                                               // 512x1024 and more (measured with the fp16 forms: one frame 0.434 vs 0.431 ms unfused, two 0.501 vs 0.526,
+                                               // four 0.675 vs 0.726; same bits either way)
     int fuse_expand_dw_stream = 1;             // frozen inference, split-bf16 modes: expand + depthwise of the stride-16 blocks
                                                // in one streaming kernel (k_xdw_stream.hip): 0 never, 1 where measured
                                                // faster (Cin 64 / 96, >= 16384 rows), 2 also the 160-channel blocks

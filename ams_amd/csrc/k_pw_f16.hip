@@ -311,6 +311,10 @@ bool pointwise_f16_applies(const PwArgs& a) {
 // y = epilogue(x @ w), w as fp16 panels [part][N][Kp] (hi at whi, lo 2^11 at whi + plane)
 int launch_pointwise_split_f16(const PwArgs& a, const uint16_t* whi, int64_t plane, int Kp, hipStream_t st) {
     AMS_REQUIRE(pointwise_f16_applies(a) && Kp % 32 == 0 && Kp >= a.K, "pointwise_split_f16: bad problem (M %lld K %d ldx %d)", (long long)a.M, a.K, a.ldx);
+    // One to four frames per pass: a launch is one block's chain of K / 32 stages per tile (~0.33 us a stage).  Measured and NOT kept (round 5):
+    // split-K inside a block — four waves on one 16-row x 32-column tile, every fourth stage each, weight fragments straight from the panels,
+    // one LDS reduction in a fixed order — 0.530 vs 0.431 ms per one-frame call (675 blocks x 123 KB of panel reads instead of 170 x 123 KB, each
+    // a dependent L2 round trip); three or four operand stages in flight in the tiled kernel 0.427 / 0.451 vs 0.432 ms
     int rm, nt;
     pw_pick_tile(a.M, a.N, &rm, &nt);
     if (rm == 2) {

@@ -47,7 +47,9 @@ struct XwrArgs {
 
 // H16: the operand and weight parts are the two fp16 parts of split_bf16.hpp (hi | lo 2^11; NP = 2): three MFMAs per 32 k, the cross terms
 // in an accumulator of their own, products and order of pw_gemm_f16x3_l (bit-identical to it followed by the depthwise kernel).
-template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false>
+// ABL: measurement-only ablations (AMS_XWR_ABL, wrong results): 1 no operand loads in the step loop, 2 no MFMAs, 4 no depthwise arithmetic,
+// 8 no result stores, 16 no ring stores
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, unsigned nblocks) {
     static_assert(!H16 || NP == 2, "the fp16 form has two parts");
     constexpr int STEP = 16 * NRG;                   // pixels per step: NRG MFMA row groups per E-wave (2 * NRG accumulator chains)
@@ -158,13 +160,13 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                     e_row[rg] += qS; e_col[rg] += rS;
                     if (e_col[rg] >= Wp) { e_col[rg] -= Wp; ++e_row[rg]; }
                 }
-                load_pieces(loader_pixel());                          // tile of step t + 1: lands during the MFMAs
+                if constexpr (!(ABL & 1)) load_pieces(loader_pixel());        // tile of step t + 1: lands during the MFMAs
                 f32x4 acc[NRG][2], accx[H16 ? NRG : 1][2];
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg) { acc[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
                 for (int rg = 0; rg < (H16 ? NRG : 1); ++rg) { accx[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-                if (active) {
+                if (active && !(ABL & 2)) {
                     const u32x4* ap = sA + par * AUNITS + q * 16 + l15;
                     // the operand fragments of k-step s + 1 are requested before the MFMAs of k-step s: with one E-wave per SIMD nothing
                     // else hides the LDS round trip (five exposed waits per step otherwise)
@@ -232,8 +234,10 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                         v.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
                         v.z = __builtin_amdgcn_fmed3f(bn.z, lo, hi);
                         v.w = __builtin_amdgcn_fmed3f(bn.w, lo, hi);
+                        if constexpr (!(ABL & 16)) {
                         st4(dst + 16 * tt, v);
                         if (mirror) st4(dst + R * PITCH + 16 * tt, v);
+                        }
                     }
                 }
                 store_pieces(par ^ 1);
@@ -280,24 +284,33 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
             __syncthreads();                                          // (A)
             __syncthreads();                                          // E-step 0
             for (int t = 0; t < a.T; ++t) {
+                // all taps of the step's centres are requested before the first is used (PX / 2 pairs of centres: 12 ds_read_b128 each): with one
+                // D-wave per SIMD nothing else hides the LDS round trip of the second pair behind the first pair's arithmetic
+                constexpr int NH = (PX + 1) / 2;
+                float4 vt[NH][3][PH + 2];
 #pragma unroll
-                for (int h = 0; h < PX; h += 2) {                     // two centres at a time: 12 taps live
-                    float4 v[3][PH + 2];
+                for (int hh = 0; hh < NH; ++hh) {
+                    const int h = 2 * hh;
 #pragma unroll
                     for (int di = 0; di < 3; ++di) {
                         unsigned slot = (unsigned)(cb + di * Wp + h);
                         slot = slot < (unsigned)R ? slot : slot - (unsigned)R;
                         const float* rp = ring + __umul24(slot, PITCH) + 4 * cg;
 #pragma unroll
-                        for (int jj = 0; jj < PH + 2; ++jj) v[di][jj] = ld4(rp + jj * PITCH);
+                        for (int jj = 0; jj < PH + 2; ++jj) vt[hh][di][jj] = (ABL & 4) ? wv[di] : ld4(rp + jj * PITCH);
                     }
+                }
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) {
+                    const int h = 2 * hh;
+                    float4 (&v)[3][PH + 2] = vt[hh];
 #pragma unroll
                     for (int u = 0; u < PH; ++u) {
                         float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int i = 0; i < 3; ++i)
+                        for (int i = 0; i < ((ABL & 4) ? 1 : 3); ++i)
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
+                            for (int j = 0; j < ((ABL & 4) ? 1 : 3); ++j) {
                                 const float4 vv = v[i][u + j];
                                 const float4 w4 = wv[i * 3 + j];
                                 AMS_DW_FMA4(acc4, vv, w4);
@@ -310,7 +323,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                         for (int w = 0; w < (PX + 1) / 2; ++w)            // PX may span several rows of a tiny segment (Wp >= 3)
                             if (col >= Wp) { col -= Wp; ++row; }
                         const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
-                        const unsigned off = ok ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
+                        const unsigned off = (ok && !(ABL & 8)) ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
                         if (H16 && a.y_fmt) {                        // wave-uniform
                             unsigned h[2], l[2];
                             split4_f16(o, h, l);
@@ -338,15 +351,30 @@ static size_t xwr_lds(int Kp, int np, int nwe, int nrg, int ring) {
     return (size_t)2 * nrg * np * (Kp / 8) * 16 * 16 + (size_t)(ring + 4) * (32 * nwe + 4) * 4;
 }
 
-template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false>
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0>
 static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
-    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16>, lds));
+    if constexpr (ABL == 0 && KS == 5 && NP == 2 && NWE == 4 && NWD == 4 && NRG == 2 && H16) {        // MEASUREMENT ONLY (AMS_XWR_ABL=<bits>)
+        switch (knobs().xwr_abl) {
+            case 1: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 1>(a, lds, st);
+            case 2: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 2>(a, lds, st);
+            case 3: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 3>(a, lds, st);
+            case 4: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 4>(a, lds, st);
+            case 8: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 8>(a, lds, st);
+            case 12: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 12>(a, lds, st);
+            case 16: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 16>(a, lds, st);
+            case 19: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 19>(a, lds, st);
+            case 28: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 28>(a, lds, st);
+            case 31: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 31>(a, lds, st);
+            default: break;
+        }
+    }
+    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>, lds));
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");
     static const std::string nm = "xdw_wreg_kernel<" + std::to_string(KS) + ", " + std::to_string(NP) + ", " + std::to_string(NWE) + ", " +
                                   std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", 1>" : ">");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

@@ -21,6 +21,7 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     int pw_percu = 0;                            // AMS_PW_PERCU
     bool pwx_no_tail = false;                    // AMS_PWX_NO_TAIL
     int pwx_rm = 0, pwx_nt = 0;                  // AMS_PWX_FORCE=<RM>,<NT>
+    int xwr_abl = 0;                             // AMS_XWR_ABL=<bits>: the same for the weight-register streaming kernel
     int pwh_abl = 0;                             // AMS_PWH_ABL=<bits>: measurement-only ablations of the fp16 GEMM's stage loop (wrong results)
     bool pwh_set = false; int pwh_nw = 4, pwh_d = 2;                   // AMS_PWH_VARIANT=<waves per block>,<operand stages in flight>: experiment switch of the fp16 GEMM
     bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE

@@ -86,6 +86,7 @@ static Knobs read_knobs() {
         if (const char* e = getenv("AMS_PW_PERCU")) v.pw_percu = atoi(e);
         v.pwx_no_tail = getenv("AMS_PWX_NO_TAIL") != nullptr;
         if (const char* e = getenv("AMS_PWH_ABL")) v.pwh_abl = atoi(e);
+        if (const char* e = getenv("AMS_XWR_ABL")) v.xwr_abl = atoi(e);
         if (const char* e = getenv("AMS_PWH_VARIANT")) { v.pwh_set = true; sscanf(e, "%d,%d", &v.pwh_nw, &v.pwh_d); }
         if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &v.pwx_rm, &v.pwx_nt);
         if (const char* e = getenv("AMS_XDS_FORCE")) { v.xds_set = true; sscanf(e, "%d,%d,%d,%d,%d,%d", &v.xds[0], &v.xds[1], &v.xds[2], &v.xds[3], &v.xds[4], &v.xds[5]); }

@@ -235,7 +235,7 @@ enum { AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRA
                                      0 everything on the caller's stream.  Same bits */,
        AMS_OPT_OVERLAP_HEAD = 20 /* frozen inference: 1 = the image-pooling branch on a side stream beside the aspp0 GEMM; 0 (default): measured slower */,
        AMS_OPT_STREAM_MIN_ROWS = 21 /* frozen inference: rows (frames x pixels at the block's resolution) from which the streaming expand+depthwise
-                                       kernels run (default 16384) */,
+                                       kernels run (default 4096: from two 512x1024 frames per pass on; same bits either way) */,
        AMS_OPT_DUAL_AUTOTUNE = 12 /* with AMS_OPT_DUAL_STREAM = 1: 1 = pick the number of parts per batch size by TIMING the plans inside the first call
                                       with that batch size (median of three passes each; that call synchronises the host and its result then depends
                                       on which plan won); 0 (default) = the static rule: the same call always runs the same plan */,

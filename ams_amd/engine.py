@@ -123,6 +123,12 @@ class StudentEngine:
         nbytes = self._out_meta * self.max_batch + self.max_batch * self.height * self.width * 4      # room for per-frame metrics too
         self._out_dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         self._out_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+        # ... and one pinned input block [frames uint8 B*H*W*3 | labels uint8 B*H*W]: host uint8 arrays are gathered there and leave with an
+        # asynchronous DMA (a pageable source makes the driver stage the copy itself, synchronously, chunk by chunk); `_in_free` is the event of
+        # the last DMA that read the block
+        self._in_frames = torch.zeros(self.max_batch * self.height * self.width * 3, dtype=torch.uint8).pin_memory()
+        self._in_labels = torch.zeros(self.max_batch * self.height * self.width, dtype=torch.uint8).pin_memory()
+        self._in_free = {}
         self._keepalive = []
         for name, opt in _ENV_OPTIONS.items():
             if name in os.environ:
@@ -155,7 +161,10 @@ class StudentEngine:
         if isinstance(frames, torch.Tensor):
             t = frames
         else:
-            a = np.ascontiguousarray(frames)
+            a = np.asarray(frames)
+            if a.dtype == np.uint8 and a.ndim == 4 and tuple(a.shape[1:]) == (self.height, self.width, 3) and 0 < a.shape[0] <= self.max_batch:
+                return self._staged(a, self._in_frames), hip.DT_U8, int(a.shape[0])
+            a = np.ascontiguousarray(a)
             if a.dtype != np.uint8:
                 a = a.astype(np.float32, copy=False)
             t = torch.from_numpy(a)
@@ -167,11 +176,26 @@ class StudentEngine:
         t = t.to(self.device, non_blocking=True).contiguous()
         return t, (hip.DT_U8 if t.dtype == torch.uint8 else hip.DT_F32), int(t.shape[0])
 
+    def _staged(self, a: np.ndarray, block: torch.Tensor) -> torch.Tensor:
+        """host uint8 array -> device tensor through the engine's pinned input block (one host copy, one asynchronous DMA)."""
+        prev = self._in_free.get(id(block))
+        if prev is not None:
+            prev.synchronize()                          # the previous DMA out of THIS block (long done in a synchronous call loop)
+        view = block[:a.size].view(a.shape)
+        np.copyto(view.numpy(), a)
+        t = view.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._in_free[id(block)] = ev
+        return t
+
     def _labels_to_device(self, labels, batch: int) -> torch.Tensor:
         if isinstance(labels, torch.Tensor):
             t = labels
         else:
             a = np.asarray(labels)
+            if a.dtype == np.uint8 and tuple(a.shape) == (batch, self.height, self.width) and a.size <= self._in_labels.numel():
+                return self._staged(a, self._in_labels)
             if a.dtype != np.uint8:
                 # tf.cast(labels, int32) truncates toward zero; ids outside 0..255 can never be selected -> 255
                 ai = a.astype(np.float32).astype(np.int64)

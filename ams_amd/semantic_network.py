@@ -125,6 +125,7 @@ class SemanticNetwork(object):
             raise ValueError("gpu_id %r: this process sees %d GPU(s) (ordinals are relative to the visible devices, "
                              "cf. HIP_VISIBLE_DEVICES)" % (gpu_id, torch.cuda.device_count()))
         assert 0 < float(mem_frac) <= 1, "mem_frac must be in (0, 1]"
+        self._mem_frac = float(mem_frac)
         if self.frozen:
             if frozen_graph is None:
                 with open(meta_dir + ".pb", 'rb') as pb_file:
@@ -154,6 +155,14 @@ class SemanticNetwork(object):
             self.curr_mask = None
             self.last_losses: List[float] = []
         self._last_train_ms = 0.0
+        # mem_frac (tf.ConfigProto per_process_gpu_memory_fraction, SemanticNetwork.py:73): TensorFlow refuses allocations past that share of
+        # the device; the engine allocates exactly one arena, so the cap is checked once, against it
+        if torch.cuda.is_available():
+            total = torch.cuda.get_device_properties(self.engine.device).total_memory
+            if self.engine.arena_bytes > self._mem_frac * total:
+                need = self.engine.arena_bytes
+                self.engine.close()
+                raise MemoryError("the student's arena (%.2f GB) exceeds mem_frac = %g of the device's %.1f GB" % (need / 1e9, self._mem_frac, total / 1e9))
 
     # ------------------------------------------------------------------ variables (SaveHelper semantics)
     def _restore_dict(self, variables: Dict[str, np.ndarray]) -> None:

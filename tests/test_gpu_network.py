@@ -465,6 +465,9 @@ def test_semantic_network_surface(W0, tmp_path):
     with pytest.raises(NameError):
         net.train_with_deque(fm, lm, 1, 'no_such_strategy')
     assert not net.process_lock.locked()
+    # mem_frac (per_process_gpu_memory_fraction, SemanticNetwork.py:73): a student whose arena does not fit the share is refused
+    with pytest.raises(MemoryError):
+        SemanticNetwork(meta, class_weights_exp=cw, height=H, frozen=False, scale=[1], mini_batch_size=4, lr=1e-3, mem_frac=1e-7)
     # server -> edge hand-off
     net.save_to_frozen_graph(str(tmp_path / "edge"))
     edge = SemanticNetwork(str(tmp_path / "edge"), class_weights_exp=cw, height=H, frozen=True)

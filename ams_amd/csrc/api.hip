@@ -284,6 +284,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
         s->wgrad_fork_every = value;
         return AMS_OK;
     }
+    if (option == AMS_OPT_TRAIN_FWD_F16) {
+        s->train_fwd_f16 = value != 0;
+        return AMS_OK;
+    }
     if (option == AMS_OPT_NAN_GRADS) {
         s->nan_grads = value != 0;
         return AMS_OK;
@@ -615,7 +619,13 @@ int ams_k_pointwise_red(const float* x, int64_t M, int32_t K, const float* w, in
     int rows = 0;
     a.red_rows_out = &rows;
     int rc;
-    if (split) {
+    if (split == 2) {                              // two fp16 parts (mode 1 only: the forward statistics)
+        const int Kp = (K + 31) / 32 * 32;
+        const size_t plane = (size_t)N * Kp;
+        AMS_REQUIRE(panels && panel_elems >= 2 * plane && pointwise_f16_applies(a), "pointwise_red: fp16 form needs mode 1, K %% 8 == 0 and %zu panel elements", 2 * plane);
+        RUN(launch_split_weights_f16(w, a.w_sk, a.w_sn, K, N, Kp, panels, panels + plane, st));
+        rc = launch_pointwise_split_f16(a, panels, (int64_t)plane, Kp, st);
+    } else if (split) {
         const int Kp = (K + 31) / 32 * 32;
         const size_t plane = (size_t)N * Kp;
         AMS_REQUIRE(panels && panel_elems >= 3 * plane && K % 8 == 0, "pointwise_red: panel scratch too small (need %zu) or K %% 8", 3 * plane);
@@ -636,6 +646,13 @@ int ams_k_pointwise_xform(const float* x, int64_t M, int32_t K, const float* w, 
     PwArgs a = pw_args(x, M, K, K, w, N, y, N);
     if (trans_w) { a.w_sk = 1; a.w_sn = K; }
     a.x_mode = x_mode; a.x_act = x_act; a.x_v0 = v0; a.x_v1 = v1; a.x_v2 = v2; a.x2 = x2; a.x_tmp = x_tmp;
+    if (split == 2) {                              // two fp16 parts (x_mode 1 only)
+        const int Kp = (K + 31) / 32 * 32;
+        const size_t plane = (size_t)N * Kp;
+        AMS_REQUIRE(panels && panel_elems >= 2 * plane && pointwise_f16_applies(a), "pointwise_xform: fp16 form needs x_mode 1, K %% 8 == 0, K <= 1024 and %zu panel elements", 2 * plane);
+        RUN(launch_split_weights_f16(w, a.w_sk, a.w_sn, K, N, Kp, panels, panels + plane, st));
+        return launch_pointwise_split_f16(a, panels, (int64_t)plane, Kp, st);
+    }
     if (split) {
         const int Kp = (K + 31) / 32 * 32;
         const size_t plane = (size_t)N * Kp;

@@ -144,6 +144,10 @@ struct ams_student {
                                      // cost more than the three small launches they hide
     int overlap_wgrad = 1;
     int wgrad_fork_every = 1;        // weight gradients per hand-over to the side stream (AMS_OPT_WGRAD_FORK_EVERY)
+    int train_fwd_f16 = 0;           // fine-tune step under AMS_MATMUL_SPLIT_F16: 1 = the FORWARD 1x1 products on two fp16 parts (AMS_OPT_TRAIN_FWD_F16).
+                                     // Off: measured 7.455 -> 7.368 ms per 8-frame step (the step's GEMMs are not bound by their MFMAs at 17160 rows), and two
+                                     // step-level agreement bars between f32 evaluations (fused vs layer-wise at 34 x 68 x 5 frames, 2 ranks vs 1) move past
+                                     // their limits with another product rounding in the forward — not worth 1.2 %
     int nan_grads = 0;               // a batch without a valid pixel: NaN loss, ZERO gradients — what TensorFlow computes for utils/graph_utils.py:408
                                      // (reduce_mean over the empty boolean_mask: its gradient is an empty tensor, densified to zeros); 1 = NaN gradients (AMS_OPT_NAN_GRADS)
     ~ams_student() {

@@ -27,6 +27,10 @@ int live_pointwise(ams_student* s, const PwArgs& a, hipStream_t st) {
             const SplitJob& j = s->tp_jobs[it->second];
             if (j.K == a.K && j.N == a.N && j.sk == a.w_sk && j.sn == a.w_sn) {
                 if (s->tp_wait) { AMS_CHECK_HIP(hipStreamWaitEvent(st, s->ev_tp, 0)); s->tp_wait = false; }      // the split ran on the side stream
+                // forward products of the step on two fp16 parts (3 MFMAs): activations and weights are O(1) there; the input-gradient GEMMs
+                // (red_mode 2, transposed panels: no fp16 planes) keep three bf16 parts — gradients span a range fp16 cannot hold
+                if (s->matmul_mode == AMS_MATMUL_SPLIT_F16 && s->train_fwd_f16 && j.f16 && pointwise_f16_applies(a))
+                    return launch_pointwise_split_f16(a, j.p0 + 3 * j.plane, j.plane, j.Kp, st);
                 return launch_pointwise_split3(a, j.p0, j.p0 + j.plane, j.p0 + 2 * j.plane, j.Kp, st);
             }
         }

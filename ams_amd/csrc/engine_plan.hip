@@ -43,7 +43,7 @@ static void plan_train_panels(ams_student* s) {
     s->tp_elems = 0;
     s->tp_blocks = 0;
     if (!s->cfg.trainable) return;
-    auto add = [&](int64_t w_off, int64_t sk, int64_t sn, int K, int N) {
+    auto add = [&](int64_t w_off, int64_t sk, int64_t sn, int K, int N, int f16) {
         if (K < 32 || K % 8 != 0) return;                  // split_pays() never takes these
         SplitJob j;
         memset(&j, 0, sizeof(j));
@@ -52,7 +52,8 @@ static void plan_train_panels(ams_student* s) {
         j.plane = (int64_t)N * j.Kp;
         j.p0 = (uint16_t*)(uintptr_t)s->tp_elems;
         j.first_block = s->tp_blocks;
-        s->tp_elems += 3 * (size_t)j.plane;
+        j.f16 = f16;
+        s->tp_elems += (f16 ? 5 : 3) * (size_t)j.plane;
         s->tp_elems = (s->tp_elems + 127) & ~(size_t)127;
         s->tp_blocks += (j.plane + 255) / 256;
         s->tp_jobs.push_back(j);
@@ -64,8 +65,8 @@ static void plan_train_panels(ams_student* s) {
         int K = l.d.cin;
         const int N = l.d.cout;
         if (l.d.role == AMS_ROLE_CONCAT_PROJ) { const int k0 = s->L[s->iPool].d.cout; w_off += (int64_t)k0 * N; K -= k0; }
-        add(w_off, N, 1, K, N);                             // forward: element (k, n) at w[k*N + n]
-        if (l.d.role != AMS_ROLE_LOGITS) add(w_off, 1, N, N, K);      // input gradient: B operand (k' = n, n' = k) = w[k][n]
+        add(w_off, N, 1, K, N, 1);                          // forward: element (k, n) at w[k*N + n]; also as two fp16 parts
+        if (l.d.role != AMS_ROLE_LOGITS) add(w_off, 1, N, N, K, 0);   // input gradient: B operand (k' = n, n' = k) = w[k][n]
     }
 }
 

@@ -75,7 +75,10 @@ constexpr int pwh_waves(int rm, int nt, int nw) { return nw == 12 ? 3 : nw == 8 
 // by 1074 blocks are MORE bytes than the activations (330 MB against 264).  D = stages of operands in flight per lane.
 // ABL: measurement-only ablations (tools/sweep_pwh_abl.sh; wrong results): 1 no activation loads in the loop, 2 no weight loads / LDS stores,
 // 4 no barrier, 8 no MFMAs
-template <int RM, int NT, int EPI, int XP, int NW = 4, int D = 2, int ABL = 0>
+// XF = 1 (fine-tune step, forward): PwArgs::x_mode 1 — BN + activation of the layer that wrote x, applied between the operand's load and its
+// split with the arithmetic of bn_act_kernel (k_pw_x3.hip has the same for its three parts); PwArgs::red_mode 1 (BN statistics of the
+// result in the epilogue) is honoured with the plain epilogue in 4-wave blocks.
+template <int RM, int NT, int EPI, int XP, int NW = 4, int D = 2, int ABL = 0, int XF = 0>
 __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_l(PwArgs a, const unsigned short* __restrict__ w0, int64_t plane, int Kp,
                                                                                   int n_tiles_n, unsigned nblocks, unsigned n_full) {
     constexpr int NP = 2, NTH = 64 * NW;
@@ -87,12 +90,16 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
     constexpr int SLAB = 16 * (16 * NT + 4) * 4;
     constexpr int EPW = (EPI == EPI_GENERIC || NW * SLAB <= 60 * 1024) ? NW : 4;
     static_assert(NW % EPW == 0, "epilogue rounds");
-    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = EPI == EPI_GENERIC ? 16 : EPW * SLAB;
+    static_assert(XF == 0 || (XP == 0 && EPI == EPI_PLAIN), "the operand transform runs on f32 operands with the plain epilogue");
+    // (+ 4 x 16 NT floats behind the slabs for the vectors of a fused column reduction, PwArgs::red_mode)
+    constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = EPI == EPI_GENERIC ? 16 : EPW * SLAB + (EPI == EPI_PLAIN && NW == 4 ? 4 * 16 * NT * 4 : 0);
     __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES > OUT_BYTES ? W_BYTES : OUT_BYTES];
     typedef unsigned short (*WStage)[NP][ROWS * PITCH];
     WStage sW = reinterpret_cast<WStage>(smem);
     float* sOutAll = reinterpret_cast<float*>(smem);
     __shared__ __attribute__((aligned(16))) float sSc[16 * NT], sSh[16 * NT];
+    constexpr int XVS = XF != 0 ? 1024 : 4;                          // floats per operand-transform vector (K <= XVS)
+    __shared__ __attribute__((aligned(16))) float sXv[XF == 1 ? 2 * XVS : 4];
     const bool half = blockIdx.x >= n_full;
     const unsigned lb = half ? xcd_remap(blockIdx.x - n_full, nblocks - n_full) : xcd_remap(blockIdx.x, n_full);
     const int tile_n = lb % n_tiles_n;
@@ -162,6 +169,13 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
         for (int t = 0; t < NT; ++t) { acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     pw_stage_affine<NT>(a, sSc, sSh, n0, tid, NTH);
+    if constexpr (XF != 0) {
+        for (int e = tid; e < XVS; e += NTH) {
+            const bool ok = e < K;
+            sXv[e] = ok ? a.x_v0[e] : 0.f;
+            sXv[XVS + e] = ok ? a.x_v1[e] : 0.f;
+        }
+    }
     store_stage(0, wring[0]);
     __syncthreads();
     auto main_loop = [&](auto Rc) {
@@ -174,9 +188,23 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
                 if constexpr (!(ABL & 1)) load_a(s + D - 1, abuf[(d + D - 1) % D], Rc);
                 if (s < n_stages) {
                     u32x4 xh[RM], xl[RM];
+                    float4 u0, u1, v0, v1;
+                    if constexpr (XF != 0) {
+                        int koff = s * 32 + 8 * q;
+                        if (koff > K - 8) koff = K - 8;
+                        u0 = ld4(sXv + koff); u1 = ld4(sXv + koff + 4); v0 = ld4(sXv + XVS + koff); v1 = ld4(sXv + XVS + koff + 4);
+                    }
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        if constexpr (XP) {
+                        if constexpr (XF != 0) {
+                            float4 y0 = muladd4_pk(abuf[d][r][0], u0, v0), y1 = muladd4_pk(abuf[d][r][1], u1, v1);
+                            y0 = make_float4(apply_act(y0.x, a.x_act), apply_act(y0.y, a.x_act), apply_act(y0.z, a.x_act), apply_act(y0.w, a.x_act));
+                            y1 = make_float4(apply_act(y1.x, a.x_act), apply_act(y1.y, a.x_act), apply_act(y1.z, a.x_act), apply_act(y1.w, a.x_act));
+                            f16x8 h, l;
+                            split8_f16(y0, y1, h, l);
+                            xh[r] = __builtin_bit_cast(u32x4, h);
+                            xl[r] = __builtin_bit_cast(u32x4, l);
+                        } else if constexpr (XP) {
                             xh[r] = __builtin_bit_cast(u32x4, abuf[d][r][0]);
                             xl[r] = __builtin_bit_cast(u32x4, abuf[d][r][1]);
                         } else {
@@ -230,6 +258,19 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
     for (int r = 0; r < RM; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = combine_f16(acc[r][t], accx[r][t]);
+    const bool red = EPI == EPI_PLAIN && NW == 4 && a.red_mode != 0;    // block-uniform (the launcher clears red_mode where it cannot be fused)
+    float4 rs1[(EPI == EPI_PLAIN && NW == 4) ? NT : 1], rs2[(EPI == EPI_PLAIN && NW == 4) ? NT : 1];
+    if constexpr (EPI == EPI_PLAIN && NW == 4) {
+        if (red) {
+            // the stage loop ended with a barrier: the weight stages are dead, their LDS holds the reduction's vectors and, later, the waves' sums
+            float* sRedVec = reinterpret_cast<float*>(smem) + 4 * 16 * (16 * NT + 4);
+            pw_red_stage<NT>(a, sRedVec, n0, tid, NTH);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { rs1[t] = make_float4(0.f, 0.f, 0.f, 0.f); rs2[t] = rs1[t]; }
+            __syncthreads();
+            pw_red_rowgroups<RM, NT>(a, acc, m_base, n0, l15, q, sRedVec, rs1, rs2, nrg);
+        }
+    }
     if (EPI == EPI_GENERIC) pw_epilogue<RM, NT>(a, acc, m_base, n0, l15, q, sSc, sSh, nrg);
     else if constexpr (EPW == NW) pw_epilogue_t<RM, NT, EPI, true>(a, acc, m_base, n0, lane, sSc, sSh, sOutAll + wave * (16 * (16 * NT + 4)), nrg);
     else {
@@ -238,22 +279,34 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
             __syncthreads();
         }
     }
+    if constexpr (EPI == EPI_PLAIN && NW == 4) {
+        if (red) {
+            __syncthreads();                                        // the epilogue slabs are consumed
+            const int64_t row = half ? (int64_t)(n_full / n_tiles_n) + tile_m : tile_m;
+            pw_red_finish<NT>(a, rs1, rs2, lane, wave, 4, reinterpret_cast<float*>(smem), row, n0, tid, NTH);
+        }
+    }
 }
 
-template <int RM, int NT, int EPI, int XP, int NW = 4, int D = 2, int ABL = 0>
+template <int RM, int NT, int EPI, int XP, int NW = 4, int D = 2, int ABL = 0, int XF = 0>
 static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     int per_cu = 1, cus = 256;
-    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL>, 64 * NW, 0, &per_cu));
+    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>, 64 * NW, 0, &per_cu));
     RUN_RC(device_cus(&cus));
     int64_t half_strips = 0;
     const int64_t full_strips = pw_plan_tail(a.M, RM, n_tiles_n, per_cu * cus, &half_strips, 16 * NW * RM);
     const int64_t n_full = full_strips * n_tiles_n;
     const int64_t nblocks = n_full + half_strips * n_tiles_n;
+    PwArgs b = a;
+    if (b.red_mode) {                               // partial rows: one per row strip of blocks
+        if (EPI == EPI_PLAIN && NW == 4 && b.red_mode == 1 && pw_red_ok(b, nblocks / n_tiles_n)) { if (b.red_rows_out) *b.red_rows_out = (int)(nblocks / n_tiles_n); }
+        else { b.red_mode = 0; if (b.red_rows_out) *b.red_rows_out = 0; }
+    }
     static const std::string nm = "pw_gemm_f16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(XP) +
-                                  (NW != 4 || D != 2 ? ", " + std::to_string(NW) + ", " + std::to_string(D) : std::string()) + ">";
+                                  (NW != 4 || D != 2 || XF ? ", " + std::to_string(NW) + ", " + std::to_string(D) : std::string()) + (XF ? ", 0, 1>" : ">");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL>), dim3((unsigned)nblocks), dim3(64 * NW), 0, st, a, w, plane, Kp, n_tiles_n,
+    hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>), dim3((unsigned)nblocks), dim3(64 * NW), 0, st, b, w, plane, Kp, n_tiles_n,
                        (unsigned)nblocks, (unsigned)n_full);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
@@ -262,6 +315,7 @@ static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, in
 template <int RM, int NT>
 static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
     const int epi = pw_pick_epi(a);
+    if (a.x_mode == 1) return launch_pw_f16_d<RM, NT, EPI_PLAIN, 0, 4, 2, 0, 1>(a, w, plane, Kp, st);      // (pointwise_f16_applies: plain epilogue only)
     if constexpr (RM == 2 && NT == 5) {                    // MEASUREMENT ONLY (AMS_PWH_ABL=<bits>, wrong results): what the stage loop is made of
         const int abl = knobs().pwh_abl;
         if (abl && a.x_fmt == 1) {
@@ -305,11 +359,15 @@ static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int 
 
 // the two-fp16-part product can take this problem (frozen inference: no fused reduction, no operand transform)
 bool pointwise_f16_applies(const PwArgs& a) {
-    return a.M > 0 && a.K >= 32 && a.K % 8 == 0 && a.ldx % 4 == 0 && a.Kw == a.K && a.red_mode == 0 && a.x_mode == 0 && (a.x_fmt == 0 || a.ldx == a.K);
+    if (!(a.M > 0 && a.K >= 32 && a.K % 8 == 0 && a.ldx % 4 == 0 && a.Kw == a.K && (a.x_fmt == 0 || a.ldx == a.K))) return false;
+    if (a.red_mode > 1) return false;               // the backward's fused reduction stays with the three-part bf16 kernel (gradients leave fp16's range)
+    if (a.x_mode == 0) return true;
+    return a.x_mode == 1 && a.x_fmt == 0 && a.x_v0 && a.x_v1 && a.K <= 1024 && pw_pick_epi(a) == EPI_PLAIN;
 }
 
 // y = epilogue(x @ w), w as fp16 panels [part][N][Kp] (hi at whi, lo 2^11 at whi + plane)
 int launch_pointwise_split_f16(const PwArgs& a, const uint16_t* whi, int64_t plane, int Kp, hipStream_t st) {
+    if (a.red_rows_out) *a.red_rows_out = 0;               // set by the launch that fuses the column reduction (PwArgs::red_mode 1)
     AMS_REQUIRE(pointwise_f16_applies(a) && Kp % 32 == 0 && Kp >= a.K, "pointwise_split_f16: bad problem (M %lld K %d ldx %d)", (long long)a.M, a.K, a.ldx);
     // One to four frames per pass: a launch is one block's chain of K / 32 stages per tile (~0.33 us a stage).  Measured and NOT kept (round 5):
     // split-K inside a block — four waves on one 16-row x 32-column tile, every fourth stage each, weight fragments straight from the panels,

@@ -59,6 +59,12 @@ __global__ void split_batch_kernel(const SplitJob* __restrict__ jobs, int njobs)
     j.p0[i] = h;
     j.p0[i + j.plane] = m;
     j.p0[i + 2 * j.plane] = bf16_rne_bits(r1 - __uint_as_float((unsigned)m << 16));
+    if (j.f16) {
+        unsigned short fh, fl;
+        split1_f16(v, fh, fl);
+        j.p0[i + 3 * j.plane] = fh;
+        j.p0[i + 4 * j.plane] = fl;
+    }
 }
 
 int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st) {

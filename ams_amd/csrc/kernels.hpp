@@ -108,7 +108,9 @@ int launch_split_weights3(const float* w, int64_t sk, int64_t sn, int K, int N, 
 int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t* wmid, const uint16_t* wlo, int Kp, hipStream_t st);
 // all live weight panels of a student in one launch (three-part split): job j splits w (element (k, n) at w[k*sk + n*sn]) into
 // p0 | p0 + plane | p0 + 2*plane as [N][Kp]; it owns the 256-thread blocks [first_block, first_block + ceil(N*Kp / 256))
-struct SplitJob { const float* w; int64_t sk, sn; int K, N, Kp; uint16_t* p0; int64_t plane; int64_t first_block; };
+// f16 != 0: the job ALSO leaves the two fp16 parts (hi | lo 2^11) at p0 + 3 * plane | p0 + 4 * plane (forward orientation: the fine-tune
+// step's forward products run on them under AMS_MATMUL_SPLIT_F16)
+struct SplitJob { const float* w; int64_t sk, sn; int K, N, Kp; uint16_t* p0; int64_t plane; int64_t first_block; int f16; };
 int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st);
 int launch_pointwise_split1(const PwArgs& a, const uint16_t* whi, int Kp, hipStream_t st);      // one part: plain bf16 products
 // two fp16 parts (k_pw_f16.hip; AMS_MATMUL_SPLIT_F16): panels [part][N][Kp] fp16, hi at whi, lo 2^11 at whi + plane; 3 MFMAs per 32 k

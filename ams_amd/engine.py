@@ -27,7 +27,7 @@ _ENV_OPTIONS = {
     "AMS_OVERLAP_HEAD": hip.OPT_OVERLAP_HEAD, "AMS_FUSE_BLOCK": hip.OPT_FUSE_BLOCK, "AMS_FUSE_XDS": hip.OPT_FUSE_EXPAND_DW_STREAM,
     "AMS_OVERLAP_WGRAD": hip.OPT_OVERLAP_WGRAD, "AMS_FUSE_DGRAD_BN": hip.OPT_FUSE_DGRAD_BN, "AMS_FUSE_GEMM_RED": hip.OPT_FUSE_GEMM_RED,
     "AMS_TRAIN_RECOMPUTE": hip.OPT_TRAIN_RECOMPUTE, "AMS_NAN_GRADS": hip.OPT_NAN_GRADS, "AMS_FUSE_OPERAND_BN": hip.OPT_FUSE_OPERAND_BN,
-    "AMS_WGRAD_FORK_EVERY": hip.OPT_WGRAD_FORK_EVERY,
+    "AMS_WGRAD_FORK_EVERY": hip.OPT_WGRAD_FORK_EVERY, "AMS_TRAIN_FWD_F16": hip.OPT_TRAIN_FWD_F16,
 }
 
 

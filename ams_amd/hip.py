@@ -37,6 +37,7 @@ OPT_EMULATE_BF16_STORAGE = 15
 OPT_DUAL_AUTOTUNE = 12
 OPT_DUAL_PARTS = 13
 OPT_NAN_GRADS = 18
+OPT_TRAIN_FWD_F16 = 24
 OPT_OVERLAP_WGRAD = 19
 OPT_OVERLAP_HEAD = 20
 OPT_STREAM_MIN_ROWS = 21

@@ -214,7 +214,12 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *   AMS_MATMUL_SPLIT_F16     frozen inference with two fp16 parts / 3 MFMAs, f32-level (see the enum below)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRAD: weight gradients handed to the side stream n at a time, 1 .. 64
+enum { AMS_OPT_TRAIN_FWD_F16 = 24 /* fine-tune step under AMS_MATMUL_SPLIT_F16: 1 = the FORWARD 1x1 products of the split layers run on two fp16
+                                      parts (3 MFMAs; the per-step weight split leaves fp16 planes beside the bf16 ones), the input-gradient and weight-
+                                      gradient products stay on three bf16 parts (gradients span a range fp16 cannot hold); 0 (default) = three bf16
+                                      parts everywhere.  Measured on MI355X: 7.455 -> 7.368 ms per 8-frame step — the step's GEMMs are not MFMA-bound
+                                      at 17160 rows — so the default keeps one product form for the whole step */,
+       AMS_OPT_WGRAD_FORK_EVERY = 23 /* fine-tune step with AMS_OPT_OVERLAP_WGRAD: weight gradients handed to the side stream n at a time, 1 .. 64
                                          (default 1 = each as soon as its operands exist).  A hand-over is an event on the main stream (a gap of
                                          6-8 us in the rocprofv3 timeline), and a weight gradient feeds only the optimizer, so it may start late —
                                          but measured on MI355X batching is SLOWER: 7.98 / 8.07 / 8.16-8.30 / 8.30 / 8.58 ms per step for n = 1 / 2 /
@@ -472,7 +477,8 @@ int ams_k_depthwise3x3_wgrad(const float* x, const float* dy, int32_t B, int32_t
  *   mode 1: partial rows [rows][2][N] of sum(y - center), sum((y - center)^2)            (forward statistics; center may be NULL)
  *   mode 2: y is the gradient wrt the ACTIVATED output of a BN layer with raw output z [M,N]: y (+ res [M,N] first, if given) is multiplied by
  *           act'(z scale + shift) BEFORE it is stored; partial rows of sum(y), sum(y (z - mean) rstd)   (first half of that layer's BN backward)
- * split != 0: the three-part bf16 kernel (panels: >= 3 N Kp bf16 scratch), else the exact-f32 streaming kernel.  *rows_out = 0 means the kernel
+ * split 1: the three-part bf16 kernel (panels: >= 3 N Kp bf16 scratch); split 2: the two-fp16-part kernel (mode 1 only: what the fine-tune step's
+ * forward runs under AMS_MATMUL_SPLIT_F16; panels >= 2 N Kp); 0: the exact-f32 streaming kernel.  *rows_out = 0 means the kernel
  * chosen for this shape cannot fuse the reduction (y is then the plain product, + res): the caller runs the separate pass.
  * part_floats >= (M / 64 + 8 or 2048) * 2 N. */
 int ams_k_pointwise_red(const float* x, int64_t M, int32_t K, const float* w, int32_t N, int32_t trans_w, int32_t split, int32_t mode,
@@ -485,7 +491,7 @@ int ams_k_pointwise_red(const float* x, int64_t M, int32_t K, const float* w, in
  * bit-identical to running the pass and then the plain kernel.
  *   ams_k_pointwise_xform: y [M,N] = x' . w with x' = act(x * v0[k] + v1[k]) (x_mode 1: BN + activation, what FusedBatchNormV3 + Relu6 are to
  *     the reference's graph) or x' = v0[k] * x + v1[k] + v2[k] * x2 (x_mode 2: the second half of FusedBatchNormGradV3, (v0, v1, v2) = (A, B, C),
- *     x2 = the BN layer's raw output).  split != 0: the three-part bf16 kernel (panels >= 3 N Kp), else the exact-f32 kernels.  A kernel that
+ *     x2 = the BN layer's raw output).  split 1: the three-part bf16 kernel (panels >= 3 N Kp), split 2 (x_mode 1 only): the two-fp16-part kernel, else the exact-f32 kernels.  A kernel that
  *     cannot transform on load writes x' into x_tmp [M,K] first (may be NULL: then such shapes fail with AMS_E_INVALID).
  *   ams_k_pointwise_wgrad_xform: dw [K,N] = x'^T . dy' with x' as x_mode 1 (x_mode 0: x' = x) and dy' = d0[n] * dy + d1[n] + d2[n] * dy2
  *     (dy_mode 2; dy_mode 0: dy' = dy); split != 0 the six-product bf16 kernel (shapes as ams_k_pointwise_wgrad_split). */

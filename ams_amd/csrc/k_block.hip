@@ -453,7 +453,7 @@ static int launch_blk_k(BlkArgs a, hipStream_t st) {
     static const std::string nm = "block_kernel<" + std::to_string(S) + ", " + std::to_string(KC) + ", " + std::to_string(NTO) + ", " +
                                   std::to_string(TH) + ", " + std::to_string(TW) +
                                   (std::is_void<TIn>::value ? ", void" : sizeof(typename std::conditional<std::is_void<TIn>::value, char, TIn>::type) == 1 ? ", unsigned char" : ", float") +
-                                  (H16 ? (HP ? ", false, true>" : ", false, true, false>") : X6 ? ", true>" : ", false>");
+                                  (X6 ? ", true" : ", false") + (H16 ? ", true" : ", false") + (HP ? ", true>" : ", false>");      // as rocprofv3 prints the symbol
     note_kernel(nm.c_str());
     hipLaunchKernelGGL((block_kernel<S, KC, NTO, TH, TW, TIn, X6, H16, HP>), dim3((unsigned)nblocks), dim3(256), lds, st, a, (unsigned)ntiles);
     AMS_CHECK_LAUNCH();

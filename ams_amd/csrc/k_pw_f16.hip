@@ -303,8 +303,8 @@ static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, in
         if (EPI == EPI_PLAIN && NW == 4 && b.red_mode == 1 && pw_red_ok(b, nblocks / n_tiles_n)) { if (b.red_rows_out) *b.red_rows_out = (int)(nblocks / n_tiles_n); }
         else { b.red_mode = 0; if (b.red_rows_out) *b.red_rows_out = 0; }
     }
-    static const std::string nm = "pw_gemm_f16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(XP) +
-                                  (NW != 4 || D != 2 || XF ? ", " + std::to_string(NW) + ", " + std::to_string(D) : std::string()) + (XF ? ", 0, 1>" : ">");
+    static const std::string nm = "pw_gemm_f16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(XP) + ", " +
+                                  std::to_string(NW) + ", " + std::to_string(D) + ", " + std::to_string(ABL) + ", " + std::to_string(XF) + ">";      // as rocprofv3 prints it
     note_kernel(nm.c_str());
     hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>), dim3((unsigned)nblocks), dim3(64 * NW), 0, st, b, w, plane, Kp, n_tiles_n,
                        (unsigned)nblocks, (unsigned)n_full);

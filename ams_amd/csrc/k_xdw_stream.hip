@@ -490,7 +490,8 @@ static int launch_xds_p(XdsArgs a, const XdsPlan& p, hipStream_t st) {
     const int64_t nblocks = (int64_t)a.groups * a.chunks;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_stream: bad grid");
     static const std::string nm = "xdw_stream_kernel<" + std::to_string(KS) + ", " + std::to_string(NT) + ", " + std::to_string(NP) + ", " +
-                                  std::to_string(NWE) + ", " + std::to_string(NWD) + ", " + std::to_string((int)PRE) + ", " + std::to_string((int)F32) + ", " + std::to_string(S) + (H16 ? ", 1>" : ">");
+                                  std::to_string(NWE) + ", " + std::to_string(NWD) + (PRE ? ", true" : ", false") + (F32 ? ", true, " : ", false, ") + std::to_string(S) +
+                                  (H16 ? ", true>" : ", false>");      // the symbol as rocprofv3 prints it
     note_kernel(nm.c_str());
     hipLaunchKernelGGL((xdw_stream_kernel<KS, NT, NP, NWE, NWD, PRE, F32, S, H16>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), p.lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();

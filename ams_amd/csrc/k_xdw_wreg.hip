@@ -372,7 +372,7 @@ static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");
     static const std::string nm = "xdw_wreg_kernel<" + std::to_string(KS) + ", " + std::to_string(NP) + ", " + std::to_string(NWE) + ", " +
-                                  std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", 1>" : ">");
+                                  std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", true, " : ", false, ") + std::to_string(ABL) + ">";
     note_kernel(nm.c_str());
     hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();

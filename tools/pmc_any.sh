@@ -10,7 +10,7 @@ out=gpurun_out/pmc_$tag.txt
 : > $out
 for ctrs in "${groups[@]}"; do
   rm -rf gpurun_out/pmca_$tag
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/pmca_$tag -o p -- "$@" > gpurun_out/pmca_$tag.log 2>&1
+  timeout 240 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/pmca_$tag -o p -- "$@" > gpurun_out/pmca_$tag.log 2>&1
   f=$(find gpurun_out/pmca_$tag -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then echo "no counter file for: $ctrs" >> $out; tail -5 gpurun_out/pmca_$tag.log >> $out; continue; fi
   python3 - "$f" "$pat" >> $out <<'PY'

@@ -17,7 +17,7 @@ g=0
 for ctrs in "${groups[@]}"; do
   g=$((g+1))
   rm -rf gpurun_out/pmcc_$tag
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/pmcc_$tag -o p -- "$@" > gpurun_out/pmcc_$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d gpurun_out/pmcc_$tag -o p -- "$@" > gpurun_out/pmcc_$tag.log 2>&1
   f=$(find gpurun_out/pmcc_$tag -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$pat" $g >> $out <<'PY'
 import csv, sys, collections

@@ -9,6 +9,6 @@ export AMS_DUAL_STREAM=0      # per-kernel traffic of the one-stream plan, whose
 [ ${#args[@]} -eq 0 ] && args=(--steps 3 --warmup 1 --settle 0 --windows 1 --only-timed)      # default batch of bench.py
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/pmc_$tag
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag/fetch -o p -- python3 bench.py "${args[@]}" > gpurun_out/pmc_${tag}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag/write -o p -- python3 bench.py "${args[@]}" > gpurun_out/pmc_${tag}_write.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag/fetch -o p -- python3 bench.py "${args[@]}" > gpurun_out/pmc_${tag}_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag/write -o p -- python3 bench.py "${args[@]}" > gpurun_out/pmc_${tag}_write.log 2>&1
 python3 tools/pmc_traffic.py gpurun_out/pmc_$tag gpurun_out/pmc_traffic_$tag.json

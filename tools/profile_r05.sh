@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round-5 artefacts on the GPU box (repo root): usage  bash tools/profile_r05.sh [part ...]   parts: bench infer train pmc sq (default: all)
+# -> gpurun_out/r05_*  (copied to profiles/ by hand after a look)
+parts=${@:-bench infer train pmc sq}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+stats() {  # <dir> <out.csv>
+  s=$(find $1 -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $2
+}
+for part in $parts; do case $part in
+bench)
+  python3 bench.py > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err ;;
+infer)
+  # the ONE-stream plan (what `roofline` prices per kernel) and the plan the headline times (two parts on two streams at 32 frames)
+  rm -rf gpurun_out/p5i
+  AMS_DUAL_STREAM=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p5i/one -o p -- python3 bench.py --only-timed --steps 20 --warmup 3 --settle 0 --windows 1 > gpurun_out/r05_prof_infer.log 2>&1
+  stats gpurun_out/p5i/one gpurun_out/r05_infer_kernel_stats.csv
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p5i/dual -o p -- python3 bench.py --only-timed --steps 20 --warmup 3 --settle 0 --windows 1 > gpurun_out/r05_prof_infer_dual.log 2>&1
+  stats gpurun_out/p5i/dual gpurun_out/r05_infer_kernel_stats_dual.csv
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p5i/b1 -o p -- python3 tools/infer_loop.py 1 512 200 20 > gpurun_out/r05_prof_infer_b1.log 2>&1
+  stats gpurun_out/p5i/b1 gpurun_out/r05_infer_b1_kernel_stats.csv
+  rm -rf gpurun_out/p5i ;;
+train)
+  rm -rf gpurun_out/p5t
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p5t -o t -- python3 tools/train_loop.py 8 512 5 3 > gpurun_out/r05_prof_train.log 2>&1
+  stats gpurun_out/p5t gpurun_out/r05_train_kernel_stats.csv
+  f=$(find gpurun_out/p5t -name "*kernel_trace.csv" | head -1)
+  python3 tools/trace_timeline.py $f > gpurun_out/r05_train_timeline.txt 2>&1
+  rm -rf gpurun_out/p5t ;;
+pmc)
+  # HBM traffic: two separate counter passes each (FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2)
+  bash tools/pmc_traffic.sh r05 > gpurun_out/r05_pmc_infer.log 2>&1           # -> gpurun_out/pmc_traffic_r05.json (32 frames, one-stream plan)
+  rm -rf gpurun_out/pmc_r05t
+  timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_r05t/fetch -o p -- python3 tools/train_loop.py 8 512 2 1 > gpurun_out/r05_pmc_train_fetch.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_r05t/write -o p -- python3 tools/train_loop.py 8 512 2 1 > gpurun_out/r05_pmc_train_write.log 2>&1
+  alg=$(python3 -c "import json;print(json.loads(open('gpurun_out/r05_bench.json').read().strip().splitlines()[-1])['distill']['roofline']['alg_bytes_per_step'])" 2>/dev/null)
+  python3 tools/pmc_train_traffic.py gpurun_out/pmc_r05t 3 gpurun_out/r05_train_pmc_traffic.json $alg
+  rm -rf gpurun_out/pmc_r05t gpurun_out/pmc_r05 ;;
+sq)
+  # SQ counters (unit-correct tables: tools/pmc_cmd.sh) of the round's inference kernels: the dominant streaming kernel, the fp16 GEMM in its
+  # 12-wave full-width form, a whole-block kernel and the first block
+  bash tools/pmc_cmd.sh r05_xwr "xdw_wreg_kernel" python3 tools/infer_loop.py 32 512 2 1 0
+  bash tools/pmc_cmd.sh r05_gemm "pw_gemm_f16x3_l<1, 10, 1" python3 tools/infer_loop.py 32 512 2 1 0
+  bash tools/pmc_cmd.sh r05_blk "block_kernel<2, 1, 2, 4, 8" python3 tools/infer_loop.py 32 512 2 1 0
+  bash tools/pmc_cmd.sh r05_fb "first_block_kernel" python3 tools/infer_loop.py 32 512 2 1 0
+  cat gpurun_out/sq_r05_xwr.txt gpurun_out/sq_r05_gemm.txt gpurun_out/sq_r05_blk.txt gpurun_out/sq_r05_fb.txt > gpurun_out/r05_infer_sq_counters.txt ;;
+esac; done
+ls -la gpurun_out/r05_* | head -30

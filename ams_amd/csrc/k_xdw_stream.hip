@@ -281,8 +281,9 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
 #pragma unroll
         for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + nch);
         const float4 dsc = ld4(a.sc_d + nch), dsh = ld4(a.sh_d + nch);
-        // byte offset of the thread's four channels within a pixel: f32, or (y_fmt 1) the hi half of its 8-channel group (k_xdw_wreg.hip)
-        const unsigned ych = a.y_fmt ? (unsigned)(nch >> 3) * 32u + (unsigned)(nch & 7) * 2u : (unsigned)nch * 4u;
+        // byte offset of what the thread stores within a pixel: its four f32 channels, or (y_fmt 1) one 16-byte half of its 8-channel group (k_xdw_wreg.hip)
+        const bool odd_cg = (cg & 1) != 0;                          // = the lane's parity (CG is even)
+        const unsigned ych = a.y_fmt ? (unsigned)(nch >> 3) * 32u + (odd_cg ? 16u : 0u) : (unsigned)nch * 4u;
         // ring position of this thread's first tap, (first centre - Wp - 1) mod R, carried across items like sbase
         int cb = (2 * R - 2 * Wp - 2 + pt * PX) % R;
         for (int item = group; item < a.items; item += a.groups) {
@@ -389,11 +390,16 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                         const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
                         const unsigned off = ok ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
                         if (H16 && a.y_fmt) {                        // wave-uniform
+                            // fp16 pairs, 8 channels per 32-byte group (16 bytes of hi | 16 bytes of lo).  Two neighbouring lanes hold the two
+                            // halves of a group (channel groups cg = 2g, 2g + 1 of the same pixel): they swap — the even lane takes the odd one's
+                            // hi, the odd lane the even one's lo (one quad_perm DPP move per dword) — and each stores ONE 16-byte piece instead of
+                            // two 8-byte ones (the result stores are the largest single item of this kernel: tools/sweep_xwr_abl.sh)
                             unsigned h[2], l[2];
                             split4_f16(o, h, l);
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){h[0], h[1]}, yrsrc, off, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){l[0], l[1]}, yrsrc, off, 16, 0);
+                            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h[0] : l[0]), 0xB1, 0xF, 0xF, false);
+                            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h[1] : l[1]), 0xB1, 0xF, 0xF, false);
+                            const u32x4 d = {odd_cg ? r0 : h[0], odd_cg ? r1 : h[1], odd_cg ? l[0] : r0, odd_cg ? l[1] : r1};
+                            __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
                         } else {
                         const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
                         __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);

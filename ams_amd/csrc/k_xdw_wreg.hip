@@ -260,9 +260,10 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #pragma unroll
         for (int k = 0; k < 9; ++k) wv[k] = ld4(a.w_dw + (int64_t)k * a.Cexp + nchc);
         const float4 dsc = ld4(a.sc_d + nchc), dsh = ld4(a.sh_d + nchc);
-        // byte offset of the thread's four channels within a pixel: f32, or (y_fmt 1) the hi half of its 8-channel group — 32-byte groups of
-        // 16 bytes hi | 16 bytes lo, this thread's 8 bytes of each at (nch % 8) * 2
-        const unsigned ych = a.y_fmt ? (unsigned)(nchc >> 3) * 32u + (unsigned)(nchc & 7) * 2u : (unsigned)nchc * 4u;
+        // byte offset of what the thread stores within a pixel: its four f32 channels, or (y_fmt 1) one 16-byte half of its 8-channel group —
+        // 32-byte groups of 16 bytes hi | 16 bytes lo: the even lane of a pair stores the hi half, the odd lane the lo half (see the store)
+        const bool odd_cg = (cg & 1) != 0;                          // = the lane's parity (CG is even)
+        const unsigned ych = a.y_fmt ? (unsigned)(nchc >> 3) * 32u + (odd_cg ? 16u : 0u) : (unsigned)nchc * 4u;
         int cb = (2 * R - 2 * Wp - 2 + pt * PX) % R;                 // ring slot of the thread's first tap, carried across items
         for (int item = group; item < a.items; item += a.groups) {
             int u1 = item;
@@ -325,11 +326,16 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                         const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
                         const unsigned off = (ok && !(ABL & 8)) ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
                         if (H16 && a.y_fmt) {                        // wave-uniform
+                            // fp16 pairs, 8 channels per 32-byte group (16 bytes of hi | 16 bytes of lo).  Two neighbouring lanes hold the two
+                            // halves of a group (channel groups cg = 2g, 2g + 1 of the same pixel): they swap — the even lane takes the odd one's
+                            // hi, the odd lane the even one's lo (one quad_perm DPP move per dword) — and each stores ONE 16-byte piece instead of
+                            // two 8-byte ones (the result stores are the largest single item of this kernel: tools/sweep_xwr_abl.sh)
                             unsigned h[2], l[2];
                             split4_f16(o, h, l);
-                            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){h[0], h[1]}, yrsrc, off, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){l[0], l[1]}, yrsrc, off, 16, 0);
+                            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h[0] : l[0]), 0xB1, 0xF, 0xF, false);
+                            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h[1] : l[1]), 0xB1, 0xF, 0xF, false);
+                            const u32x4 d = {odd_cg ? r0 : h[0], odd_cg ? r1 : h[1], odd_cg ? l[0] : r0, odd_cg ? l[1] : r1};
+                            __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
                         } else {
                         const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
                         __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);

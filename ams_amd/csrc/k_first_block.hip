@@ -37,6 +37,9 @@ struct FirstBlockArgs {
     // hs = the stem's panels [part][32 channels][32 k], hj = the project layer's [part][16 channels][32 k]
     const uint16_t* hs; int64_t hs_plane;
     const uint16_t* hj; int64_t hj_plane;
+    // the rectangle of interior tiles [ity0, ity1] x [itx0, itx1] (every stem position of the halo tile exists, every tap lies inside the frame);
+    // nix * niy = 0: none.  border_only: first_block_kernel computes the tiles outside the rectangle (first_block_walk_kernel the ones inside)
+    int ity0, itx0, niy, nix, border_only;
 };
 
 // X6 form: index into the normalisation table of the tap (0..255 the byte, 256 the 127.5 padding row / column, 257 = zero: outside)
@@ -88,10 +91,28 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     __shared__ unsigned sTabH[(TAB && H16) ? 258 : 1];                          // H16: hi | lo << 16, fp16 parts
 
     const unsigned lb = xcd_remap(blockIdx.x, nblocks);
-    const int tx = lb % a.tiles_x;
-    unsigned t1 = lb / a.tiles_x;
-    const int ty = t1 % a.tiles_y;
-    const int b = t1 / a.tiles_y;
+    int tx, ty, b;
+    if (a.border_only) {                              // the tiles outside the interior rectangle: rows above, rows below, then the side columns
+        const unsigned per_frame = (unsigned)(a.tiles_x * a.tiles_y - a.nix * a.niy);
+        b = lb / per_frame;
+        unsigned j = lb - (unsigned)b * per_frame;
+        const unsigned above = (unsigned)(a.ity0 * a.tiles_x), below = (unsigned)((a.tiles_y - a.ity0 - a.niy) * a.tiles_x);
+        if (j < above) { ty = j / a.tiles_x; tx = j - ty * a.tiles_x; }
+        else if (j < above + below) { j -= above; ty = j / a.tiles_x; tx = j - ty * a.tiles_x; ty += a.ity0 + a.niy; }
+        else {
+            j -= above + below;
+            const unsigned side = (unsigned)(a.tiles_x - a.nix);
+            ty = j / side;
+            tx = j - ty * side;
+            ty += a.ity0;
+            if (tx >= a.itx0) tx += a.nix;
+        }
+    } else {
+        tx = lb % a.tiles_x;
+        const unsigned t1 = lb / a.tiles_x;
+        ty = t1 % a.tiles_y;
+        b = t1 / a.tiles_y;
+    }
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int oy0 = ty * TH, ox0 = tx * TW;
@@ -376,6 +397,262 @@ __global__ __launch_bounds__(256) void first_block_kernel(FirstBlockArgs a, unsi
     }
 }
 
+// Walking form of first_block_kernel<uint8_t, false, true> for the INTERIOR tiles (FirstBlockArgs::ity0 ..; the border tiles — clamps, padding
+// classes, 3-4x the gather work — are a second launch of the one-tile kernel with border_only: keeping their path out of this kernel keeps its
+// registers and its s_waitcnt free of them): the same arithmetic per element (same bits), a block walks the tiles t = blockIdx.x,
+// blockIdx.x + gridDim.x, ... of the interior rectangle
+//   * everything that does not depend on the tile is staged once per block: the fp16 table, the depthwise taps and coefficients in LDS, the weight
+//     fragments of the stem and the project layer and the stem's coefficients in registers;
+//   * the taps of an interior tile are TWO 8-byte loads per stem position instead of eight byte loads: the lane's taps k = 8q .. 8q + 7 are the
+//     last q bytes of the 9-byte window row q - 1 followed by the first 8 - q bytes of row q (RGB rows are contiguous), joined by two v_perm with
+//     per-lane selectors; byte loads cost the texture-address unit a quad-cycle pass per lane each (the one-tile kernel: 96 µs of its 303);
+//   * the bytes of the NEXT tile are requested as soon as this tile's table look-ups have consumed the registers: they arrive under the stem's
+//     MFMAs and the depthwise + project phase.  This only works without a single spill inside the walk: hipcc follows a scratch reload with
+//     s_waitcnt vmcnt(0), which waits for the prefetch as well (measured: 40 % of the wave's cycles);
+//   * depthwise and project are ONE phase: lane = (pixel column, 8 channels), two output rows per wave, so the depthwise result of a lane IS its
+//     operand of the project MFMAs (no second LDS tile, no second barrier), and the stem tile is double-buffered: one barrier per tile.
+// Taps k >= 27 read a valid byte and meet the zero rows of the weight panels (launch_split_weights_f16 pads with zeros).
+//
+// tools/ only (AMS_FB_ABL=32): shader-clock cycles per wave summed over the launch — [0] tile decode, [1] stem phase, [2] wait at the barrier,
+// [3] depthwise + project phase, [6] wave-tiles; read and cleared by ams_debug_phase_cycles
+__device__ unsigned long long g_fb_cycles[8];
+
+// ABL: measurement-only ablations (AMS_FB_ABL=<bits>, wrong results): 1 no result stores, 2 no depthwise arithmetic, 4 no byte loads / table
+// look-ups, 8 no project MFMAs, 16 no stem MFMAs
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs a, unsigned ntiles) {
+    constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, NPIX = IH * IW, NRG = (NPIX + 15) / 16, MRG = 3, P = 36;
+    static_assert(NRG == 4 * MRG, "three row groups of stem positions per wave");
+    __shared__ __attribute__((aligned(16))) float sS[2][NPIX * P];     // stem tile, double-buffered: 3 blocks per CU = 3 x 54272 B
+    __shared__ __attribute__((aligned(16))) float sDw[9 * 32];
+    __shared__ __attribute__((aligned(16))) float sAffD[64];           // sc_d, sh_d
+    __shared__ unsigned sTabH[256];                                    // hi | lo << 16 of byte * ps - 1
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float lo_s = a.act_s == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_s = a.act_s == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+    const float lo_d = a.act_d == AMS_ACT_NONE ? -__builtin_huge_valf() : 0.f, hi_d = a.act_d == AMS_ACT_RELU6 ? 6.f : __builtin_huge_valf();
+
+    {
+        unsigned short h, l;
+        split1_f16(__fsub_rn(__fmul_rn((float)tid, a.ps), 1.0f), h, l);
+        sTabH[tid] = (unsigned)h | ((unsigned)l << 16);
+    }
+    for (int e = tid; e < 9 * 32; e += 256) sDw[e] = a.w_dw[e];
+    if (tid < 32) { sAffD[tid] = a.sc_d[tid]; sAffD[32 + tid] = a.sh_d[tid]; }
+    float4 sc_s[2], sh_s[2];                          // stem coefficients of this lane's output channels 16 t + 4q .. + 3
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { sc_s[t] = ld4(a.sc_s + 16 * t + 4 * q); sh_s[t] = ld4(a.sh_s + 16 * t + 4 * q); }
+    const float4 sc_p = ld4(a.sc_p + 4 * q), sh_p = ld4(a.sh_p + 4 * q);
+    u32x4 wh[2][2];                                   // stem weights, channel 16 t + l15, k = 8q .. 8q + 7, [t][hi | lo]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+            wh[t][pp] = *reinterpret_cast<const u32x4*>(a.hs + pp * a.hs_plane + (int64_t)(16 * t + l15) * 32 + 8 * q);
+    const f16x8 jh = *reinterpret_cast<const f16x8*>(a.hj + (int64_t)l15 * 32 + 8 * q);
+    const f16x8 jl = *reinterpret_cast<const f16x8*>(a.hj + a.hj_plane + (int64_t)l15 * 32 + 8 * q);
+    const uint8_t* frames = reinterpret_cast<const uint8_t*>(a.frames);
+    const int frame_bytes = a.H * a.W * 3;            // (the launcher checks that the batch of frames is below 2 GB)
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frames), 0, a.B * frame_bytes, 0x00020000);
+    // interior tiles: piece A = 4 bytes from byte 9 - q of window row q - 1 (its first q bytes are taps 8q .. 9q - 1), piece B = the first 8 bytes of
+    // window row q (taps 9q ..); lanes that need no A (q = 0) / no B (q = 3) read the other piece's address
+    const int row_bytes = a.W * 3;
+    const unsigned off_b = q < 3 ? (unsigned)(q * row_bytes) : (unsigned)(2 * row_bytes + 6);
+    const unsigned off_a = q > 0 ? (unsigned)((q - 1) * row_bytes + 9 - q) : off_b;
+    // byte i of the joined 8 bytes = i < q ? A[i] : B[i - q]; v_perm selector bytes: 0-3 = second operand's bytes, 4-7 = first operand's
+    unsigned sel0 = 0, sel1 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sel0 |= (unsigned)(i < q ? 4 + i : i - q) << (8 * i);          // perm(A.lo, B.lo)
+        sel1 |= (unsigned)(4 + i - q) << (8 * i);                       // perm(B.hi, B.lo): B bytes 4 + i - q
+    }
+    // this lane's stem positions: row groups wave, wave + 4, wave + 8 of the 10 x 18 halo tile
+    // (the last row group has 4 positions: its other 12 lanes repeat them — same window, same result, same LDS row — so that no store is
+    // predicated and the three row groups are one straight-line block that hipcc can interleave)
+    unsigned poff[MRG];                               // byte offset of the position's window from the tile's first byte
+    int prow[MRG];                                    // the position's row of the LDS tile
+#pragma unroll
+    for (int i = 0; i < MRG; ++i) {
+        const int m = (wave + 4 * i) * 16 + l15;
+        const int mc = m < NPIX ? m : NPIX - 4 + (l15 & 3);
+        const int ty = mc / IW, tx = mc - ty * IW;
+        poff[i] = (unsigned)(2 * ty * row_bytes + 2 * tx * 3);
+        prow[i] = mc * P;
+    }
+
+    struct Tile { int b, oy0, ox0; };
+    auto decode = [&](unsigned t) {
+        const unsigned lb = xcd_remap(t, ntiles);
+        Tile r;
+        const unsigned t1 = lb / a.nix;
+        r.ox0 = (a.itx0 + (int)(lb - t1 * a.nix)) * TW;
+        r.b = (int)(t1 / a.niy);
+        r.oy0 = (a.ity0 + (int)(t1 - (unsigned)r.b * a.niy)) * TH;
+        return r;
+    };
+    auto tile_base = [&](const Tile& tl) { return tl.b * frame_bytes + (((tl.oy0 - 1) * 2 - a.pt) * a.W + ((tl.ox0 - 1) * 2 - a.pl)) * 3; };
+    unsigned pa[MRG];                                 // the pieces of each row group, in flight or landed (A: at most its first 3 bytes are taps — a
+    uint2 pb[MRG];                                    // dword; a loaded register that nothing reads would be reused, behind a wait for the load)
+    auto request = [&](int base, int i) {
+        unsigned p = poff[i];
+        asm volatile("" : "+v"(p));                   // two adds per row group instead of six registers held over the walk
+        pa[i] = __builtin_amdgcn_raw_buffer_load_b32(frsrc, (int)(p + off_a), base, 0);
+        pb[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(frsrc, (int)(p + off_b), base, 0));
+    };
+    constexpr bool TIMED = (ABL & 32) != 0;
+    unsigned long long tc[4] = {0, 0, 0, 0}, tl_ = 0, ntile = 0;
+    auto lap = [&](int slot) {
+        if constexpr (TIMED) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tc[slot] += now - tl_;
+            tl_ = now;
+        }
+    };
+    unsigned t = blockIdx.x;
+    if (t >= ntiles) return;                          // block-uniform
+    Tile cur = decode(t);
+    bool ready = false;                               // the pieces of `cur` are in flight / in registers (requested during the previous tile)
+    int buf = 0;
+    __syncthreads();                                  // table, taps and coefficients are staged
+    if constexpr (TIMED) tl_ = __builtin_amdgcn_s_memtime();
+    for (;;) {
+        if (!ready && !(ABL & 4)) {                    // (the block's first tile)
+            const int base = tile_base(cur);
+#pragma unroll
+            for (int i = 0; i < MRG; ++i) request(base, i);
+        }
+        const unsigned tn = t + gridDim.x;
+        const bool more = tn < ntiles;                // block-uniform
+        Tile nxt = cur;
+        if (more) nxt = decode(tn);
+        const int nbase = tile_base(nxt);
+        float* sT = sS[buf];
+        lap(0);
+        // ---- phase 1: stem over the halo tile; the registers of a row group's pieces are refilled for the next tile as soon as the table
+        // look-ups have consumed them
+#pragma unroll
+        for (int i = 0; i < MRG; ++i) {
+            unsigned e[8];
+            if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = 0x3c00u + (unsigned)(lane + u + i);
+            } else {
+                const unsigned d0 = __builtin_amdgcn_perm(pa[i], pb[i].x, sel0), d1 = __builtin_amdgcn_perm(pb[i].y, pb[i].x, sel1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned d = u < 4 ? d0 : d1;
+                    e[u] = *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(sTabH) + (((d >> (8 * (u & 3))) & 0xffu) << 2));
+                }
+            }
+            if constexpr (!(ABL & 4)) request(nbase, i);        // unconditional (the last tile re-reads its own window): behind a branch hipcc's wait for the
+                                                                // older pieces becomes vmcnt(0), which waits for these loads as well
+            u32x4 xh, xl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);
+                xl[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);
+            }
+            const float lo = lo_s, hi = hi_s;        // (every position of an interior tile's halo lies inside the feature map)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr ((ABL & 16) != 0) { acc[0] = __uint_as_float(xh[0] ^ wh[tt][0][1]); acc[1] = __uint_as_float(xl[1]); acc[2] = __uint_as_float(xh[2]); acc[3] = __uint_as_float(xl[3] ^ xh[3]); }
+                else {
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[tt][1]), __builtin_bit_cast(f16x8, xh), accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[tt][0]), __builtin_bit_cast(f16x8, xl), accx, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[tt][0]), __builtin_bit_cast(f16x8, xh), acc, 0, 0, 0);
+                    acc = combine_f16(acc, accx);
+                }
+                const float4 bn = muladd4_pk(make_float4(acc[0], acc[1], acc[2], acc[3]), sc_s[tt], sh_s[tt]);
+                float4 o;
+                o.x = __builtin_amdgcn_fmed3f(bn.x, lo, hi);
+                o.y = __builtin_amdgcn_fmed3f(bn.y, lo, hi);
+                o.z = __builtin_amdgcn_fmed3f(bn.z, lo, hi);
+                o.w = __builtin_amdgcn_fmed3f(bn.w, lo, hi);
+                st4(sT + prow[i] + 16 * tt + 4 * q, o);
+            }
+        }
+        lap(1);
+        __syncthreads();
+        lap(2);
+        // ---- phase 2: depthwise 3x3 + project for output rows 2 wave, 2 wave + 1: lane = (pixel column l15, channels 8q .. 8q + 7), the depthwise
+        // taps in the one-tile kernel's order (tap rows outer, columns inner, fma), four channels at a time
+        {
+            float4 d[2][2];                           // [row][channel half]
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __builtin_amdgcn_sched_barrier(0);    // one half's taps and window in registers at a time (hipcc otherwise hoists every LDS read and spills)
+                const int c4 = 8 * q + 4 * h;
+                float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+                if constexpr (!(ABL & 2)) {
+                    float4 w[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) w[k] = ld4(sDw + k * 32 + c4);
+                    const float* col = sT + ((2 * wave) * IW + l15) * P + c4;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u == 2) __builtin_amdgcn_sched_barrier(0);
+                        float4 x3[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) x3[j] = ld4(col + (u * IW + j) * P);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            if (u - i >= 0 && u - i < 2) {            // input row u is tap row i of output row u - i
+#pragma unroll
+                                for (int j = 0; j < 3; ++j) fma4_pk(acc[u - i], x3[j], w[i * 3 + j]);
+                            }
+                        }
+                    }
+                } else { acc[0] = ld4(sT + (2 * wave * IW + l15) * P + c4); acc[1] = acc[0]; }
+                const float4 sc = ld4(sAffD + c4), sh = ld4(sAffD + 32 + c4);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float4 bn = muladd4_pk(acc[r], sc, sh);
+                    d[r][h].x = __builtin_amdgcn_fmed3f(bn.x, lo_d, hi_d); d[r][h].y = __builtin_amdgcn_fmed3f(bn.y, lo_d, hi_d);
+                    d[r][h].z = __builtin_amdgcn_fmed3f(bn.z, lo_d, hi_d); d[r][h].w = __builtin_amdgcn_fmed3f(bn.w, lo_d, hi_d);
+                }
+                // both rows of this half exist HERE: without the pin hipcc sinks the second row's arithmetic behind the first row's project MFMAs and
+                // keeps (spills) both halves' taps and windows until then
+                asm volatile("" : "+v"(d[0][h].x), "+v"(d[0][h].y), "+v"(d[0][h].z), "+v"(d[0][h].w), "+v"(d[1][h].x), "+v"(d[1][h].y), "+v"(d[1][h].z), "+v"(d[1][h].w));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float* yb = a.y + (int64_t)cur.b * a.Ho * a.Wo * 16;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                f16x8 dh, dl;
+                split8_f16(d[r][0], d[r][1], dh, dl);
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr ((ABL & 8) != 0) { acc[0] = d[r][0].x; acc[1] = d[r][0].y; acc[2] = d[r][1].z; acc[3] = d[r][1].w; }
+                else {
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(jl, dh, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x32_f16(jh, dl, accx, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(jh, dh, acc, 0, 0, 0);
+                    acc = combine_f16(acc, accx);
+                }
+                const float4 bn = muladd4_pk(make_float4(acc[0], acc[1], acc[2], acc[3]), sc_p, sh_p);
+                float4 o;
+                o.x = apply_act(bn.x, a.act_p); o.y = apply_act(bn.y, a.act_p);
+                o.z = apply_act(bn.z, a.act_p); o.w = apply_act(bn.w, a.act_p);
+                const int oy = cur.oy0 + 2 * wave + r, ox = cur.ox0 + l15;
+                if (!(ABL & 1) || o.x == 12345.f) st4(yb + ((int64_t)oy * a.Wo + ox) * 16 + 4 * q, o);      // (interior tiles lie inside the map)
+            }
+        }
+        lap(3);
+        if constexpr (TIMED) ntile += 1;
+        if (!more) break;
+        t = tn;
+        cur = nxt;
+        ready = true;
+        buf ^= 1;
+    }
+    if constexpr (TIMED) {
+        if (lane == 0) {
+            for (int i = 0; i < 4; ++i) atomicAdd(&g_fb_cycles[i], tc[i]);
+            atomicAdd(&g_fb_cycles[6], ntile);
+        }
+    }
+}
+
 int launch_first_block(const void* frames, int dtype, int B, int H, int W, float pixel_scale, const float* w_stem,
                        const float* sc_s, const float* sh_s, int act_s, const float* w_dw, const float* sc_d, const float* sh_d,
                        int act_d, const float* w_pj, const float* sc_p, const float* sh_p, int act_p, float* y, hipStream_t st,
@@ -396,6 +673,45 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "first_block: bad grid");
     if (h_stem && h_pj) {                           // two fp16 parts in the stem and the project layer (takes precedence over w_parts)
         a.hs = h_stem; a.hs_plane = h_stem_plane; a.hj = h_pj; a.hj_plane = h_pj_plane;
+        if (dtype == AMS_DT_U8 && knobs().fb_walk != 0 && (int64_t)B * H * W * 3 < 0x7fffffffLL) {
+            // interior tiles (first_block_walk_kernel's header) form a rectangle: the conditions are separate in y and x
+            auto range = [](int tiles, int T, int Osize, int pad, int Isize, int* first, int* count) {
+                *first = 0; *count = 0;
+                for (int t = 0; t < tiles; ++t) {
+                    const int o0 = t * T;
+                    const bool in = o0 >= 1 && o0 + T < Osize && (o0 - 1) * 2 - pad >= 0 && (o0 + T) * 2 - pad + 2 <= Isize - 1;
+                    if (in) { if (!*count) *first = t; ++*count; }
+                }
+            };
+            range(a.tiles_y, 8, a.Ho, a.pt, H, &a.ity0, &a.niy);
+            range(a.tiles_x, 16, a.Wo, a.pl, W, &a.itx0, &a.nix);
+            const int64_t n_in = (int64_t)B * a.niy * a.nix;
+            if (n_in > 0) {
+                int per_cu = 1, cus = 256;
+                RUN_RC(func_blocks_per_cu((const void*)first_block_walk_kernel<0>, 256, 0, &per_cu));
+                RUN_RC(device_cus(&cus));
+                const int64_t slots = (int64_t)per_cu * cus;
+                int64_t rounds = cdiv(n_in, slots);
+                if (knobs().fb_walk > 0 && rounds > knobs().fb_walk) rounds = knobs().fb_walk;      // AMS_FB_WALK=<n>: at most n tiles per block
+                int64_t grid = cdiv(cdiv(n_in, rounds), 8) * 8;           // equal shares; a multiple of 8: a block's tiles stay on its XCD's share
+                if (grid > n_in) grid = n_in;
+                note_kernel("first_block_walk_kernel<0>");                // (a profiled launch bracket covers the border launch below as well)
+                switch (knobs().fb_abl) {           // MEASUREMENT ONLY (tools/sweep_fb_abl.sh, tools/fb_phases.py)
+#define FB_A(A_) case A_: hipLaunchKernelGGL(first_block_walk_kernel<A_>, dim3((unsigned)grid), dim3(256), 0, st, a, (unsigned)n_in); break;
+                    FB_A(1) FB_A(2) FB_A(4) FB_A(8) FB_A(16) FB_A(6) FB_A(14) FB_A(30) FB_A(31) FB_A(32) FB_A(33) FB_A(34) FB_A(36) FB_A(40) FB_A(48) FB_A(63)
+#undef FB_A
+                    default: hipLaunchKernelGGL(first_block_walk_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, a, (unsigned)n_in);
+                }
+                AMS_CHECK_LAUNCH();
+                const int64_t n_border = nblocks - n_in;
+                if (n_border > 0) {
+                    a.border_only = 1;
+                    hipLaunchKernelGGL((first_block_kernel<uint8_t, false, true>), dim3((unsigned)n_border), dim3(256), 0, st, a, (unsigned)n_border);
+                    AMS_CHECK_LAUNCH();
+                }
+                return AMS_OK;
+            }
+        }
         note_kernel(dtype == AMS_DT_U8 ? "first_block_kernel<unsigned char, false, true>" : "first_block_kernel<float, false, true>");
         if (dtype == AMS_DT_U8) hipLaunchKernelGGL((first_block_kernel<uint8_t, false, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
         else hipLaunchKernelGGL((first_block_kernel<float, false, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a, (unsigned)nblocks);
@@ -417,3 +733,12 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
 }
 
 }  // namespace ams
+
+// tools/ only: the walking first block's per-phase shader-clock sums (AMS_FB_ABL=32), read and cleared
+extern "C" int ams_debug_phase_cycles(uint64_t* out, int32_t n) {
+    unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ams::g_fb_cycles), sizeof(h)) != hipSuccess) return AMS_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ams::g_fb_cycles), z, sizeof(z)) != hipSuccess) return AMS_E_HIP;
+    for (int i = 0; i < n && i < 8; ++i) out[i] = h[i];
+    return AMS_OK;
+}

@@ -16,6 +16,8 @@ int device_cus(int* cus);
 bool launch_table_needs_attr(int device, const void* fn, size_t lds);
 struct Knobs {                   // tuning knobs of tools/*: environment variables, read at first use, never on the launch path
     int blk_th = 0, blk_tw = 0;                  // AMS_BLK_TILE=<th>x<tw>
+    int fb_walk = -1;                            // AMS_FB_WALK=<0|n>: first block of the frozen path as one tile per block (0) / at most n tiles per walking block
+    int fb_abl = 0;                              // AMS_FB_ABL=<bits>: measurement-only ablations of the walking first block (wrong results)
     int blk_hp = -1;                             // AMS_BLK_HP=<0|1>: fp16 whole-block kernels with exact-f32 (0) / fp16 (1) project products
     char pw_force = 0; int pw_rm = 0, pw_nt = 0; // AMS_PW_FORCE=<s|l>,<RM>,<NT>
     int pw_percu = 0;                            // AMS_PW_PERCU

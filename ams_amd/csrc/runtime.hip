@@ -82,6 +82,8 @@ static Knobs read_knobs() {
         Knobs v;
         if (const char* e = getenv("AMS_BLK_TILE")) sscanf(e, "%dx%d", &v.blk_th, &v.blk_tw);
         if (const char* e = getenv("AMS_BLK_HP")) v.blk_hp = atoi(e);
+        if (const char* e = getenv("AMS_FB_WALK")) v.fb_walk = atoi(e);
+        if (const char* e = getenv("AMS_FB_ABL")) v.fb_abl = atoi(e);
         if (const char* e = getenv("AMS_PW_FORCE")) sscanf(e, "%c,%d,%d", &v.pw_force, &v.pw_rm, &v.pw_nt);
         if (const char* e = getenv("AMS_PW_PERCU")) v.pw_percu = atoi(e);
         v.pwx_no_tail = getenv("AMS_PWX_NO_TAIL") != nullptr;

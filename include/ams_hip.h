@@ -583,6 +583,10 @@ int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_
  * stream-ordering events — these two change stream semantics and exist for measurements only) are read ONCE, at first use; this re-reads
  * them.  Not thread-safe against launches in flight. */
 int ams_debug_reload_knobs(void);
+/* tools/ only.  With AMS_FB_ABL=32 the walking first block sums shader-clock cycles per wave and phase into a device array ([0] tile decode,
+ * [1] stem, [2] wait at barrier 1, [3] depthwise, [4] wait at barrier 2, [5] project, [6] tiles walked, per wave); this copies out[0..n) (n <= 8)
+ * and clears the array. */
+int ams_debug_phase_cycles(uint64_t* out, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,27 @@ def test_frozen_inference_matches_oracle(W0, H, B, matmul):
     eng.close()
 
 
+@pytest.mark.parametrize("H,W,B", [(64, 128, 3), (34, 68, 5), (50, 100, 1), (128, 256, 2), (256, 512, 3), (512, 1024, 2), (200, 72, 2)])
+def test_first_block_walking_form_same_bits(W0, H, W, B, knobs):
+    """first_block_walk_kernel (a block walks tiles; table, taps and weight fragments staged once, the bytes of the next tile's taps requested
+    under this tile's phases) against one tile per block (AMS_FB_WALK=0): identical bits at any cap of tiles per block, border tiles,
+    interior tiles and sizes that are no multiple of the tile included."""
+    frames = np.random.default_rng(H + B).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    eng = StudentEngine(CI, H, W, max_batch=B, trainable=False)
+    eng.load_variables(W0)
+    eng.freeze()
+    h, w = eng.lowres
+    low = lambda: eng.logits_lowres.view(-1, h, w, 32)[:B, :, :, :19].cpu().numpy().copy()
+    knobs(AMS_FB_WALK="0")
+    lab0 = eng.predict(frames)
+    low0 = low()
+    for cap in (None, "1", "2", "5"):
+        knobs(AMS_FB_WALK=cap)
+        lab = eng.predict(frames)
+        assert torch.equal(lab, lab0) and np.array_equal(low(), low0), cap
+    eng.close()
+
+
 def test_live_forward_uses_batch_statistics(W0, clip64):
     frames, labels = clip64
     B = 3

@@ -57,7 +57,12 @@ struct BlkArgs {
     // he = the expand layer's fp16 panels [part][Cexp][32], hp = the project layer's [part][Cout][kp_p] (k contiguous, zero-padded)
     const uint16_t* he; int64_t he_plane;
     const uint16_t* hp; int64_t hp_plane; int kp_p;
+    int timed;               // tools/ only (AMS_BLK_TIMED=1): sum shader-clock cycles per phase into g_blk_cycles (ams_debug_phase_cycles(1, ..))
 };
+
+// tools/ only: [0] prologue (vectors, input fragments, first weights), [1] expand phases, [2] depthwise + project phases, [3] epilogue, [6] waves
+// (1024 rows, a wave adds to row (4 block + wave) mod 1024: one shared row serialises 10^5 atomics and slows the kernel 7x)
+__device__ unsigned long long g_blk_cycles[1024][8];
 
 // value of the normalised, 127.5-padded frame at (iy, ix, ch) in padded coordinates; outside of it the stem's SAME zero padding
 template <typename TIn>
@@ -86,6 +91,7 @@ template <int S, int KC, int NTO, int TH, int TW, typename TIn = void, bool X6 =
 __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntiles) {
     static_assert(!HP || H16, "HP is a refinement of H16");
     constexpr bool PKDW = S == 1 || TH == 2;          // packed f32 in the depthwise phase (see there)
+    constexpr bool SLIDE = S == 1 && TW == 16 && TH % 2 == 0;      // the depthwise taps slide down the lane's column (see there)
     constexpr bool STEM = !std::is_void<TIn>::value;
     static_assert(!(X6 && STEM) && !(H16 && STEM) && !(X6 && H16), "the stem stays exact f32; one split form at a time");
     constexpr bool H16W = H16 && KC == 2;             // expand fragments of 8 k per lane (16x16x32); KC == 1: 4 k per lane (16x16x16)
@@ -103,6 +109,14 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
     float* sVec = smem;                               // [13][Cexp]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l15 = lane & 15, q = lane >> 4;
     float* sAct = smem + 13 * a.Cexp + wave * (NRG * 16 * AP);       // this wave's expanded tile, 16 channels at a time
+    unsigned long long tc[4] = {0, 0, 0, 0}, tl_ = a.timed ? __builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int slot) {
+        if (a.timed) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tc[slot] += now - tl_;
+            tl_ = now;
+        }
+    };
 
     // ---- every WAVE owns a TH x TW tile of output pixels: no block barrier after the prologue, the four waves of a block
     // drift apart and one wave's MFMA-heavy expand phase overlaps another's VALU/LDS-heavy depthwise phase on the same SIMD
@@ -297,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
 #pragma unroll
         for (int t = 0; t < (HP ? NTO : 1); ++t) outx[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                   // sVec is staged: the only block barrier of the kernel
+    lap(0);
 
     const int chunks = a.Cexp / 16;
     for (int ci = 0; ci < chunks; ++ci) {
@@ -351,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lap(1);
 
         // ---- phases 2 + 3 per 16-pixel output row group: lane (l15, q) forms the depthwise result of pixel l15 for the channels
         // n0 + 4q .. +3 — exactly its operand of the project MFMAs (k = n0 + 4q + j), so `d` never leaves the registers
@@ -359,6 +375,62 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) w9[tp] = ld4(sVec + (4 + tp) * a.Cexp + n0 + 4 * q);
             const float4 scd = ld4(sVec + 2 * a.Cexp + n0 + 4 * q), shd = ld4(sVec + 3 * a.Cexp + n0 + 4 * q);
+            // BN + activation of a finished depthwise accumulator, then the lane's share of the project MFMAs of row group i
+            auto finish = [&](int i, const float4& acc) {
+                float dv[4];
+                const float4 bn = PKDW ? muladd4_pk(acc, scd, shd)
+                                       : make_float4(acc.x * scd.x + shd.x, acc.y * scd.y + shd.y, acc.z * scd.z + shd.z, acc.w * scd.w + shd.w);
+                dv[0] = __builtin_amdgcn_fmed3f(bn.x, lo_d, hi_d); dv[1] = __builtin_amdgcn_fmed3f(bn.y, lo_d, hi_d);
+                dv[2] = __builtin_amdgcn_fmed3f(bn.z, lo_d, hi_d); dv[3] = __builtin_amdgcn_fmed3f(bn.w, lo_d, hi_d);
+                if constexpr (HP) {
+                    unsigned h[2], l[2];
+                    split4_f16(make_float4(dv[0], dv[1], dv[2], dv[3]), h, l);
+                    const u32x2_t dh = {h[0], h[1]}, dl = {l[0], l[1]};
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t) outx[i][t] = mma16_f16(pl[t], dh, outx[i][t]);
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t) outx[i][t] = mma16_f16(ph[t], dl, outx[i][t]);
+#pragma unroll
+                    for (int t = 0; t < NTO; ++t) out[i][t] = mma16_f16(ph[t], dh, out[i][t]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int t = 0; t < NTO; ++t) out[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t], dv[j], out[i][t], 0, 0, 0);
+                }
+            };
+            if constexpr (SLIDE) {
+                // stride 1, 16-pixel tile rows: row group i IS tile row i and the lane keeps its column, so the taps slide down the column — (TH + 2) x 3
+                // LDS reads per chunk instead of TH x 9 (the tap reads were the largest item on the LDS pipe, which bounds these kernels: per chunk
+                // and wave 47 b128 reads + 7 writes against 2 x 16 MFMA-pipe passes), two input rows per round trip.  A row group's FMAs keep their
+                // order (tap rows outer, columns inner): same bits
+                const float* col = sAct + l15 * AP + 4 * q;
+                float4 acc[MRO];
+#pragma unroll
+                for (int i = 0; i < MRO; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u0 = 0; u0 < TH + 2; u0 += 2) {
+                    float4 r[2][3];
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                        for (int jj = 0; jj < 3; ++jj) r[uu][jj] = ld4(col + ((u0 + uu) * IW + jj) * AP);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu) {
+                        const int u = u0 + uu;                 // input row u is tap row ii of tile row u - ii
+#pragma unroll
+                        for (int ii = 0; ii < 3; ++ii) {
+                            const int i = u - ii;
+                            if (i >= 0 && i < MRO) {
+#pragma unroll
+                                for (int jj = 0; jj < 3; ++jj) fma4_pk(acc[i], r[uu][jj], w9[ii * 3 + jj]);
+                            }
+                        }
+                        if (u >= 2) finish(u - 2, acc[u - 2]);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < MRO; ++i) {
                 const int P = i * 16 + l15;
@@ -383,37 +455,41 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
                         acc.z = fmaf(tp9[k].z, w9[k].z, acc.z); acc.w = fmaf(tp9[k].w, w9[k].w, acc.w);
                     }
                 }
-                float dv[4];
-                const float4 bn = PKDW ? muladd4_pk(acc, scd, shd)
-                                       : make_float4(acc.x * scd.x + shd.x, acc.y * scd.y + shd.y, acc.z * scd.z + shd.z, acc.w * scd.w + shd.w);
-                dv[0] = __builtin_amdgcn_fmed3f(bn.x, lo_d, hi_d); dv[1] = __builtin_amdgcn_fmed3f(bn.y, lo_d, hi_d);
-                dv[2] = __builtin_amdgcn_fmed3f(bn.z, lo_d, hi_d); dv[3] = __builtin_amdgcn_fmed3f(bn.w, lo_d, hi_d);
-                if constexpr (HP) {
-                    unsigned h[2], l[2];
-                    split4_f16(make_float4(dv[0], dv[1], dv[2], dv[3]), h, l);
-                    const u32x2_t dh = {h[0], h[1]}, dl = {l[0], l[1]};
-#pragma unroll
-                    for (int t = 0; t < NTO; ++t) outx[i][t] = mma16_f16(pl[t], dh, outx[i][t]);
-#pragma unroll
-                    for (int t = 0; t < NTO; ++t) outx[i][t] = mma16_f16(ph[t], dl, outx[i][t]);
-#pragma unroll
-                    for (int t = 0; t < NTO; ++t) out[i][t] = mma16_f16(ph[t], dh, out[i][t]);
-                } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < NTO; ++t) out[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wp[j][t], dv[j], out[i][t], 0, 0, 0);
-                }
+                finish(i, acc);
+            }
             }
         }
         load_wp(n_next);                               // in flight across the next chunk's expand phase
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lap(2);
     }
 
-    // ---- project epilogue: BN, residual = block input at the output pixel (stride 1, Cin == Cout), 16-byte stores
+    // ---- project epilogue: BN, residual = block input at the output pixel (stride 1, Cin == Cout), 16-byte stores.  Coefficients and residual
+    // values of ALL the wave's row groups are requested before the first store: y may alias x for all hipcc knows, so a load placed behind a
+    // store waits for its own round trip (measured: 7-10 k cycles of a residual block's 45-63 k per wave in this epilogue, one round trip per
+    // row group and column tile)
     float* yb = a.y + (int64_t)b * a.Ho * a.Wo * a.Cout;
+    float4 scp[NTO], shp[NTO], rres[(!STEM) ? MRO : 1][(!STEM) ? NTO : 1];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) {
+        const int c4 = 16 * t + 4 * q < a.Cout ? 16 * t + 4 * q : 0;
+        scp[t] = ld4(a.sc_p + c4);
+        shp[t] = ld4(a.sh_p + c4);
+    }
+    if constexpr (!STEM) {
+        if (a.residual) {                              // block-uniform
+#pragma unroll
+            for (int i = 0; i < MRO; ++i) {
+                const int P = i * 16 + l15;
+                const int ly = P / TW, lx = P - ly * TW;
+                const int oy = oy0 + ly < a.Ho ? oy0 + ly : a.Ho - 1, ox = ox0 + lx < a.Wo ? ox0 + lx : a.Wo - 1;
+#pragma unroll
+                for (int t = 0; t < NTO; ++t) rres[i][t] = ld4(xb + ((int64_t)oy * a.W + ox) * a.Cin + (16 * t + 4 * q < a.Cout ? 16 * t + 4 * q : 0));
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MRO; ++i) {
         const int P = i * 16 + l15;
@@ -424,17 +500,26 @@ __global__ __launch_bounds__(256, 2) void block_kernel(BlkArgs a, unsigned ntile
         for (int t = 0; t < NTO; ++t) {
             const int c4 = 16 * t + 4 * q;
             if (c4 >= a.Cout) continue;
-            const float4 sc = ld4(a.sc_p + c4), sh = ld4(a.sh_p + c4);
             float4 v;
             if constexpr (HP) out[i][t] = combine_f16(out[i][t], outx[HP ? i : 0][HP ? t : 0]);
-            const float4 bn = muladd4_pk(make_float4(out[i][t][0], out[i][t][1], out[i][t][2], out[i][t][3]), sc, sh);
+            const float4 bn = muladd4_pk(make_float4(out[i][t][0], out[i][t][1], out[i][t][2], out[i][t][3]), scp[t], shp[t]);
             v.x = apply_act(bn.x, a.act_p); v.y = apply_act(bn.y, a.act_p);
             v.z = apply_act(bn.z, a.act_p); v.w = apply_act(bn.w, a.act_p);
-            if (!STEM && a.residual) {
-                const float4 r = ld4(xb + ((int64_t)oy * a.W + ox) * a.Cin + c4);
-                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            if constexpr (!STEM) {
+                if (a.residual) {
+                    const float4 r = rres[i][t];
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
             }
             st4(yb + ((int64_t)oy * a.Wo + ox) * a.Cout + c4, v);
+        }
+    }
+    if (a.timed) {
+        lap(3);
+        if (lane == 0) {
+            unsigned long long* row = g_blk_cycles[(blockIdx.x * 4 + wave) & 1023];
+            for (int i = 0; i < 4; ++i) atomicAdd(&row[i], tc[i]);
+            atomicAdd(&row[6], 1ull);
         }
     }
 }
@@ -533,7 +618,7 @@ int launch_block_fused(const float* x, int B, int H, int W, int Cin, const float
     memset(&a, 0, sizeof(a));
     a.x = x; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.w_exp = w_exp; a.sc_e = sc_e; a.sh_e = sh_e; a.act_e = act_e; a.Cexp = Cexp;
     a.w_dw = w_dw; a.sc_d = sc_d; a.sh_d = sh_d; a.act_d = act_d; a.w_pj = w_pj; a.sc_p = sc_p; a.sh_p = sh_p; a.act_p = act_p; a.Cout = Cout;
-    a.residual = residual ? 1 : 0; a.y = y; a.vecs = vecs;
+    a.residual = residual ? 1 : 0; a.y = y; a.vecs = vecs; a.timed = knobs().blk_timed;
     if (h_exp && h_pj) { a.he = h_exp; a.he_plane = h_exp_plane; a.hp = h_pj; a.hp_plane = h_pj_plane; a.kp_p = h_pj_kp; }      // fp16 form: expand and project
     else if (wparts && Cin > 16) { a.wparts = wparts; a.wplane = wplane; }      // X6 pays from K = 24 on (at K = 16 half of every bf16 MFMA is padding)
     same_pad(H, 3, stride, 1, &a.Ho, &a.pt);
@@ -568,6 +653,17 @@ int launch_first_block_tiles(const void* frames, int dtype, int B, int H, int W,
     a.Ho = a.H; a.Wo = a.W; a.pt = 1; a.pl = 1;        // depthwise 3x3, stride 1, SAME
     if (dtype == AMS_DT_U8) return launch_blk_k<1, 2, 1, 8, 8, uint8_t>(a, st);
     return launch_blk_k<1, 2, 1, 8, 8, float>(a, st);
+}
+
+// tools/ only: read and clear the per-phase cycle sums of block_kernel (AMS_BLK_TIMED=1)
+int blk_phase_cycles(unsigned long long* h) {
+    static unsigned long long rows[1024][8], z[1024][8];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_blk_cycles), sizeof(rows)) != hipSuccess) return AMS_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_blk_cycles), z, sizeof(z)) != hipSuccess) return AMS_E_HIP;
+    for (int i = 0; i < 8; ++i) h[i] = 0;
+    for (int r = 0; r < 1024; ++r)
+        for (int i = 0; i < 8; ++i) h[i] += rows[r][i];
+    return AMS_OK;
 }
 
 }  // namespace ams

@@ -42,8 +42,13 @@ struct XwrArgs {
     int nsy, nsx;
     int cgroups;                     // channel groups of 32 * NWE channels
     int items, groups;               // work items per channel group; blocks per channel group
+    int timed;                       // tools/ only (AMS_XWR_TIMED=1): per-role cycle sums into g_xwr_cycles (ams_debug_phase_cycles(2, ..))
     int y_fmt;                       // 0: y as f32; 1 (H16 only): y as fp16 pairs interleaved per 8 channels ("H2I", PwArgs::x_fmt) — same bytes
 };
+
+// tools/ only: [0] E-waves between barriers, [1] E-waves at the step barrier, [2] D-waves between barriers, [3] D-waves at the barrier,
+// [4] D-waves from the barrier until their taps have landed (part of [2]'s span, counted separately), [6] E-wave steps, [7] D-wave steps
+__device__ unsigned long long g_xwr_cycles[1024][8];
 
 // H16: the operand and weight parts are the two fp16 parts of split_bf16.hpp (hi | lo 2^11; NP = 2): three MFMAs per 32 k, the cross terms
 // in an accumulator of their own, products and order of pw_gemm_f16x3_l (bit-identical to it followed by the depthwise kernel).
@@ -77,6 +82,23 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Wp = a.Wp, rate = a.rate, R = a.ring;
     const int qS = STEP / Wp, rS = STEP - qS * Wp;
+    unsigned long long tc[3] = {0, 0, 0}, tl_ = a.timed ? __builtin_amdgcn_s_memtime() : 0, nstep = 0;
+    auto lap = [&](int slot) {
+        if (a.timed) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tc[slot] += now - tl_;
+            tl_ = now;
+        }
+    };
+    auto flush = [&](int base) {
+        if (a.timed && lane == 0) {
+            unsigned long long* row = g_xwr_cycles[(blockIdx.x * 8 + wave) & 1023];
+            atomicAdd(&row[base], tc[0]);
+            atomicAdd(&row[base + 1], tc[1]);
+            atomicAdd(&row[base ? 7 : 6], nstep);
+            if (base) atomicAdd(&row[4], tc[2]);
+        }
+    };
 
     if (wave < NWE) {
         // =================================== E-waves ===================================
@@ -170,23 +192,26 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                     const u32x4* ap = sA + par * AUNITS + q * 16 + l15;
                     // the operand fragments of k-step s + 1 are requested before the MFMAs of k-step s: with one E-wave per SIMD nothing
                     // else hides the LDS round trip (five exposed waits per step otherwise)
-                    bf16x8 xa[2][NP][NRG];
+                    constexpr bool XA2 = NWD <= 4;        // (with two D-waves beside it on the SIMD the E-wave has no registers for the second set)
+                    bf16x8 xa[XA2 ? 2 : 1][NP][NRG];
                     auto load_x = [&](int s, bf16x8 (&dst)[NP][NRG]) {
 #pragma unroll
                         for (int rg = 0; rg < NRG; ++rg)
 #pragma unroll
                             for (int pp = 0; pp < NP; ++pp) dst[pp][rg] = __builtin_bit_cast(bf16x8, ap[((rg * NP + pp) * KS + s) * 64]);
                     };
-                    load_x(0, xa[0]);
+                    if constexpr (XA2) load_x(0, xa[0]);
 #pragma unroll
                     for (int s = 0; s < KS; ++s) {
-                        if (s + 1 < KS) load_x(s + 1, xa[(s + 1) & 1]);
+                        if constexpr (XA2) { if (s + 1 < KS) load_x(s + 1, xa[(s + 1) & 1]); }
+                        else load_x(s, xa[0]);
+                        constexpr int XS = XA2 ? 1 : 0;
                         bf16x8 x0[NRG], x1[NRG], x2[NRG];
 #pragma unroll
                         for (int rg = 0; rg < NRG; ++rg) {
-                            x0[rg] = xa[s & 1][0][rg];
-                            if (NP >= 2) x1[rg] = xa[s & 1][NP >= 2 ? 1 : 0][rg];
-                            if (NP == 3) x2[rg] = xa[s & 1][NP - 1][rg];
+                            x0[rg] = xa[s & XS][0][rg];
+                            if (NP >= 2) x1[rg] = xa[s & XS][NP >= 2 ? 1 : 0][rg];
+                            if (NP == 3) x2[rg] = xa[s & XS][NP - 1][rg];
                         }
                         // per accumulator the products of pw_gemm_bf16x3_l in its order (smallest terms first); consecutive MFMAs
                         // go to different accumulators
@@ -244,11 +269,15 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 par ^= 1;
                 sbase += STEP;
                 if (sbase == R) sbase = 0;
+                lap(0);
                 __syncthreads();
+                lap(1);
+                ++nstep;
             }
             __syncthreads();                                          // the D-waves finish the item
             par = 0;
         }
+        flush(0);
     } else {
         // =================================== D-waves ===================================
         const int dt = tid - 64 * NWE;
@@ -301,6 +330,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                         for (int jj = 0; jj < PH + 2; ++jj) vt[hh][di][jj] = (ABL & 4) ? wv[di] : ld4(rp + jj * PITCH);
                     }
                 }
+                if (a.timed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(2); }     // [4]: the taps have landed
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
                     const int h = 2 * hh;
@@ -346,10 +376,25 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 if (d_col >= Wp) { d_col -= Wp; ++d_row; }
                 cb += STEP;
                 if (cb >= R) cb -= R;
+                lap(0);
                 __syncthreads();
+                lap(1);
+                ++nstep;
             }
         }
+        flush(2);
     }
+}
+
+// tools/ only: read and clear the per-role cycle sums of xdw_wreg_kernel (AMS_XWR_TIMED=1)
+int xwr_phase_cycles(unsigned long long* h) {
+    static unsigned long long rows[1024][8], z[1024][8];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_xwr_cycles), sizeof(rows)) != hipSuccess) return AMS_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_xwr_cycles), z, sizeof(z)) != hipSuccess) return AMS_E_HIP;
+    for (int i = 0; i < 8; ++i) h[i] = 0;
+    for (int r = 0; r < 1024; ++r)
+        for (int i = 0; i < 8; ++i) h[i] += rows[r][i];
+    return AMS_OK;
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
@@ -388,6 +433,8 @@ static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
 template <int KS, int NP, bool H16 = false>
 static int launch_xwr_w(const XwrArgs& a, int nwe, int nrg, size_t lds, hipStream_t st) {
     if (nwe == 8) return launch_xwr_k<KS, NP, 8, 4, 1, H16>(a, lds, st);
+    // (eight D-waves beside the four E-waves — <KS, NP, 4, 8, 2>, the operand fragments single-buffered to fit 168 VGPRs: measured in round 5, the
+    // D-waves then finish a step in 2.7 k cycles instead of 4.0 k but the E-waves need 5.6 k instead of 3.2 k: 2.96 vs 2.74 ms per 32-frame pass)
     if (nrg == 2) return launch_xwr_k<KS, NP, 4, 4, 2, H16>(a, lds, st);
     return launch_xwr_k<KS, NP, 4, 4, 1, H16>(a, lds, st);
 }
@@ -433,6 +480,7 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     a.nsy = nsy; a.nsx = nsx; a.cgroups = cgroups;
     a.items = B * rate * rate * nsy * nsx;
     a.y_fmt = y_fmt;
+    a.timed = knobs().xwr_timed;
     int64_t groups = groups_force > 0 ? groups_force : (512 + cgroups - 1) / cgroups;      // one block per CU (LDS), twice over
     if (groups > a.items) groups = a.items;
     a.groups = (int)groups;

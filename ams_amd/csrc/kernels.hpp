@@ -18,6 +18,8 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     int blk_th = 0, blk_tw = 0;                  // AMS_BLK_TILE=<th>x<tw>
     int fb_walk = -1;                            // AMS_FB_WALK=<0|n>: first block of the frozen path as one tile per block (0) / at most n tiles per walking block
     int fb_abl = 0;                              // AMS_FB_ABL=<bits>: measurement-only ablations of the walking first block (wrong results)
+    int xwr_timed = 0;                           // AMS_XWR_TIMED=1: xdw_wreg_kernel sums per-role cycles (ams_debug_phase_cycles(2, ..))
+    int blk_timed = 0;                           // AMS_BLK_TIMED=1: block_kernel sums per-phase cycles (ams_debug_phase_cycles)
     int blk_hp = -1;                             // AMS_BLK_HP=<0|1>: fp16 whole-block kernels with exact-f32 (0) / fp16 (1) project products
     char pw_force = 0; int pw_rm = 0, pw_nt = 0; // AMS_PW_FORCE=<s|l>,<RM>,<NT>
     int pw_percu = 0;                            // AMS_PW_PERCU
@@ -34,6 +36,8 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     unsigned side_cu_mask = 0;                   // AMS_SIDE_CU_MASK=<hex word>: the fine-tune step's side stream only on the CUs whose bit is set (word repeated over the chip)
 };
 const Knobs& knobs();
+int blk_phase_cycles(unsigned long long* h);      // k_block.hip (tools/ only)
+int xwr_phase_cycles(unsigned long long* h);      // k_xdw_wreg.hip (tools/ only)
 int create_side_stream(hipStream_t* out);        // non-blocking stream for the weight gradients (runtime.hip)
 int create_sync_event(hipEvent_t* out);          // event that orders streams of ONE device (runtime.hip)
 

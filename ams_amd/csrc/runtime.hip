@@ -84,6 +84,8 @@ static Knobs read_knobs() {
         if (const char* e = getenv("AMS_BLK_HP")) v.blk_hp = atoi(e);
         if (const char* e = getenv("AMS_FB_WALK")) v.fb_walk = atoi(e);
         if (const char* e = getenv("AMS_FB_ABL")) v.fb_abl = atoi(e);
+        if (const char* e = getenv("AMS_BLK_TIMED")) v.blk_timed = atoi(e);
+        if (const char* e = getenv("AMS_XWR_TIMED")) v.xwr_timed = atoi(e);
         if (const char* e = getenv("AMS_PW_FORCE")) sscanf(e, "%c,%d,%d", &v.pw_force, &v.pw_rm, &v.pw_nt);
         if (const char* e = getenv("AMS_PW_PERCU")) v.pw_percu = atoi(e);
         v.pwx_no_tail = getenv("AMS_PWX_NO_TAIL") != nullptr;

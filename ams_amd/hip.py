@@ -124,7 +124,7 @@ SIGNATURES = {
     "ams_k_ce_loss_grad_scratch": (_sz, [_i32, _i32, _i32, _i32]),
     "ams_debug_launch_table_needs_attr": (C.c_int, [_i32, C.c_uint64, _sz]),
     "ams_debug_reload_knobs": (C.c_int, []),
-    "ams_debug_phase_cycles": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
+    "ams_debug_phase_cycles": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.c_int32]),
     "ams_k_pointwise_wgrad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "ams_k_pointwise_wgrad_scratch": (_sz, [_i64, _i32, _i32]),
     "ams_k_pointwise_wgrad_split": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),

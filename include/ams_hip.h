@@ -583,10 +583,12 @@ int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_
  * stream-ordering events — these two change stream semantics and exist for measurements only) are read ONCE, at first use; this re-reads
  * them.  Not thread-safe against launches in flight. */
 int ams_debug_reload_knobs(void);
-/* tools/ only.  With AMS_FB_ABL=32 the walking first block sums shader-clock cycles per wave and phase into a device array ([0] tile decode,
- * [1] stem, [2] wait at barrier 1, [3] depthwise, [4] wait at barrier 2, [5] project, [6] tiles walked, per wave); this copies out[0..n) (n <= 8)
- * and clears the array. */
-int ams_debug_phase_cycles(uint64_t* out, int32_t n);
+/* tools/ only.  Shader-clock cycles per wave and phase, summed over the launches since the last call, copied to out[0..n) (n <= 8) and cleared.
+ * which = 0: the walking first block with AMS_FB_ABL=32 ([0] tile decode, [1] stem, [2] wait at the barrier, [3] depthwise + project, [6] wave-tiles);
+ * which = 1: the whole-block kernels with AMS_BLK_TIMED=1 ([0] prologue, [1] expand phases, [2] depthwise + project phases, [3] epilogue, [6] waves);
+ * which = 2: the weight-register streaming kernel with AMS_XWR_TIMED=1 ([0] E-waves between the step barriers, [1] E-waves at the barrier, [2] / [3]
+ * the same for the D-waves, [6] E-wave steps, [7] D-wave steps). */
+int ams_debug_phase_cycles(int32_t which, uint64_t* out, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Per-phase cycle sums of the walking first block (AMS_FB_ABL=32|bits in the environment): usage fb_phases.py [B]"""
+"""Per-role cycle sums of the weight-register streaming kernel inside the 32-frame step (AMS_XWR_TIMED=1 is set here): usage xwr_phases.py [B]"""
 import ctypes as C
 import os
 import sys
 sys.path.insert(0, ".")
-os.environ.setdefault("AMS_FB_ABL", "32")
+os.environ["AMS_XWR_TIMED"] = "1"
 import torch
 from ams_amd import hip, spec as S, synth, weights as Wt
 from ams_amd.engine import StudentEngine
@@ -21,16 +21,12 @@ for _ in range(3):
     eng.predict(f)
 torch.cuda.synchronize()
 out = (C.c_uint64 * 8)()
-hip.check(hip.lib().ams_debug_phase_cycles(0, out, 8))
+hip.check(hip.lib().ams_debug_phase_cycles(2, out, 8))
 n = 5
 for _ in range(n):
     eng.predict(f)
 torch.cuda.synchronize()
-hip.check(hip.lib().ams_debug_phase_cycles(0, out, 8))
-v = [x / n for x in out]
-tiles = v[6]
-names = ["tile decode", "stem", "barrier", "depthwise + project"]
-tot = sum(v[:4])
-print("AMS_FB_ABL=%s  wave-tiles per launch %.0f, cycles per wave-tile %.0f" % (os.environ["AMS_FB_ABL"], tiles, tot / tiles))
-for nm, x in zip(names, v[:4]):
-    print("  %-20s %8.0f cycles per wave-tile  %5.1f %%" % (nm, x / tiles, 100 * x / tot))
+hip.check(hip.lib().ams_debug_phase_cycles(2, out, 8))
+es, ds = out[6], out[7]
+print("E-waves: %d wave-steps per pass, %.0f cycles between barriers + %.0f at the barrier per step" % (es / n, out[0] / es, out[1] / es))
+print("D-waves: %d wave-steps per pass, %.0f cycles until the taps have landed + %.0f arithmetic and stores + %.0f at the barrier per step" % (ds / n, out[4] / ds, out[2] / ds, out[3] / ds))

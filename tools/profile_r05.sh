@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round-5 artefacts on the GPU box (repo root): usage  bash tools/profile_r05.sh [part ...]   parts: bench infer train pmc sq (default: all)
+# Round-5 artefacts on the GPU box (repo root): usage  bash tools/profile_r05.sh [part ...]   parts: bench infer train pmc sq phases (default: all)
 # -> gpurun_out/r05_*  (copied to profiles/ by hand after a look)
-parts=${@:-bench infer train pmc sq}
+parts=${@:-bench infer train pmc sq phases}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 stats() {  # <dir> <out.csv>
   s=$(find $1 -name "*kernel_stats.csv" | head -1); [ -n "$s" ] && cp $s $2
@@ -41,7 +41,16 @@ sq)
   bash tools/pmc_cmd.sh r05_xwr "xdw_wreg_kernel" python3 tools/infer_loop.py 32 512 2 1 0
   bash tools/pmc_cmd.sh r05_gemm "pw_gemm_f16x3_l<1, 10, 1" python3 tools/infer_loop.py 32 512 2 1 0
   bash tools/pmc_cmd.sh r05_blk "block_kernel<2, 1, 2, 4, 8" python3 tools/infer_loop.py 32 512 2 1 0
-  bash tools/pmc_cmd.sh r05_fb "first_block_kernel" python3 tools/infer_loop.py 32 512 2 1 0
+  bash tools/pmc_cmd.sh r05_fb "first_block" python3 tools/infer_loop.py 32 512 2 1 0
   cat gpurun_out/sq_r05_xwr.txt gpurun_out/sq_r05_gemm.txt gpurun_out/sq_r05_blk.txt gpurun_out/sq_r05_fb.txt > gpurun_out/r05_infer_sq_counters.txt ;;
+phases)
+  # in-kernel phase clocks (s_memtime laps summed per wave; ams_debug_phase_cycles): the walking first block, the weight-register streaming kernel
+  # inside the 32-frame step, the five whole-block shapes alone
+  { echo "# shader-clock cycles per wave and phase (tools/fb_phases.py, tools/xwr_phases.py, tools/block_one.py with AMS_BLK_TIMED=1)"
+    python3 tools/fb_phases.py 32
+    python3 tools/xwr_phases.py 32
+    for sh in "256 512 16 96 24 2 0" "128 256 24 144 24 1 1" "128 256 24 144 32 2 0" "64 128 32 192 32 1 1" "64 128 32 192 64 2 0"; do
+      BLK_F16=1 AMS_BLK_TIMED=1 python3 tools/block_one.py 32 $sh
+    done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_phase_clocks.txt ;;
 esac; done
 ls -la gpurun_out/r05_* | head -30

@@ -419,8 +419,13 @@ __device__ unsigned long long g_fb_cycles[8];
 
 // ABL: measurement-only ablations (AMS_FB_ABL=<bits>, wrong results): 1 no result stores, 2 no depthwise arithmetic, 4 no byte loads / table
 // look-ups, 8 no project MFMAs, 16 no stem MFMAs
-template <int ABL = 0>
-__global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs a, unsigned ntiles) {
+// BORDER: the tiles OUTSIDE the interior rectangle (a second launch): the same two loads per position without clamps — an offset before the
+// batch's first byte is out of the buffer's range and reads 0, one inside another row or frame reads bytes that the tap's class replaces — plus
+// the class of every tap (inside / the 127.5 padding row or column / outside: zero) from the position's three row and three column classes
+// (7 VALU instructions per tap against the one-tile kernel's clamped byte gather: 35 instead of 65 us for the 6048 border tiles of 32 frames), the
+// position's own existence in the stem's output map, and bounds on the result stores.
+template <int ABL = 0, bool BORDER = false>
+__global__ __launch_bounds__(256, BORDER ? 2 : 3) void first_block_walk_kernel(FirstBlockArgs a, unsigned ntiles) {      // (BORDER: 2 blocks per CU — its extra state spills at 168 registers, and a spill reload waits for the prefetch)
     constexpr int TH = 8, TW = 16, IH = TH + 2, IW = TW + 2, NPIX = IH * IW, NRG = (NPIX + 15) / 16, MRG = 3, P = 36;
     static_assert(NRG == 4 * MRG, "three row groups of stem positions per wave");
     __shared__ __attribute__((aligned(16))) float sS[2][NPIX * P];     // stem tile, double-buffered: 3 blocks per CU = 3 x 54272 B
@@ -471,6 +476,7 @@ __global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs
     // predicated and the three row groups are one straight-line block that hipcc can interleave)
     unsigned poff[MRG];                               // byte offset of the position's window from the tile's first byte
     int prow[MRG];                                    // the position's row of the LDS tile
+    int ppos[BORDER ? MRG : 1];                       // BORDER: its (row, column) in the halo tile
 #pragma unroll
     for (int i = 0; i < MRG; ++i) {
         const int m = (wave + 4 * i) * 16 + l15;
@@ -478,12 +484,45 @@ __global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs
         const int ty = mc / IW, tx = mc - ty * IW;
         poff[i] = (unsigned)(2 * ty * row_bytes + 2 * tx * 3);
         prow[i] = mc * P;
+        if constexpr (BORDER) ppos[i] = ty | (tx << 8);
+    }
+    // BORDER: bit offsets of this lane's taps in the packed row / column classes (2 bits per dy / dx; offset 6 = the constant "outside" for k >= 27)
+    unsigned tsel[2] = {0, 0};                        // six bits per tap (row offset | column offset << 3), four taps per register
+    unsigned e_pad = 0;
+    if constexpr (BORDER) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = 8 * q + u, tap = k / 3, dy = tap / 3, dx = tap - dy * 3;
+            tsel[u >> 2] |= (k < 27 ? (unsigned)(2 * dy) | ((unsigned)(2 * dx) << 3) : 6u | (6u << 3)) << (6 * (u & 3));
+        }
+        unsigned short h, l;
+        split1_f16(__fsub_rn(__fmul_rn(127.5f, a.ps), 1.0f), h, l);
+        e_pad = (unsigned)h | ((unsigned)l << 16);
     }
 
     struct Tile { int b, oy0, ox0; };
     auto decode = [&](unsigned t) {
         const unsigned lb = xcd_remap(t, ntiles);
         Tile r;
+        if constexpr (BORDER) {                       // rows above the rectangle, rows below, then the side columns (as first_block_kernel's border_only)
+            const unsigned per_frame = (unsigned)(a.tiles_x * a.tiles_y - a.nix * a.niy);
+            r.b = (int)(lb / per_frame);
+            unsigned j = lb - (unsigned)r.b * per_frame;
+            const unsigned above = (unsigned)(a.ity0 * a.tiles_x), below = (unsigned)((a.tiles_y - a.ity0 - a.niy) * a.tiles_x);
+            int ty, tx;
+            if (j < above) { ty = (int)(j / a.tiles_x); tx = (int)j - ty * a.tiles_x; }
+            else if (j < above + below) { j -= above; ty = (int)(j / a.tiles_x); tx = (int)j - ty * a.tiles_x; ty += a.ity0 + a.niy; }
+            else {
+                j -= above + below;
+                const unsigned side = (unsigned)(a.tiles_x - a.nix);
+                ty = (int)(j / side);
+                tx = (int)j - ty * (int)side;
+                ty += a.ity0;
+                if (tx >= a.itx0) tx += a.nix;
+            }
+            r.oy0 = ty * TH; r.ox0 = tx * TW;
+            return r;
+        }
         const unsigned t1 = lb / a.nix;
         r.ox0 = (a.itx0 + (int)(lb - t1 * a.nix)) * TW;
         r.b = (int)(t1 / a.niy);
@@ -491,13 +530,26 @@ __global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs
         return r;
     };
     auto tile_base = [&](const Tile& tl) { return tl.b * frame_bytes + (((tl.oy0 - 1) * 2 - a.pt) * a.W + ((tl.ox0 - 1) * 2 - a.pl)) * 3; };
+    int psh[BORDER ? MRG : 1];                        // BORDER: bit shifts that undo the clamps of the two loads (A's + 128 x B's)
     unsigned pa[MRG];                                 // the pieces of each row group, in flight or landed (A: at most its first 3 bytes are taps — a
     uint2 pb[MRG];                                    // dword; a loaded register that nothing reads would be reused, behind a wait for the load)
     auto request = [&](int base, int i) {
         unsigned p = poff[i];
         asm volatile("" : "+v"(p));                   // two adds per row group instead of six registers held over the walk
-        pa[i] = __builtin_amdgcn_raw_buffer_load_b32(frsrc, (int)(p + off_a), base, 0);
-        pb[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(frsrc, (int)(p + off_b), base, 0));
+        if constexpr (BORDER) {
+            // a piece may start before the batch's first byte or end behind its last one while some of its bytes are real taps (the first / last
+            // pixels of the first / last frame): the load is moved inside and the bytes are shifted back (the vacated bytes belong to taps
+            // whose class replaces them); shifts beyond a piece's length only occur where every tap is outside
+            const int total = a.B * frame_bytes;
+            const int oa = base + (int)(p + off_a), ob = base + (int)(p + off_b);
+            const int ca = oa < 0 ? 0 : (oa > total - 4 ? total - 4 : oa), cb = ob < 0 ? 0 : (ob > total - 8 ? total - 8 : ob);
+            pa[i] = __builtin_amdgcn_raw_buffer_load_b32(frsrc, ca, 0, 0);
+            pb[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(frsrc, cb, 0, 0));
+            psh[i] = (oa - ca < -3 ? -3 : (oa - ca > 3 ? 3 : oa - ca)) * 8 + 128 * ((ob - cb < -7 ? -7 : (ob - cb > 7 ? 7 : ob - cb)) * 8);
+        } else {
+            pa[i] = __builtin_amdgcn_raw_buffer_load_b32(frsrc, (int)(p + off_a), base, 0);
+            pb[i] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(frsrc, (int)(p + off_b), base, 0));
+        }
     };
     constexpr bool TIMED = (ABL & 32) != 0;
     unsigned long long tc[4] = {0, 0, 0, 0}, tl_ = 0, ntile = 0;
@@ -537,7 +589,17 @@ __global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs
 #pragma unroll
                 for (int u = 0; u < 8; ++u) e[u] = 0x3c00u + (unsigned)(lane + u + i);
             } else {
-                const unsigned d0 = __builtin_amdgcn_perm(pa[i], pb[i].x, sel0), d1 = __builtin_amdgcn_perm(pb[i].y, pb[i].x, sel1);
+                unsigned va = pa[i];
+                uint2 vb = pb[i];
+                if constexpr (BORDER) {
+                    const int sb = psh[i] >= 0 ? (psh[i] + 64) / 128 : -((64 - psh[i]) / 128);      // B's shift (a multiple of 8 in -56 .. 56) ...
+                    const int sa = psh[i] - 128 * sb;                                                // ... and A's (-24 .. 24)
+                    va = sa >= 0 ? va >> sa : va << -sa;
+                    const unsigned long long w = ((unsigned long long)vb.y << 32) | vb.x;
+                    const unsigned long long ws = sb >= 0 ? w >> sb : w << -sb;
+                    vb = make_uint2((unsigned)ws, (unsigned)(ws >> 32));
+                }
+                const unsigned d0 = __builtin_amdgcn_perm(va, vb.x, sel0), d1 = __builtin_amdgcn_perm(vb.y, vb.x, sel1);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const unsigned d = u < 4 ? d0 : d1;
@@ -546,13 +608,33 @@ __global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs
             }
             if constexpr (!(ABL & 4)) request(nbase, i);        // unconditional (the last tile re-reads its own window): behind a branch hipcc's wait for the
                                                                 // older pieces becomes vmcnt(0), which waits for these loads as well
+            bool lives = true;
+            if constexpr (BORDER) {
+                const int sy = cur.oy0 - 1 + (ppos[i] & 255), sx = cur.ox0 - 1 + (ppos[i] >> 8);      // position in the stem's output map
+                lives = sy >= 0 && sy < a.Ho && sx >= 0 && sx < a.Wo;
+                const int iy0 = 2 * sy - a.pt, ix0 = 2 * sx - a.pl;
+                unsigned rcp = 2u << 6, ccp = 2u << 6;       // classes of the window's rows / columns: 0 inside, 1 the 127.5 padding, 2 outside
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+                    const int iy = iy0 + dd, ix = ix0 + dd;
+                    rcp |= (unsigned)(iy < 0 ? 2 : (iy < a.H ? 0 : (iy == a.H ? 1 : 2))) << (2 * dd);
+                    ccp |= (unsigned)(ix < 0 ? 2 : (ix < a.W ? 0 : (ix == a.W ? 1 : 2))) << (2 * dd);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned sd = (tsel[u >> 2] >> (6 * (u & 3))) & 63u;
+                    const unsigned rc = (rcp >> (sd & 7u)) & 3u, cc = (ccp >> (sd >> 3)) & 3u;
+                    const unsigned cls = rc > cc ? rc : cc;
+                    e[u] = cls == 0u ? e[u] : (cls == 1u ? e_pad : 0u);
+                }
+            }
             u32x4 xh, xl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xh[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x05040100u);
                 xl[j] = __builtin_amdgcn_perm(e[2 * j + 1], e[2 * j], 0x07060302u);
             }
-            const float lo = lo_s, hi = hi_s;        // (every position of an interior tile's halo lies inside the feature map)
+            const float lo = lives ? lo_s : 0.f, hi = lives ? hi_s : 0.f;      // (interior tiles: always the activation's bounds; outside the map both 0: the depthwise conv's padding)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, accx = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -634,7 +716,7 @@ __global__ __launch_bounds__(256, 3) void first_block_walk_kernel(FirstBlockArgs
                 o.x = apply_act(bn.x, a.act_p); o.y = apply_act(bn.y, a.act_p);
                 o.z = apply_act(bn.z, a.act_p); o.w = apply_act(bn.w, a.act_p);
                 const int oy = cur.oy0 + 2 * wave + r, ox = cur.ox0 + l15;
-                if (!(ABL & 1) || o.x == 12345.f) st4(yb + ((int64_t)oy * a.Wo + ox) * 16 + 4 * q, o);      // (interior tiles lie inside the map)
+                if ((!BORDER || (oy < a.Ho && ox < a.Wo)) && (!(ABL & 1) || o.x == 12345.f)) st4(yb + ((int64_t)oy * a.Wo + ox) * 16 + 4 * q, o);
             }
         }
         lap(3);
@@ -673,7 +755,7 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "first_block: bad grid");
     if (h_stem && h_pj) {                           // two fp16 parts in the stem and the project layer (takes precedence over w_parts)
         a.hs = h_stem; a.hs_plane = h_stem_plane; a.hj = h_pj; a.hj_plane = h_pj_plane;
-        if (dtype == AMS_DT_U8 && knobs().fb_walk != 0 && (int64_t)B * H * W * 3 < 0x7fffffffLL) {
+        if (dtype == AMS_DT_U8 && knobs().fb_walk != 0 && (int64_t)B * H * W * 3 + 16 < 0x7fffffffLL) {
             // interior tiles (first_block_walk_kernel's header) form a rectangle: the conditions are separate in y and x
             auto range = [](int tiles, int T, int Osize, int pad, int Isize, int* first, int* count) {
                 *first = 0; *count = 0;
@@ -706,7 +788,18 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
                 const int64_t n_border = nblocks - n_in;
                 if (n_border > 0) {
                     a.border_only = 1;
-                    hipLaunchKernelGGL((first_block_kernel<uint8_t, false, true>), dim3((unsigned)n_border), dim3(256), 0, st, a, (unsigned)n_border);
+                    if (knobs().fb_walk == -2)          // AMS_FB_WALK=-2: the border tiles on the one-tile kernel (A/B of the two border forms)
+                        hipLaunchKernelGGL((first_block_kernel<uint8_t, false, true>), dim3((unsigned)n_border), dim3(256), 0, st, a, (unsigned)n_border);
+                    else {
+                        int bper_cu = 1;
+                        RUN_RC(func_blocks_per_cu((const void*)first_block_walk_kernel<0, true>, 256, 0, &bper_cu));
+                        const int64_t bslots = (int64_t)bper_cu * cus;
+                        int64_t brounds = cdiv(n_border, bslots);
+                        if (knobs().fb_walk > 0 && brounds > knobs().fb_walk) brounds = knobs().fb_walk;
+                        int64_t bgrid = cdiv(cdiv(n_border, brounds), 8) * 8;
+                        if (bgrid > n_border) bgrid = n_border;
+                        hipLaunchKernelGGL((first_block_walk_kernel<0, true>), dim3((unsigned)bgrid), dim3(256), 0, st, a, (unsigned)n_border);
+                    }
                     AMS_CHECK_LAUNCH();
                 }
                 return AMS_OK;

@@ -16,7 +16,7 @@ int device_cus(int* cus);
 bool launch_table_needs_attr(int device, const void* fn, size_t lds);
 struct Knobs {                   // tuning knobs of tools/*: environment variables, read at first use, never on the launch path
     int blk_th = 0, blk_tw = 0;                  // AMS_BLK_TILE=<th>x<tw>
-    int fb_walk = -1;                            // AMS_FB_WALK=<0|n>: first block of the frozen path as one tile per block (0) / at most n tiles per walking block
+    int fb_walk = -1;                            // AMS_FB_WALK=<0|-2|n>: first block of the frozen path as one tile per block (0) / only the border tiles so (-2) / at most n tiles per walking block
     int fb_abl = 0;                              // AMS_FB_ABL=<bits>: measurement-only ablations of the walking first block (wrong results)
     int xwr_timed = 0;                           // AMS_XWR_TIMED=1: xdw_wreg_kernel sums per-role cycles (ams_debug_phase_cycles(2, ..))
     int blk_timed = 0;                           // AMS_BLK_TIMED=1: block_kernel sums per-phase cycles (ams_debug_phase_cycles)

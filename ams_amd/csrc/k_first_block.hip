@@ -827,11 +827,12 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
 
 }  // namespace ams
 
-// tools/ only: per-phase shader-clock sums, read and cleared: which = 0 the walking first block (AMS_FB_ABL=32), 1 block_kernel (AMS_BLK_TIMED=1), 2 xdw_wreg_kernel (AMS_XWR_TIMED=1)
+// tools/ only: per-phase shader-clock sums, read and cleared: which = 0 the walking first block (AMS_FB_ABL=32), 1 block_kernel (AMS_BLK_TIMED=1), 2 xdw_wreg_kernel, 3 xdw_stream_kernel (AMS_XWR_TIMED=1)
 extern "C" int ams_debug_phase_cycles(int32_t which, uint64_t* out, int32_t n) {
     unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (which == 1) { RUN_RC(ams::blk_phase_cycles(h)); }
     else if (which == 2) { RUN_RC(ams::xwr_phase_cycles(h)); }
+    else if (which == 3) { RUN_RC(ams::xds_phase_cycles(h)); }
     else {
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(ams::g_fb_cycles), sizeof(h)) != hipSuccess) return AMS_E_HIP;
         if (hipMemcpyToSymbol(HIP_SYMBOL(ams::g_fb_cycles), z, sizeof(z)) != hipSuccess) return AMS_E_HIP;

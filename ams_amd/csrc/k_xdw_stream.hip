@@ -58,6 +58,7 @@ struct XdsArgs {
     int items;                       // B * rate^2 * nsy * nsx work items per chunk
     int groups;                      // blocks per chunk; block g walks items g, g + groups, ...
     int y_fmt;                       // 0: y as f32; 1 (H16 only): y as fp16 pairs interleaved per 8 channels ("H2I", PwArgs::x_fmt) — same bytes
+    int timed;                       // tools/ only (AMS_XWR_TIMED=1): per-role cycle sums into g_xds_cycles (ams_debug_phase_cycles(3, ..))
 };
 
 // Roles: waves [0, NWE) run the E-steps (operand loads, split, MFMAs, BN + ReLU6 into the ring), waves [NWE, NWE + NWD) the
@@ -68,6 +69,9 @@ struct XdsArgs {
 // than six bf16 MFMAs plus the split.  Otherwise KS = 32-k stages of the split-bf16 product.
 // H16: parts are the two fp16 parts of split_bf16.hpp (NP = 2): three MFMAs per 32 k with the cross terms in an accumulator of their own,
 // products and order of pw_gemm_f16x3_l.
+// tools/ only: [0] E-waves between the step barriers, [1] E-waves at the barrier, [2] / [3] the same for the D-waves, [6] E-wave steps, [7] D-wave steps
+__device__ unsigned long long g_xds_cycles[1024][8];
+
 template <int KS, int NT, int NP, int NWE, int NWD, bool PRE, bool F32, int S = 1, bool H16 = false>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a, unsigned nblocks) {
     static_assert(!H16 || (NP == 2 && !F32 && S == 1), "the fp16 form: two parts, stride 1");
@@ -122,6 +126,22 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
     }
     __syncthreads();
     const int qS = STEP / Wp, rS = STEP - qS * Wp;                   // both walkers advance by STEP pixels a step
+    unsigned long long tc[2] = {0, 0}, tl_ = a.timed ? __builtin_amdgcn_s_memtime() : 0, nstep = 0;
+    auto lap = [&](int slot) {
+        if (a.timed) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            tc[slot] += now - tl_;
+            tl_ = now;
+        }
+    };
+    auto flush = [&](int base) {
+        if (a.timed && lane == 0) {
+            unsigned long long* row = g_xds_cycles[(blockIdx.x * 8 + wave) & 1023];
+            atomicAdd(&row[base], tc[0]);
+            atomicAdd(&row[base + 1], tc[1]);
+            atomicAdd(&row[base ? 7 : 6], nstep);
+        }
+    };
 
     if (wave < NWE) {
         // =================================== E-waves ===================================
@@ -267,10 +287,14 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                 }
                 sbase += STEP;
                 if (sbase == R) sbase = 0;
+                lap(0);
                 __syncthreads();
+                lap(1);
+                ++nstep;
             }
             __syncthreads();                                          // the D-waves finish the item (their step T - 1)
         }
+        flush(0);
     } else {
         // =================================== D-waves ===================================
         const int dt = tid - 64 * NWE;
@@ -410,10 +434,25 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_stream_kernel(XdsArgs a,
                 if (d_col >= Wp) { d_col -= Wp; ++d_row; }
                 cb += STEP;
                 if (cb >= R) cb -= R;
+                lap(0);
                 __syncthreads();                                      // E-step t + 1 (after the last step: the next item may start)
+                lap(1);
+                ++nstep;
             }
         }
+        flush(2);
     }
+}
+
+// tools/ only: read and clear the per-role cycle sums of xdw_stream_kernel (AMS_XWR_TIMED=1)
+int xds_phase_cycles(unsigned long long* h) {
+    static unsigned long long rows[1024][8], z[1024][8];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_xds_cycles), sizeof(rows)) != hipSuccess) return AMS_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_xds_cycles), z, sizeof(z)) != hipSuccess) return AMS_E_HIP;
+    for (int i = 0; i < 8; ++i) h[i] = 0;
+    for (int r = 0; r < 1024; ++r)
+        for (int i = 0; i < 8; ++i) h[i] += rows[r][i];
+    return AMS_OK;
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
@@ -572,6 +611,7 @@ int launch_expand_dw_stream(const float* x, const uint16_t* x_parts, int64_t x_p
     a.nsy = p.nsy; a.nsx = p.nsx; a.chunks = (Cexp + 16 * p.nt - 1) / (16 * p.nt);
     a.items = B * rate * rate * p.nsy * p.nsx; a.groups = p.groups;
     a.y_fmt = y_fmt;
+    a.timed = knobs().xwr_timed;
     if (h16) {
         AMS_REQUIRE(p.nwe == 4 && p.nwd == 4, "expand_dw_stream: the fp16 form runs with 4 + 4 waves");
         switch (Cin / 32) {

@@ -38,6 +38,7 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
 const Knobs& knobs();
 int blk_phase_cycles(unsigned long long* h);      // k_block.hip (tools/ only)
 int xwr_phase_cycles(unsigned long long* h);      // k_xdw_wreg.hip (tools/ only)
+int xds_phase_cycles(unsigned long long* h);      // k_xdw_stream.hip (tools/ only)
 int create_side_stream(hipStream_t* out);        // non-blocking stream for the weight gradients (runtime.hip)
 int create_sync_event(hipEvent_t* out);          // event that orders streams of ONE device (runtime.hip)
 

@@ -586,7 +586,7 @@ int ams_debug_reload_knobs(void);
 /* tools/ only.  Shader-clock cycles per wave and phase, summed over the launches since the last call, copied to out[0..n) (n <= 8) and cleared.
  * which = 0: the walking first block with AMS_FB_ABL=32 ([0] tile decode, [1] stem, [2] wait at the barrier, [3] depthwise + project, [6] wave-tiles);
  * which = 1: the whole-block kernels with AMS_BLK_TIMED=1 ([0] prologue, [1] expand phases, [2] depthwise + project phases, [3] epilogue, [6] waves);
- * which = 2: the weight-register streaming kernel with AMS_XWR_TIMED=1 ([0] E-waves between the step barriers, [1] E-waves at the barrier, [2] / [3]
+ * which = 2 / 3: the weight-register / the LDS-weight streaming kernel with AMS_XWR_TIMED=1 ([0] E-waves between the step barriers, [1] E-waves at the barrier, [2] / [3]
  * the same for the D-waves, [6] E-wave steps, [7] D-wave steps). */
 int ams_debug_phase_cycles(int32_t which, uint64_t* out, int32_t n);
 

@@ -22,11 +22,26 @@ for _ in range(3):
 torch.cuda.synchronize()
 out = (C.c_uint64 * 8)()
 hip.check(hip.lib().ams_debug_phase_cycles(2, out, 8))
+hip.check(hip.lib().ams_debug_phase_cycles(3, out, 8))
 n = 5
 for _ in range(n):
     eng.predict(f)
 torch.cuda.synchronize()
 hip.check(hip.lib().ams_debug_phase_cycles(2, out, 8))
+def show(name, out, taps):
+    es, ds = out[6], out[7]
+    print("%s  E-waves: %d wave-steps per pass, %.0f cycles between barriers + %.0f at the barrier per step" % (name, es / n, out[0] / es, out[1] / es))
+    if taps:
+        print("%s  D-waves: %d wave-steps per pass, %.0f cycles until the taps have landed + %.0f arithmetic and stores + %.0f at the barrier per step" % (name, ds / n, out[4] / ds, out[2] / ds, out[3] / ds))
+    else:
+        print("%s  D-waves: %d wave-steps per pass, %.0f cycles between barriers + %.0f at the barrier per step" % (name, ds / n, out[2] / ds, out[3] / ds))
+
+
+show("xdw_wreg  ", out, True)
+out3 = (C.c_uint64 * 8)()
+hip.check(hip.lib().ams_debug_phase_cycles(3, out3, 8))
+show("xdw_stream", out3, False)
+sys.exit(0)
 es, ds = out[6], out[7]
 print("E-waves: %d wave-steps per pass, %.0f cycles between barriers + %.0f at the barrier per step" % (es / n, out[0] / es, out[1] / es))
 print("D-waves: %d wave-steps per pass, %.0f cycles until the taps have landed + %.0f arithmetic and stores + %.0f at the barrier per step" % (ds / n, out[4] / ds, out[2] / ds, out[3] / ds))

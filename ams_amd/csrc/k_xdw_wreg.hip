@@ -42,7 +42,6 @@ struct XwrArgs {
     int nsy, nsx;
     int cgroups;                     // channel groups of 32 * NWE channels
     int items, groups;               // work items per channel group; blocks per channel group
-    int timed;                       // tools/ only (AMS_XWR_TIMED=1): per-role cycle sums into g_xwr_cycles (ams_debug_phase_cycles(2, ..))
     int y_fmt;                       // 0: y as f32; 1 (H16 only): y as fp16 pairs interleaved per 8 channels ("H2I", PwArgs::x_fmt) — same bytes
 };
 
@@ -82,16 +81,17 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Wp = a.Wp, rate = a.rate, R = a.ring;
     const int qS = STEP / Wp, rS = STEP - qS * Wp;
-    unsigned long long tc[3] = {0, 0, 0}, tl_ = a.timed ? __builtin_amdgcn_s_memtime() : 0, nstep = 0;
+    constexpr bool TIMED = (ABL & 32) != 0;          // compile-time: the laps' state costs the untimed kernel 4 % when it is a run-time switch
+    unsigned long long tc[3] = {0, 0, 0}, tl_ = TIMED ? __builtin_amdgcn_s_memtime() : 0, nstep = 0;
     auto lap = [&](int slot) {
-        if (a.timed) {
+        if constexpr (TIMED) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             tc[slot] += now - tl_;
             tl_ = now;
         }
     };
     auto flush = [&](int base) {
-        if (a.timed && lane == 0) {
+        if (TIMED && lane == 0) {
             unsigned long long* row = g_xwr_cycles[(blockIdx.x * 8 + wave) & 1023];
             atomicAdd(&row[base], tc[0]);
             atomicAdd(&row[base + 1], tc[1]);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 lap(0);
                 __syncthreads();
                 lap(1);
-                ++nstep;
+                if constexpr (TIMED) ++nstep;
             }
             __syncthreads();                                          // the D-waves finish the item
             par = 0;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                         for (int jj = 0; jj < PH + 2; ++jj) vt[hh][di][jj] = (ABL & 4) ? wv[di] : ld4(rp + jj * PITCH);
                     }
                 }
-                if (a.timed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(2); }     // [4]: the taps have landed
+                if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(2); }     // [4]: the taps have landed
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
                     const int h = 2 * hh;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 lap(0);
                 __syncthreads();
                 lap(1);
-                ++nstep;
+                if constexpr (TIMED) ++nstep;
             }
         }
         flush(2);
@@ -418,6 +418,7 @@ static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
             case 31: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 31>(a, lds, st);
             default: break;
         }
+        if (knobs().xwr_timed) return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 32>(a, lds, st);      // AMS_XWR_TIMED=1: the kernel with its role clocks
     }
     RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>, lds));
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
@@ -480,7 +481,6 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     a.nsy = nsy; a.nsx = nsx; a.cgroups = cgroups;
     a.items = B * rate * rate * nsy * nsx;
     a.y_fmt = y_fmt;
-    a.timed = knobs().xwr_timed;
     int64_t groups = groups_force > 0 ? groups_force : (512 + cgroups - 1) / cgroups;      // one block per CU (LDS), twice over
     if (groups > a.items) groups = a.items;
     a.groups = (int)groups;

@@ -655,14 +655,14 @@ static int forward_frozen_dual(ams_student* s, const void* frames, int dtype, in
     return rc;
 }
 
-// Parts of the static rule (AMS_OPT_DUAL_STREAM = 1): where the one-stream grids quantise badly at 512 x 1024 (round-2 sweep on MI355X:
-// two parts +3.5 % at 32-36 frames and at 64, three at 48; a loss of 1-5 % at 24-30 and 40; nothing either way elsewhere).  A fixed
-// function of the batch size: the same call always runs the same plan, and nothing is timed inside a call.
+// Parts of the static rule (AMS_OPT_DUAL_STREAM = 1).  Round-5 sweep on MI355X at 512 x 1024 (tools/sweep_parts.py, 1 / 2 / 3 / 4 parts at 8 .. 64
+// frames): two parts are 1-8 % ahead of one stream at every size from 8 frames on (0.94 vs 0.98 ms at 8, 1.81 vs 1.96 at 20, 2.56 vs 2.78 at 32,
+// 3.28 vs 3.52 at 40, 5.12 vs 5.36 at 64), three at 12, 24 and 48 (1.27 vs 1.29, 2.11 vs 2.22, 3.91 vs 4.00 against two).  A fixed function
+// of the batch size: the same call always runs the same plan, and nothing is timed inside a call.
 static int dual_parts_static(int batch) {
-    if (batch >= 32 && batch <= 36) return 2;
-    if (batch == 48) return 3;
-    if (batch == 64) return 2;
-    return 1;
+    if (batch < 8) return 1;
+    if (batch == 12 || batch == 24 || batch == 48) return 3;
+    return 2;
 }
 
 int run_forward(ams_student* s, const void* frames, int dtype, int batch, int mode, hipStream_t st) {

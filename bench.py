@@ -371,12 +371,12 @@ def main():
                                  "AMS_OPT_DUAL_STREAM; profiles/*_infer_kernel_stats.csv is taken with AMS_DUAL_STREAM=0 likewise); algorithmic bytes = "
                                  "f32 operands read once + results written once, algorithmic FLOPs = 2 x MACs of the block without halo or "
                                  "padding (DESIGN.md); launches of one kernel symbol are pooled (sum of work / sum of time)"})
-        parts_timed = {True: 1}.get(B < 2, 2 if (32 <= B <= 36 or B == 64) else 3 if B == 48 else 1)
+        parts_timed = 1 if B < 8 else 3 if B in (12, 24, 48) else 2          # dual_parts_static (engine_forward.hip)
         if os.environ.get("AMS_DUAL_STREAM") == "0":
             parts_timed = 1
         roofline["plan"] = "one stream (the engine's per-launch profiler replays the step on ONE stream)"
         roofline["timed_plan"] = ("%d parts of the batch on %d streams (AMS_OPT_DUAL_STREAM static rule); rocprofv3 trace of this plan: "
-                                  "profiles/r04_infer_kernel_stats_dual.csv" % (parts_timed, parts_timed)) if parts_timed > 1 else "one stream"
+                                  "profiles/r05_infer_kernel_stats_dual.csv" % (parts_timed, parts_timed)) if parts_timed > 1 else "one stream"
         roofline.update(pmc_traffic(dom[0], B, H))
         # the whole step against the three denominators of SURVEY 8 d4, over the TIMED step (not the profiled replay)
         as_built = total_bytes / n_prof

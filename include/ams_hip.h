@@ -266,8 +266,8 @@ enum { AMS_OPT_TRAIN_FWD_F16 = 24 /* fine-tune step under AMS_MATMUL_SPLIT_F16: 
                                        cheap pass over x, k_xx_stats.hip) instead of a pass that recomputes z_e.  Same mathematics, f32-level differences. */,
        AMS_OPT_DUAL_STREAM = 10 /* frozen inference: a batch as two to four parts on as many streams (the caller's and up to three the student
                                    owns, created with the student; one fork and one join per call), each frame computed exactly as in a batch of the
-                                   part's size.  0 never; 1 (default) a fixed function of the batch size (two parts at 32-36 and 64 frames, three at
-                                   48: where the single-stream grids quantise badly at 512x1024, +3.5 %) — nothing is timed, the call never
+                                   part's size.  0 never; 1 (default) a fixed function of the batch size (from 8 frames on two parts, three at 12, 24 and
+                                   48 frames: 1-8 % at 512x1024, tools/sweep_parts.py) — nothing is timed, the call never
                                    synchronises; n >= 2 always AMS_OPT_DUAL_PARTS parts from n frames on (the caller decides). */,
        AMS_OPT_BLOCK_X6 = 8 /* whole-block kernels: 1 (default) the expand products of the blocks with 24 / 32 input channels, and the stem's
                                products in the one-kernel first block (operands from a 258-entry table of the normalised byte values), run as six bf16

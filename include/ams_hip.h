@@ -577,8 +577,10 @@ int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint
  * when (device, kernel_key) has not yet been granted `lds` bytes — i.e. the launcher would call hipFuncSetAttribute now — and
  * records the grant; 0 otherwise.  Two students on two GPUs of one process each get their attributes set. */
 int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_t lds);
-/* Tests and tools/ only.  The tuning knobs (environment variables AMS_BLK_TILE, AMS_PW_FORCE, AMS_PW_PERCU, AMS_PWX_NO_TAIL, AMS_PWX_FORCE,
- * AMS_XDS_FORCE, AMS_XWR_FORCE, AMS_WG6_SPLITS, AMS_WG6_EIGHT_WAVES: tile / grid overrides of single kernels; AMS_SIDE_CU_MASK=<hex>: the
+/* Tests and tools/ only.  The tuning knobs (environment variables AMS_BLK_TILE, AMS_BLK_HP, AMS_PW_FORCE, AMS_PW_PERCU, AMS_PWX_NO_TAIL, AMS_PWX_FORCE,
+ * AMS_PWH_VARIANT, AMS_XDS_FORCE, AMS_XWR_FORCE, AMS_WG6_SPLITS, AMS_WG6_EIGHT_WAVES, AMS_FB_WALK (first block: 0 one tile per block, -2 only the border
+ * tiles so, n at most n tiles per walking block): tile / grid / form overrides of single kernels, same results; AMS_PWH_ABL, AMS_XWR_ABL, AMS_FB_ABL:
+ * measurement-only ablations, WRONG results; AMS_BLK_TIMED, AMS_XWR_TIMED, AMS_FB_ABL=32: the kernels' phase clocks (ams_debug_phase_cycles); AMS_SIDE_CU_MASK=<hex>: the
  * fine-tune step's side stream confined to the CUs whose bit is set; AMS_EVENT_FLAGS=<hex>: hipEventCreateWithFlags flags of the
  * stream-ordering events — these two change stream semantics and exist for measurements only) are read ONCE, at first use; this re-reads
  * them.  Not thread-safe against launches in flight. */

@@ -778,12 +778,16 @@ int launch_first_block(const void* frames, int dtype, int B, int H, int W, float
                 int64_t grid = cdiv(cdiv(n_in, rounds), 8) * 8;           // equal shares; a multiple of 8: a block's tiles stay on its XCD's share
                 if (grid > n_in) grid = n_in;
                 note_kernel("first_block_walk_kernel<0>");                // (a profiled launch bracket covers the border launch below as well)
-                switch (knobs().fb_abl) {           // MEASUREMENT ONLY (tools/sweep_fb_abl.sh, tools/fb_phases.py)
+#ifdef AMS_MEASURE
+                switch (knobs().fb_abl) {           // MEASUREMENT BUILD ONLY (libams_hip_measure.so: tools/sweep_fb_abl.sh, tools/fb_phases.py)
 #define FB_A(A_) case A_: hipLaunchKernelGGL(first_block_walk_kernel<A_>, dim3((unsigned)grid), dim3(256), 0, st, a, (unsigned)n_in); break;
                     FB_A(1) FB_A(2) FB_A(4) FB_A(8) FB_A(16) FB_A(6) FB_A(14) FB_A(30) FB_A(31) FB_A(32) FB_A(33) FB_A(34) FB_A(36) FB_A(40) FB_A(48) FB_A(63)
 #undef FB_A
                     default: hipLaunchKernelGGL(first_block_walk_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, a, (unsigned)n_in);
                 }
+#else
+                hipLaunchKernelGGL(first_block_walk_kernel<0>, dim3((unsigned)grid), dim3(256), 0, st, a, (unsigned)n_in);
+#endif
                 AMS_CHECK_LAUNCH();
                 const int64_t n_border = nblocks - n_in;
                 if (n_border > 0) {

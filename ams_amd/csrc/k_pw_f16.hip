@@ -316,7 +316,8 @@ template <int RM, int NT>
 static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
     const int epi = pw_pick_epi(a);
     if (a.x_mode == 1) return launch_pw_f16_d<RM, NT, EPI_PLAIN, 0, 4, 2, 0, 1>(a, w, plane, Kp, st);      // (pointwise_f16_applies: plain epilogue only)
-    if constexpr (RM == 2 && NT == 5) {                    // MEASUREMENT ONLY (AMS_PWH_ABL=<bits>, wrong results): what the stage loop is made of
+#ifdef AMS_MEASURE
+    if constexpr (RM == 2 && NT == 5) {                    // MEASUREMENT BUILD ONLY (libams_hip_measure.so, AMS_PWH_ABL=<bits>, wrong results): what the stage loop is made of
         const int abl = knobs().pwh_abl;
         if (abl && a.x_fmt == 1) {
 #define PWH_A(A_) if (abl == A_) return launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, 4, 2, A_>(a, w, plane, Kp, st);
@@ -324,6 +325,7 @@ static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int 
 #undef PWH_A
         }
     }
+#endif
     if constexpr (NT == 10 && RM <= 2) {                   // full-width 160-column tiles (the operand crosses L2 -> CU once), 8- / 12-wave blocks
         int nw = knobs().pwh_nw, dd = knobs().pwh_d;
         if (!knobs().pwh_set && RM == 1) { nw = 12; dd = 3; }      // what launch_pointwise_split_f16 picks the (1, 10) tile for

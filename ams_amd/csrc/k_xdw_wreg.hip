@@ -404,7 +404,8 @@ static size_t xwr_lds(int Kp, int np, int nwe, int nrg, int ring) {
 
 template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0>
 static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
-    if constexpr (ABL == 0 && KS == 5 && NP == 2 && NWE == 4 && NWD == 4 && NRG == 2 && H16) {        // MEASUREMENT ONLY (AMS_XWR_ABL=<bits>)
+#ifdef AMS_MEASURE
+    if constexpr (ABL == 0 && KS == 5 && NP == 2 && NWE == 4 && NWD == 4 && NRG == 2 && H16) {        // MEASUREMENT BUILD ONLY (libams_hip_measure.so, AMS_XWR_ABL=<bits>)
         switch (knobs().xwr_abl) {
             case 1: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 1>(a, lds, st);
             case 2: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 2>(a, lds, st);
@@ -420,6 +421,7 @@ static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
         }
         if (knobs().xwr_timed) return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 32>(a, lds, st);      // AMS_XWR_TIMED=1: the kernel with its role clocks
     }
+#endif
     RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>, lds));
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");

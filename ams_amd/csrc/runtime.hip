@@ -83,14 +83,22 @@ static Knobs read_knobs() {
         if (const char* e = getenv("AMS_BLK_TILE")) sscanf(e, "%dx%d", &v.blk_th, &v.blk_tw);
         if (const char* e = getenv("AMS_BLK_HP")) v.blk_hp = atoi(e);
         if (const char* e = getenv("AMS_FB_WALK")) v.fb_walk = atoi(e);
-        if (const char* e = getenv("AMS_FB_ABL")) v.fb_abl = atoi(e);
         if (const char* e = getenv("AMS_BLK_TIMED")) v.blk_timed = atoi(e);
         if (const char* e = getenv("AMS_XWR_TIMED")) v.xwr_timed = atoi(e);
         if (const char* e = getenv("AMS_PW_FORCE")) sscanf(e, "%c,%d,%d", &v.pw_force, &v.pw_rm, &v.pw_nt);
         if (const char* e = getenv("AMS_PW_PERCU")) v.pw_percu = atoi(e);
         v.pwx_no_tail = getenv("AMS_PWX_NO_TAIL") != nullptr;
+#ifdef AMS_MEASURE
+        // measurement build only (make measure -> libams_hip_measure.so): kernels with loads / MFMAs / stores removed — WRONG results by design
+        if (const char* e = getenv("AMS_FB_ABL")) v.fb_abl = atoi(e);
         if (const char* e = getenv("AMS_PWH_ABL")) v.pwh_abl = atoi(e);
         if (const char* e = getenv("AMS_XWR_ABL")) v.xwr_abl = atoi(e);
+#else
+        // the product library has no ablated kernels: the variables are refused loudly, never obeyed
+        for (const char* name : {"AMS_FB_ABL", "AMS_PWH_ABL", "AMS_XWR_ABL"})
+            if (const char* e = getenv(name))
+                if (atoi(e) != 0) fprintf(stderr, "libams_hip: %s=%s ignored — ablated kernels exist only in libams_hip_measure.so (make -C ams_amd/csrc measure)\n", name, e);
+#endif
         if (const char* e = getenv("AMS_PWH_VARIANT")) { v.pwh_set = true; sscanf(e, "%d,%d", &v.pwh_nw, &v.pwh_d); }
         if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &v.pwx_rm, &v.pwx_nt);
         if (const char* e = getenv("AMS_XDS_FORCE")) { v.xds_set = true; sscanf(e, "%d,%d,%d,%d,%d,%d", &v.xds[0], &v.xds[1], &v.xds[2], &v.xds[3], &v.xds[4], &v.xds[5]); }

@@ -579,13 +579,16 @@ int ams_k_adam(float* params, const float* grads, float* m, float* v, const uint
 int ams_debug_launch_table_needs_attr(int32_t device, uint64_t kernel_key, size_t lds);
 /* Tests and tools/ only.  The tuning knobs (environment variables AMS_BLK_TILE, AMS_BLK_HP, AMS_PW_FORCE, AMS_PW_PERCU, AMS_PWX_NO_TAIL, AMS_PWX_FORCE,
  * AMS_PWH_VARIANT, AMS_XDS_FORCE, AMS_XWR_FORCE, AMS_WG6_SPLITS, AMS_WG6_EIGHT_WAVES, AMS_FB_WALK (first block: 0 one tile per block, -2 only the border
- * tiles so, n at most n tiles per walking block): tile / grid / form overrides of single kernels, same results; AMS_PWH_ABL, AMS_XWR_ABL, AMS_FB_ABL:
- * measurement-only ablations, WRONG results; AMS_BLK_TIMED, AMS_XWR_TIMED, AMS_FB_ABL=32: the kernels' phase clocks (ams_debug_phase_cycles); AMS_SIDE_CU_MASK=<hex>: the
+ * tiles so, n at most n tiles per walking block): tile / grid / form overrides of single kernels, same results; AMS_BLK_TIMED, AMS_XWR_TIMED: the kernels' phase clocks
+ * (ams_debug_phase_cycles; correct results).  AMS_PWH_ABL, AMS_XWR_ABL, AMS_FB_ABL (kernels with loads / MFMAs / stores removed: WRONG results by design; AMS_FB_ABL=32
+ * and AMS_XWR_TIMED on the weight-register kernel: clocked forms) exist ONLY in the measurement build libams_hip_measure.so (`make -C ams_amd/csrc measure`, compiled with
+ * -DAMS_MEASURE, selected by tools/ through AMS_HIP_LIB): this library has no such kernels, names the variables on stderr and ignores them.  AMS_SIDE_CU_MASK=<hex>: the
  * fine-tune step's side stream confined to the CUs whose bit is set; AMS_EVENT_FLAGS=<hex>: hipEventCreateWithFlags flags of the
  * stream-ordering events — these two change stream semantics and exist for measurements only) are read ONCE, at first use; this re-reads
  * them.  Not thread-safe against launches in flight. */
 int ams_debug_reload_knobs(void);
 /* tools/ only.  Shader-clock cycles per wave and phase, summed over the launches since the last call, copied to out[0..n) (n <= 8) and cleared.
+ * (which = 0 and 2 need the measurement build, see ams_debug_reload_knobs.)
  * which = 0: the walking first block with AMS_FB_ABL=32 ([0] tile decode, [1] stem, [2] wait at the barrier, [3] depthwise + project, [6] wave-tiles);
  * which = 1: the whole-block kernels with AMS_BLK_TIMED=1 ([0] prologue, [1] expand phases, [2] depthwise + project phases, [3] epilogue, [6] waves);
  * which = 2 / 3: the weight-register / the LDS-weight streaming kernel with AMS_XWR_TIMED=1 ([0] E-waves between the step barriers, [1] E-waves at the barrier, [2] / [3]

@@ -108,3 +108,26 @@ def test_no_launch_path_reads_the_environment():
         text = f.read_text()
         assert "getenv" not in text, f.name
         assert not re.search(r"static\s+(bool|size_t|int)\s+(attr_set|attr_lds|slots|per_cu_cache)", text), f.name
+
+
+def test_product_library_has_no_ablated_kernels():
+    """kernels with loads / MFMAs / stores removed ("wrong results by design") and their AMS_*_ABL switches are compiled only
+    under -DAMS_MEASURE into libams_hip_measure.so (make measure).  The product library carries the ABL = 0 instantiations alone, and an
+    environment variable cannot select anything else."""
+    hip.lib()
+    out = subprocess.run(["nm", "-C", str(hip.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    kernels = set(re.findall(r"ams::(xdw_wreg_kernel<[^>]*>|first_block_walk_kernel<[^>]*>|pw_gemm_f16x3_l<[^>]*>)", out))
+    assert kernels, "kernel symbols not found"
+    for k in kernels:
+        args = [a.strip() for a in k[k.index("<") + 1:-1].split(",")]
+        if k.startswith("xdw_wreg_kernel"):
+            abl = args[6] if len(args) > 6 else "0"
+        elif k.startswith("first_block_walk_kernel"):
+            abl = args[0]
+        else:
+            abl = args[6] if len(args) > 6 else "0"
+        assert abl == "0", "ablated kernel in the product library: %s" % k
+    src = (Path(__file__).resolve().parent.parent / "ams_amd" / "csrc" / "runtime.hip").read_text()
+    product = re.sub(r"#ifdef AMS_MEASURE.*?(#else|#endif)", "", src, flags=re.S)       # what the product build compiles of the knob reader
+    assert "AMS_XWR_ABL" in product and "ignored" in product                              # (it names them only to refuse them)
+    assert "v.xwr_abl" not in product and "v.pwh_abl" not in product and "v.fb_abl" not in product

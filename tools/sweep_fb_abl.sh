@@ -1,6 +1,9 @@
 #!/bin/bash
 # What the walking first block's time is made of: AMS_FB_ABL=<bits> (wrong results): 1 no result stores, 2 no depthwise arithmetic, 4 no byte loads /
 # table look-ups, 8 no project MFMAs, 16 no stem MFMAs.  Kernel time from rocprofv3 --kernel-trace --stats of a 32-frame one-stream loop.
+# needs the measurement build: make -C ams_amd/csrc measure (libams_hip_measure.so; the product library has no ablated kernels)
+export AMS_HIP_LIB=${AMS_HIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/ams_amd/libams_hip_measure.so}
+[ -f "$AMS_HIP_LIB" ] || { echo "build it first: make -C ams_amd/csrc measure"; exit 1; }
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for abl in ${@:-0 1 2 4 8 16 6 14 30 31}; do
   export AMS_FB_ABL=$abl

@@ -5,6 +5,9 @@ import os
 import sys
 sys.path.insert(0, ".")
 os.environ["AMS_XWR_TIMED"] = "1"
+_MEASURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ams_amd", "libams_hip_measure.so")
+os.environ.setdefault("AMS_HIP_LIB", _MEASURE)      # the clocked / ablated kernels are in the measurement build only: make -C ams_amd/csrc measure
+assert os.path.exists(os.environ["AMS_HIP_LIB"]), "build it first: make -C ams_amd/csrc measure"
 import torch
 from ams_amd import hip, spec as S, synth, weights as Wt
 from ams_amd.engine import StudentEngine

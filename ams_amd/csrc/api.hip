@@ -207,6 +207,24 @@ int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frame
     return train_step_impl(s, frames_dev, frames_dtype, teacher_dev, batch, batch, lr, mask_dev, loss_dev, nullptr, nullptr, nullptr, stream);
 }
 
+int ams_student_feed_teacher_logits(ams_student* s, const float* teacher_logits_dev, int32_t th, int32_t tw) {
+    AMS_REQUIRE(s, "feed_teacher_logits: null student");
+    if (!teacher_logits_dev) { s->teacher_logits = nullptr; s->teacher_th = s->teacher_tw = 0; return AMS_OK; }
+    AMS_REQUIRE(th >= 1 && tw >= 1 && th <= s->cfg.height && tw <= s->cfg.width, "feed_teacher_logits: %d x %d teacher logits for %d x %d labels", th, tw,
+                s->cfg.height, s->cfg.width);
+    s->teacher_logits = teacher_logits_dev; s->teacher_th = th; s->teacher_tw = tw;
+    return AMS_OK;
+}
+
+int ams_student_set_regularizer(ams_student* s, const uint8_t* reg_mask_dev, int32_t n_vars, float coef) {
+    AMS_REQUIRE(s, "set_regularizer: null student");
+    if (!reg_mask_dev) { s->reg_mask = nullptr; s->reg_nvars = 0; s->reg_coef = 0.f; return AMS_OK; }
+    AMS_REQUIRE(s->cfg.trainable, "set_regularizer: this student was created frozen");
+    AMS_REQUIRE(n_vars > 0 && coef >= 0.f, "set_regularizer: n_vars=%d coef=%g", n_vars, (double)coef);
+    s->reg_mask = reg_mask_dev; s->reg_nvars = n_vars; s->reg_coef = coef;
+    return AMS_OK;
+}
+
 int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     AMS_REQUIRE(s, "set_option: null student");
     s->dual_choice.clear();                            // any option may change the plans the autotune compared
@@ -286,6 +304,10 @@ int ams_student_set_option(ams_student* s, int32_t option, int32_t value) {
     }
     if (option == AMS_OPT_TRAIN_FWD_F16) {
         s->train_fwd_f16 = value != 0;
+        return AMS_OK;
+    }
+    if (option == AMS_OPT_SOFT_TEACHER) {
+        s->soft_teacher = value != 0;
         return AMS_OK;
     }
     if (option == AMS_OPT_NAN_GRADS) {
@@ -574,6 +596,18 @@ int ams_k_ce_loss_grad(const float* logits, int32_t B, int32_t h, int32_t w, int
                 ce_loss_grad_scratch(B, h, w, K));
     hipStream_t st = (hipStream_t)stream;
     RUN(launch_ce_loss_grad(logits, NC, B, h, w, class_idx_host, K, H, W, teacher, NC, loss_dev, scratch, st));
+    return launch_ce_combine(B, h, w, class_idx_host, K, NC, loss_dev, scratch, dlogits, NC, st);
+}
+
+int ams_k_ce_loss_grad_soft(const float* logits, int32_t B, int32_t h, int32_t w, int32_t NC, const int32_t* class_idx_host, int32_t K, int32_t H,
+                            int32_t W, const uint8_t* teacher, const float* teacher_logits, int32_t th, int32_t tw, double* loss_dev, float* dlogits,
+                            float* scratch, size_t scratch_floats, void* stream) {
+    AMS_REQUIRE(teacher_logits, "ce_loss_grad_soft: null teacher logits");
+    AMS_REQUIRE(ce_loss_grad_supported(w, W), "ce_loss_grad: %d output columns on %d source columns is outside the one-pass kernel", W, w);
+    AMS_REQUIRE(scratch && scratch_floats >= ce_loss_grad_scratch(B, h, w, K), "ce_loss_grad: scratch too small (need %zu floats)",
+                ce_loss_grad_scratch(B, h, w, K));
+    hipStream_t st = (hipStream_t)stream;
+    RUN(launch_ce_loss_grad(logits, NC, B, h, w, class_idx_host, K, H, W, teacher, NC, loss_dev, scratch, st, teacher_logits, th, tw));
     return launch_ce_combine(B, h, w, class_idx_host, K, NC, loss_dev, scratch, dlogits, NC, st);
 }
 

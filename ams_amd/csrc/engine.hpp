@@ -148,6 +148,12 @@ struct ams_student {
                                      // Off: measured 7.455 -> 7.368 ms per 8-frame step (the step's GEMMs are not bound by their MFMAs at 17160 rows), and two
                                      // step-level agreement bars between f32 evaluations (fused vs layer-wise at 34 x 68 x 5 frames, 2 ranks vs 1) move past
                                      // their limits with another product rounding in the forward — not worth 1.2 %
+    // create_student_v3's kwargs that run.py leaves off (utils/graph_utils.py:338-339): soft_teacher — the loss's target is softmax(gather(teacher
+    // logits)) (:375-376, 403-404), the logits fed per step (ams_student_feed_teacher_logits = feed_dict[teacher_labels_logits_pl]); regularize /
+    // train_biases_only — 0.01 * mean of the l2 losses of tvars added to the loss (:451-456; ams_student_set_regularizer)
+    int soft_teacher = 0;
+    const float* teacher_logits = nullptr; int teacher_th = 0, teacher_tw = 0;
+    const uint8_t* reg_mask = nullptr; int reg_nvars = 0; float reg_coef = 0.f;
     int nan_grads = 0;               // a batch without a valid pixel: NaN loss, ZERO gradients — what TensorFlow computes for utils/graph_utils.py:408
                                      // (reduce_mean over the empty boolean_mask: its gradient is an empty tensor, densified to zeros); 1 = NaN gradients (AMS_OPT_NAN_GRADS)
     ~ams_student() {

@@ -382,10 +382,12 @@ int loss_forward(ams_student* s, const uint8_t* teacher, int B, int32_t* labels,
     const ams_student_config& c = s->cfg;
     if (!labels && ce_loss_grad_supported(s->w, c.width)) {
         // the fine-tune step: loss sums and the unnormalised gradient in one pass over the pixels
+        const bool soft = s->soft_teacher != 0;
         RUNK(0, 0.0, launch_ce_loss_grad(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher, c.num_classes,
-                                         s->loss_buf, s->ce_scratch, st));
+                                         s->loss_buf, s->ce_scratch, st, soft ? s->teacher_logits : nullptr, s->teacher_th, s->teacher_tw));
         return AMS_OK;
     }
+    AMS_REQUIRE(labels || !s->soft_teacher, "soft_teacher: %d output columns on %d logit columns is outside the one-pass loss kernel", c.width, s->w);
     return launch_upsample_argmax(s->logits, 32, B, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher,
                                   c.num_classes, labels, s->conf_buf, s->loss_buf, st);
 }
@@ -397,6 +399,8 @@ int train_step_impl(ams_student* s, const void* frames_dev, int32_t frames_dtype
     AMS_REQUIRE(teacher_dev, "train_step: null teacher labels");
     if (!s->cfg.trainable) { set_error("train_step: this student was created frozen (trainable=0)"); return AMS_E_STATE; }
     AMS_REQUIRE(global_batch >= batch, "train_step: global batch %d < local batch %d", global_batch, batch);
+    // soft_teacher=True without the feed: TensorFlow's "You must feed a value for placeholder tensor" (teacher_labels_logits_pl)
+    AMS_REQUIRE(!s->soft_teacher || s->teacher_logits, "train_step: soft_teacher is on but no teacher logits are fed (ams_student_feed_teacher_logits)");
     hipStream_t st = (hipStream_t)stream;
     if (comm) cb = comm_as_cb;
     SyncCtx sc{cb, user, s, comm};
@@ -406,6 +410,10 @@ int train_step_impl(ams_student* s, const void* frames_dev, int32_t frames_dtype
     RUN(sync_doubles(psc, s->loss_buf, 2, st));         // loss sum and valid-pixel count over all ranks
     RUN(backward(s, frames_dev, frames_dtype, teacher_dev, batch, global_batch, psc, st));
     RUN(sync_any(psc, s->grads, (size_t)s->cfg.n_trainable, AMS_DT_F32, st));       // one flat 8.45 MB message
+    // regularize=True: after the cross-rank sum of the gradients (every rank holds the same variables: the term is not a per-shard quantity)
+    if (s->reg_mask)
+        RUN(launch_l2_regularizer(s->params, s->grads, s->reg_mask, s->cfg.n_trainable, s->reg_nvars, s->reg_coef, reinterpret_cast<double*>(s->tmp_c),
+                                  s->loss_buf, st));
     if (loss_dev) AMS_CHECK_HIP(hipMemcpyAsync(loss_dev, s->loss_buf, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     // Adam, TF1 form; the step counter is never reset (SemanticNetwork.py:25, :154-156)
     s->adam_t += 1;

@@ -179,7 +179,8 @@ static int forward_frozen(ams_student* s, const void* frames, int dtype, const i
             LayerRt& le = s->L[i];
             LayerRt& ld = s->L[i + 1];
             const int o = other(cur_i, -1);
-            const bool h16 = s->matmul_mode == AMS_MATMUL_SPLIT_F16 && le.whf;
+            // (Cin <= 32 streams on the exact-f32 form whatever the mode: no fp16 parts there, so no fp16-pair hand-over of d either)
+            const bool h16 = s->matmul_mode == AMS_MATMUL_SPLIT_F16 && le.whf && le.d.cin > 32;
             const int np = h16 ? AMS_NP_F16 : s->matmul_mode == AMS_MATMUL_SPLIT_BF16_X6 || s->matmul_mode == AMS_MATMUL_SPLIT_F16 ? 3 : s->matmul_mode == AMS_MATMUL_BF16 ? 1 : 2;
             const uint16_t* wparts = h16 ? le.whf : le.whi;
             const int64_t wplane = h16 ? (int64_t)le.d.cout * le.Kp : (int64_t)(le.wlo - le.whi);

@@ -476,6 +476,44 @@ int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mas
     return AMS_OK;
 }
 
+// regularize=True of create_student_v3 (utils/graph_utils.py:451-456): loss += 0.01 * reduce_mean([l2_loss(v) for v in tvars]), l2_loss(v) =
+// sum(v^2) / 2, tvars = every trainable variable or (train_biases_only) those without 'weight' in their name.  Over the flat arena with a byte
+// mask of the regularised entries: g += (coef / n_vars) * p, and the blocks' sums of p^2 (f64, fixed order) for the loss term.
+__global__ __launch_bounds__(256) void l2_reg_kernel(const float* __restrict__ p, float* __restrict__ g, const uint8_t* __restrict__ mask, int64_t n,
+                                                     float gscale, double* __restrict__ part) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!mask[i]) continue;
+        const float v = p[i];
+        g[i] = g[i] + gscale * v;
+        acc += (double)v * (double)v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// loss[0] (the CE sum over the valid pixels) += lscale * sum(p^2) * loss[1]: the caller's mean loss[0] / loss[1] then carries the regulariser
+__global__ __launch_bounds__(64) void l2_reg_finish_kernel(const double* __restrict__ part, int nparts, double lscale, double* __restrict__ loss) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) acc += part[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss[0] += lscale * acc * loss[1];
+}
+
+int launch_l2_regularizer(const float* p, float* g, const uint8_t* mask, int64_t n, int n_vars, float coef, double* part_scratch, double* loss, hipStream_t st) {
+    AMS_REQUIRE(p && g && mask && part_scratch && loss && n_vars > 0, "l2_regularizer: bad arguments");
+    const int grid = 256;
+    note_kernel("l2_reg_kernel");
+    hipLaunchKernelGGL(l2_reg_kernel, dim3(grid), dim3(256), 0, st, p, g, mask, n, coef / (float)n_vars, part_scratch);
+    AMS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l2_reg_finish_kernel, dim3(1), dim3(64), 0, st, part_scratch, grid, 0.5 * (double)coef / (double)n_vars, loss);
+    AMS_CHECK_LAUNCH();
+    return AMS_OK;
+}
+
 // out[i] = sum_k part[k*n + i].  One block per 16 outputs: thread t owns output (t & 15) and every LP-th split starting at (t >> 4),
 // eight loads in flight; the LP f64 partials of an output are added in a fixed order (deterministic, and LP x shorter dependent load
 // chains than one thread per output: with ~1000 splits the serial form cost > 100 us per call, 16 lanes with two loads in flight

@@ -31,6 +31,16 @@ __device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, 
     return __fadd_rn(top, __fmul_rn(__fsub_rn(bot, top), ty));
 }
 
+// Soft-teacher targets (create_student_v3 with soft_teacher=True, utils/graph_utils.py:359, 375-376, 403-404): teacher logits
+// [B][th][tw][ld] f32 fed through teacher_labels_logits_pl; the target of a pixel is softmax(gather(teacher_logits, class_weights)).  th x tw is
+// either the label size (the reference's feed: the loss needs the shape of filtered_logits) or any smaller grid, which is then interpolated
+// to H x W exactly as the student's own logits are (align corners) — at th == H, tw == W that interpolation is the identity, bit for bit.
+struct SoftTeacher {
+    const float* t;
+    int th, tw, ld;
+    float sy, sx;
+};
+
 struct ClassTable {
     int32_t idx[kMaxK];      // selected class ids
     int32_t lut[256];        // teacher id -> subset index, -1 = ignored
@@ -299,10 +309,13 @@ int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32
 // (7 x 33 x 8 = 1848 blocks) fits ONE round of the 2048 resident blocks; with eight it was 2376 blocks of 155 live threads: two rounds
 constexpr int kCeCB = 10;
 
-template <int KMAX>
+// SOFT: the target distribution of a pixel is the softmax of the K gathered teacher logits instead of the one-hot row of its label: per-pixel
+// loss sum_k p_k (log sum exp(z - max) - (z_k - max)) (TensorFlow's xent kernel), gradient softmax(z) - p; the mask and the mean's denominator
+// still come from the hard labels (weights = reduce_sum(filtered_labels_onehot), utils/graph_utils.py:397, 406-408).
+template <int KMAX, bool SOFT = false>
 __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restrict__ logits, HeadGeom g, ClassTable ct,
                                                            const uint8_t* __restrict__ teacher, double* __restrict__ loss,
-                                                           float* __restrict__ partT, float* __restrict__ partB) {
+                                                           float* __restrict__ partT, float* __restrict__ partB, SoftTeacher sft) {
     __shared__ float s_val[192][2 * KMAX + 1];
     __shared__ float s_wx[192][2];            // weight of the column towards its left / right source column
     __shared__ int s_x0[192];
@@ -355,6 +368,13 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
         }
         // only columns whose x0 is an OWNED cell column count towards the loss (the overlap column belongs to the block on the left)
         const bool own = x0 >= j_lo;
+        // soft targets: the pixel column's taps into the teacher grid are fixed for the thread
+        int qx0 = 0, qx1 = 0; float qtx = 0.f;
+        const float* qbase = nullptr;
+        if constexpr (SOFT) {
+            src_tap(x, sft.sx, sft.tw, qx0, qx1, qtx);
+            qbase = sft.t + (int64_t)b * sft.th * sft.tw * sft.ld;
+        }
         // Eight rows at a time: their label bytes, then their class-table entries, are requested together — the two dependent loads per
         // row were the kernel (63 % of the wave cycles waiting with six waves per SIMD to hide a ~1 us chain per row).  Same arithmetic,
         // same row order: the same bits.
@@ -380,17 +400,57 @@ __global__ __launch_bounds__(192) void ce_loss_grad_kernel(const float* __restri
                 if (k < g.K) zmax = fmaxf(zmax, z[k]);
                 if (k == target) zt = z[k];
             }
+            float pt[SOFT ? KMAX : 1];
+            float zs[SOFT ? KMAX : 1];                    // z_k - max, kept for the soft loss
+            if constexpr (SOFT) {
+                int qy0, qy1; float qty;
+                src_tap(y, sft.sy, sft.th, qy0, qy1, qty);
+                const float* qtl = qbase + ((int64_t)qy0 * sft.tw + qx0) * sft.ld;
+                float pmax = -3.0e38f;
+                if (qty == 0.f && qtx == 0.f) {           // on a grid point (always, when the teacher logits come at the label size)
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) { pt[k] = qtl[ct.idx[k < g.K ? k : 0]]; if (k < g.K) pmax = fmaxf(pmax, pt[k]); }
+                } else {
+                    const float* qtr = qbase + ((int64_t)qy0 * sft.tw + qx1) * sft.ld;
+                    const float* qbl = qbase + ((int64_t)qy1 * sft.tw + qx0) * sft.ld;
+                    const float* qbr = qbase + ((int64_t)qy1 * sft.tw + qx1) * sft.ld;
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        const int c = ct.idx[k < g.K ? k : 0];
+                        pt[k] = bilerp(qtl[c], qtr[c], qbl[c], qbr[c], qtx, qty);
+                        if (k < g.K) pmax = fmaxf(pmax, pt[k]);
+                    }
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < g.K) { pt[k] = __expf(pt[k] - pmax); psum += pt[k]; } else pt[k] = 0.f;
+                const float rp = 1.f / psum;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) pt[k] *= rp;
+            }
             float ssum = 0.f;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
-                if (k < g.K) { z[k] = __expf(z[k] - zmax); ssum += z[k]; }
+                if (k < g.K) { if constexpr (SOFT) zs[k] = z[k] - zmax; z[k] = __expf(z[k] - zmax); ssum += z[k]; }
             const float rs = 1.f / ssum;
+            if constexpr (SOFT) {
+                const float lse = __logf(ssum);
+                float lp = 0.f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < g.K) lp += pt[k] * (lse - zs[k]);
+                if (own) { my_loss += rint((double)lp * 1048576.0); my_cnt += 1; }
+            } else {
             if (own) { my_loss += rint((double)((zmax + __logf(ssum)) - zt) * 1048576.0); my_cnt += 1; }
+            }
             const float wt = 1.f - ty;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
                 if (k < g.K) {
-                    const float d = z[k] * rs - (k == target ? 1.f : 0.f);
+                    float want;
+                    if constexpr (SOFT) want = pt[k]; else want = k == target ? 1.f : 0.f;
+                    const float d = z[k] * rs - want;
                     gt[k] += wt * d;
                     gb[k] += ty * d;
                 }
@@ -477,7 +537,7 @@ __global__ __launch_bounds__(256) void ce_loss_sum_kernel(const double* __restri
 
 // pass 1: loss[0] += CE sum, loss[1] += valid pixels (loss zeroed here), unnormalised gradient planes into scratch
 int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W, const uint8_t* teacher,
-                        int NC, double* loss, float* scratch, hipStream_t st) {
+                        int NC, double* loss, float* scratch, hipStream_t st, const float* soft_logits, int soft_h, int soft_w) {
     ClassTable ct;
     int rc = fill_class_table(cls, K, NC, &ct);
     if (rc) return rc;
@@ -492,10 +552,24 @@ int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const 
     const dim3 grid(cdiv(w, kCeCB), h, B);
     const size_t planes = (size_t)2 * B * h * w * KM;
     double* blk = reinterpret_cast<double*>(scratch + (planes + 3) / 4 * 4);          // 16-byte aligned behind the planes
-    note_kernel("ce_loss_grad_kernel");
-    if (KM == 8) hipLaunchKernelGGL(ce_loss_grad_kernel<8>, grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB);
-    else if (KM == 20) hipLaunchKernelGGL(ce_loss_grad_kernel<20>, grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB);
-    else hipLaunchKernelGGL(ce_loss_grad_kernel<32>, grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB);
+    SoftTeacher sft;
+    memset(&sft, 0, sizeof(sft));
+    if (soft_logits) {
+        AMS_REQUIRE(soft_h >= 1 && soft_w >= 1 && soft_h <= H && soft_w <= W, "ce_loss_grad: teacher logits of %d x %d for labels of %d x %d", soft_h, soft_w, H, W);
+        sft.t = soft_logits; sft.th = soft_h; sft.tw = soft_w; sft.ld = NC;
+        sft.sy = H > 1 ? (float)(soft_h - 1) / (float)(H - 1) : 0.f;          // as head_geom does for the student's own logits
+        sft.sx = W > 1 ? (float)(soft_w - 1) / (float)(W - 1) : 0.f;
+    }
+    note_kernel(soft_logits ? "ce_loss_grad_kernel<soft>" : "ce_loss_grad_kernel");
+    if (soft_logits) {
+        if (KM == 8) hipLaunchKernelGGL((ce_loss_grad_kernel<8, true>), grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB, sft);
+        else if (KM == 20) hipLaunchKernelGGL((ce_loss_grad_kernel<20, true>), grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB, sft);
+        else hipLaunchKernelGGL((ce_loss_grad_kernel<32, true>), grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB, sft);
+    } else {
+    if (KM == 8) hipLaunchKernelGGL((ce_loss_grad_kernel<8, false>), grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB, sft);
+    else if (KM == 20) hipLaunchKernelGGL((ce_loss_grad_kernel<20, false>), grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB, sft);
+    else hipLaunchKernelGGL((ce_loss_grad_kernel<32, false>), grid, dim3(192), 0, st, logits, g, ct, teacher, blk, partT, partB, sft);
+    }
     AMS_CHECK_LAUNCH();
     hipLaunchKernelGGL(ce_loss_sum_kernel, dim3(1), dim3(256), 0, st, blk, (int)(grid.x * grid.y * grid.z), loss);
     AMS_CHECK_LAUNCH();

@@ -46,14 +46,15 @@ struct XwrArgs {
 };
 
 // tools/ only: [0] E-waves between barriers, [1] E-waves at the step barrier, [2] D-waves between barriers, [3] D-waves at the barrier,
-// [4] D-waves from the barrier until their taps have landed (part of [2]'s span, counted separately), [6] E-wave steps, [7] D-wave steps
+// [4] D-waves from the barrier until their taps have landed, [5] from there until their FMAs are done, [2] the rest (epilogue + stores), [6] E-wave steps, [7] D-wave steps
 __device__ unsigned long long g_xwr_cycles[1024][8];
 
 // H16: the operand and weight parts are the two fp16 parts of split_bf16.hpp (hi | lo 2^11; NP = 2): three MFMAs per 32 k, the cross terms
 // in an accumulator of their own, products and order of pw_gemm_f16x3_l (bit-identical to it followed by the depthwise kernel).
 // ABL: measurement-only ablations (AMS_XWR_ABL, wrong results): 1 no operand loads in the step loop, 2 no MFMAs, 4 no depthwise arithmetic,
 // 8 no result stores, 16 no ring stores
-template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0>
+// PRE: the D-waves request the top and middle window rows of a step one step AHEAD (needs Wp >= STEP: see the D-waves' loop)
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0, bool PRE = false>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, unsigned nblocks) {
     static_assert(!H16 || NP == 2, "the fp16 form has two parts");
     constexpr int STEP = 16 * NRG;                   // pixels per step: NRG MFMA row groups per E-wave (2 * NRG accumulator chains)
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
     const int Wp = a.Wp, rate = a.rate, R = a.ring;
     const int qS = STEP / Wp, rS = STEP - qS * Wp;
     constexpr bool TIMED = (ABL & 32) != 0;          // compile-time: the laps' state costs the untimed kernel 4 % when it is a run-time switch
-    unsigned long long tc[3] = {0, 0, 0}, tl_ = TIMED ? __builtin_amdgcn_s_memtime() : 0, nstep = 0;
+    unsigned long long tc[4] = {0, 0, 0, 0}, tl_ = TIMED ? __builtin_amdgcn_s_memtime() : 0, nstep = 0;
     auto lap = [&](int slot) {
         if constexpr (TIMED) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
             atomicAdd(&row[base], tc[0]);
             atomicAdd(&row[base + 1], tc[1]);
             atomicAdd(&row[base ? 7 : 6], nstep);
-            if (base) atomicAdd(&row[4], tc[2]);
+            if (base) { atomicAdd(&row[4], tc[2]); atomicAdd(&row[5], tc[3]); }
         }
     };
 
@@ -313,43 +314,94 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
             { const int c0 = Wp - 1 + pt * PX; d_row = c0 / Wp; d_col = c0 - d_row * Wp; d_row -= 2; }
             __syncthreads();                                          // (A)
             __syncthreads();                                          // E-step 0
-            for (int t = 0; t < a.T; ++t) {
-                // all taps of the step's centres are requested before the first is used (PX / 2 pairs of centres: 12 ds_read_b128 each): with one
-                // D-wave per SIMD nothing else hides the LDS round trip of the second pair behind the first pair's arithmetic
-                constexpr int NH = (PX + 1) / 2;
-                float4 vt[NH][3][PH + 2];
+            // The taps of a step's centres, one window ROW at a time: vt[hh][di][jj] = row di of the pair of centres hh.  With one D-wave per SIMD
+            // nothing else hides an LDS round trip, and the D-waves are the critical path of the step (tools/xwr_phases.py, round 5: 1.3 k of a
+            // step's 4.1 k cycles went by until all 24 reads issued behind the barrier had landed).  PRE: the windows of D-step t + 1 reach the
+            // ring slots (t + 2) STEP - (2 - di) Wp - 1 at most and E-step t + 1 — the one running beside D-step t — writes from (t + 1) STEP on,
+            // so with Wp >= STEP the top and the middle row of the NEXT step were written by E-steps that are complete when this D-step begins:
+            // they are requested one step ahead, straight after this step's FMAs have freed the registers, and land under the epilogue and the
+            // stores; only the bottom row waits for the barrier, and the top / middle FMAs (pinned ahead of the bottom row's) cover its round
+            // trip.  The D-waves' step barrier is a bare s_barrier: they write nothing to LDS, and __syncthreads' fence would wait for the reads
+            // in flight.  (Ring reuse: the slots requested ahead are the slots D-step t + 1 reads anyway, one step of E-writes further from
+            // being overwritten.)
+            constexpr int NH = (PX + 1) / 2;
+            float4 vt[NH][3][PH + 2];
+            auto load_row = [&](int di) {
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
-                    const int h = 2 * hh;
+                    unsigned slot = (unsigned)(cb + di * Wp + 2 * hh);
+                    slot = slot < (unsigned)R ? slot : slot - (unsigned)R;
+                    slot = slot < (unsigned)R ? slot : slot - (unsigned)R;          // (cb + 2 Wp + PX may pass the end twice over on a tiny ring)
+                    const float* rp = ring + __umul24(slot, PITCH) + 4 * cg;
 #pragma unroll
-                    for (int di = 0; di < 3; ++di) {
-                        unsigned slot = (unsigned)(cb + di * Wp + h);
-                        slot = slot < (unsigned)R ? slot : slot - (unsigned)R;
-                        const float* rp = ring + __umul24(slot, PITCH) + 4 * cg;
-#pragma unroll
-                        for (int jj = 0; jj < PH + 2; ++jj) vt[hh][di][jj] = (ABL & 4) ? wv[di] : ld4(rp + jj * PITCH);
-                    }
+                    for (int jj = 0; jj < PH + 2; ++jj) vt[hh][di][jj] = (ABL & 4) ? wv[di] : ld4(rp + jj * PITCH);
                 }
+            };
+            if constexpr (PRE) { load_row(0); load_row(1); }
+            for (int t = 0; t < a.T; ++t) {
+                if constexpr (!PRE) { load_row(0); load_row(1); }
+                load_row(2);
                 if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(2); }     // [4]: the taps have landed
+                float4 acc4[NH][PH];
 #pragma unroll
-                for (int hh = 0; hh < NH; ++hh) {
-                    const int h = 2 * hh;
-                    float4 (&v)[3][PH + 2] = vt[hh];
+                for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
-                    for (int u = 0; u < PH; ++u) {
-                        float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < PH; ++u) acc4[hh][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                // per centre the taps in the order (row, column) of dw3x3_fwd_kernel: row by row, so that the bottom row is needed last
 #pragma unroll
-                        for (int i = 0; i < ((ABL & 4) ? 1 : 3); ++i)
+                for (int i = 0; i < ((ABL & 4) ? 1 : 3); ++i) {
+                    if (PRE && i == 2) {                                  // every top / middle FMA ahead of the first bottom one
+#pragma unroll
+                        for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                            for (int u = 0; u < PH; ++u)
+                                asm volatile("" : "+v"(acc4[hh][u].x), "+v"(acc4[hh][u].y), "+v"(acc4[hh][u].z), "+v"(acc4[hh][u].w));
+                    }
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                        for (int u = 0; u < PH; ++u)
 #pragma unroll
                             for (int j = 0; j < ((ABL & 4) ? 1 : 3); ++j) {
-                                const float4 vv = v[i][u + j];
+                                const float4 vv = vt[hh][i][u + j];
                                 const float4 w4 = wv[i * 3 + j];
-                                AMS_DW_FMA4(acc4, vv, w4);
+                                AMS_DW_FMA4(acc4[hh][u], vv, w4);
                             }
+                }
+                const int d_row_now = d_row, d_col_now = d_col;
+                d_row += qS; d_col += rS;
+                if (d_col >= Wp) { d_col -= Wp; ++d_row; }
+                cb += STEP;
+                if (cb >= R) cb -= R;
+                if constexpr (PRE) {
+                    // the requests for the next step: behind this step's last FMA (the ring index is made to depend on the sums: nothing else
+                    // keeps hipcc from issuing them ahead of the FMAs, where the wait for the bottom row would wait for them too) and ahead of
+                    // the epilogue
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                        for (int u = 0; u < PH; ++u) asm volatile("" : "+v"(cb) : "v"(acc4[hh][u].x), "v"(acc4[hh][u].y), "v"(acc4[hh][u].z), "v"(acc4[hh][u].w));
+                    load_row(0);
+                    load_row(1);
+                    asm volatile("" ::: "memory");
+                }
+                if constexpr (TIMED) {                                // [5]: the FMAs are done (and the next step's rows requested)
+#pragma unroll
+                    for (int hh = 0; hh < NH; ++hh)
+#pragma unroll
+                        for (int u = 0; u < PH; ++u) asm volatile("" : "+v"(acc4[hh][u].x), "+v"(acc4[hh][u].y), "+v"(acc4[hh][u].z), "+v"(acc4[hh][u].w));
+                    lap(3);
+                }
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) {
+                    const int h = 2 * hh;
+#pragma unroll
+                    for (int u = 0; u < PH; ++u) {
+                        const float4 a4 = acc4[hh][u];
                         float4 o;
-                        o.x = apply_act(acc4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(acc4.y * dsc.y + dsh.y, a.act_d);
-                        o.z = apply_act(acc4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(acc4.w * dsc.w + dsh.w, a.act_d);
-                        int row = d_row, col = d_col + h + u;
+                        o.x = apply_act(a4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(a4.y * dsc.y + dsh.y, a.act_d);
+                        o.z = apply_act(a4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(a4.w * dsc.w + dsh.w, a.act_d);
+                        int row = d_row_now, col = d_col_now + h + u;
 #pragma unroll
                         for (int w = 0; w < (PX + 1) / 2; ++w)            // PX may span several rows of a tiny segment (Wp >= 3)
                             if (col >= Wp) { col -= Wp; ++row; }
@@ -360,11 +412,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                             // halves of a group (channel groups cg = 2g, 2g + 1 of the same pixel): they swap — the even lane takes the odd one's
                             // hi, the odd lane the even one's lo (one quad_perm DPP move per dword) — and each stores ONE 16-byte piece instead of
                             // two 8-byte ones (the result stores are the largest single item of this kernel: tools/sweep_xwr_abl.sh)
-                            unsigned h[2], l[2];
-                            split4_f16(o, h, l);
-                            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h[0] : l[0]), 0xB1, 0xF, 0xF, false);
-                            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h[1] : l[1]), 0xB1, 0xF, 0xF, false);
-                            const u32x4 d = {odd_cg ? r0 : h[0], odd_cg ? r1 : h[1], odd_cg ? l[0] : r0, odd_cg ? l[1] : r1};
+                            unsigned h2[2], l2[2];
+                            split4_f16(o, h2, l2);
+                            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[0] : l2[0]), 0xB1, 0xF, 0xF, false);
+                            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[1] : l2[1]), 0xB1, 0xF, 0xF, false);
+                            const u32x4 d = {odd_cg ? r0 : h2[0], odd_cg ? r1 : h2[1], odd_cg ? l2[0] : r0, odd_cg ? l2[1] : r1};
                             __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
                         } else {
                         const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
@@ -372,12 +424,10 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                         }
                     }
                 }
-                d_row += qS; d_col += rS;
-                if (d_col >= Wp) { d_col -= Wp; ++d_row; }
-                cb += STEP;
-                if (cb >= R) cb -= R;
                 lap(0);
-                __syncthreads();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
                 lap(1);
                 if constexpr (TIMED) ++nstep;
             }
@@ -402,10 +452,10 @@ static size_t xwr_lds(int Kp, int np, int nwe, int nrg, int ring) {
     return (size_t)2 * nrg * np * (Kp / 8) * 16 * 16 + (size_t)(ring + 4) * (32 * nwe + 4) * 4;
 }
 
-template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0>
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0, bool PRE = false>
 static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
 #ifdef AMS_MEASURE
-    if constexpr (ABL == 0 && KS == 5 && NP == 2 && NWE == 4 && NWD == 4 && NRG == 2 && H16) {        // MEASUREMENT BUILD ONLY (libams_hip_measure.so, AMS_XWR_ABL=<bits>)
+    if constexpr (ABL == 0 && !PRE && KS == 5 && NP == 2 && NWE == 4 && NWD == 4 && NRG == 2 && H16) {        // MEASUREMENT BUILD ONLY (libams_hip_measure.so, AMS_XWR_ABL=<bits>)
         switch (knobs().xwr_abl) {
             case 1: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 1>(a, lds, st);
             case 2: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 2>(a, lds, st);
@@ -422,13 +472,18 @@ static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
         if (knobs().xwr_timed) return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 32>(a, lds, st);      // AMS_XWR_TIMED=1: the kernel with its role clocks
     }
 #endif
-    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>, lds));
+    // the taps-ahead form: where the segment is at least a step wide (the 160 -> 960 blocks at 512 x 1024: Wp = 34, STEP = 32); built for the
+    // fp16 4 + 4-wave, two-row-group kernels only (what frozen inference launches)
+    if constexpr (!PRE && H16 && NWE == 4 && NWD == 4 && NRG == 2) {
+        if (a.Wp >= 16 * NRG && !knobs().xwr_no_pre) return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, ABL, true>(a, lds, st);
+    }
+    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL, PRE>, lds));
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");
     static const std::string nm = "xdw_wreg_kernel<" + std::to_string(KS) + ", " + std::to_string(NP) + ", " + std::to_string(NWE) + ", " +
-                                  std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", true, " : ", false, ") + std::to_string(ABL) + ">";
+                                  std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", true, " : ", false, ") + std::to_string(ABL) + (PRE ? ", true>" : ", false>");
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL, PRE>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

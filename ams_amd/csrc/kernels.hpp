@@ -30,6 +30,7 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     bool pwh_set = false; int pwh_nw = 4, pwh_d = 2;                   // AMS_PWH_VARIANT=<waves per block>,<operand stages in flight>: experiment switch of the fp16 GEMM
     bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE
     bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
+    bool xwr_no_pre = false;                     // AMS_XWR_NO_PRE: the weight-register kernel without its taps-ahead form (A/B; same results)
     bool wg6_eight_waves = false;                // AMS_WG6_EIGHT_WAVES: the wide tiles of the six-product weight gradient with eight waves, split 4 (k) x 2 (n)
     int wg6_split_cap = 0;                       // AMS_WG6_SPLITS: most pixel splits of the six-product weight gradient (default 32)
     int event_flags = -1;                        // AMS_EVENT_FLAGS=<hex>: flags of the stream-ordering events (default: hipEventDisableTiming)
@@ -357,12 +358,15 @@ int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32
 // scratch (ce_loss_grad_scratch floats); pass 2 scales by 1 / count (after its cross-rank sum) and writes dlogits [B*h*w, ldd]
 bool ce_loss_grad_supported(int w, int W);
 size_t ce_loss_grad_scratch(int B, int h, int w, int K);
+// soft_logits != nullptr: soft-teacher targets, teacher logits [B][soft_h][soft_w][NC] f32 (utils/graph_utils.py:375-376, 403-404; k_head.hip SoftTeacher)
 int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W, const uint8_t* teacher,
-                        int NC, double* loss, float* scratch, hipStream_t st);
+                        int NC, double* loss, float* scratch, hipStream_t st, const float* soft_logits = nullptr, int soft_h = 0, int soft_w = 0);
 // empty_val: every selected class's gradient when NO pixel of the (global) batch is valid: 0, or NaN = the reference's 0 / 0
 // (utils/graph_utils.py:408: loss = sum(w ce) / sum(w))
 int launch_ce_combine(int B, int h, int w, const int32_t* cls, int K, int NC, const double* loss_and_count, const float* scratch,
                       float* dlogits, int ldd, hipStream_t st, float empty_val = 0.f);
+int launch_l2_regularizer(const float* p, float* g, const uint8_t* mask, int64_t n, int n_vars, float coef, double* part_scratch /*256 doubles*/,
+                          double* loss, hipStream_t st);
 int launch_cross_confusion(const uint8_t* a, const uint8_t* b, int64_t n, const int32_t* lut /*[256] -> subset idx or -1*/,
                            int K, int64_t* conf, hipStream_t st);
 

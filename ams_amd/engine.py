@@ -81,6 +81,9 @@ class StudentEngine:
         self.height, self.width = int(height), int(width if width is not None else 2 * height)
         self.max_batch = int(max_batch)
         self.trainable = bool(trainable)
+        self.num_classes = int(num_classes)
+        self.soft_teacher = False
+        self._reg_mask = self._teacher_logits_dev = None
         self.class_indices = [int(c) for c in class_indices]
         self.K = len(self.class_indices)
         cfg = hip.StudentConfig()
@@ -266,6 +269,44 @@ class StudentEngine:
         if fuse_dgrad_bn is not None:
             hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_FUSE_DGRAD_BN, 2 if fuse_dgrad_bn is True else int(fuse_dgrad_bn)), "ams_student_set_option")
 
+    def set_soft_teacher(self, on: bool) -> None:
+        """create_student_v3(soft_teacher=True) (utils/graph_utils.py:403-404): the fine-tune loss targets softmax(gather(teacher logits)); every
+        ``train_step`` then needs ``teacher_logits``."""
+        hip.check(self.lib.ams_student_set_option(self._h, hip.OPT_SOFT_TEACHER, int(bool(on))), "ams_student_set_option")
+        self.soft_teacher = bool(on)
+
+    def set_regularizer(self, on: bool, biases_only: bool = False, coef: float = 0.01) -> None:
+        """create_student_v3(regularize=True[, train_biases_only=True]) (utils/graph_utils.py:451-456): loss += coef * mean over tvars of
+        l2_loss(v); tvars = every trainable variable, or those without 'weight' in their name."""
+        if not on:
+            hip.check(self.lib.ams_student_set_regularizer(self._h, None, 0, 0.0), "ams_student_set_regularizer")
+            self._reg_mask = None
+            return
+        flat = np.zeros(self.spec.n_trainable, dtype=np.uint8)
+        n_vars = 0
+        for v in self.spec.trainable:
+            if biases_only and 'weight' in v.name:
+                continue
+            flat[v.offset:v.offset + v.size] = 1
+            n_vars += 1
+        self._reg_mask = torch.from_numpy(flat).to(self.device)          # referenced by the handle: kept alive here
+        hip.check(self.lib.ams_student_set_regularizer(self._h, C.c_void_p(self._reg_mask.data_ptr()), n_vars, float(coef)),
+                  "ams_student_set_regularizer")
+
+    def _feed_teacher_logits(self, teacher_logits, b: int):
+        """feed_dict[student['teacher_labels_logits_pl']]: f32 [b, th, tw, num_classes] (host array or device tensor); returns the device tensor
+        (the caller keeps it alive until the step has been enqueued on the same stream order)."""
+        if teacher_logits is None:
+            assert not getattr(self, "soft_teacher", False), "soft_teacher is on: teacher_logits must be fed (teacher_labels_logits_pl)"
+            return None
+        t = teacher_logits if isinstance(teacher_logits, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(teacher_logits, dtype=np.float32))
+        assert t.dim() == 4 and t.shape[0] == b and t.shape[3] == self.num_classes, "teacher logits must be [batch, th, tw, %d]" % self.num_classes
+        assert t.shape[1] <= self.height and t.shape[2] <= self.width
+        t = t.to(self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        hip.check(self.lib.ams_student_feed_teacher_logits(self._h, C.c_void_p(t.data_ptr()), int(t.shape[1]), int(t.shape[2])),
+                  "ams_student_feed_teacher_logits")
+        return t
+
     def set_nan_grads(self, on: bool) -> None:
         """A fine-tune batch without one valid pixel: False (default) NaN loss and ZERO gradients, TensorFlow's result for
         utils/graph_utils.py:408 (reduce_mean over the empty boolean_mask: the weights survive); True NaN gradients instead."""
@@ -417,7 +458,7 @@ class StudentEngine:
         return conf.view(self.K, self.K)
 
     def train_step(self, frames, labels_teacher, lr: float, mask: Optional[torch.Tensor] = None,
-                   allreduce=None, global_batch: Optional[int] = None, comm=None) -> torch.Tensor:
+                   allreduce=None, global_batch: Optional[int] = None, comm=None, teacher_logits=None) -> torch.Tensor:
         """One Adam iteration; returns the device tensor f64[2] = (CE sum over valid pixels, valid pixel count).
 
         Data-parallel step, ``global_batch`` = frames over all ranks: ``comm`` = an ``ams_amd.dist.RcclComm``
@@ -426,6 +467,7 @@ class StudentEngine:
         assert self.trainable, "Can't train frozen graph!!!"
         t, dt, b = self._frames_to_device(frames)
         lab = self._labels_to_device(labels_teacher, b)
+        self._teacher_logits_dev = self._feed_teacher_logits(teacher_logits, b)          # soft_teacher only; alive until the next step replaces it
         loss = torch.empty(2, dtype=torch.float64, device=self.device)
         mptr = C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0)
         if mask is not None:

@@ -38,6 +38,7 @@ OPT_DUAL_AUTOTUNE = 12
 OPT_DUAL_PARTS = 13
 OPT_NAN_GRADS = 18
 OPT_TRAIN_FWD_F16 = 24
+OPT_SOFT_TEACHER = 25
 OPT_OVERLAP_WGRAD = 19
 OPT_OVERLAP_HEAD = 20
 OPT_STREAM_MIN_ROWS = 21
@@ -95,6 +96,8 @@ SIGNATURES = {
     "ams_comm_allreduce": (C.c_int, [_vp, _vp, _sz, _i32, _vp]),
     "ams_student_train_step_rccl": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "ams_student_set_option": (C.c_int, [_vp, _i32, _i32]),
+    "ams_student_feed_teacher_logits": (C.c_int, [_vp, _vp, _i32, _i32]),
+    "ams_student_set_regularizer": (C.c_int, [_vp, _vp, _i32, _f32]),
     "ams_student_profile": (C.c_int, [_vp, _i32]),
     "ams_student_profile_read": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),
     "ams_student_get_adam_step": (C.c_int, [_vp, C.POINTER(_i64)]),
@@ -122,6 +125,7 @@ SIGNATURES = {
     "ams_k_ce_grad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "ams_k_ce_loss_grad": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ams_k_ce_loss_grad_scratch": (_sz, [_i32, _i32, _i32, _i32]),
+    "ams_k_ce_loss_grad_soft": (C.c_int, [_vp, _i32, _i32, _i32, _i32, C.POINTER(_i32), _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "ams_debug_launch_table_needs_attr": (C.c_int, [_i32, C.c_uint64, _sz]),
     "ams_debug_reload_knobs": (C.c_int, []),
     "ams_debug_phase_cycles": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.c_int32]),

@@ -106,9 +106,11 @@ class SemanticNetwork(object):
         self.masked_gradients = bool(kwargs.pop("masked_gradients", False))
         for dead in ("threshold", "map_misc", "test_mode"):
             kwargs.pop(dead, None)
-        assert not kwargs.pop("train_biases_only", False), "train_biases_only is not supported"
-        assert not kwargs.pop("regularize", False), "regularize is not supported"
-        assert not kwargs.pop("soft_teacher", False), "soft_teacher is never fed by the reference and is not supported"
+        # create_student_v3's remaining kwargs (utils/graph_utils.py:338-339, 403-404, 451-456); run.py:150 leaves them off
+        self.train_biases_only = bool(kwargs.pop("train_biases_only", False))
+        self.regularize = bool(kwargs.pop("regularize", False))
+        self.soft_teacher = bool(kwargs.pop("soft_teacher", False))
+        assert not (frozen and (self.soft_teacher or self.regularize)), "soft_teacher / regularize belong to the trainable graph"
         initial_variables = kwargs.pop("initial_variables", None)
         frozen_graph = kwargs.pop("frozen_graph", None)
         max_batch = kwargs.pop("max_batch", None)
@@ -150,6 +152,10 @@ class SemanticNetwork(object):
                 keyword not in elem for keyword in self.OPT_FILTER) and elem not in self.OP_FILTER else None
             self._initial = initial_variables if initial_variables is not None else load_npy("%s.npy" % self.meta_dir)
             self._restore_dict(self._initial)
+            if self.soft_teacher:
+                self.engine.set_soft_teacher(True)
+            if self.regularize:
+                self.engine.set_regularizer(True, biases_only=self.train_biases_only)
             self.mask = None
             self.train_params = None
             self.curr_mask = None
@@ -291,8 +297,15 @@ class SemanticNetwork(object):
 
     # ------------------------------------------------------------------ training
     def train_with_deque(self, frame_deque, label_deque, num_of_iterations, train_strategy='full_model',
-                         keep_mask=False):
+                         keep_mask=False, teacher_logits_deque=None):
+        """``teacher_logits_deque`` (soft_teacher=True only; the reference's _train never feeds teacher_labels_logits_pl, so its soft graph cannot
+        run through this method at all): the cached teacher logits of the replay memory, one f32 [th, tw, TOTAL_CLASSES] array per frame of
+        ``frame_deque``; a mini-batch takes the logits of the frames it drew."""
         assert not self.frozen, "Can't train frozen graph!!!"
+        assert (teacher_logits_deque is not None) == bool(getattr(self, "soft_teacher", False)), \
+            "teacher_logits_deque goes with soft_teacher=True (and is required then)"
+        if teacher_logits_deque is not None:
+            assert len(teacher_logits_deque) == len(frame_deque), "one teacher-logit array per frame of the replay memory"
         if not keep_mask:
             self.mask = None
         self.process_lock.acquire()
@@ -304,7 +317,7 @@ class SemanticNetwork(object):
         try:
             batch_deque = deque()
             batch_thr = threading.Thread(target=self._guarded, args=(ctx, self._fill_batch, batch_deque, frame_deque, label_deque,
-                                                                     num_of_iterations,))
+                                                                     num_of_iterations, teacher_logits_deque))
             batch_thr.start()
             self._train(batch_deque, num_of_iterations, train_strategy)
         finally:
@@ -337,15 +350,18 @@ class SemanticNetwork(object):
     class _Aborted(Exception):
         """a wait was cut short because another helper of the same call failed"""
 
-    def train_step(self, frames, labels_teacher, train_strategy='full_model'):
-        """North-star alias: ONE optimisation step on an explicit batch; returns the loss (float)."""
+    def train_step(self, frames, labels_teacher, train_strategy='full_model', teacher_logits=None):
+        """North-star alias: ONE optimisation step on an explicit batch; returns the loss (float).  With ``soft_teacher=True`` the cached teacher
+        logits of the batch are fed as ``teacher_logits`` f32 [B, th, tw, TOTAL_CLASSES] — what a caller of the reference puts into
+        ``feed_dict[student['teacher_labels_logits_pl']]`` (th x tw = the label size, or a smaller cached grid: include/ams_hip.h)."""
         assert not self.frozen, "Can't train frozen graph!!!"
+        assert (teacher_logits is not None) == self.soft_teacher, "teacher_logits go with soft_teacher=True (and are required then)"
         with self.process_lock:
             mask_dev = None
             if 'coord_desc_' in train_strategy:
                 _before, train_mask_ = self.get_train_mask(train_strategy)
                 mask_dev = self._mask_to_device(train_mask_)
-            ls = self.engine.train_step(frames, labels_teacher, self.lr, mask_dev).cpu().numpy()
+            ls = self.engine.train_step(frames, labels_teacher, self.lr, mask_dev, teacher_logits=teacher_logits).cpu().numpy()
         return float(ls[0] / ls[1]) if ls[1] > 0 else float("nan")
 
     def _mask_to_device(self, train_mask_: Dict[str, np.ndarray]) -> torch.Tensor:
@@ -376,7 +392,13 @@ class SemanticNetwork(object):
                     time.sleep(self.THREAD_SLEEP_INTERVAL)
             t1 = time.time()
             frames_dev, labels_dev = self._consume_staged(staged)
-            loss_dev = self.engine.train_step(frames_dev, labels_dev, self.lr, mask_dev)
+            logits_dev = staged[3] if len(staged) > 3 else None
+            if logits_dev is not None:
+                logits_dev.record_stream(torch.cuda.current_stream(self.engine.device))
+            if logits_dev is not None:
+                loss_dev = self.engine.train_step(frames_dev, labels_dev, self.lr, mask_dev, teacher_logits=logits_dev)
+            else:
+                loss_dev = self.engine.train_step(frames_dev, labels_dev, self.lr, mask_dev)
             losses.append(loss_dev)
             if self.verbose:
                 ls = loss_dev.cpu().numpy()
@@ -419,7 +441,7 @@ class SemanticNetwork(object):
 
     def _consume_staged(self, staged):
         """Make the compute stream wait for a staged batch's copy; returns its device tensors."""
-        frames_dev, labels_dev, ready = staged
+        frames_dev, labels_dev, ready = staged[:3]
         compute = torch.cuda.current_stream(self.engine.device)
         compute.wait_event(ready)
         # the buffers were allocated on the stager's copy stream: tell the caching allocator that the compute stream uses
@@ -478,7 +500,7 @@ class SemanticNetwork(object):
         train_vars_len = sum(int(np.sum(m)) for m in train_mask_.values())
         return all_vars, train_vars_len
 
-    def _fill_batch(self, batch_deque, frame_deque, label_deque, number_of_batches):
+    def _fill_batch(self, batch_deque, frame_deque, label_deque, number_of_batches, teacher_logits_deque=None):
         """Producer thread: sample mini-batches from the replay memory (utils.mini_batch contract).
 
         Fast path (the only one run.py exercises: scale == [1], frames already at network size): draws the same
@@ -489,6 +511,9 @@ class SemanticNetwork(object):
         crop = [self.height, self.height * 2]
         fast = (list(self.scale) == [1] and all(f.shape[:2] == tuple(crop) for f in frames))
         fast = fast and all(f.dtype == np.uint8 for f in frames) and all(l.dtype == np.uint8 and l.shape == tuple(crop) for l in labels)
+        soft = list(teacher_logits_deque) if teacher_logits_deque is not None else None
+        # soft targets follow the frames a batch drew: only where frames are taken as they are (no rescale / crop of the logits is defined)
+        assert soft is None or fast, "teacher_logits_deque needs uint8 frames and labels at the network size and scale == [1]"
         for _ in range(number_of_batches):
             if self._aborted():
                 return
@@ -515,7 +540,10 @@ class SemanticNetwork(object):
                 image_batch, label_batch = ib[0], lb[0]
             assert np.shape(label_batch) == (self.mini_batch_size, self.height, self.height * 2)
             assert np.shape(image_batch) == (self.mini_batch_size, self.height, self.height * 2, 3)
-            batch_deque.append({'frames': image_batch, 'labels': label_batch, 'slot': slot})
+            batch = {'frames': image_batch, 'labels': label_batch, 'slot': slot}
+            if soft is not None:
+                batch['teacher_logits'] = np.stack([np.asarray(soft[p], dtype=np.float32) for p in picks])
+            batch_deque.append(batch)
 
     def _staging_slot(self):
         """Next slot of a small ring of pinned host buffers [mini_batch, H, 2H, 3] / [mini_batch, H, 2H] uint8 (created on first use).  A slot
@@ -603,6 +631,14 @@ class SemanticNetwork(object):
                 l_dev = torch.from_numpy(np.ascontiguousarray(lb)).pin_memory().to(dev, non_blocking=True)
                 ready = torch.cuda.Event()
                 ready.record(copy_stream)
+        if batch.get('teacher_logits') is not None:       # soft_teacher: the batch's cached teacher logits travel with it
+            with torch.cuda.stream(copy_stream):
+                t_dev = torch.from_numpy(batch['teacher_logits']).pin_memory().to(dev, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(copy_stream)
+            if slot is not None:
+                slot[2] = ready
+            return f_dev, l_dev, ready, t_dev
         return f_dev, l_dev, ready
 
     # ------------------------------------------------------------------ freeze / export

@@ -287,7 +287,8 @@ def main():
                 pe.predict_frames(fmb)
             b1_micro[mb] = mb * n1 / window(lambda: pe.predict_frames(fmb))
             lab_mb, _c, _l = pe.predict_frames(fmb)
-            assert torch.equal(lab_mb[:1], eng.predict(one)), "a frame of a %d-frame pass differs from its one-frame call" % mb
+            ablated = any(os.environ.get(k, "0") not in ("", "0") for k in ("AMS_XWR_ABL", "AMS_PWH_ABL", "AMS_FB_ABL"))      # measurement build, tools/ only
+            assert ablated or torch.equal(lab_mb[:1], eng.predict(one)), "a frame of a %d-frame pass differs from its one-frame call" % mb
             pe.close()
             del pe
         try:

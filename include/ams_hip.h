@@ -169,6 +169,24 @@ int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t
 int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
                            int32_t batch, float lr, const uint8_t* mask_dev, double* loss_dev, void* stream);
 
+/* ---- create_student_v3's remaining kwargs (utils/graph_utils.py:338-339; run.py:150 leaves all three off) -------------------------------
+ * soft_teacher=True (option AMS_OPT_SOFT_TEACHER): pixel_loss = softmax_cross_entropy_with_logits(logits = filtered_logits, labels =
+ * softmax(gather(teacher_labels_logits_pl, class_weights))) (:375-376, 403-404) — per pixel sum_k p_k (logsumexp(z) - z_k), gradient
+ * softmax(z) - p; the pixel mask and the mean's denominator still come from the hard labels (:397, 406-408), which every step keeps taking.
+ * ams_student_feed_teacher_logits replaces feed_dict[student['teacher_labels_logits_pl']]: f32 [batch, th, tw, num_classes] on the device,
+ * valid until the step that uses it has run; it stays armed until replaced or cleared with NULL.  th x tw = height x width is the reference's
+ * feed (the loss needs the shape of filtered_logits); a smaller grid (cached low-resolution teacher logits: 1 / 256 of the bytes at output
+ * stride 16) is interpolated to height x width like the student's own logits (ResizeBilinear, align_corners) — an extension, at the full size
+ * the identity bit for bit.  A step with the option on and nothing fed fails (TensorFlow: "You must feed a value for placeholder tensor").
+ *
+ * regularize=True / train_biases_only=True: loss += coef * reduce_mean([l2_loss(v) for v in tvars]) with coef = 0.01, l2_loss(v) = sum(v^2) / 2,
+ * tvars = the trainable variables, or only those without 'weight' in their name (:451-456; the optimizer still updates every variable — the
+ * reference's minimize() has no var_list).  reg_mask_dev: uint8 [n_trainable], 1 on the entries of tvars (it stays referenced: keep it alive;
+ * NULL switches the term off); n_vars = len(tvars).  The gradient term (coef / n_vars) v is added after the cross-rank gradient sum of a
+ * data-parallel step, the loss term to loss_dev[0] scaled by the valid-pixel count, so that loss_dev[0] / loss_dev[1] is the fetched loss. */
+int ams_student_feed_teacher_logits(ams_student* s, const float* teacher_logits_dev, int32_t th, int32_t tw);
+int ams_student_set_regularizer(ams_student* s, const uint8_t* reg_mask_dev, int32_t n_vars, float coef);
+
 /* ---- data-parallel split of the same step (one process per GPU) -------------------------
  * Callback form (any transport; what the gloo CPU tests and a host without RCCL use): `cb` is invoked on the host
  * whenever cross-rank sums are needed and must all-reduce (sum) `count` values of `dtype` at arena byte offset
@@ -214,7 +232,8 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
  *   AMS_MATMUL_SPLIT_F16     frozen inference with two fp16 parts / 3 MFMAs, f32-level (see the enum below)
  *   AMS_MATMUL_SPLIT_BF16    frozen inference with two parts / 3 MFMAs: +5 % frames/s, ~1e-5 per layer, 2e-4 .. 5e-4 on
  *                            the logits (inside the 1e-3 tolerance, not at f32 level); the fine-tune step stays three-part. */
-enum { AMS_OPT_TRAIN_FWD_F16 = 24 /* fine-tune step under AMS_MATMUL_SPLIT_F16: 1 = the FORWARD 1x1 products of the split layers run on two fp16
+enum { AMS_OPT_SOFT_TEACHER = 25 /* fine-tune step: 1 = soft-teacher loss (ams_student_feed_teacher_logits); 0 (default) hard labels */,
+       AMS_OPT_TRAIN_FWD_F16 = 24 /* fine-tune step under AMS_MATMUL_SPLIT_F16: 1 = the FORWARD 1x1 products of the split layers run on two fp16
                                       parts (3 MFMAs; the per-step weight split leaves fp16 planes beside the bf16 ones), the input-gradient and weight-
                                       gradient products stay on three bf16 parts (gradients span a range fp16 cannot hold); 0 (default) = three bf16
                                       parts everywhere.  Measured on MI355X: 7.455 -> 7.368 ms per 8-frame step — the step's GEMMs are not MFMA-bound
@@ -454,6 +473,10 @@ int ams_k_ce_loss_grad(const float* logits, int32_t B, int32_t h, int32_t w, int
                        int32_t K, int32_t H, int32_t W, const uint8_t* teacher, double* loss_dev, float* dlogits,
                        float* scratch, size_t scratch_floats, void* stream);
 size_t ams_k_ce_loss_grad_scratch(int32_t B, int32_t h, int32_t w, int32_t K);
+/* The same with soft-teacher targets: teacher_logits f32 [B, th, tw, NC] (ams_student_feed_teacher_logits); `teacher` still masks the pixels. */
+int ams_k_ce_loss_grad_soft(const float* logits, int32_t B, int32_t h, int32_t w, int32_t NC, const int32_t* class_idx_host,
+                            int32_t K, int32_t H, int32_t W, const uint8_t* teacher, const float* teacher_logits, int32_t th, int32_t tw,
+                            double* loss_dev, float* dlogits, float* scratch, size_t scratch_floats, void* stream);
 
 /* K13: weight gradient of a 1x1 conv: dw[K,N] = x[M,K]^T @ dy[M,N]. scratch: >= ams_k_pointwise_wgrad_scratch floats */
 int ams_k_pointwise_wgrad(const float* x, const float* dy, int64_t M, int32_t K, int32_t N, float* dw,

@@ -237,6 +237,27 @@ class StudentOracle:
         valid = weight > 0
         return pixel[valid].mean()                                          # NaN when no pixel is valid
 
+    def soft_targets(self, teacher_logits, out_h: int, out_w: int) -> torch.Tensor:
+        """filtered_teacher_labels_probs (graph_utils.py:375-376): gather the K classes of the fed teacher logits, softmax.  The reference feeds
+        logits of the label size; a smaller grid is first resized like the student's logits (align corners) — the identity at the full size."""
+        t = torch.as_tensor(np.asarray(teacher_logits)).to(self.dtype)
+        if t.shape[1] != out_h or t.shape[2] != out_w:
+            t = resize_bilinear_align_corners(t, out_h, out_w)
+        return torch.softmax(t.index_select(3, self.class_indices), dim=-1)
+
+    def soft_loss_from_reduced(self, z: torch.Tensor, probs: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """soft_teacher=True (graph_utils.py:403-404, 406-408): softmax_cross_entropy_with_logits(labels = teacher probabilities), masked by the
+        HARD labels' weights, mean.  (The v1 op does not back-propagate into its labels; they come from a placeholder anyway.)"""
+        pixel = -(probs.detach() * torch.log_softmax(z, dim=-1)).sum(dim=-1)
+        valid = weight > 0
+        return pixel[valid].mean()
+
+    def regularizer(self, params: Dict[str, torch.Tensor], biases_only: bool) -> torch.Tensor:
+        """regularize=True (graph_utils.py:451-456): 0.01 * reduce_mean([l2_loss(v) for v in tvars]); tvars loses every name with 'weight'
+        in it under train_biases_only."""
+        terms = [params[v.name].pow(2).sum() / 2 for v in self.spec.trainable if not (biases_only and 'weight' in v.name)]
+        return 0.01 * torch.stack(terms).mean()
+
     def predict_with_metric(self, frames, labels_teacher, mode: str = "frozen"):
         """(labels, conf_mat f64 [K,K], loss) like SemanticNetwork.predict_with_metric (:196-213)."""
         with torch.no_grad():
@@ -249,8 +270,9 @@ class StudentOracle:
         return pred.to(torch.int32).numpy(), cm.view(self.K, self.K).numpy(), float(loss)
 
     # ------------------------------------------------------------------ one optimisation step
-    def gradients(self, frames, labels_teacher) -> Tuple[float, Dict[str, torch.Tensor]]:
-        """Loss and d(loss)/d(trainable) of the live graph (BN in training mode)."""
+    def gradients(self, frames, labels_teacher, teacher_logits=None, regularize: bool = False,
+                  train_biases_only: bool = False) -> Tuple[float, Dict[str, torch.Tensor]]:
+        """Loss and d(loss)/d(trainable) of the live graph (BN in training mode).  ``teacher_logits``: the soft_teacher graph's feed."""
         params = dict(self.vars)
         leaves = {}
         for v in self.spec.trainable:
@@ -259,18 +281,24 @@ class StudentOracle:
             leaves[v.name] = leaf
         z = self.reduced_logits(self.logits_full(frames, "train", params))
         target, weight = self.label_targets(labels_teacher)
-        loss = self.loss_from_reduced(z, target, weight)
+        if teacher_logits is not None:
+            loss = self.soft_loss_from_reduced(z, self.soft_targets(teacher_logits, z.shape[1], z.shape[2]), weight)
+        else:
+            loss = self.loss_from_reduced(z, target, weight)
+        if regularize:
+            loss = loss + self.regularizer(params, train_biases_only)
         grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=False)
         return float(loss.detach()), {k: g for k, g in zip(leaves, grads)}
 
     def train_step(self, frames, labels_teacher, lr: float, mask: Optional[Dict[str, np.ndarray]] = None,
-                   grads_override: Optional[Dict[str, torch.Tensor]] = None) -> float:
+                   grads_override: Optional[Dict[str, torch.Tensor]] = None, teacher_logits=None, regularize: bool = False,
+                   train_biases_only: bool = False) -> float:
         """forward (BN batch stats) -> CE -> backward -> BN EMA (decay 0.9) -> Adam (TF1 form) [-> mask].
 
         Adam (Appendix C.10): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMAs; w -= lr_t*m/(sqrt(v)+1e-8).
         With ``mask`` (coordinate descent, graph_utils.py:482-493) every variable first takes the full Adam
         step and is then reverted where mask is False; the moments advance for all entries regardless."""
-        loss, grads = self.gradients(frames, labels_teacher)
+        loss, grads = self.gradients(frames, labels_teacher, teacher_logits, regularize, train_biases_only)
         if grads_override is not None:
             grads = grads_override
         for l in self.spec.layers:

@@ -151,6 +151,25 @@ def test_full_size_properties(W0, clip):
     eng.close()
 
 
+@pytest.mark.parametrize("height,batch", [(512, 1), (512, 2), (512, 3), (256, 2), (256, 8)])
+def test_whole_block_kernels_off_at_small_batches(W0, height, batch):
+    """with the whole-block kernels off, the 24 -> 144 and 32 -> 192 stride-1 blocks stream on the exact-f32 form of the
+    streaming kernel; their depthwise result must then NOT be handed over as fp16 pairs (that hand-over belongs to the fp16 form, Cin > 32) —
+    at 512x1024 with 1..3 frames and at 256x512 the project GEMM is below its split threshold's other side and the plan used to ask for it:
+    predict failed with AMS_E_INVALID.  The plan runs and stays f32-level from the default plan."""
+    frames, _ = synth.SyntheticVideo(height, batch, CI, seed=11).clip()
+    eng = StudentEngine(CI, height, 2 * height, max_batch=batch, trainable=False)
+    eng.load_variables(W0)
+    eng.freeze()
+    lab = eng.predict(frames)
+    low = _lowres(eng, batch).copy()
+    eng.set_fuse_block(False)
+    lab1 = eng.predict(frames)
+    assert rel(_lowres(eng, batch), low) < 5e-5
+    assert (lab1 != lab).float().mean().item() < 1e-4
+    eng.close()
+
+
 def test_bench_batch_fused_equals_unfused(W0):
     """At the benchmark's batch (32 frames: other segment / chunk plans than at 8) the streaming and weight-register kernels
     give the bits of the kernels they replace, and a frame's logits do not depend on the batch it travels in beyond the

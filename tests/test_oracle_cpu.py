@@ -112,3 +112,67 @@ def test_cross_miou_confusion():
     b = np.array([[0, 2, 13, 0, 0, 7]])
     cm = OT.cross_miou_confusion(a, b, CI)
     assert cm.sum() == 3 and cm[0, 0] == 1 and cm[1, 2] == 1 and cm[5, 5] == 1
+
+
+def test_soft_teacher_loss_follows_the_published_definition(setup):
+    """soft_teacher=True (utils/graph_utils.py:375-376, 403-408): labels = softmax(gather(teacher logits)), pixel loss = -sum_k p_k log softmax(z)_k
+    (tf.nn.softmax_cross_entropy_with_logits), mask and mean from the HARD labels.  Checked against scalar Python on a 2 x 3 image, against the
+    hard loss in the one-hot limit, and its gradient against (softmax(z) - p) / N."""
+    import math
+    W0, _frames, _labels = setup
+    o = OT.StudentOracle(W0, CI, dtype=torch.float64)
+    rng = np.random.default_rng(5)
+    z19 = rng.standard_normal((1, 2, 3, 19))
+    t19 = 2.0 * rng.standard_normal((1, 2, 3, 19))
+    labels = np.array([[[0, 5, 13], [255, 1, 10]]], dtype=np.uint8)            # 5 and 255: outside the subset -> weight 0
+    z = torch.as_tensor(z19).index_select(3, o.class_indices).requires_grad_(True)
+    target, weight = o.label_targets(labels)
+    probs = o.soft_targets(t19, 2, 3)
+    loss = o.soft_loss_from_reduced(z, probs, weight)
+    want, n = 0.0, 0
+    for i in range(2):
+        for j in range(3):
+            if int(labels[0, i, j]) not in CI:
+                continue
+            zz = [z19[0, i, j, c] for c in CI]
+            tt = [t19[0, i, j, c] for c in CI]
+            zs = math.log(sum(math.exp(v) for v in zz))
+            ts = sum(math.exp(v) for v in tt)
+            want += -sum(math.exp(tv) / ts * (zv - zs) for tv, zv in zip(tt, zz))
+            n += 1
+    assert n == 4 and float(loss) == pytest.approx(want / n, rel=1e-12)
+    (g,) = torch.autograd.grad(loss, z)
+    sm = torch.softmax(z.detach(), dim=-1)
+    want_g = (sm - probs) * (weight > 0).unsqueeze(-1) / n
+    assert torch.allclose(g, want_g, atol=1e-14)
+    # the one-hot limit: teacher logits that put all mass on the label's class give the hard loss
+    peaked = np.full((1, 2, 3, 19), -1e4)
+    for i in range(2):
+        for j in range(3):
+            if int(labels[0, i, j]) in CI:
+                peaked[0, i, j, int(labels[0, i, j])] = 1e4
+    hard = o.loss_from_reduced(z.detach(), target, weight)
+    assert float(o.soft_loss_from_reduced(z.detach(), o.soft_targets(peaked, 2, 3), weight)) == pytest.approx(float(hard), rel=1e-12)
+    # low-resolution teacher logits are resized like the student's own (align corners): grid points are reproduced exactly
+    low = rng.standard_normal((1, 2, 2, 19))
+    up = o.soft_targets(low, 2, 3)
+    assert torch.allclose(up[:, :, 0], torch.softmax(torch.as_tensor(low)[:, :, 0].index_select(-1, o.class_indices), -1))
+    assert torch.allclose(up[:, :, 2], torch.softmax(torch.as_tensor(low)[:, :, 1].index_select(-1, o.class_indices), -1))
+
+
+def test_regularizer_follows_the_published_definition(setup):
+    """regularize=True (utils/graph_utils.py:451-456): 0.01 * mean over tvars of sum(v^2) / 2; train_biases_only drops every name with 'weight'."""
+    W0, frames, labels = setup
+    o = OT.StudentOracle(W0, CI, dtype=torch.float64)
+    names = [v.name for v in o.spec.trainable]
+    assert len(names) == 164
+    all_terms = [float((np.asarray(W0[n], np.float64) ** 2).sum() / 2) for n in names]
+    assert float(o.regularizer(o.vars, False)) == pytest.approx(0.01 * np.mean(all_terms), rel=1e-12)
+    bias_terms = [t for n, t in zip(names, all_terms) if 'weight' not in n]
+    assert len(bias_terms) == 109                                               # 54 x (gamma, beta) + the logits biases
+    assert float(o.regularizer(o.vars, True)) == pytest.approx(0.01 * np.mean(bias_terms), rel=1e-12)
+    l0, g0 = o.gradients(frames[:1], labels[:1])
+    l1, g1 = o.gradients(frames[:1], labels[:1], regularize=True)
+    assert l1 == pytest.approx(l0 + 0.01 * np.mean(all_terms), rel=1e-10)
+    n = "logits/semantic/biases:0" if "logits/semantic/biases:0" in g0 else [k for k in names if k.endswith("biases:0")][0]
+    assert torch.allclose(g1[n] - g0[n], 0.01 / 164 * o.vars[n], atol=1e-12)

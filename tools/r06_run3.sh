@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+echo "== role clocks, taps-ahead"
+python3 tools/xwr_phases.py 32 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== role clocks, no taps-ahead"
+AMS_XWR_NO_PRE=1 python3 tools/xwr_phases.py 32 2>&1 | grep -v amdgpu.ids | tail -4

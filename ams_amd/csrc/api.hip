@@ -130,16 +130,39 @@ int ams_student_freeze(ams_student* s, void* stream) {
     }
     if (s->L[1].whi)        // stem: [27][32] -> parts [32][32], k = tap * 3 + channel
         RUN(launch_split_weights3(s->fparams + s->L[1].d.w_off, 32, 1, 27, 32, 32, s->L[1].whi, s->L[1].wlo, s->L[1].wlo3, st));
-    if (s->L[1].whf) RUN(launch_split_weights_f16(s->fparams + s->L[1].d.w_off, 32, 1, 27, 32, 32, s->L[1].whf, s->L[1].whf + 32 * 32, st));
+    if (s->L[1].whf_mem) RUN(launch_split_weights_f16(s->fparams + s->L[1].d.w_off, 32, 1, 27, 32, 32, s->L[1].whf_mem, s->L[1].whf_mem + 32 * 32, st));
     for (int i = 2; i <= s->cfg.n_layers; ++i) {
         LayerRt& l = s->L[i];
         if (!l.whi) continue;
         const int K = l.d.cin - l.split_k0;
         RUN(launch_split_weights3(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whi, l.wlo,
                                   l.wlo3, st));
-        if (l.whf)
-            RUN(launch_split_weights_f16(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whf,
-                                         l.whf + (size_t)l.d.cout * l.Kp, st));
+        if (l.whf_mem)
+            RUN(launch_split_weights_f16(s->fparams + l.d.w_off + (int64_t)l.split_k0 * l.d.cout, l.d.cout, 1, K, l.d.cout, l.Kp, l.whf_mem,
+                                         l.whf_mem + (size_t)l.d.cout * l.Kp, st));
+    }
+    // fp16's range: a weight of 65520 or more has hi = inf, lo = -inf -> NaN logits.  Every freeze checks the frozen weights of the
+    // layers that hold fp16 panels (one small launch, one 4-byte-per-layer copy, one wait on `stream`: freeze is a phase boundary, not the hot
+    // path) and a layer outside the range loses its fp16 form until a later freeze finds it inside again: it runs on three bf16 parts (f32's
+    // range) like the fine-tune step.  Activations are not checked: see INTEGRATION.md "Range of the fp16 product form".
+    {
+        std::vector<WeightRange> jobs;
+        std::vector<int> which;
+        for (int i = 1; i <= s->cfg.n_layers; ++i) {
+            LayerRt& l = s->L[i];
+            l.whf = l.whf_mem;
+            if (!l.whf_mem) continue;
+            const int64_t n = i == 1 ? 27 * 32 : (int64_t)l.d.cin * l.d.cout;
+            jobs.push_back(WeightRange{s->fparams + l.d.w_off, n});
+            which.push_back(i);
+        }
+        if (!jobs.empty()) {
+            std::vector<int> over(jobs.size(), 0);
+            RUN(weights_beyond(jobs, 65504.f, reinterpret_cast<int*>(s->tmp_c), over.data(), st));
+            s->f16_fallback_layers = 0;
+            for (size_t k = 0; k < jobs.size(); ++k)
+                if (over[k]) { s->L[which[k]].whf = nullptr; ++s->f16_fallback_layers; }
+        }
     }
     s->frozen_ready = true;
     return AMS_OK;
@@ -205,6 +228,12 @@ int ams_student_train_step_rccl(ams_student* s, const void* frames_dev, int32_t 
 int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev, int32_t batch,
                            float lr, const uint8_t* mask_dev, double* loss_dev, void* stream) {
     return train_step_impl(s, frames_dev, frames_dtype, teacher_dev, batch, batch, lr, mask_dev, loss_dev, nullptr, nullptr, nullptr, stream);
+}
+
+int ams_student_f16_fallback_layers(const ams_student* s, int32_t* n_layers) {
+    AMS_REQUIRE(s && n_layers, "f16_fallback_layers: null pointer");
+    *n_layers = s->f16_fallback_layers;
+    return AMS_OK;
 }
 
 int ams_student_feed_teacher_logits(ams_student* s, const float* teacher_logits_dev, int32_t th, int32_t tw) {

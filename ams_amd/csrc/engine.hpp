@@ -56,6 +56,8 @@ struct LayerRt {
     float* dw_rows = nullptr; size_t dw_rows_floats = 0;
     // frozen weights split into bf16 hi / lo panels [cout][Kp] for the bf16x3 late-layer GEMM (1x1 layers only)
     uint16_t *whi = nullptr, *wlo = nullptr, *wlo3 = nullptr;   // hi, mid (= the 2-part lo), lo of the 3-part split; equally spaced
+    uint16_t* whf_mem = nullptr;           // arena home of the fp16 panels; `whf` below is that pointer while the layer's frozen weights fit fp16's
+                                           // range (checked by every freeze) and nullptr otherwise: the layer then runs the three-part bf16 form
     uint16_t* whf = nullptr;               // the same panels as two fp16 parts (hi | lo 2^11), plane = cout * Kp apart (AMS_MATMUL_SPLIT_F16)
     int Kp = 0, split_k0 = 0;              // split_k0: first weight row of the panel (concat_projection skips the pool rows)
     float* blk_vecs = nullptr;             // expand layer of a whole-block kernel: [13][cout] table of BN vectors + depthwise taps (freeze)
@@ -151,6 +153,7 @@ struct ams_student {
     // create_student_v3's kwargs that run.py leaves off (utils/graph_utils.py:338-339): soft_teacher — the loss's target is softmax(gather(teacher
     // logits)) (:375-376, 403-404), the logits fed per step (ams_student_feed_teacher_logits = feed_dict[teacher_labels_logits_pl]); regularize /
     // train_biases_only — 0.01 * mean of the l2 losses of tvars added to the loss (:451-456; ams_student_set_regularizer)
+    int f16_fallback_layers = 0;     // layers whose frozen weights are beyond fp16's range (they run the three-part bf16 form); set by freeze
     int soft_teacher = 0;
     const float* teacher_logits = nullptr; int teacher_th = 0, teacher_tw = 0;
     const uint8_t* reg_mask = nullptr; int reg_nvars = 0; float reg_coef = 0.f;
@@ -230,7 +233,8 @@ static inline PwArgs pw_args(const float* x, int64_t M, int K, int ldx, const fl
 
 // algorithmic bytes (f32 storage): every operand read once, every result written once
 static inline double pw_bytes(const PwArgs& a) {
-    return 4.0 * ((double)a.M * (a.K + a.N + (a.res ? a.N : 0)) + (double)a.Kw * a.N);
+    // (+ the part planes of the result a project GEMM leaves for the streaming kernel of the next block: 2 bytes per value and part)
+    return 4.0 * ((double)a.M * (a.K + a.N + (a.res ? a.N : 0)) + (double)a.Kw * a.N) + (a.ysplit ? 2.0 * a.ysplit_np * (double)a.M * a.N : 0.0);
 }
 static inline double dw_bytes(const LayerRt& l, int B) { return 4.0 * ((double)B * (l.px_in + l.px_out) * l.d.cin + 9.0 * l.d.cin); }
 

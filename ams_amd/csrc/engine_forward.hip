@@ -450,7 +450,8 @@ int forward_live(ams_student* s, const void* frames, int dtype, int B, int globa
             AMS_CHECK_HIP(hipStreamWaitEvent(s->side, s->ev_fork, 0));
             ts = s->side;
         }
-        RUNK(0, 0.0, launch_split_batch(s->tp_jobs_dev, (int)s->tp_jobs.size(), s->tp_blocks, ts));
+        RUNK(0, 0.0, launch_split_batch(s->tp_jobs_dev, (int)s->tp_jobs.size(), s->tp_blocks, ts,
+                                        s->train_fwd_f16 && s->matmul_mode == AMS_MATMUL_SPLIT_F16));
         if (ts != st) { AMS_CHECK_HIP(hipEventRecord(s->ev_tp, ts)); s->tp_wait = true; }
         s->tp_fresh = true;
     }

@@ -118,7 +118,7 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
             l.whi = cv.take<uint16_t>(3 * plane);          // one allocation: the planes must be equally spaced
             l.wlo = l.whi ? l.whi + plane : nullptr;
             l.wlo3 = l.whi ? l.whi + 2 * plane : nullptr;
-            l.whf = cv.take<uint16_t>(2 * plane);
+            l.whf = l.whf_mem = cv.take<uint16_t>(2 * plane);
         }
     }
     if (s->n_backbone >= 3 && s->L[1].d.cout == 32 && s->L[2].d.role == AMS_ROLE_DEPTHWISE) {
@@ -128,7 +128,7 @@ int student_layout(ams_student* s, void* arena, size_t* bytes_out) {
         l1.whi = cv.take<uint16_t>(3 * 32 * 32);
         l1.wlo = l1.whi ? l1.whi + 32 * 32 : nullptr;
         l1.wlo3 = l1.whi ? l1.whi + 2 * 32 * 32 : nullptr;
-        l1.whf = cv.take<uint16_t>(2 * 32 * 32);           // ... and as two fp16 parts
+        l1.whf = l1.whf_mem = cv.take<uint16_t>(2 * 32 * 32);           // ... and as two fp16 parts
     }
     for (int i = 2; i + 2 <= s->n_backbone; ++i) {      // whole-block kernels: packed per-channel tables, filled by freeze
         LayerRt& l = s->L[i];

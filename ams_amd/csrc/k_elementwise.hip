@@ -476,6 +476,29 @@ int launch_adam(float* p, const float* g, float* m, float* v, const uint8_t* mas
     return AMS_OK;
 }
 
+// one block per job: does any |w| exceed `limit` (or fail to be finite)?
+__global__ __launch_bounds__(256) void weights_beyond_kernel(const WeightRange* __restrict__ jobs, float limit, int* __restrict__ flags) {
+    const WeightRange j = jobs[blockIdx.x];
+    int bad = 0;
+    for (int64_t i = threadIdx.x; i < j.n; i += 256) bad |= !(fabsf(j.w[i]) <= limit);
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) flags[blockIdx.x] = bad ? 1 : 0;
+}
+
+int weights_beyond(const std::vector<WeightRange>& jobs, float limit, int* scratch_dev, int* over_host, hipStream_t st) {
+    const size_t n = jobs.size();
+    AMS_REQUIRE(n * (sizeof(WeightRange) + sizeof(int)) <= 4096 * sizeof(float), "weights_beyond: %zu jobs do not fit the scratch", n);
+    WeightRange* jobs_dev = reinterpret_cast<WeightRange*>(scratch_dev);
+    int* flags_dev = reinterpret_cast<int*>(jobs_dev + n);
+    AMS_CHECK_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), n * sizeof(WeightRange), hipMemcpyHostToDevice, st));
+    AMS_CHECK_HIP(hipStreamSynchronize(st));             // (the table is a pageable host vector: it must not be read after this function returns)
+    hipLaunchKernelGGL(weights_beyond_kernel, dim3((unsigned)n), dim3(256), 0, st, jobs_dev, limit, flags_dev);
+    AMS_CHECK_LAUNCH();
+    AMS_CHECK_HIP(hipMemcpyAsync(over_host, flags_dev, n * sizeof(int), hipMemcpyDeviceToHost, st));
+    AMS_CHECK_HIP(hipStreamSynchronize(st));
+    return AMS_OK;
+}
+
 // regularize=True of create_student_v3 (utils/graph_utils.py:451-456): loss += 0.01 * reduce_mean([l2_loss(v) for v in tvars]), l2_loss(v) =
 // sum(v^2) / 2, tvars = every trainable variable or (train_biases_only) those without 'weight' in their name.  Over the flat arena with a byte
 // mask of the regularised entries: g += (coef / n_vars) * p, and the blocks' sums of p^2 (f64, fixed order) for the loss term.

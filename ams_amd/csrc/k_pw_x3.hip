@@ -42,7 +42,8 @@ __global__ void split_w_kernel(const float* __restrict__ w, int64_t sk, int64_t 
 }
 
 // every live (training) weight panel of the student in ONE launch: job j owns blocks [first_block_j, first_block_{j+1})
-__global__ void split_batch_kernel(const SplitJob* __restrict__ jobs, int njobs) {
+// write_f16: the two fp16 planes of the forward jobs too (only the fine-tune step under AMS_OPT_TRAIN_FWD_F16 reads them)
+__global__ void split_batch_kernel(const SplitJob* __restrict__ jobs, int njobs, int write_f16) {
     int lo = 0, hi = njobs - 1;                          // last job whose first block is <= blockIdx.x (block-uniform search)
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -59,7 +60,7 @@ __global__ void split_batch_kernel(const SplitJob* __restrict__ jobs, int njobs)
     j.p0[i] = h;
     j.p0[i + j.plane] = m;
     j.p0[i + 2 * j.plane] = bf16_rne_bits(r1 - __uint_as_float((unsigned)m << 16));
-    if (j.f16) {
+    if (j.f16 && write_f16) {
         unsigned short fh, fl;
         split1_f16(v, fh, fl);
         j.p0[i + 3 * j.plane] = fh;
@@ -67,9 +68,9 @@ __global__ void split_batch_kernel(const SplitJob* __restrict__ jobs, int njobs)
     }
 }
 
-int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st) {
+int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st, int write_f16) {
     if (njobs <= 0) return AMS_OK;
-    hipLaunchKernelGGL(split_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs_dev, njobs);
+    hipLaunchKernelGGL(split_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jobs_dev, njobs, write_f16);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }

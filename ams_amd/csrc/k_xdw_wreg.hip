@@ -42,6 +42,7 @@ struct XwrArgs {
     int nsy, nsx;
     int cgroups;                     // channel groups of 32 * NWE channels
     int items, groups;               // work items per channel group; blocks per channel group
+    int prio;                        // AMS_XWR_PRIO: 1 the D-waves at s_setprio 1 (default), 2 the E-waves, 0 neither
     int y_fmt;                       // 0: y as f32; 1 (H16 only): y as fp16 pairs interleaved per 8 channels ("H2I", PwArgs::x_fmt) — same bytes
 };
 
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 
     if (wave < NWE) {
         // =================================== E-waves ===================================
+        if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
         const int l15 = lane & 15, q = lane >> 4;
         const int n0 = cgi * NCB + 32 * wave;                        // this wave's 32 channels
         const bool active = n0 < a.Cexp;                             // the last channel group may be short (wave-uniform)
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
         flush(0);
     } else {
         // =================================== D-waves ===================================
+        if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
         const int dt = tid - 64 * NWE;
         const int cg = dt % CG, pt = dt / CG;
         const int nch = cgi * NCB + 4 * cg;                          // first of this thread's 4 channels
@@ -538,6 +541,7 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     a.nsy = nsy; a.nsx = nsx; a.cgroups = cgroups;
     a.items = B * rate * rate * nsy * nsx;
     a.y_fmt = y_fmt;
+    a.prio = knobs().xwr_prio;
     int64_t groups = groups_force > 0 ? groups_force : (512 + cgroups - 1) / cgroups;      // one block per CU (LDS), twice over
     if (groups > a.items) groups = a.items;
     a.groups = (int)groups;

@@ -1,5 +1,7 @@
 // Launcher prototypes shared by the engine (engine.hip) and the kernel-level C ABI (api.hip).
 #pragma once
+#include <vector>
+
 #include "common.hpp"
 
 struct ams_comm;
@@ -30,6 +32,8 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     bool pwh_set = false; int pwh_nw = 4, pwh_d = 2;                   // AMS_PWH_VARIANT=<waves per block>,<operand stages in flight>: experiment switch of the fp16 GEMM
     bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE
     bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
+    int xwr_prio = 1;                            // AMS_XWR_PRIO: 1 (default) = the D-waves of the weight-register kernel — the critical path of a step — at s_setprio 1
+                                                 // (146 vs 149 us per launch over two A/B rounds), 2 = the E-waves (no gain), 0 = neither
     bool xwr_no_pre = false;                     // AMS_XWR_NO_PRE: the weight-register kernel without its taps-ahead form (A/B; same results)
     bool wg6_eight_waves = false;                // AMS_WG6_EIGHT_WAVES: the wide tiles of the six-product weight gradient with eight waves, split 4 (k) x 2 (n)
     int wg6_split_cap = 0;                       // AMS_WG6_SPLITS: most pixel splits of the six-product weight gradient (default 32)
@@ -119,7 +123,7 @@ int launch_pointwise_split3(const PwArgs& a, const uint16_t* whi, const uint16_t
 // f16 != 0: the job ALSO leaves the two fp16 parts (hi | lo 2^11) at p0 + 3 * plane | p0 + 4 * plane (forward orientation: the fine-tune
 // step's forward products run on them under AMS_MATMUL_SPLIT_F16)
 struct SplitJob { const float* w; int64_t sk, sn; int K, N, Kp; uint16_t* p0; int64_t plane; int64_t first_block; int f16; };
-int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st);
+int launch_split_batch(const SplitJob* jobs_dev, int njobs, int64_t total_blocks, hipStream_t st, int write_f16);
 int launch_pointwise_split1(const PwArgs& a, const uint16_t* whi, int Kp, hipStream_t st);      // one part: plain bf16 products
 // two fp16 parts (k_pw_f16.hip; AMS_MATMUL_SPLIT_F16): panels [part][N][Kp] fp16, hi at whi, lo 2^11 at whi + plane; 3 MFMAs per 32 k
 int launch_split_weights_f16(const float* w, int64_t sk, int64_t sn, int K, int N, int Kp, uint16_t* hi, uint16_t* lo, hipStream_t st);
@@ -365,6 +369,9 @@ int launch_ce_loss_grad(const float* logits, int ld, int B, int h, int w, const 
 // (utils/graph_utils.py:408: loss = sum(w ce) / sum(w))
 int launch_ce_combine(int B, int h, int w, const int32_t* cls, int K, int NC, const double* loss_and_count, const float* scratch,
                       float* dlogits, int ldd, hipStream_t st, float empty_val = 0.f);
+// freeze-time range check of the fp16 product form: over_host[j] = 1 when any |w| of job j is > limit or not finite.  Synchronises `st`.
+struct WeightRange { const float* w; int64_t n; };
+int weights_beyond(const std::vector<WeightRange>& jobs, float limit, int* flags_dev /*>= jobs.size() ints + the job table*/, int* over_host, hipStream_t st);
 int launch_l2_regularizer(const float* p, float* g, const uint8_t* mask, int64_t n, int n_vars, float coef, double* part_scratch /*256 doubles*/,
                           double* loss, hipStream_t st);
 int launch_cross_confusion(const uint8_t* a, const uint8_t* b, int64_t n, const int32_t* lut /*[256] -> subset idx or -1*/,

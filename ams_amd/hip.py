@@ -97,6 +97,7 @@ SIGNATURES = {
     "ams_student_train_step_rccl": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "ams_student_set_option": (C.c_int, [_vp, _i32, _i32]),
     "ams_student_feed_teacher_logits": (C.c_int, [_vp, _vp, _i32, _i32]),
+    "ams_student_f16_fallback_layers": (C.c_int, [_vp, C.POINTER(_i32)]),
     "ams_student_set_regularizer": (C.c_int, [_vp, _vp, _i32, _f32]),
     "ams_student_profile": (C.c_int, [_vp, _i32]),
     "ams_student_profile_read": (C.c_int, [_vp, C.c_char_p, _sz, C.POINTER(_sz)]),

@@ -807,7 +807,7 @@ def main():
             "metric": "frames/sec student infer (DeeplabV3+MobileNetV2, 512x1024) + distill-steps/sec",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "settle_s": args.settle,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "spread": spread, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (2xfp16 split products)", "data": "synthetic",
             "rccl_ranks": (rccl_seen[1] if rccl_seen else (1 if dist is None else None)),
             "rccl_ranks_source": ("ams_comm_stats (the library's RCCL communicator)" if rccl_seen else
                                   "no RCCL communicator in this run" + ("" if dist is None else " (ranks share GPUs: gloo host callback)")),
@@ -816,7 +816,7 @@ def main():
                               "operands, x ~ hi + lo 2^-11 (22 significand bits; AMS_MATMUL_SPLIT_F16): f32-level — 512x1024 logits 3-4e-5 from the f64 "
                               "oracle, as exact f32 MFMA (3.7e-5), the three-part bf16 split of rounds 1-4 (3.7e-5) and the f32 CPU oracle (4.2e-5): "
                               "tools/logit_error.py; the depthwise result of a stride-16 block travels to its project GEMM as those fp16 pairs (4 bytes per "
-                              "value, like f32); the first block's stem keeps three bf16 parts (6 MFMAs), the 64-wide project of block 6 exact f32 MFMA; "
+                              "value, like f32); the first block's stem and project run on the same two fp16 parts (an fp16 table of the 256 byte values; first_block_walk_kernel), the 64-wide project of block 6 on exact f32 MFMA; "
                               "the fine-tune step forms every split product on three bf16 parts (6 MFMAs)",
             "kernels": kernels,
             "config": {"workload": "student infer only, %dx%d synthetic clip, frozen BN, uint8 frames resident in HBM, "

@@ -169,6 +169,11 @@ int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t
 int ams_student_train_step(ams_student* s, const void* frames_dev, int32_t frames_dtype, const uint8_t* teacher_dev,
                            int32_t batch, float lr, const uint8_t* mask_dev, double* loss_dev, void* stream);
 
+/* Range of the default product form (AMS_MATMUL_SPLIT_F16): fp16 holds |x| < 65520.  ams_student_freeze checks the frozen weights of every layer
+ * that has fp16 panels; a layer with a weight beyond 65504 (or a non-finite one) runs on three bf16 parts (f32's range) until a later freeze finds
+ * it inside again — *n_layers = how many layers the last freeze moved.  Activations are not checked. */
+int ams_student_f16_fallback_layers(const ams_student* s, int32_t* n_layers);
+
 /* ---- create_student_v3's remaining kwargs (utils/graph_utils.py:338-339; run.py:150 leaves all three off) -------------------------------
  * soft_teacher=True (option AMS_OPT_SOFT_TEACHER): pixel_loss = softmax_cross_entropy_with_logits(logits = filtered_logits, labels =
  * softmax(gather(teacher_labels_logits_pl, class_weights))) (:375-376, 403-404) — per pixel sum_k p_k (logsumexp(z) - z_k), gradient

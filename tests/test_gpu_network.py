@@ -5,6 +5,7 @@ oracle's except where the oracle's own top-2 margin is below the logit tolerance
 would break by summation order), confusion matrix / loss consistent with the labels, one optimisation step's
 gradients, Adam update and BN moving averages within 1e-3 relative.
 """
+import ctypes as C
 import random
 from collections import deque
 
@@ -651,3 +652,37 @@ def test_rccl_communicator_inside_the_engine(W0):
     assert spans == 54 * 2 + 2 and 0.0 < longest_ms <= total_ms < 1e3
     assert np.array_equal(ls_t, outs[0][0])                            # timing changes nothing
     comm.close()
+
+
+def test_weights_beyond_fp16_range_fall_back_to_three_bf16_parts(W0):
+    """the default product form splits operands into two fp16 parts; a weight of 65520 or more would become hi = inf, lo = -inf and the
+    logits NaN.  Every freeze checks the frozen weights: a layer outside fp16's range runs the three-part bf16 form (f32's range) instead.  One
+    project layer and one head layer scaled by 1e6 (their BN folds the scale back, so the network's function is unchanged up to rounding)."""
+    H, B = 64, 2
+    frames, _ = synth.SyntheticVideo(H, B, CI, seed=3).clip()
+    W = {k: np.array(v, copy=True) for k, v in W0.items()}
+    scaled = ["MobilenetV2/expanded_conv_14/project", "aspp0"]
+    for scope in scaled:
+        W[scope + "/weights:0"] = W[scope + "/weights:0"] * np.float32(1e6)
+        W[scope + "/BatchNorm/moving_mean:0"] = W[scope + "/BatchNorm/moving_mean:0"] * np.float32(1e6)
+        W[scope + "/BatchNorm/moving_variance:0"] = W[scope + "/BatchNorm/moving_variance:0"] * np.float32(1e12)
+    assert max(float(np.abs(W[s_ + "/weights:0"]).max()) for s_ in scaled) > 65504
+    o = _oracle(W, torch.float64)
+    with torch.no_grad():
+        low = o.forward_lowres(frames.astype(np.float32), "frozen").numpy()
+    eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
+    eng.load_variables(W)
+    eng.freeze()
+    n = C.c_int32()
+    hip.check(eng.lib.ams_student_f16_fallback_layers(eng._h, C.byref(n)))
+    assert n.value == 2
+    eng.predict(frames)
+    h, w = eng.lowres
+    got = eng.logits_lowres.view(-1, h, w, 32)[:B, :, :, :19].cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel(got, low) < 2e-4
+    eng.load_variables(W0)                                 # back inside the range: the fp16 form returns
+    eng.freeze()
+    hip.check(eng.lib.ams_student_f16_fallback_layers(eng._h, C.byref(n)))
+    assert n.value == 0
+    eng.close()

@@ -144,10 +144,33 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
         arow[r] = a.x + m * (int64_t)a.ldx;
     }
     float4 abuf[D][RM][2];
+    // ABL & 16 (probe, wrong operands): the same bytes requested in FULL-LINE lane order — a request instruction covers 8 rows x 128 bytes (lane ->
+    // row lane / 8, 16-byte piece lane % 8) instead of 16 rows x 64 bytes: what the texture path would see behind a lane-order hop
+    const float* aline[RM][2];
+    if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                int64_t m = m_base + (r < nrg ? r : nrg - 1) * 16 + 8 * hf + (lane >> 3);
+                if (m > a.M - 1) m = a.M - 1;
+                aline[r][hf] = a.x + m * (int64_t)a.ldx + 4 * (lane & 7);
+            }
+    }
     auto load_a = [&](int s, float4 (&dst)[RM][2], auto Rc) {
         constexpr int R = decltype(Rc)::value;
         int koff = s * 32 + 8 * q;
         if (koff > K - 8) koff = K - 8;                 // k >= K repeats the last 8 k of the row: the weight panels are zero there
+        if constexpr ((ABL & 16) != 0) {
+            int ks = s * 32;
+            if (ks > K - 32) ks = K - 32;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                dst[r][0] = ld4(aline[r][0] + ks);
+                dst[r][1] = ld4(aline[r][1] + ks);
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             dst[r][0] = ld4(arow[r] + koff);
@@ -329,6 +352,16 @@ static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int 
     if constexpr (NT == 10 && RM <= 2) {                   // full-width 160-column tiles (the operand crosses L2 -> CU once), 8- / 12-wave blocks
         int nw = knobs().pwh_nw, dd = knobs().pwh_d;
         if (!knobs().pwh_set && RM == 1) { nw = 12; dd = 3; }      // what launch_pointwise_split_f16 picks the (1, 10) tile for
+#ifdef AMS_MEASURE
+        if constexpr (RM == 1) {                               // MEASUREMENT BUILD ONLY: the 12-wave form's stage loop taken apart (AMS_PWH_ABL, wrong results)
+            const int abl = knobs().pwh_abl;
+            if (abl && a.x_fmt == 1 && nw == 12 && dd == 3) {
+#define PWH_A(A_) if (abl == A_) return launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, 12, 3, A_>(a, w, plane, Kp, st);
+                PWH_A(1) PWH_A(2) PWH_A(3) PWH_A(8) PWH_A(9) PWH_A(10) PWH_A(11) PWH_A(16) PWH_A(18) PWH_A(24) PWH_A(26)
+#undef PWH_A
+            }
+        }
+#endif
         if (a.x_fmt == 1 && (epi == EPI_PLAIN || epi == EPI_RES) && (nw > 4 || dd > 2)) {
 #define PWH_V(NW_, D_) if (nw == NW_ && dd == D_) return epi == EPI_PLAIN ? launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, NW_, D_>(a, w, plane, Kp, st) : launch_pw_f16_d<RM, NT, EPI_RES, 1, NW_, D_>(a, w, plane, Kp, st);
             PWH_V(8, 2) PWH_V(12, 2) PWH_V(8, 3) PWH_V(12, 3)

@@ -42,7 +42,6 @@ struct XwrArgs {
     int nsy, nsx;
     int cgroups;                     // channel groups of 32 * NWE channels
     int items, groups;               // work items per channel group; blocks per channel group
-    int prio;                        // AMS_XWR_PRIO: 1 the D-waves at s_setprio 1 (default), 2 the E-waves, 0 neither
     int y_fmt;                       // 0: y as f32; 1 (H16 only): y as fp16 pairs interleaved per 8 channels ("H2I", PwArgs::x_fmt) — same bytes
 };
 
@@ -54,8 +53,7 @@ __device__ unsigned long long g_xwr_cycles[1024][8];
 // in an accumulator of their own, products and order of pw_gemm_f16x3_l (bit-identical to it followed by the depthwise kernel).
 // ABL: measurement-only ablations (AMS_XWR_ABL, wrong results): 1 no operand loads in the step loop, 2 no MFMAs, 4 no depthwise arithmetic,
 // 8 no result stores, 16 no ring stores
-// PRE: the D-waves request the top and middle window rows of a step one step AHEAD (needs Wp >= STEP: see the D-waves' loop)
-template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0, bool PRE = false>
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0>
 __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, unsigned nblocks) {
     static_assert(!H16 || NP == 2, "the fp16 form has two parts");
     constexpr int STEP = 16 * NRG;                   // pixels per step: NRG MFMA row groups per E-wave (2 * NRG accumulator chains)
@@ -104,7 +102,6 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 
     if (wave < NWE) {
         // =================================== E-waves ===================================
-        if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
         const int l15 = lane & 15, q = lane >> 4;
         const int n0 = cgi * NCB + 32 * wave;                        // this wave's 32 channels
         const bool active = n0 < a.Cexp;                             // the last channel group may be short (wave-uniform)
@@ -186,12 +183,19 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                     if (e_col[rg] >= Wp) { e_col[rg] -= Wp; ++e_row[rg]; }
                 }
                 if constexpr (!(ABL & 1)) load_pieces(loader_pixel());        // tile of step t + 1: lands during the MFMAs
+                // The accumulators start at zero INSIDE the active branch (there the first MFMA of each takes the constant 0 as its C operand); a wave of
+                // a short last channel group skips the products and the ring stores alike — nothing valid reads its ring columns (the D-threads of
+                // those channels store nothing) — so no path needs 32 zeroed registers (they were 32 v_mov per step on every path)
                 f32x4 acc[NRG][2], accx[H16 ? NRG : 1][2];
+                auto zero_acc = [&]() {
 #pragma unroll
-                for (int rg = 0; rg < NRG; ++rg) { acc[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                    for (int rg = 0; rg < NRG; ++rg) { acc[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int rg = 0; rg < (H16 ? NRG : 1); ++rg) { accx[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-                if (active && !(ABL & 2)) {
+                    for (int rg = 0; rg < (H16 ? NRG : 1); ++rg) { accx[rg][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; accx[rg][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                };
+                if constexpr ((ABL & 2) != 0) zero_acc();
+                else if (active) {
+                    zero_acc();
                     const u32x4* ap = sA + par * AUNITS + q * 16 + l15;
                     // the operand fragments of k-step s + 1 are requested before the MFMAs of k-step s: with one E-wave per SIMD nothing
                     // else hides the LDS round trip (five exposed waits per step otherwise)
@@ -246,6 +250,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
 #undef AMS_XWR_TERM_H
                     }
                 }
+                if (active || (ABL & 2) != 0)
 #pragma unroll
                 for (int rg = 0; rg < NRG; ++rg) {
                     // one v_med3 per value: the activation's bounds, both 0 for a position outside the feature map (the depthwise
@@ -283,7 +288,6 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
         flush(0);
     } else {
         // =================================== D-waves ===================================
-        if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
         const int dt = tid - 64 * NWE;
         const int cg = dt % CG, pt = dt / CG;
         const int nch = cgi * NCB + 4 * cg;                          // first of this thread's 4 channels
@@ -315,18 +319,19 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
             const int off0 = ((sy + rate * (i0 - 1)) * a.W + sx + rate * (j0 - 1)) * a.Cexp * 4 + (int)ych;
             int d_row, d_col;                                        // first centre of this thread at step 0: -Wp - 1 + pt * PX
             { const int c0 = Wp - 1 + pt * PX; d_row = c0 / Wp; d_col = c0 - d_row * Wp; d_row -= 2; }
+            // byte offset of that centre's result, carried from centre to centre and from step to step by additions (the product form
+            // row * rowpitch + col * colpitch cost two quarter-rate integer multiplies per centre)
+            const int wrapdelta = rowpitch - Wp * colpitch;          // a centre that passes the end of a padded row
+            const int stepdelta = qS * rowpitch + rS * colpitch;
+            int d_off = d_row * rowpitch + d_col * colpitch + off0;
             __syncthreads();                                          // (A)
             __syncthreads();                                          // E-step 0
-            // The taps of a step's centres, one window ROW at a time: vt[hh][di][jj] = row di of the pair of centres hh.  With one D-wave per SIMD
-            // nothing else hides an LDS round trip, and the D-waves are the critical path of the step (tools/xwr_phases.py, round 5: 1.3 k of a
-            // step's 4.1 k cycles went by until all 24 reads issued behind the barrier had landed).  PRE: the windows of D-step t + 1 reach the
-            // ring slots (t + 2) STEP - (2 - di) Wp - 1 at most and E-step t + 1 — the one running beside D-step t — writes from (t + 1) STEP on,
-            // so with Wp >= STEP the top and the middle row of the NEXT step were written by E-steps that are complete when this D-step begins:
-            // they are requested one step ahead, straight after this step's FMAs have freed the registers, and land under the epilogue and the
-            // stores; only the bottom row waits for the barrier, and the top / middle FMAs (pinned ahead of the bottom row's) cover its round
-            // trip.  The D-waves' step barrier is a bare s_barrier: they write nothing to LDS, and __syncthreads' fence would wait for the reads
-            // in flight.  (Ring reuse: the slots requested ahead are the slots D-step t + 1 reads anyway, one step of E-writes further from
-            // being overwritten.)
+            // The taps of a step's centres: vt[hh][di][jj] = window row di of the pair of centres hh, all requested before the first is used (with
+            // one D-wave per SIMD nothing else hides the LDS round trip of the second pair behind the first pair's arithmetic).
+            // Measured and NOT kept (round 6): the top and middle rows of step t + 1 requested one step AHEAD (with Wp >= STEP they were written by
+            // E-steps <= t; the D-waves then behind a bare s_barrier so that the requests stay in flight) — bit-identical, the wait behind the
+            // barrier shrinks to the bottom row's 8 reads, and the kernel does not move (146 vs 147 us over four A/B rounds): the round-5 clocks'
+            // "1.3 k cycles until the taps have landed" were not what bounds the step; the same on xdw_stream_kernel: 485 vs 452 us (slower).
             constexpr int NH = (PX + 1) / 2;
             float4 vt[NH][3][PH + 2];
             auto load_row = [&](int di) {
@@ -340,9 +345,43 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                     for (int jj = 0; jj < PH + 2; ++jj) vt[hh][di][jj] = (ABL & 4) ? wv[di] : ld4(rp + jj * PITCH);
                 }
             };
-            if constexpr (PRE) { load_row(0); load_row(1); }
+            // BN + activation + fp16 split + store of a step's centres (first centre at (row, col), byte offset off_c)
+            auto epilogue = [&](const float4 (&accs)[NH][PH], int row, int col, int off_c) {
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) {
+                    const int h = 2 * hh;
+#pragma unroll
+                    for (int u = 0; u < PH; ++u) {
+                        const float4 a4 = accs[hh][u];
+                        float4 o;
+                        o.x = apply_act(a4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(a4.y * dsc.y + dsh.y, a.act_d);
+                        o.z = apply_act(a4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(a4.w * dsc.w + dsh.w, a.act_d);
+                        (void)h;
+                        const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
+                        const unsigned off = (ok && !(ABL & 8)) ? (unsigned)off_c : 0xfffffff0u;
+                        ++col; off_c += colpitch;                    // the next centre (one wrap at most per increment, whatever Wp)
+                        if (col >= Wp) { col -= Wp; ++row; off_c += wrapdelta; }
+                        if (H16 && a.y_fmt) {                        // wave-uniform
+                            // fp16 pairs, 8 channels per 32-byte group (16 bytes of hi | 16 bytes of lo).  Two neighbouring lanes hold the two
+                            // halves of a group (channel groups cg = 2g, 2g + 1 of the same pixel): they swap — the even lane takes the odd one's
+                            // hi, the odd lane the even one's lo (one quad_perm DPP move per dword) — and each stores ONE 16-byte piece instead of
+                            // two 8-byte ones (the result stores are the largest single item of this kernel: tools/sweep_xwr_abl.sh)
+                            unsigned h2[2], l2[2];
+                            split4_f16_mix(o, h2, l2);
+                            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[0] : l2[0]), 0xB1, 0xF, 0xF, false);
+                            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[1] : l2[1]), 0xB1, 0xF, 0xF, false);
+                            const u32x4 d = {odd_cg ? r0 : h2[0], odd_cg ? r1 : h2[1], odd_cg ? l2[0] : r0, odd_cg ? l2[1] : r1};
+                            __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                        } else {
+                        const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                        }
+                    }
+                }
+            };
             for (int t = 0; t < a.T; ++t) {
-                if constexpr (!PRE) { load_row(0); load_row(1); }
+                load_row(0);
+                load_row(1);
                 load_row(2);
                 if constexpr (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lap(2); }     // [4]: the taps have landed
                 float4 acc4[NH][PH];
@@ -353,13 +392,6 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 // per centre the taps in the order (row, column) of dw3x3_fwd_kernel: row by row, so that the bottom row is needed last
 #pragma unroll
                 for (int i = 0; i < ((ABL & 4) ? 1 : 3); ++i) {
-                    if (PRE && i == 2) {                                  // every top / middle FMA ahead of the first bottom one
-#pragma unroll
-                        for (int hh = 0; hh < NH; ++hh)
-#pragma unroll
-                            for (int u = 0; u < PH; ++u)
-                                asm volatile("" : "+v"(acc4[hh][u].x), "+v"(acc4[hh][u].y), "+v"(acc4[hh][u].z), "+v"(acc4[hh][u].w));
-                    }
 #pragma unroll
                     for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
@@ -371,23 +403,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                                 AMS_DW_FMA4(acc4[hh][u], vv, w4);
                             }
                 }
-                const int d_row_now = d_row, d_col_now = d_col;
-                d_row += qS; d_col += rS;
-                if (d_col >= Wp) { d_col -= Wp; ++d_row; }
+                const int row0 = d_row, col0 = d_col, off0c = d_off;     // the step's first centre; the next ones follow by increments
+                d_row += qS; d_col += rS; d_off += stepdelta;
+                if (d_col >= Wp) { d_col -= Wp; ++d_row; d_off += wrapdelta; }
                 cb += STEP;
                 if (cb >= R) cb -= R;
-                if constexpr (PRE) {
-                    // the requests for the next step: behind this step's last FMA (the ring index is made to depend on the sums: nothing else
-                    // keeps hipcc from issuing them ahead of the FMAs, where the wait for the bottom row would wait for them too) and ahead of
-                    // the epilogue
-#pragma unroll
-                    for (int hh = 0; hh < NH; ++hh)
-#pragma unroll
-                        for (int u = 0; u < PH; ++u) asm volatile("" : "+v"(cb) : "v"(acc4[hh][u].x), "v"(acc4[hh][u].y), "v"(acc4[hh][u].z), "v"(acc4[hh][u].w));
-                    load_row(0);
-                    load_row(1);
-                    asm volatile("" ::: "memory");
-                }
                 if constexpr (TIMED) {                                // [5]: the FMAs are done (and the next step's rows requested)
 #pragma unroll
                     for (int hh = 0; hh < NH; ++hh)
@@ -395,42 +415,9 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                         for (int u = 0; u < PH; ++u) asm volatile("" : "+v"(acc4[hh][u].x), "+v"(acc4[hh][u].y), "+v"(acc4[hh][u].z), "+v"(acc4[hh][u].w));
                     lap(3);
                 }
-#pragma unroll
-                for (int hh = 0; hh < NH; ++hh) {
-                    const int h = 2 * hh;
-#pragma unroll
-                    for (int u = 0; u < PH; ++u) {
-                        const float4 a4 = acc4[hh][u];
-                        float4 o;
-                        o.x = apply_act(a4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(a4.y * dsc.y + dsh.y, a.act_d);
-                        o.z = apply_act(a4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(a4.w * dsc.w + dsh.w, a.act_d);
-                        int row = d_row_now, col = d_col_now + h + u;
-#pragma unroll
-                        for (int w = 0; w < (PX + 1) / 2; ++w)            // PX may span several rows of a tiny segment (Wp >= 3)
-                            if (col >= Wp) { col -= Wp; ++row; }
-                        const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
-                        const unsigned off = (ok && !(ABL & 8)) ? (unsigned)(row * rowpitch + col * colpitch + off0) : 0xfffffff0u;
-                        if (H16 && a.y_fmt) {                        // wave-uniform
-                            // fp16 pairs, 8 channels per 32-byte group (16 bytes of hi | 16 bytes of lo).  Two neighbouring lanes hold the two
-                            // halves of a group (channel groups cg = 2g, 2g + 1 of the same pixel): they swap — the even lane takes the odd one's
-                            // hi, the odd lane the even one's lo (one quad_perm DPP move per dword) — and each stores ONE 16-byte piece instead of
-                            // two 8-byte ones (the result stores are the largest single item of this kernel: tools/sweep_xwr_abl.sh)
-                            unsigned h2[2], l2[2];
-                            split4_f16(o, h2, l2);
-                            const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[0] : l2[0]), 0xB1, 0xF, 0xF, false);
-                            const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[1] : l2[1]), 0xB1, 0xF, 0xF, false);
-                            const u32x4 d = {odd_cg ? r0 : h2[0], odd_cg ? r1 : h2[1], odd_cg ? l2[0] : r0, odd_cg ? l2[1] : r1};
-                            __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
-                        } else {
-                        const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
-                        }
-                    }
-                }
+                epilogue(acc4, row0, col0, off0c);
                 lap(0);
-                asm volatile("" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
+                __syncthreads();
                 lap(1);
                 if constexpr (TIMED) ++nstep;
             }
@@ -455,10 +442,10 @@ static size_t xwr_lds(int Kp, int np, int nwe, int nrg, int ring) {
     return (size_t)2 * nrg * np * (Kp / 8) * 16 * 16 + (size_t)(ring + 4) * (32 * nwe + 4) * 4;
 }
 
-template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0, bool PRE = false>
+template <int KS, int NP, int NWE, int NWD, int NRG, bool H16 = false, int ABL = 0>
 static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
 #ifdef AMS_MEASURE
-    if constexpr (ABL == 0 && !PRE && KS == 5 && NP == 2 && NWE == 4 && NWD == 4 && NRG == 2 && H16) {        // MEASUREMENT BUILD ONLY (libams_hip_measure.so, AMS_XWR_ABL=<bits>)
+    if constexpr (ABL == 0 && KS == 5 && NP == 2 && NWE == 4 && NWD == 4 && NRG == 2 && H16) {        // MEASUREMENT BUILD ONLY (libams_hip_measure.so, AMS_XWR_ABL=<bits>)
         switch (knobs().xwr_abl) {
             case 1: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 1>(a, lds, st);
             case 2: return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 2>(a, lds, st);
@@ -475,18 +462,13 @@ static int launch_xwr_k(const XwrArgs& a, size_t lds, hipStream_t st) {
         if (knobs().xwr_timed) return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, 32>(a, lds, st);      // AMS_XWR_TIMED=1: the kernel with its role clocks
     }
 #endif
-    // the taps-ahead form: where the segment is at least a step wide (the 160 -> 960 blocks at 512 x 1024: Wp = 34, STEP = 32); built for the
-    // fp16 4 + 4-wave, two-row-group kernels only (what frozen inference launches)
-    if constexpr (!PRE && H16 && NWE == 4 && NWD == 4 && NRG == 2) {
-        if (a.Wp >= 16 * NRG && !knobs().xwr_no_pre) return launch_xwr_k<KS, NP, NWE, NWD, NRG, H16, ABL, true>(a, lds, st);
-    }
-    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL, PRE>, lds));
+    RUN_RC(func_allow_lds((const void*)xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>, lds));
     const int64_t nblocks = (int64_t)a.groups * a.cgroups;
     AMS_REQUIRE(nblocks > 0 && nblocks < 0x7fffffffLL, "expand_dw_wreg: bad grid");
     static const std::string nm = "xdw_wreg_kernel<" + std::to_string(KS) + ", " + std::to_string(NP) + ", " + std::to_string(NWE) + ", " +
-                                  std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", true, " : ", false, ") + std::to_string(ABL) + (PRE ? ", true>" : ", false>");
+                                  std::to_string(NWD) + ", " + std::to_string(NRG) + (H16 ? ", true, " : ", false, ") + std::to_string(ABL) + ">";
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL, PRE>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
+    hipLaunchKernelGGL((xdw_wreg_kernel<KS, NP, NWE, NWD, NRG, H16, ABL>), dim3((unsigned)nblocks), dim3(64 * (NWE + NWD)), lds, st, a, (unsigned)nblocks);
     AMS_CHECK_LAUNCH();
     return AMS_OK;
 }
@@ -541,7 +523,6 @@ int launch_expand_dw_wreg(const uint16_t* x_parts, int64_t x_plane, int B, int H
     a.nsy = nsy; a.nsx = nsx; a.cgroups = cgroups;
     a.items = B * rate * rate * nsy * nsx;
     a.y_fmt = y_fmt;
-    a.prio = knobs().xwr_prio;
     int64_t groups = groups_force > 0 ? groups_force : (512 + cgroups - 1) / cgroups;      // one block per CU (LDS), twice over
     if (groups > a.items) groups = a.items;
     a.groups = (int)groups;

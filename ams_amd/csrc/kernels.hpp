@@ -32,9 +32,6 @@ struct Knobs {                   // tuning knobs of tools/*: environment variabl
     bool pwh_set = false; int pwh_nw = 4, pwh_d = 2;                   // AMS_PWH_VARIANT=<waves per block>,<operand stages in flight>: experiment switch of the fp16 GEMM
     bool xds_set = false; int xds[6] = {0, 0, 0, 0, 0, 0};      // AMS_XDS_FORCE
     bool xwr_set = false; int xwr[5] = {0, 0, 0, 0, 0};         // AMS_XWR_FORCE
-    int xwr_prio = 1;                            // AMS_XWR_PRIO: 1 (default) = the D-waves of the weight-register kernel — the critical path of a step — at s_setprio 1
-                                                 // (146 vs 149 us per launch over two A/B rounds), 2 = the E-waves (no gain), 0 = neither
-    bool xwr_no_pre = false;                     // AMS_XWR_NO_PRE: the weight-register kernel without its taps-ahead form (A/B; same results)
     bool wg6_eight_waves = false;                // AMS_WG6_EIGHT_WAVES: the wide tiles of the six-product weight gradient with eight waves, split 4 (k) x 2 (n)
     int wg6_split_cap = 0;                       // AMS_WG6_SPLITS: most pixel splits of the six-product weight gradient (default 32)
     int event_flags = -1;                        // AMS_EVENT_FLAGS=<hex>: flags of the stream-ordering events (default: hipEventDisableTiming)

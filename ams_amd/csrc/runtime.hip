@@ -103,8 +103,6 @@ static Knobs read_knobs() {
         if (const char* e = getenv("AMS_PWX_FORCE")) sscanf(e, "%d,%d", &v.pwx_rm, &v.pwx_nt);
         if (const char* e = getenv("AMS_XDS_FORCE")) { v.xds_set = true; sscanf(e, "%d,%d,%d,%d,%d,%d", &v.xds[0], &v.xds[1], &v.xds[2], &v.xds[3], &v.xds[4], &v.xds[5]); }
         if (const char* e = getenv("AMS_XWR_FORCE")) { v.xwr_set = true; sscanf(e, "%d,%d,%d,%d,%d", &v.xwr[0], &v.xwr[1], &v.xwr[2], &v.xwr[3], &v.xwr[4]); }
-        v.xwr_no_pre = getenv("AMS_XWR_NO_PRE") != nullptr;
-        if (const char* e = getenv("AMS_XWR_PRIO")) v.xwr_prio = atoi(e);
         if (const char* e = getenv("AMS_WG6_SPLITS")) v.wg6_split_cap = atoi(e);
         v.wg6_eight_waves = getenv("AMS_WG6_EIGHT_WAVES") != nullptr;
         if (const char* e = getenv("AMS_SIDE_CU_MASK")) v.side_cu_mask = (unsigned)strtoul(e, nullptr, 16);

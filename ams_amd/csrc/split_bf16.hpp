@@ -84,6 +84,22 @@ __device__ __forceinline__ void split4_f16(const float4& v, unsigned (&h)[2], un
     split_pair_f16(v.x, v.y, h[0], l[0]);
     split_pair_f16(v.z, v.w, h[1], l[1]);
 }
+// The same bits with the remainder taken by v_fma_mix_f32, which reads hi as fp16 straight from the packed dword: r = fma(f32(hi), -2^11, x 2^11)
+// without the two v_cvt_f32_f16 per pair (VALU-bound kernels: the D-waves of k_xdw_wreg.hip)
+__device__ __forceinline__ void split_pair_f16_mix(float a, float b, unsigned& h, unsigned& l) {
+    const f32x2s_t f = {a, b};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2_t));                      // v_cvt_pk_f16_f32 (RNE)
+    const float sa = a * kF16LoScale, sb = b * kF16LoScale;
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(-kF16LoScale), "v"(sa));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(-kF16LoScale), "v"(sb));
+    const f32x2s_t r = {ra, rb};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
+}
+__device__ __forceinline__ void split4_f16_mix(const float4& v, unsigned (&h)[2], unsigned (&l)[2]) {
+    split_pair_f16_mix(v.x, v.y, h[0], l[0]);
+    split_pair_f16_mix(v.z, v.w, h[1], l[1]);
+}
 // scalar form (weight panels): bit patterns of (hi, lo)
 __device__ __forceinline__ void split1_f16(float v, unsigned short& h, unsigned short& l) {
     const _Float16 hh = (_Float16)v;

@@ -65,7 +65,8 @@ __device__ __forceinline__ f32x4 mma_f16(const u32x4& a, const u32x4& b, const f
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-constexpr int pwh_waves(int rm, int nt, int nw) { return nw == 12 ? 3 : nw == 8 ? 2 : rm * nt > 12 ? 1 : rm * nt > 6 ? 2 : 3; }
+constexpr int pwh_waves(int rm, int nt, int nw) { return nw >= 9 ? 3 : nw == 8 ? 2 : rm * nt > 12 ? 1 : rm * nt > 6 ? 2 : 3; }
+constexpr int pwh_epw(int nw, int slab) { return nw * slab <= 60 * 1024 ? nw : nw % 5 == 0 && 5 * slab <= 60 * 1024 ? 5 : nw % 4 == 0 ? 4 : nw % 3 == 0 ? 3 : 1; }
 
 // Same frame as pw_gemm_bf16x3_l (64 RM x 16 NT tiles, four waves with RM row groups each, weight stages double-buffered in XOR-swizzled
 // 64-byte LDS rows, operand ring of depth 2 in registers, all loads unconditional, half-height tail blocks) with NP = 2 and two
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
     constexpr int NREG = (NPIECE + NTH - 1) / NTH;
     // the epilogue's per-wave slabs share the weight stages' LDS; when NW of them would pass 60 KB the waves take turns, EPW at a time
     constexpr int SLAB = 16 * (16 * NT + 4) * 4;
-    constexpr int EPW = (EPI == EPI_GENERIC || NW * SLAB <= 60 * 1024) ? NW : 4;
+    constexpr int EPW = EPI == EPI_GENERIC ? NW : pwh_epw(NW, SLAB);
     static_assert(NW % EPW == 0, "epilogue rounds");
     static_assert(XF == 0 || (XP == 0 && EPI == EPI_PLAIN), "the operand transform runs on f32 operands with the plain epilogue");
     // (+ 4 x 16 NT floats behind the slabs for the vectors of a fused column reduction, PwArgs::red_mode)
@@ -351,7 +352,10 @@ static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int 
 #endif
     if constexpr (NT == 10 && RM <= 2) {                   // full-width 160-column tiles (the operand crosses L2 -> CU once), 8- / 12-wave blocks
         int nw = knobs().pwh_nw, dd = knobs().pwh_d;
-        if (!knobs().pwh_set && RM == 1) { nw = 12; dd = 3; }      // what launch_pointwise_split_f16 picks the (1, 10) tile for
+        // what launch_pointwise_split_f16 picks the (1, 10) tile for.  160 columns (one column tile): 10-wave blocks — 160 rows a block: 429 blocks at
+        // 68640 rows, 215 at the 34320 of a two-part plan, where 12-wave blocks are 358 / 179: fuller rounds on 256 CUs — 110 vs 117 us at 960 -> 160,
+        // 64 vs 67 at 576 -> 160, 50.5 vs 53 at 34320 rows (round 6, AMS_PWH_VARIANT sweep); 320 columns keep 12 waves (182 vs 201 us)
+        if (!knobs().pwh_set && RM == 1) { nw = a.N <= 160 ? 10 : 12; dd = 3; }
 #ifdef AMS_MEASURE
         if constexpr (RM == 1) {                               // MEASUREMENT BUILD ONLY: the 12-wave form's stage loop taken apart (AMS_PWH_ABL, wrong results)
             const int abl = knobs().pwh_abl;
@@ -364,7 +368,7 @@ static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int 
 #endif
         if (a.x_fmt == 1 && (epi == EPI_PLAIN || epi == EPI_RES) && (nw > 4 || dd > 2)) {
 #define PWH_V(NW_, D_) if (nw == NW_ && dd == D_) return epi == EPI_PLAIN ? launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, NW_, D_>(a, w, plane, Kp, st) : launch_pw_f16_d<RM, NT, EPI_RES, 1, NW_, D_>(a, w, plane, Kp, st);
-            PWH_V(8, 2) PWH_V(12, 2) PWH_V(8, 3) PWH_V(12, 3)
+            PWH_V(8, 2) PWH_V(12, 2) PWH_V(8, 3) PWH_V(12, 3) PWH_V(9, 3) PWH_V(10, 3)
 #undef PWH_V
         }
     }

@@ -368,7 +368,7 @@ static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int 
 #endif
         if (a.x_fmt == 1 && (epi == EPI_PLAIN || epi == EPI_RES) && (nw > 4 || dd > 2)) {
 #define PWH_V(NW_, D_) if (nw == NW_ && dd == D_) return epi == EPI_PLAIN ? launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, NW_, D_>(a, w, plane, Kp, st) : launch_pw_f16_d<RM, NT, EPI_RES, 1, NW_, D_>(a, w, plane, Kp, st);
-            PWH_V(8, 2) PWH_V(12, 2) PWH_V(8, 3) PWH_V(12, 3) PWH_V(9, 3) PWH_V(10, 3)
+            PWH_V(8, 2) PWH_V(12, 2) PWH_V(8, 3) PWH_V(12, 3) PWH_V(10, 3)
 #undef PWH_V
         }
     }

@@ -377,7 +377,7 @@ def main():
             parts_timed = 1
         roofline["plan"] = "one stream (the engine's per-launch profiler replays the step on ONE stream)"
         roofline["timed_plan"] = ("%d parts of the batch on %d streams (AMS_OPT_DUAL_STREAM static rule); rocprofv3 trace of this plan: "
-                                  "profiles/r05_infer_kernel_stats_dual.csv" % (parts_timed, parts_timed)) if parts_timed > 1 else "one stream"
+                                  "profiles/r06_infer_kernel_stats_dual.csv" % (parts_timed, parts_timed)) if parts_timed > 1 else "one stream"
         roofline.update(pmc_traffic(dom[0], B, H))
         # the whole step against the three denominators of SURVEY 8 d4, over the TIMED step (not the profiled replay)
         as_built = total_bytes / n_prof

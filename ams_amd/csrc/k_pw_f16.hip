@@ -239,7 +239,8 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
                         }
                     }
                     const unsigned short* bw = &sW[s & 1][0][l15 * PITCH + 8 * (q ^ ((l15 >> 3) << 1))];      // LDS stages alternate with s (D may be odd)
-                    constexpr int TG = (NT >= 2 && RM <= 2) ? 2 : 1;
+                    // ABL & 32 (probe): ONE accumulator per tile (the cross terms join the main sum: other rounding, same instruction mix) and five tiles' fragments in flight
+                    constexpr int TG = (ABL & 32) ? 5 : (NT >= 2 && RM <= 2) ? 2 : 1;
 #pragma unroll
                     for (int t0 = 0; t0 < NT; t0 += TG) {
                         u32x4 qh[TG], ql[TG];
@@ -254,12 +255,12 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
                         for (int g = 0; g < TG; ++g)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-                                if (t0 + g < NT && !(ABL & 8)) accx[r][t0 + g] = mma_f16(ql[g], xh[r], accx[r][t0 + g]);
+                                if (t0 + g < NT && !(ABL & 8)) { if constexpr ((ABL & 32) != 0) acc[r][t0 + g] = mma_f16(ql[g], xh[r], acc[r][t0 + g]); else accx[r][t0 + g] = mma_f16(ql[g], xh[r], accx[r][t0 + g]); }
 #pragma unroll
                         for (int g = 0; g < TG; ++g)
 #pragma unroll
                             for (int r = 0; r < R; ++r)
-                                if (t0 + g < NT && !(ABL & 8)) accx[r][t0 + g] = mma_f16(qh[g], xl[r], accx[r][t0 + g]);
+                                if (t0 + g < NT && !(ABL & 8)) { if constexpr ((ABL & 32) != 0) acc[r][t0 + g] = mma_f16(qh[g], xl[r], acc[r][t0 + g]); else accx[r][t0 + g] = mma_f16(qh[g], xl[r], accx[r][t0 + g]); }
 #pragma unroll
                         for (int g = 0; g < TG; ++g)
 #pragma unroll
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
 #pragma unroll
     for (int r = 0; r < RM; ++r)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[r][t] = combine_f16(acc[r][t], accx[r][t]);
+        for (int t = 0; t < NT; ++t) if constexpr (!(ABL & 32)) acc[r][t] = combine_f16(acc[r][t], accx[r][t]);
     const bool red = EPI == EPI_PLAIN && NW == 4 && a.red_mode != 0;    // block-uniform (the launcher clears red_mode where it cannot be fused)
     float4 rs1[(EPI == EPI_PLAIN && NW == 4) ? NT : 1], rs2[(EPI == EPI_PLAIN && NW == 4) ? NT : 1];
     if constexpr (EPI == EPI_PLAIN && NW == 4) {
@@ -361,7 +362,7 @@ static int launch_pw_f16(const PwArgs& a, const uint16_t* w, int64_t plane, int 
             const int abl = knobs().pwh_abl;
             if (abl && a.x_fmt == 1 && nw == 12 && dd == 3) {
 #define PWH_A(A_) if (abl == A_) return launch_pw_f16_d<RM, NT, EPI_PLAIN, 1, 12, 3, A_>(a, w, plane, Kp, st);
-                PWH_A(1) PWH_A(2) PWH_A(3) PWH_A(8) PWH_A(9) PWH_A(10) PWH_A(11) PWH_A(16) PWH_A(18) PWH_A(24) PWH_A(26)
+                PWH_A(1) PWH_A(2) PWH_A(3) PWH_A(8) PWH_A(9) PWH_A(10) PWH_A(11) PWH_A(16) PWH_A(18) PWH_A(24) PWH_A(26) PWH_A(32) PWH_A(35) PWH_A(48) PWH_A(15) PWH_A(4)
 #undef PWH_A
             }
         }

@@ -349,14 +349,12 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
             auto epilogue = [&](const float4 (&accs)[NH][PH], int row, int col, int off_c) {
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
-                    const int h = 2 * hh;
 #pragma unroll
-                    for (int u = 0; u < PH; ++u) {
+                    for (int u = 0; u < PH; ++u) {                    // centres in raster order: (hh, u) = centre 2 hh + u of the thread
                         const float4 a4 = accs[hh][u];
                         float4 o;
                         o.x = apply_act(a4.x * dsc.x + dsh.x, a.act_d); o.y = apply_act(a4.y * dsc.y + dsh.y, a.act_d);
                         o.z = apply_act(a4.z * dsc.z + dsh.z, a.act_d); o.w = apply_act(a4.w * dsc.w + dsh.w, a.act_d);
-                        (void)h;
                         const bool ok = ((unsigned)(row - 1) < (unsigned)rmax) & ((unsigned)(col - 1) < (unsigned)cmax);
                         const unsigned off = (ok && !(ABL & 8)) ? (unsigned)off_c : 0xfffffff0u;
                         ++col; off_c += colpitch;                    // the next centre (one wrap at most per increment, whatever Wp)
@@ -389,7 +387,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 for (int hh = 0; hh < NH; ++hh)
 #pragma unroll
                     for (int u = 0; u < PH; ++u) acc4[hh][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                // per centre the taps in the order (row, column) of dw3x3_fwd_kernel: row by row, so that the bottom row is needed last
+                // per centre the taps in the order (row, column) of dw3x3_fwd_kernel
 #pragma unroll
                 for (int i = 0; i < ((ABL & 4) ? 1 : 3); ++i) {
 #pragma unroll
@@ -408,7 +406,7 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                 if (d_col >= Wp) { d_col -= Wp; ++d_row; d_off += wrapdelta; }
                 cb += STEP;
                 if (cb >= R) cb -= R;
-                if constexpr (TIMED) {                                // [5]: the FMAs are done (and the next step's rows requested)
+                if constexpr (TIMED) {                                // [5]: the FMAs are done
 #pragma unroll
                     for (int hh = 0; hh < NH; ++hh)
 #pragma unroll

@@ -5,7 +5,8 @@
 cd "$(dirname "$0")/.."
 export AMS_HIP_LIB=${AMS_HIP_LIB:-$PWD/ams_amd/libams_hip_measure.so}
 [ -f "$AMS_HIP_LIB" ] || { echo "build it first: make -C ams_amd/csrc measure"; exit 1; }
-for a in 0 16 1 2 3 8 9 10 11 18 24 26; do
+export AMS_PWH_VARIANT=12,3      # (the 160-column layers run 10-wave blocks since round 6: the ablated forms are 12-wave)
+for a in ${ABLS:-0 16 1 2 3 8 9 10 11 18 24 26 32 35 48}; do
   export AMS_PWH_ABL=$a
   echo -n "abl=$a  "
   python3 tools/bench_kernel.py ${1:-68640} ${2:-960} ${3:-160} f16p 2>&1 | grep -v amdgpu.ids | tail -1

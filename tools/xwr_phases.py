@@ -35,7 +35,7 @@ def show(name, out, taps):
     es, ds = max(out[6], 1), max(out[7], 1)
     print("%s  E-waves: %d wave-steps per pass, %.0f cycles between barriers + %.0f at the barrier per step" % (name, es / n, out[0] / es, out[1] / es))
     if taps:
-        print("%s  D-waves: %d wave-steps per pass, %.0f cycles until the taps have landed + %.0f FMAs (+ next step's requests) + %.0f epilogue and stores + %.0f at the barrier per step" % (name, ds / n, out[4] / ds, out[5] / ds, out[2] / ds, out[3] / ds))
+        print("%s  D-waves: %d wave-steps per pass, %.0f cycles until the taps have landed + %.0f FMAs + %.0f epilogue and stores + %.0f at the barrier per step" % (name, ds / n, out[4] / ds, out[5] / ds, out[2] / ds, out[3] / ds))
     else:
         print("%s  D-waves: %d wave-steps per pass, %.0f cycles between barriers + %.0f at the barrier per step" % (name, ds / n, out[2] / ds, out[3] / ds))
 

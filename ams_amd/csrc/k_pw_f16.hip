@@ -67,6 +67,9 @@ __device__ __forceinline__ f32x4 mma_f16(const u32x4& a, const u32x4& b, const f
 
 constexpr int pwh_waves(int rm, int nt, int nw) { return nw >= 9 ? 3 : nw == 8 ? 2 : rm * nt > 12 ? 1 : rm * nt > 6 ? 2 : 3; }
 constexpr int pwh_epw(int nw, int slab) { return nw * slab <= 60 * 1024 ? nw : nw % 5 == 0 && 5 * slab <= 60 * 1024 ? 5 : nw % 4 == 0 ? 4 : nw % 3 == 0 ? 3 : 1; }
+// blocks of 9 waves and more take their LDS dynamically (one block per CU anyway: 160 KB are theirs) and every wave has its own epilogue slab: ONE
+// epilogue round instead of NW / EPW rounds of EPW waves with a block barrier between them
+constexpr bool pwh_dyn(int nw, int epi) { return nw >= 9 && epi != EPI_GENERIC; }
 
 // Same frame as pw_gemm_bf16x3_l (64 RM x 16 NT tiles, four waves with RM row groups each, weight stages double-buffered in XOR-swizzled
 // 64-byte LDS rows, operand ring of depth 2 in registers, all loads unconditional, half-height tail blocks) with NP = 2 and two
@@ -89,12 +92,15 @@ __global__ __launch_bounds__(64 * NW, pwh_waves(RM, NT, NW)) void pw_gemm_f16x3_
     constexpr int NREG = (NPIECE + NTH - 1) / NTH;
     // the epilogue's per-wave slabs share the weight stages' LDS; when NW of them would pass 60 KB the waves take turns, EPW at a time
     constexpr int SLAB = 16 * (16 * NT + 4) * 4;
-    constexpr int EPW = EPI == EPI_GENERIC ? NW : pwh_epw(NW, SLAB);
+    constexpr bool DYN = pwh_dyn(NW, EPI);
+    constexpr int EPW = (EPI == EPI_GENERIC || DYN) ? NW : pwh_epw(NW, SLAB);
     static_assert(NW % EPW == 0, "epilogue rounds");
     static_assert(XF == 0 || (XP == 0 && EPI == EPI_PLAIN), "the operand transform runs on f32 operands with the plain epilogue");
     // (+ 4 x 16 NT floats behind the slabs for the vectors of a fused column reduction, PwArgs::red_mode)
     constexpr int W_BYTES = 2 * NP * ROWS * PITCH * 2, OUT_BYTES = EPI == EPI_GENERIC ? 16 : EPW * SLAB + (EPI == EPI_PLAIN && NW == 4 ? 4 * 16 * NT * 4 : 0);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES > OUT_BYTES ? W_BYTES : OUT_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem_static[DYN ? 16 : (W_BYTES > OUT_BYTES ? W_BYTES : OUT_BYTES)];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    unsigned char* smem = DYN ? smem_dyn : smem_static;
     typedef unsigned short (*WStage)[NP][ROWS * PITCH];
     WStage sW = reinterpret_cast<WStage>(smem);
     float* sOutAll = reinterpret_cast<float*>(smem);
@@ -317,7 +323,11 @@ template <int RM, int NT, int EPI, int XP, int NW = 4, int D = 2, int ABL = 0, i
 static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, int Kp, hipStream_t st) {
     const int n_tiles_n = cdiv(a.N, 16 * NT);
     int per_cu = 1, cus = 256;
-    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>, 64 * NW, 0, &per_cu));
+    // dynamic LDS of the wide blocks: max(weight stages, NW epilogue slabs) — the kernel's own W_BYTES / OUT_BYTES
+    constexpr size_t kSlab = 16 * (16 * NT + 4) * 4, kW = (size_t)2 * 2 * 16 * NT * 32 * 2;
+    const size_t dyn = pwh_dyn(NW, EPI) ? (NW * kSlab > kW ? NW * kSlab : kW) : 0;
+    if (dyn) RUN_RC(func_allow_lds((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>, dyn));
+    RUN_RC(func_blocks_per_cu((const void*)pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>, 64 * NW, dyn, &per_cu));
     RUN_RC(device_cus(&cus));
     int64_t half_strips = 0;
     const int64_t full_strips = pw_plan_tail(a.M, RM, n_tiles_n, per_cu * cus, &half_strips, 16 * NW * RM);
@@ -331,7 +341,7 @@ static int launch_pw_f16_d(const PwArgs& a, const uint16_t* w, int64_t plane, in
     static const std::string nm = "pw_gemm_f16x3_l<" + std::to_string(RM) + ", " + std::to_string(NT) + ", " + std::to_string(EPI) + ", " + std::to_string(XP) + ", " +
                                   std::to_string(NW) + ", " + std::to_string(D) + ", " + std::to_string(ABL) + ", " + std::to_string(XF) + ">";      // as rocprofv3 prints it
     note_kernel(nm.c_str());
-    hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>), dim3((unsigned)nblocks), dim3(64 * NW), 0, st, b, w, plane, Kp, n_tiles_n,
+    hipLaunchKernelGGL((pw_gemm_f16x3_l<RM, NT, EPI, XP, NW, D, ABL, XF>), dim3((unsigned)nblocks), dim3(64 * NW), dyn, st, b, w, plane, Kp, n_tiles_n,
                        (unsigned)nblocks, (unsigned)n_full);
     AMS_CHECK_LAUNCH();
     return AMS_OK;

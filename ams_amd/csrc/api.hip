@@ -203,6 +203,19 @@ int ams_student_predict_frames(ams_student* s, const void* frames_dev, int32_t f
                                   labels_out_dev, teacher_dev ? conf_mats_dev : nullptr, teacher_dev ? losses_dev : nullptr, st, /*per_frame=*/1);
 }
 
+int ams_student_predict_frames_u8(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch, int32_t mode, const uint8_t* teacher_dev,
+                                  uint8_t* labels_out_dev, int64_t* conf_mats_dev, double* losses_dev, void* stream) {
+    RUN(check_call(s, frames_dev, frames_dtype, batch));
+    AMS_REQUIRE(labels_out_dev, "predict_frames_u8: null output");
+    AMS_REQUIRE(teacher_dev == nullptr || (conf_mats_dev && losses_dev), "predict_frames_u8: metrics need conf and loss buffers");
+    hipStream_t st = (hipStream_t)stream;
+    RUN(run_forward(s, frames_dev, frames_dtype, batch, mode, st));
+    const ams_student_config& c = s->cfg;
+    return launch_upsample_argmax(s->logits, 32, batch, s->h, s->w, c.class_indices, c.n_selected, c.height, c.width, teacher_dev, c.num_classes,
+                                  reinterpret_cast<int32_t*>(labels_out_dev), teacher_dev ? conf_mats_dev : nullptr, teacher_dev ? losses_dev : nullptr, st,
+                                  /*per_frame=*/1, /*labels_u8=*/1);
+}
+
 int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t n_pixels, int64_t* conf_mat_dev, void* stream) {
     AMS_REQUIRE(s && labels_dev && conf_mat_dev && n_pixels > 0, "cross_confusion: bad argument");
     int32_t lut[256];

@@ -13,6 +13,7 @@ constexpr int kMaxK = 32;
 struct HeadGeom {
     int B, h, w, ld, K, H, W, NC;
     int per_frame;         // metrics per frame: conf [B][K][K], loss [B][2] instead of the batch totals
+    int labels_u8;         // the label map as uint8 [B][H][W] through the same pointer (K <= 32 fits a byte: a quarter of the device -> host bytes)
     float sy, sx;          // (h-1)/(H-1), (w-1)/(W-1) as f32 (TF: CalculateResizeScale with align_corners)
 };
 
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(const float* __res
                 visit(k, bilerp(ptl[c], ptr[c], pbl[c], pbr[c], tx, ty));
             }
         }
-        if (labels) labels[pix] = arg;
+        if (labels) { if (g.labels_u8) reinterpret_cast<uint8_t*>(labels)[pix] = (uint8_t)arg; else labels[pix] = arg; }
         if (target >= 0) {
             my_loss += rint((double)((zmax + __logf(ssum)) - zt) * 1048576.0);
             my_cnt += 1;
@@ -159,7 +160,7 @@ static int fill_class_table(const int32_t* cls_host, int K, int NC, ClassTable* 
 
 static HeadGeom head_geom(int ld, int B, int h, int w, int K, int H, int W, int NC) {
     HeadGeom g;
-    g.B = B; g.h = h; g.w = w; g.ld = ld; g.K = K; g.H = H; g.W = W; g.NC = NC; g.per_frame = 0;
+    g.B = B; g.h = h; g.w = w; g.ld = ld; g.K = K; g.H = H; g.W = W; g.NC = NC; g.per_frame = 0; g.labels_u8 = 0;
     g.sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     g.sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     return g;
@@ -167,7 +168,7 @@ static HeadGeom head_geom(int ld, int B, int h, int w, int K, int H, int W, int 
 
 // cls: HOST pointer to the K selected class ids (they travel to the kernel by value)
 int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
-                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st, int per_frame) {
+                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st, int per_frame, int labels_u8) {
     ClassTable ct;
     int rc = fill_class_table(cls, K, NC, &ct);
     if (rc) return rc;
@@ -179,6 +180,7 @@ int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, con
     }
     HeadGeom g = head_geom(ld, B, h, w, K, H, W, NC);
     g.per_frame = per_frame;
+    g.labels_u8 = labels_u8;
     note_kernel("upsample_argmax_kernel");
     // bands of consecutive rows per block: 32 per column strip and image, fewer rows per band when that leaves the chip short of blocks
     int rows_y = H < 32 ? H : 32;

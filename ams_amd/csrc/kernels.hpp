@@ -352,7 +352,8 @@ int launch_pack_fp16(const float* p, const uint8_t* mask, int64_t n, uint16_t* o
 // ---- k_head.hip : fused upsample + argmax + metrics, CE gradient, phi-score confusion --------------------
 // per_frame != 0: conf [B][K][K] and loss [B][2] (one confusion matrix / loss pair per frame) instead of the batch totals
 int launch_upsample_argmax(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
-                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st, int per_frame = 0);
+                           const uint8_t* teacher, int NC, int32_t* labels, int64_t* conf, double* loss, hipStream_t st, int per_frame = 0,
+                           int labels_u8 = 0 /* labels as uint8 [B][H][W] through the same pointer */);
 int launch_ce_grad(const float* logits, int ld, int B, int h, int w, const int32_t* cls, int K, int H, int W,
                    const uint8_t* teacher, int NC, const double* loss_and_count, float* dlogits, int ldd, hipStream_t st, float empty_val = 0.f);
 // loss + gradient in one pass (fine-tune step): pass 1 leaves the CE sum / valid count in loss[2] and the unnormalised gradient in

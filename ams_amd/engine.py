@@ -84,6 +84,7 @@ class StudentEngine:
         self.num_classes = int(num_classes)
         self.soft_teacher = False
         self._reg_mask = self._teacher_logits_dev = None
+        self._frames_b, self._frames_u8, self._frames_metric = 0, False, False
         self.class_indices = [int(c) for c in class_indices]
         self.K = len(self.class_indices)
         cfg = hip.StudentConfig()
@@ -384,67 +385,64 @@ class StudentEngine:
             C.c_void_p(conf.data_ptr()), C.c_void_p(loss.data_ptr()), self._stream()), "ams_student_predict_with_metric")
         return out, conf.view(self.K, self.K), loss
 
-    def _fetch_outputs(self, b: int):
-        """labels / conf / loss of the last host-returning call: one async copy into the pinned mirror, one stream sync."""
-        n = self._out_meta + b * self.height * self.width * 4
-        self._out_host[:n].copy_(self._out_dev[:n], non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
-        host = self._out_host.numpy()
-        kk = self.K * self.K
-        conf = host[:kk * 8].view(np.int64).reshape(self.K, self.K).copy()
-        loss = host[kk * 8:self._out_meta].view(np.float64).copy()
-        labels = host[self._out_meta:n].view(np.int32).reshape(b, self.height, self.width).copy()
-        return labels, conf, loss
-
+    # Host-returning calls (what SemanticNetwork.predict_input / predict_with_metric make): the label maps leave the device as uint8 (an index
+    # inside the subset of K <= 32 classes) and are widened to the reference's int32 on the host: 0.5 MB instead of 2 MB per 512 x 1024 frame over
+    # PCIe, and the widening writes the fresh array the caller gets anyway (copying 2 MB of int32 out of the pinned mirror took longer than the
+    # transfer).  Metrics come back per frame (ams_student_predict_frames_u8) and are summed here: integers and exact fixed-point sums.
     def predict_host(self, frames, mode: int = hip.MODE_FROZEN) -> np.ndarray:
         """predict() with the label maps returned as a fresh int32 ndarray (one device -> host copy, preallocated buffers)."""
-        t, dt, b = self._frames_to_device(frames)
-        lab_ptr = self._out_dev.data_ptr() + self._out_meta
-        hip.check(self.lib.ams_student_predict(self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab_ptr), self._stream()),
-                  "ams_student_predict")
-        return self._fetch_outputs(b)[0]
+        self.predict_frames(frames, None, mode, u8=True)
+        return self.fetch_frames(labels_only=True)[0]
 
     def predict_with_metric_host(self, frames, labels_teacher, mode: int = hip.MODE_FROZEN):
         """predict_with_metric() -> (labels int32 [B,H,W], conf_mat int64 [K,K], loss_sum_count f64[2]) as fresh ndarrays."""
-        t, dt, b = self._frames_to_device(frames)
-        lab = self._labels_to_device(labels_teacher, b)
-        base = self._out_dev.data_ptr()
-        hip.check(self.lib.ams_student_predict_with_metric(
-            self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()), C.c_void_p(base + self._out_meta),
-            C.c_void_p(base), C.c_void_p(base + self.K * self.K * 8), self._stream()), "ams_student_predict_with_metric")
-        return self._fetch_outputs(b)
+        self.predict_frames(frames, labels_teacher, mode, u8=True)
+        labels, confs, losses = self.fetch_frames()
+        return labels, confs.sum(axis=0), losses.sum(axis=0)
 
-    def predict_frames(self, frames, labels_teacher=None, mode: int = hip.MODE_FROZEN):
-        """Per-FRAME results of one batched pass (ams_student_predict_frames): device tensors labels int32 [B,H,W], conf int64 [B,K,K],
-        loss f64 [B,2] (views of the engine's output block, valid until the next host-returning / predict_frames call).  Nothing is
-        synchronised; ``fetch_frames`` brings them to the host."""
+    def predict_frames(self, frames, labels_teacher=None, mode: int = hip.MODE_FROZEN, u8: bool = False):
+        """Per-FRAME results of one batched pass (ams_student_predict_frames): device tensors labels int32 [B,H,W] (``u8``: uint8, for results
+        that go to the host), conf int64 [B,K,K], loss f64 [B,2] (views of the engine's output block, valid until the next host-returning /
+        predict_frames call).  Nothing is synchronised; ``fetch_frames`` brings them to the host."""
         t, dt, b = self._frames_to_device(frames)
         lab = self._labels_to_device(labels_teacher, b) if labels_teacher is not None else None
         kk = self.K * self.K
         base = self._out_dev.data_ptr()
         meta = self._out_meta * b
-        hip.check(self.lib.ams_student_predict_frames(
-            self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()) if lab is not None else None, C.c_void_p(base + meta),
-            C.c_void_p(base), C.c_void_p(base + kk * 8 * b), self._stream()), "ams_student_predict_frames")
+        fn = self.lib.ams_student_predict_frames_u8 if u8 else self.lib.ams_student_predict_frames
+        hip.check(fn(self._h, C.c_void_p(t.data_ptr()), dt, b, mode, C.c_void_p(lab.data_ptr()) if lab is not None else None, C.c_void_p(base + meta),
+                     C.c_void_p(base), C.c_void_p(base + kk * 8 * b), self._stream()), "ams_student_predict_frames")
         self._keepalive = [t, lab]
         self._frames_b = b
+        self._frames_u8 = bool(u8)
+        self._frames_metric = lab is not None
         conf = self._out_dev[:kk * 8 * b].view(torch.int64).view(b, self.K, self.K)
         loss = self._out_dev[kk * 8 * b:meta].view(torch.float64).view(b, 2)
-        labels = self._out_dev[meta:meta + b * self.height * self.width * 4].view(torch.int32).view(b, self.height, self.width)
+        px = b * self.height * self.width
+        labels = (self._out_dev[meta:meta + px].view(b, self.height, self.width) if u8 else
+                  self._out_dev[meta:meta + px * 4].view(torch.int32).view(b, self.height, self.width))
         return labels, conf, loss
 
-    def fetch_frames(self):
-        """(labels [B,H,W] int32, conf [B,K,K] int64, loss [B,2] f64) of the last ``predict_frames`` as fresh ndarrays: one copy, one sync."""
+    def fetch_frames(self, labels_only: bool = False):
+        """(labels [B,H,W] int32, conf [B,K,K] int64, loss [B,2] f64) of the last ``predict_frames`` as fresh ndarrays: one copy, one sync.
+        (``labels_only``, or a pass without teacher labels: conf and loss are None and only the label bytes cross PCIe.)"""
         b = self._frames_b
         kk = self.K * self.K
         meta = self._out_meta * b
-        n = meta + b * self.height * self.width * 4
-        self._out_host[:n].copy_(self._out_dev[:n], non_blocking=True)
+        px = b * self.height * self.width
+        n = meta + (px if self._frames_u8 else px * 4)
+        first = meta if (labels_only or not self._frames_metric) else 0
+        self._out_host[first:n].copy_(self._out_dev[first:n], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         host = self._out_host.numpy()
-        conf = host[:kk * 8 * b].view(np.int64).reshape(b, self.K, self.K).copy()
-        loss = host[kk * 8 * b:meta].view(np.float64).reshape(b, 2).copy()
-        labels = host[meta:n].view(np.int32).reshape(b, self.height, self.width).copy()
+        conf = loss = None
+        if first == 0:
+            conf = host[:kk * 8 * b].view(np.int64).reshape(b, self.K, self.K).copy()
+            loss = host[kk * 8 * b:meta].view(np.float64).reshape(b, 2).copy()
+        if self._frames_u8:
+            labels = host[meta:n].reshape(b, self.height, self.width).astype(np.int32)       # widened into the fresh array the caller gets
+        else:
+            labels = host[meta:n].view(np.int32).reshape(b, self.height, self.width).copy()
         return labels, conf, loss
 
     def cross_confusion(self, labels_pair) -> torch.Tensor:

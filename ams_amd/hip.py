@@ -84,6 +84,7 @@ SIGNATURES = {
     "ams_student_predict": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ams_student_predict_with_metric": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ams_student_predict_frames": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ams_student_predict_frames_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ams_cross_confusion": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "ams_student_train_step": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _f32, _vp, _vp, _vp]),
     "ams_student_train_step_dp": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, ALLREDUCE_CB, _vp, _vp]),

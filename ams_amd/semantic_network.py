@@ -284,7 +284,7 @@ class SemanticNetwork(object):
         labels = cat(q[2] for q in self._queued)
         self._pending = [q[0] for q in self._queued]
         self._queued = []
-        self.engine.predict_frames(frames, labels, self._mode())     # returns at once: the pass runs while the caller goes on
+        self.engine.predict_frames(frames, labels, self._mode(), u8=True)     # returns at once: the pass runs while the caller goes on (labels leave as uint8)
 
     def collect(self, ticket):
         with self.process_lock:

@@ -157,6 +157,12 @@ int ams_student_predict_with_metric(ams_student* s, const void* frames_dev, int3
 int ams_student_predict_frames(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch, int32_t mode,
                                const uint8_t* teacher_dev, int32_t* labels_out_dev, int64_t* conf_mats_dev, double* losses_dev, void* stream);
 
+/* The same with the label maps as uint8 [batch,H,W] (an index inside the subset of K <= 32 classes fits a byte): what a caller that takes the
+ * results to the HOST uses — a quarter of the device -> host bytes of the int32 maps, widened on the host (SemanticNetwork.predict_input /
+ * predict_with_metric return int32 as the reference does: the widening of 0.5 MB costs less there than copying 2 MB out of the pinned buffer). */
+int ams_student_predict_frames_u8(ams_student* s, const void* frames_dev, int32_t frames_dtype, int32_t batch, int32_t mode,
+                                  const uint8_t* teacher_dev, uint8_t* labels_out_dev, int64_t* conf_mats_dev, double* losses_dev, void* stream);
+
 int ams_cross_confusion(const ams_student* s, const uint8_t* labels_dev, int64_t n_pixels, int64_t* conf_mat_dev,
                         void* stream);
 

@@ -686,3 +686,25 @@ def test_weights_beyond_fp16_range_fall_back_to_three_bf16_parts(W0):
     hip.check(eng.lib.ams_student_f16_fallback_layers(eng._h, C.byref(n)))
     assert n.value == 0
     eng.close()
+
+
+def test_host_returning_calls_hand_back_uint8_labels(W0):
+    """predict_host / predict_with_metric_host (what SemanticNetwork.predict_input / predict_with_metric call): the label maps cross PCIe as
+    uint8 and are widened on the host, the metrics come per frame and are summed there — the same int32 maps, confusion matrix and loss sums
+    (bit for bit) as the device-side calls."""
+    H, B = 64, 3
+    frames, labels = synth.SyntheticVideo(H, B, CI, seed=6).clip()
+    eng = StudentEngine(CI, H, 2 * H, max_batch=B, trainable=False)
+    eng.load_variables(W0)
+    eng.freeze()
+    lab_dev = eng.predict(frames).cpu().numpy()
+    lab_host = eng.predict_host(frames)
+    assert lab_host.dtype == np.int32 and lab_host.shape == (B, H, 2 * H) and np.array_equal(lab_host, lab_dev)
+    l_d, c_d, s_d = eng.predict_with_metric(frames, labels)
+    l_h, c_h, s_h = eng.predict_with_metric_host(frames, labels)
+    assert l_h.dtype == np.int32 and np.array_equal(l_h, l_d.cpu().numpy())
+    assert c_h.dtype == np.int64 and np.array_equal(c_h, c_d.cpu().numpy())
+    assert s_h.dtype == np.float64 and np.array_equal(s_h, s_d.cpu().numpy())
+    one = eng.predict_host(frames[:1])                      # a smaller call after a larger one: the output block is re-laid out
+    assert np.array_equal(one, lab_dev[:1])
+    eng.close()

@@ -110,7 +110,8 @@ class SemanticNetwork(object):
         self.train_biases_only = bool(kwargs.pop("train_biases_only", False))
         self.regularize = bool(kwargs.pop("regularize", False))
         self.soft_teacher = bool(kwargs.pop("soft_teacher", False))
-        assert not (frozen and (self.soft_teacher or self.regularize)), "soft_teacher / regularize belong to the trainable graph"
+        if frozen:                 # the reference's frozen branch never calls create_student_v3: the kwargs are accepted and unused there too
+            self.soft_teacher = self.regularize = self.train_biases_only = False
         initial_variables = kwargs.pop("initial_variables", None)
         frozen_graph = kwargs.pop("frozen_graph", None)
         max_batch = kwargs.pop("max_batch", None)

@@ -369,7 +369,11 @@ __global__ __launch_bounds__(64 * (NWE + NWD)) void xdw_wreg_kernel(XwrArgs a, u
                             const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[0] : l2[0]), 0xB1, 0xF, 0xF, false);
                             const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd_cg ? h2[1] : l2[1]), 0xB1, 0xF, 0xF, false);
                             const u32x4 d = {odd_cg ? r0 : h2[0], odd_cg ? r1 : h2[1], odd_cg ? l2[0] : r0, odd_cg ? l2[1] : r1};
-                            __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);
+                            // non-temporal (aux 2): the 264 MB of a 32-frame launch pass through the caches once on their way to the project GEMM; with
+                            // the hint they do not push that GEMM's weight panels and this kernel's operand out of L2 — the GEMM behind it 116 vs 123 us,
+                            // this kernel 146 vs 149, the step +0.5 % over four leases.  (The same hint on the smaller results of xdw_stream_kernel: -1.8 %;
+                            // on the GEMM's operand loads: -4 %.)
+                            __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 2);
                         } else {
                         const u32x4 d = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
                         __builtin_amdgcn_raw_buffer_store_b128(d, yrsrc, off, 0, 0);

@@ -163,7 +163,12 @@ __device__ __forceinline__ void pw_epilogue_t(const PwArgs& a, f32x4 (&acc)[RM][
             const int64_t m = m0 + row;
             float4 v = ld4(sOut + row * OP + c4);
             if (EPI == EPI_RES) { v.x += rv[uu].x; v.y += rv[uu].y; v.z += rv[uu].z; v.w += rv[uu].w; }
-            if (m < a.M && n0 + c4 < a.N) st4(a.y + m * a.ldy + n0 + c4, v);
+            if (m < a.M && n0 + c4 < a.N) {
+                // a result that also leaves as part planes is read next through THOSE (8 - 18 times, by the streaming kernel's channel blocks); its f32
+                // form waits for the residual add a whole block later: stored non-temporal, it does not push the planes out of L2 (+0.4 % on the step)
+                if (SPLIT_OUT && a.ysplit) __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(a.y + m * a.ldy + n0 + c4));
+                else st4(a.y + m * a.ldy + n0 + c4, v);
+            }
             if (SPLIT_OUT && a.ysplit && a.ysplit_fmt == 1 && m < a.M && n0 + c4 < a.N) {
                 // two fp16 parts (hi | lo 2^11, split_bf16.hpp): planes [part][M][N]
                 unsigned h[2], l[2];

@@ -271,3 +271,52 @@ def test_semantic_network_soft_teacher_surface(W0):
                                                                     for v in reg.engine.spec.trainable if 'weight' not in v.name]), rel=1e-4)
     for n in (net, ref, hard, reg):
         n.close_model()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the soft-teacher step sharded over the batch: 2 ranks (gloo, both on cuda:0) x 2 frames == 1 rank x 4 frames
+# ---------------------------------------------------------------------------------------------------------
+def _dp_soft_worker(rank, world, port, tmp):
+    import os
+    import torch.distributed as dist
+    from ams_amd.dist import ArenaAllReduce, init_from_env, shard_bounds
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    init_from_env("gloo")
+    W0 = Wt.synthetic_weights(S.build_spec(), seed=0)
+    frames, labels = synth.SyntheticVideo(64, 4, CI, seed=9).clip()
+    tl = _teacher_logits(labels.astype(np.int64), np.random.default_rng(21), th=9, tw=17)
+    b, e = shard_bounds(4, rank, world)
+    eng = StudentEngine(CI, 64, 128, max_batch=2, trainable=True)
+    eng.load_variables(W0)
+    eng.set_soft_teacher(True)
+    red = ArenaAllReduce(eng.arena)
+    ls = eng.train_step(frames[b:e], labels[b:e], 1e-3, allreduce=red, global_batch=4, teacher_logits=tl[b:e]).cpu().numpy()
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(os.path.join(tmp, "dps_grads.npy"), eng.grads.cpu().numpy())
+        np.save(os.path.join(tmp, "dps_loss.npy"), ls)
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_soft_teacher_step_equals_single_process(W0, tmp_path):
+    """Every rank feeds the cached teacher logits of ITS shard; the loss sums and the valid-pixel count are all-reduced as in the hard-label step:
+    the sharded soft step is the single-process step on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_dp_soft_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    frames, labels = synth.SyntheticVideo(64, 4, CI, seed=9).clip()
+    tl = _teacher_logits(labels.astype(np.int64), np.random.default_rng(21), th=9, tw=17)
+    eng = StudentEngine(CI, 64, 128, max_batch=4, trainable=True)
+    eng.load_variables(W0)
+    eng.set_soft_teacher(True)
+    ls = eng.train_step(frames, labels, 1e-3, teacher_logits=tl).cpu().numpy()
+    dp_ls = np.load(tmp_path / "dps_loss.npy")
+    assert dp_ls[1] == ls[1] and dp_ls[0] == pytest.approx(ls[0], rel=1e-5)
+    g, dg = eng.grads.cpu().numpy().astype(np.float64), np.load(tmp_path / "dps_grads.npy").astype(np.float64)
+    cos = float(g @ dg / (np.linalg.norm(g) * np.linalg.norm(dg)))
+    assert cos > 0.99999, cos
+    eng.close()
